@@ -1,0 +1,157 @@
+/*
+ * orphics_amd C-ABI -- MI355X (gfx950) kernels for the flat-sky CMB lensing
+ * quadratic-estimator hot path of msyriac/orphics.
+ *
+ * The reference has NO native/FFI layer: the hot path is Python
+ * calling NumPy / pixell.  Each entry point below therefore replaces a NumPy /
+ * pixell expression inside a reference function; the reference file:line is
+ * cited per function.  The Python classes in orphics_amd/{maps,stats,lensing}.py
+ * mirror the reference signatures and bind these symbols with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - every function returns 0 on success, non-zero on error; oa_last_error()
+ *    returns the message of the calling thread's last failure; nothing throws;
+ *  - all data pointers are DEVICE pointers unless the name says `host_`;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *    work is stream-ordered, no call synchronises unless documented;
+ *  - dtype: OA_F32 (float / complex64 planes) or OA_F64 (double / complex128);
+ *  - real planes are (ny, nx) row-major; "hc" (half-complex) planes are
+ *    (ny, kpitch) complex row-major with kpitch = oa_plan_kpitch(plan)
+ *    = nx/2 + 16; columns [0, nx/2] are valid (numpy rfft2 layout), the pad
+ *    columns are never read as data and are left untouched;
+ *    "full" complex planes are (ny, nx) row-major (numpy fft2 layout);
+ *  - a plan is bound to the device current at creation, owns its twiddle tables
+ *    and scratch planes, and is not thread-safe (one plan per stream user).
+ */
+#ifndef ORPHICS_AMD_H
+#define ORPHICS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OA_F32 0
+#define OA_F64 1
+
+typedef struct oa_plan oa_plan;
+
+/* ---- library ----------------------------------------------------------- */
+const char* oa_last_error(void);
+int oa_version(void);
+/* number of HIP devices visible; <0 on error (no compute) */
+int oa_device_count(void);
+
+/* ---- plan --------------------------------------------------------------
+ * Replaces the per-geometry precomputation of FourierCalc.__init__
+ * (maps.py:1600-1607).  ny, nx: powers of two, >= 32.  */
+int oa_plan_create(int ny, int nx, int dtype, oa_plan** out);
+int oa_plan_destroy(oa_plan* p);
+long oa_plan_kpitch(const oa_plan* p);
+/* bytes of device scratch currently held by the plan */
+long oa_plan_scratch_bytes(const oa_plan* p);
+/* Upload the signed multipole axes ly[ny], lx[nx] (host float64; pixell
+ * enmap.laxes as used by maps.py:1607,1938).  Needed by the oa_qe_* calls. */
+int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx);
+
+/* ---- 2-D FFTs ------------------------------------------------------------
+ * oa_fft_r2c : real (ny,nx) -> hc, out = scale * sum x e^{-i l.x}
+ *              (enmap.fft(normalize=False), maps.py:1613,1636, restricted to
+ *              the non-redundant half plane of a real map)
+ * oa_fft_c2r : hc -> real, out = scale * sum_k X e^{+i l.x} (input preserved)
+ *              (pixell fft.ifft(...,normalize=True) + np.real, maps.py:1633,1923,
+ *              with scale = 1/(ny*nx))
+ * oa_fft_c2c : full -> full, forward (inverse=0) or inverse (inverse=1),
+ *              out != in (MapGen non-Hermitian draws maps.py:1578-1587, pol legs). */
+int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, void* stream);
+int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, void* stream);
+int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream);
+
+/* ---- layout helpers ------------------------------------------------------ */
+/* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of
+ * a real map holds, maps.py:1613) */
+int oa_hc_to_full(oa_plan* p, const void* hc_in, void* full_out, void* stream);
+/* full -> hc (drops the redundant half) */
+int oa_full_to_hc(oa_plan* p, const void* full_in, void* hc_out, void* stream);
+/* real-valued hc-layout plane (ny,kpitch) <-> full real (ny,nx), even symmetry */
+int oa_hcreal_to_full(oa_plan* p, const void* hcreal_in, void* fullreal_out, void* stream);
+int oa_fullreal_to_hc(oa_plan* p, const void* fullreal_in, void* hcreal_out, void* stream);
+
+/* ---- flat elementwise kernels (n = number of elements) --------------------
+ * oa_f2power    : out = Re(conj(k1)*k2)*norm        (FourierCalc.f2power, maps.py:1620-1624)
+ * oa_cmul_real  : out = k * f (complex * real)      (filter_map's `* kfilter`, maps.py:1923;
+ *                                                   MapGen covsqrt*rand scalar case, maps.py:1579)
+ * oa_mul_real   : out = a * b (real)                (QE real-space product)
+ * oa_axpby_real : out = alpha*a + beta*b (real)     (observed = beamed + noise, lensing.py:516) */
+int oa_f2power(int dtype, const void* k1, const void* k2, void* out_real, double norm, long n, void* stream);
+int oa_cmul_real(int dtype, const void* k_in, const void* filt_real, void* k_out, long n, void* stream);
+int oa_mul_real(int dtype, const void* a, const void* b, void* out, long n, void* stream);
+int oa_axpby_real(int dtype, const void* a, const void* b, void* out, double alpha, double beta, long n, void* stream);
+/* per-mode 2x2 rotation of two complex planes: [o1;o2] = [[c,-s],[s,c]] [i1;i2]
+ * with c,s real planes (QU<->EB, enmap.map_mul(self.rot, ...), maps.py:1614-1615) */
+int oa_rot2(int dtype, const void* c, const void* s, const void* i1, const void* i2, void* o1, void* o2, long n, void* stream);
+
+/* ---- quadratic-estimator legs (hc layout) ---------------------------------
+ * The reference class (lensing.Estimator/qest) is absent from the snapshot
+ * (SURVEY.md F2); the contract is qest.kappa_from_map (lensing.py:973-976).
+ * Real-space Hu-DeDeo-Vale form, spin = 0 (TT) or spin-2 phase variants:
+ *  oa_qe_legs : from kX (gradient leg) and kY: Gx = i lx FG kX P, Gy = i ly FG kX P,
+ *               H = FH kY Q, where FG, FH are real hc-layout filter planes and the
+ *               optional spin-2 phase factors P,Q = exp(+-2 i phi_l) are selected by
+ *               `phase_g`/`phase_h` (0: none, +1: e^{2i phi}, -1: e^{-2i phi}), and
+ *               `h_times_i` multiplies H by i (B-mode leg).
+ *  oa_qe_div  : out = Fnorm * (i lx Px + i ly Py)  (divergence * normalisation) */
+int oa_qe_legs(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH,
+               void* Gx, void* Gy, void* H, int phase_g, int phase_h, int h_times_i, void* stream);
+int oa_qe_div(oa_plan* p, const void* Px, const void* Py, const void* Fnorm, void* out, int accumulate, void* stream);
+
+/* ---- radial binning (stats.bin2D, stats.py:782-811) ------------------------
+ * oa_digitize : ids[i] = np.digitize(x[i], edges, right=True) (stats.py:786):
+ *               e[id-1] < x <= e[id]; 0 = underflow, nedges = overflow. x, edges
+ *               are float64 (bit-exact comparisons); ids are int32.
+ * oa_modl_digitize : same, with x = sqrt(ly[y]^2 + lx[x]^2) computed on device in
+ *               float64 with IEEE round-to-nearest mul/add/sqrt and no FMA
+ *               contraction (NumPy op order of enmap.modlmap).  `pitch`/`width`
+ *               select the plane layout: full plane pitch=width=nx; hc plane
+ *               pitch=kpitch,width=nx/2+1 (pad columns get id -1 = ignored).
+ * oa_bin      : sums[id] += v, counts[id] += m over all i with ids[i] >= 0 where
+ *                 v = data[i] (mode 0) | (data[i]-aux[id])^2 (mode 1), times
+ *                 weights[i] if weights != NULL, times the Hermitian multiplicity m,
+ *                 m = 1 (herm_nxh < 0) or {1 for col 0 and col nxh, 2 for 0<col<nxh}
+ *                 with col = i % herm_pitch;
+ *               counts[] are exact int64 (unweighted) ; wsums[] = sum of weights*m (f64).
+ *               skip_nan != 0 drops NaN data (mask_nan=True, stats.py:793).
+ *               Output arrays have nids = nedges+1 entries and are OVERWRITTEN.
+ *               Deterministic: per-workgroup partials reduced in fixed order.
+ *               `scratch` must hold oa_bin_scratch_bytes(nids) bytes. */
+int oa_digitize(const double* x, long n, const double* edges, int nedges, int32_t* ids, void* stream);
+int oa_modl_digitize(const double* ly, const double* lx, int ny, int nx, long pitch, int width,
+                     const double* edges, int nedges, int32_t* ids, double* modl_out, void* stream);
+long oa_bin_scratch_bytes(int nids);
+int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights, const double* aux, long n,
+           int nids, int mode, int skip_nan, long herm_pitch, int herm_nxh, double* sums, int64_t* counts,
+           double* wsums, void* scratch, void* stream);
+
+/* ---- Gaussian random fields (MapGen.get_map, maps.py:1576-1587) --------------
+ * Fills an hc plane with Hermitian-consistent complex white noise of unit
+ * variance per full-plane mode, scaled per mode by the real hc-layout plane
+ * `covsqrt` (may be NULL): the C2R of the result with the unitary scale
+ * 1/sqrt(ny*nx) is statistically identical to
+ * enmap.ifft(covsqrt*rand_gauss_harm).real.  Counter-based Philox4x32-10,
+ * key = (seed, stream_id), so realisations are independent of launch geometry. */
+int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream);
+/* real white noise N(0,1) plane of n elements (enmap.rand_gauss) */
+int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, void* stream);
+
+/* ---- one-pass moment accumulation (Statistics.add, stats.py:1068-1090) ---------
+ * n += 1 ; S += x ; C += x x^T  for a device vector x of length d (float64). */
+int oa_moments_add(const double* x, int d, int64_t* n, double* S, double* C, void* stream);
+/* stack accumulation (Statistics.add_stack, stats.py:1124-1150): acc(f64) += x (dtype) */
+int oa_stack_add(int dtype, const void* x, double* acc, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORPHICS_AMD_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of liborphics_amd.so (C-ABI declared in include/orphics_amd.h).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, every
+product entry point raises.  Build it with ``python -c "import __graft_entry__
+as g; g.build()"`` or ``make -C orphics_amd/csrc``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborphics_amd.so")
+
+OA_F32 = 0
+OA_F64 = 1
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_long = ctypes.c_long
+c_double = ctypes.c_double
+c_u64 = ctypes.c_uint64
+
+# name -> (restype, argtypes); mirrors include/orphics_amd.h one to one
+SIGNATURES = {
+    "oa_last_error": (ctypes.c_char_p, []),
+    "oa_version": (c_int, []),
+    "oa_device_count": (c_int, []),
+    "oa_plan_create": (c_int, [c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "oa_plan_destroy": (c_int, [c_void_p]),
+    "oa_plan_kpitch": (c_long, [c_void_p]),
+    "oa_plan_scratch_bytes": (c_long, [c_void_p]),
+    "oa_plan_set_laxes": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "oa_fft_r2c": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    "oa_fft_c2r": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    "oa_fft_c2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
+    "oa_hc_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_fullreal_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_f2power": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p]),
+    "oa_cmul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_mul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_axpby_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_double, c_long, c_void_p]),
+    "oa_rot2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_qe_legs": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
+    "oa_qe_div": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "oa_digitize": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p]),
+    "oa_modl_digitize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "oa_bin_scratch_bytes": (c_long, [c_int]),
+    "oa_bin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int,
+                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_grf_hc": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
+    "oa_randn": (c_int, [c_int, c_u64, c_u64, c_void_p, c_long, c_void_p]),
+    "oa_moments_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_stack_add": (c_int, [c_int, c_void_p, c_void_p, c_long, c_void_p]),
+}
+
+_lib = None
+
+
+class OrphicsAmdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it is absent -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OrphicsAmdError(
+            "orphics_amd: HIP extension %s not built; run __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().oa_last_error()
+        raise OrphicsAmdError(msg.decode() if msg else "orphics_amd: unknown error %d" % rc)
+
+
+def require_gpu():
+    lib = load()
+    n = lib.oa_device_count()
+    if n <= 0:
+        raise OrphicsAmdError("orphics_amd: no HIP device visible; the product path has no CPU fallback")
+    return n

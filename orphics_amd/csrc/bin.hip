@@ -1,0 +1,287 @@
+// K7: radial binning (stats.bin2D).  digitize = bit-exact float64 comparisons;
+// bin = streaming histogram: per-lane run merge -> wavefront match/shuffle
+// reduce -> wave-private LDS rows (no atomics) -> per-workgroup partials ->
+// fixed-order final reduce (deterministic float64 sums, exact int64 counts).
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace oa {
+
+constexpr int BIN_BLOCK = 256;
+constexpr int BIN_WAVES = BIN_BLOCK / 64;
+constexpr int BIN_GMAX = 1024;
+constexpr int BIN_MAX_IDS = 1024;
+constexpr int DIG_MAX_EDGES = 4096;
+
+// np.digitize(x, edges, right=True) for increasing edges: #edges strictly < x; NaN -> nedges
+OA_D int digitize_one(double x, const double* e, int ne) {
+    if (x != x) return ne;
+    int lo = 0, hi = ne;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (e[mid] < x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void digitize_kernel(const double* __restrict__ x, long n, const double* __restrict__ edges,
+                                                       int ne, int32_t* __restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    double* e = reinterpret_cast<double*>(sm_raw);
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) e[i] = edges[i];
+    __syncthreads();
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) ids[i] = digitize_one(x[i], e, ne);
+}
+
+__global__ __launch_bounds__(256) void modl_digitize_kernel(const double* __restrict__ ly, const double* __restrict__ lx,
+                                                            int ny, int nx, long pitch, int width,
+                                                            const double* __restrict__ edges, int ne,
+                                                            int32_t* __restrict__ ids, double* __restrict__ modl_out) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    double* e = reinterpret_cast<double*>(sm_raw);
+    for (int i = threadIdx.x; i < ne; i += blockDim.x) e[i] = edges[i];
+    __syncthreads();
+    const int y = blockIdx.y;
+    for (long x = (long)blockIdx.x * blockDim.x + threadIdx.x; x < pitch; x += (long)gridDim.x * blockDim.x) {
+        const long i = (long)y * pitch + x;
+        if (x >= width) {
+            ids[i] = -1;
+            if (modl_out) modl_out[i] = 0.0;
+            continue;
+        }
+        // NumPy order of enmap.modlmap: sqrt(ly**2 + lx**2), each op rounded to nearest
+        const double a = __dmul_rn(ly[y], ly[y]);
+        const double b = __dmul_rn(lx[x], lx[x]);
+        const double m = __dsqrt_rn(__dadd_rn(a, b));
+        ids[i] = digitize_one(m, e, ne);
+        if (modl_out) modl_out[i] = m;
+    }
+}
+
+OA_D double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// All lanes call; lanes with valid==false contribute nothing.
+template <bool WEIGHTED>
+OA_D void wave_accum(bool valid, int id, double v, double cw, int ci, double* row_sum, double* row_w,
+                     unsigned long long* row_cnt, int lane) {
+    unsigned long long act = __ballot(valid);
+    while (act) {
+        const int leader = __ffsll((long long)act) - 1;
+        const int lid = __shfl(id, leader, 64);
+        const bool mine = valid && (id == lid);
+        const unsigned long long mm = __ballot(mine);
+        const double sv = wave_sum(mine ? v : 0.0);
+        if (WEIGHTED) {
+            const double sw = wave_sum(mine ? cw : 0.0);
+            if (lane == leader) { row_sum[lid] += sv; row_w[lid] += sw; }
+        } else {
+            // counts are 1, 2 (merged runs: up to 8): reduce as integers, exactly
+            int c = mine ? ci : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            if (lane == leader) { row_sum[lid] += sv; row_cnt[lid] += (unsigned long long)c; }
+        }
+        act &= ~mm;
+    }
+}
+
+template <typename T, bool WEIGHTED>
+__global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ data, const int32_t* __restrict__ ids,
+                                                        const T* __restrict__ w, const double* __restrict__ aux, long n,
+                                                        int nids, int mode, int skip_nan, unsigned hp, int nxh,
+                                                        double* __restrict__ part_sum, double* __restrict__ part_w,
+                                                        unsigned long long* __restrict__ part_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    double* s_sum = reinterpret_cast<double*>(sm_raw);                        // [WAVES][nids]
+    double* s_w = s_sum + BIN_WAVES * nids;                                   // [WAVES][nids] (weighted)
+    unsigned long long* s_cnt = reinterpret_cast<unsigned long long*>(s_w);   // aliases s_w (unweighted)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 2 * BIN_WAVES * nids; i += BIN_BLOCK) s_sum[i] = 0.0;  // zero bits == 0ull
+    __syncthreads();
+    double* row_sum = s_sum + wv * nids;
+    double* row_w = s_w + wv * nids;
+    unsigned long long* row_cnt = s_cnt + wv * nids;
+
+    const long nchunks = (n + 3) / 4;
+    for (long base = (long)blockIdx.x * BIN_BLOCK; base < nchunks; base += (long)gridDim.x * BIN_BLOCK) {
+        const long c = base + tid;
+        const long i0 = c * 4;
+        int id[4];
+        double v[4], cw[4];
+        int ci[4];
+        bool ok[4];
+        if (c < nchunks && i0 + 3 < n) {
+            const Arr<int32_t, 4> I = reinterpret_cast<const Arr<int32_t, 4>*>(ids)[c];
+            const Arr<T, 4> D = reinterpret_cast<const Arr<T, 4>*>(data)[c];
+            Arr<T, 4> W;
+            if (WEIGHTED) W = reinterpret_cast<const Arr<T, 4>*>(w)[c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { id[j] = I.v[j]; v[j] = (double)D.v[j]; cw[j] = WEIGHTED ? (double)W.v[j] : 1.0; ok[j] = true; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ok[j] = (c < nchunks) && (i0 + j < n);
+                id[j] = ok[j] ? ids[i0 + j] : -1;
+                v[j] = ok[j] ? (double)data[i0 + j] : 0.0;
+                cw[j] = (WEIGHTED && ok[j]) ? (double)w[i0 + j] : 1.0;
+            }
+        }
+        unsigned col0 = 0;
+        if (nxh >= 0) col0 = (unsigned)((unsigned long long)i0 % hp);  // hp % 4 == 0: the chunk stays in one row
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = 1;
+            if (nxh >= 0) {
+                const int col = (int)col0 + j;
+                m = (col == 0 || col == nxh) ? 1 : (col < nxh ? 2 : 0);
+            }
+            ok[j] = ok[j] && id[j] >= 0 && id[j] < nids && m > 0;
+            if (skip_nan && v[j] != v[j]) ok[j] = false;
+            if (ok[j] && mode == 1) { const double d = v[j] - aux[id[j]]; v[j] = d * d; }
+            if (WEIGHTED) { v[j] = v[j] * cw[j] * (double)m; cw[j] = cw[j] * (double)m; }
+            else v[j] = v[j] * (double)m;
+            ci[j] = m;
+        }
+        // per-lane run merge, then wave-level flushes
+        bool cur_ok = ok[0];
+        int cur_id = id[0], cur_ci = ci[0];
+        double cur_v = v[0], cur_w = cw[0];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+            const bool same = cur_ok && ok[j] && id[j] == cur_id;
+            const bool flush = cur_ok && !same;
+            wave_accum<WEIGHTED>(flush, cur_id, cur_v, cur_w, cur_ci, row_sum, row_w, row_cnt, lane);
+            if (same) { cur_v += v[j]; cur_w += cw[j]; cur_ci += ci[j]; }
+            else { cur_ok = ok[j]; cur_id = id[j]; cur_v = v[j]; cur_w = cw[j]; cur_ci = ci[j]; }
+        }
+        wave_accum<WEIGHTED>(cur_ok, cur_id, cur_v, cur_w, cur_ci, row_sum, row_w, row_cnt, lane);
+    }
+    __syncthreads();
+    for (int i = tid; i < nids; i += BIN_BLOCK) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < BIN_WAVES; ++k) s += s_sum[k * nids + i];
+        part_sum[(long)blockIdx.x * nids + i] = s;
+        if (WEIGHTED) {
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < BIN_WAVES; ++k) q += s_w[k * nids + i];
+            part_w[(long)blockIdx.x * nids + i] = q;
+        } else {
+            unsigned long long q = 0;
+#pragma unroll
+            for (int k = 0; k < BIN_WAVES; ++k) q += s_cnt[k * nids + i];
+            part_cnt[(long)blockIdx.x * nids + i] = q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict__ part_sum, const double* __restrict__ part_w,
+                                                        const unsigned long long* __restrict__ part_cnt, int nblocks,
+                                                        int nids, int weighted, double* __restrict__ sums,
+                                                        int64_t* __restrict__ counts, double* __restrict__ wsums) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nids) return;
+    double s = 0.0, q = 0.0;
+    unsigned long long c = 0;
+    for (int b = 0; b < nblocks; ++b) {
+        s += part_sum[(long)b * nids + i];
+        if (weighted) q += part_w[(long)b * nids + i];
+        else c += part_cnt[(long)b * nids + i];
+    }
+    sums[i] = s;
+    if (weighted) { if (wsums) wsums[i] = q; }
+    else if (counts) counts[i] = (int64_t)c;
+}
+
+template <typename T>
+static int bin_impl(const void* data, const int32_t* ids, const void* weights, const double* aux, long n, int nids, int mode,
+                    int skip_nan, long hp, int nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
+                    hipStream_t st) {
+    const long nchunks = (n + 3) / 4;
+    int G = (int)((nchunks + BIN_BLOCK - 1) / BIN_BLOCK);
+    if (G < 1) G = 1;
+    if (G > BIN_GMAX) G = BIN_GMAX;
+    double* part_sum = reinterpret_cast<double*>(scratch);
+    double* part_w = part_sum + (long)BIN_GMAX * nids;
+    unsigned long long* part_cnt = reinterpret_cast<unsigned long long*>(part_w);
+    const size_t smem = (size_t)2 * BIN_WAVES * nids * sizeof(double);
+    const bool weighted = weights != nullptr;
+    if (weighted) {
+        auto k = bin_kernel<T, true>;
+        if (smem > 48 * 1024)
+            OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, ids, (const T*)weights, aux, n, nids, mode,
+                           skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, part_sum, part_w, part_cnt);
+    } else {
+        auto k = bin_kernel<T, false>;
+        if (smem > 48 * 1024)
+            OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, ids, (const T*)nullptr, aux, n, nids, mode,
+                           skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, part_sum, part_w, part_cnt);
+    }
+    OA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bin_final_kernel, dim3((nids + 255) / 256), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
+                       weighted ? 1 : 0, sums, counts, wsums);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace oa
+
+using namespace oa;
+
+extern "C" {
+
+int oa_digitize(const double* x, long n, const double* edges, int nedges, int32_t* ids, void* stream) {
+    OA_REQUIRE(x && edges && ids && n >= 0, "oa_digitize: bad argument");
+    OA_REQUIRE(nedges >= 1 && nedges <= DIG_MAX_EDGES, "oa_digitize: nedges must be in [1,4096]");
+    hipLaunchKernelGGL(digitize_kernel, dim3(flat_grid(n > 0 ? n : 1)), dim3(256), nedges * sizeof(double),
+                       (hipStream_t)stream, x, n, edges, nedges, ids);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_modl_digitize(const double* ly, const double* lx, int ny, int nx, long pitch, int width, const double* edges,
+                     int nedges, int32_t* ids, double* modl_out, void* stream) {
+    OA_REQUIRE(ly && lx && edges && ids, "oa_modl_digitize: NULL argument");
+    OA_REQUIRE(ny > 0 && nx > 0 && width > 0 && width <= nx && pitch >= width, "oa_modl_digitize: bad geometry");
+    OA_REQUIRE(nedges >= 1 && nedges <= DIG_MAX_EDGES, "oa_modl_digitize: nedges must be in [1,4096]");
+    int gx = (int)((pitch + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(modl_digitize_kernel, dim3(gx, ny), dim3(256), nedges * sizeof(double), (hipStream_t)stream, ly, lx,
+                       ny, nx, pitch, width, edges, nedges, ids, modl_out);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+long oa_bin_scratch_bytes(int nids) {
+    if (nids < 1) return -1;
+    return (long)2 * BIN_GMAX * nids * (long)sizeof(double);
+}
+
+int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights, const double* aux, long n, int nids,
+           int mode, int skip_nan, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums,
+           void* scratch, void* stream) {
+    OA_REQUIRE(data && ids && sums && scratch && n >= 0, "oa_bin: bad argument");
+    OA_REQUIRE(nids >= 1 && nids <= BIN_MAX_IDS, "oa_bin: nids (= nedges+1) must be in [1,1024]");
+    OA_REQUIRE(mode == 0 || (mode == 1 && aux != nullptr && weights == nullptr), "oa_bin: mode 1 needs aux and no weights");
+    OA_REQUIRE(weights ? (wsums != nullptr) : (counts != nullptr), "oa_bin: counts (unweighted) / wsums (weighted) required");
+    if (herm_nxh >= 0) OA_REQUIRE(herm_pitch > 0 && herm_pitch % 4 == 0, "oa_bin: herm_pitch must be a positive multiple of 4");
+    if (dtype == OA_F32)
+        return bin_impl<float>(data, ids, weights, aux, n, nids, mode, skip_nan, herm_pitch, herm_nxh, sums, counts, wsums,
+                               scratch, (hipStream_t)stream);
+    if (dtype == OA_F64)
+        return bin_impl<double>(data, ids, weights, aux, n, nids, mode, skip_nan, herm_pitch, herm_nxh, sums, counts, wsums,
+                                scratch, (hipStream_t)stream);
+    return fail("oa_bin: bad dtype");
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// Memory-bound per-mode kernels (K2 f2power, K3 filter multiply / QE legs,
+// K4 real-space product, K5 divergence, K6 QU<->EB rotation) + layout helpers.
+// All are streaming kernels: 16-byte vector accesses, grid-stride, no LDS.
+#include "common.hpp"
+
+namespace oa {
+
+constexpr int EW = 4;  // elements per thread per iteration
+
+// ---------------------------------------------------------------- flat kernels
+template <typename T>
+__global__ __launch_bounds__(256) void f2power_kernel(const cx<T>* __restrict__ k1, const cx<T>* __restrict__ k2,
+                                                      T* __restrict__ out, T norm, long n4, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const Arr<T, 8> a = reinterpret_cast<const Arr<T, 8>*>(k1)[i];
+        const Arr<T, 8> b = reinterpret_cast<const Arr<T, 8>*>(k2)[i];
+        Arr<T, 4> o;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) o.v[j] = (a.v[2 * j] * b.v[2 * j] + a.v[2 * j + 1] * b.v[2 * j + 1]) * norm;
+        reinterpret_cast<Arr<T, 4>*>(out)[i] = o;
+    }
+    // scalar tail
+    const long t0 = n4 * EW + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 < n) out[t0] = (k1[t0].x * k2[t0].x + k1[t0].y * k2[t0].y) * norm;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cmul_real_kernel(const cx<T>* __restrict__ k, const T* __restrict__ f,
+                                                        cx<T>* __restrict__ out, long n4, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const Arr<T, 8> a = reinterpret_cast<const Arr<T, 8>*>(k)[i];
+        const Arr<T, 4> w = reinterpret_cast<const Arr<T, 4>*>(f)[i];
+        Arr<T, 8> o;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) {
+            o.v[2 * j] = a.v[2 * j] * w.v[j];
+            o.v[2 * j + 1] = a.v[2 * j + 1] * w.v[j];
+        }
+        reinterpret_cast<Arr<T, 8>*>(out)[i] = o;
+    }
+    const long t0 = n4 * EW + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 < n) out[t0] = k[t0] * f[t0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                    T alpha, T beta, int mul, long n4, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const Arr<T, 4> x = reinterpret_cast<const Arr<T, 4>*>(a)[i];
+        const Arr<T, 4> y = reinterpret_cast<const Arr<T, 4>*>(b)[i];
+        Arr<T, 4> o;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) o.v[j] = mul ? x.v[j] * y.v[j] : alpha * x.v[j] + beta * y.v[j];
+        reinterpret_cast<Arr<T, 4>*>(out)[i] = o;
+    }
+    const long t0 = n4 * EW + (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 < n) out[t0] = mul ? a[t0] * b[t0] : alpha * a[t0] + beta * b[t0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rot2_kernel(const T* __restrict__ c, const T* __restrict__ s,
+                                                   const cx<T>* __restrict__ i1, const cx<T>* __restrict__ i2,
+                                                   cx<T>* __restrict__ o1, cx<T>* __restrict__ o2, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T cc = c[i], ss = s[i];
+        const cx<T> a = i1[i], b = i2[i];
+        o1[i] = a * cc - b * ss;
+        o2[i] = a * ss + b * cc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stack_add_kernel(const T* __restrict__ x, double* __restrict__ acc, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc[i] += (double)x[i];
+}
+
+// ---------------------------------------------------------------- layout helpers
+// hc -> full complex plane by X(-l) = conj X(l)
+template <typename T>
+__global__ __launch_bounds__(256) void hc_to_full_kernel(const cx<T>* __restrict__ hc, cx<T>* __restrict__ full, int ny,
+                                                         int nx, long kp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const int nxh = nx / 2;
+    cx<T> v;
+    if (x <= nxh) v = hc[(long)y * kp + x];
+    else {
+        const int ym = (ny - y) & (ny - 1);
+        v = conj(hc[(long)ym * kp + (nx - x)]);
+    }
+    full[(long)y * nx + x] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void full_to_hc_kernel(const cx<T>* __restrict__ full, cx<T>* __restrict__ hc, int ny,
+                                                         int nx, long kp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x > nx / 2) return;
+    hc[(long)y * kp + x] = full[(long)y * nx + x];
+}
+
+// real-valued planes on the hc grid <-> full grid (even symmetry f(-l) = f(l))
+template <typename T>
+__global__ __launch_bounds__(256) void hcreal_to_full_kernel(const T* __restrict__ hc, T* __restrict__ full, int ny, int nx,
+                                                             long kp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const int nxh = nx / 2;
+    T v;
+    if (x <= nxh) v = hc[(long)y * kp + x];
+    else v = hc[(long)((ny - y) & (ny - 1)) * kp + (nx - x)];
+    full[(long)y * nx + x] = v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fullreal_to_hc_kernel(const T* __restrict__ full, T* __restrict__ hc, int ny, int nx,
+                                                             long kp) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= kp) return;
+    hc[(long)y * kp + x] = (x <= nx / 2) ? full[(long)y * nx + x] : (T)0;
+}
+
+// ---------------------------------------------------------------- QE legs
+// spin-2 phase e^{i sgn 2 psi}, psi = atan2(-lx, ly) (pixell queb_rotmat angle)
+template <typename T>
+OA_D cx<T> phase2(T lx, T ly, int sgn) {
+    const T u = -lx, v = ly;
+    const T r2 = u * u + v * v;
+    if (r2 == (T)0) return mk<T>((T)1, (T)0);
+    const T inv = (T)1 / r2;
+    return mk<T>((v * v - u * u) * inv, (T)sgn * (T)2 * u * v * inv);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void qe_legs_kernel(const cx<T>* __restrict__ kX, const cx<T>* __restrict__ kY,
+                                                      const T* __restrict__ FG, const T* __restrict__ FH,
+                                                      cx<T>* __restrict__ Gx, cx<T>* __restrict__ Gy, cx<T>* __restrict__ H,
+                                                      const T* __restrict__ lxv, const T* __restrict__ lyv, int nxh, long kp,
+                                                      int phase_g, int phase_h, int h_times_i) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x > nxh) return;
+    const long i = (long)y * kp + x;
+    const T lx = lxv[x], ly = lyv[y];
+    cx<T> g = kX[i] * FG[i];
+    cx<T> h = kY[i] * FH[i];
+    if (phase_g) g = g * phase2<T>(lx, ly, phase_g);
+    if (phase_h) h = h * phase2<T>(lx, ly, phase_h);
+    if (h_times_i) h = mul_pi(h);
+    Gx[i] = mul_pi(g) * lx;
+    Gy[i] = mul_pi(g) * ly;
+    H[i] = h;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void qe_div_kernel(const cx<T>* __restrict__ Px, const cx<T>* __restrict__ Py,
+                                                     const T* __restrict__ Fn, cx<T>* __restrict__ out,
+                                                     const T* __restrict__ lxv, const T* __restrict__ lyv, int nxh, long kp,
+                                                     int accumulate) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x > nxh) return;
+    const long i = (long)y * kp + x;
+    const cx<T> d = mul_pi(Px[i] * lxv[x] + Py[i] * lyv[y]) * Fn[i];
+    out[i] = accumulate ? out[i] + d : d;
+}
+
+}  // namespace oa
+
+using namespace oa;
+
+#define DISPATCH(dtype, CALL_F, CALL_D) \
+    if ((dtype) == OA_F32) { CALL_F; } else if ((dtype) == OA_F64) { CALL_D; } else return fail("bad dtype")
+
+extern "C" {
+
+int oa_f2power(int dtype, const void* k1, const void* k2, void* out, double norm, long n, void* stream) {
+    OA_REQUIRE(k1 && k2 && out && n >= 0, "oa_f2power: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long n4 = n / EW;
+    const int g = flat_grid(n4 > 0 ? n4 : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(f2power_kernel<float>, dim3(g), dim3(256), 0, st, (const cx<float>*)k1, (const cx<float>*)k2,
+                                (float*)out, (float)norm, n4, n),
+             hipLaunchKernelGGL(f2power_kernel<double>, dim3(g), dim3(256), 0, st, (const cx<double>*)k1,
+                                (const cx<double>*)k2, (double*)out, norm, n4, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_cmul_real(int dtype, const void* k, const void* f, void* out, long n, void* stream) {
+    OA_REQUIRE(k && f && out && n >= 0, "oa_cmul_real: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long n4 = n / EW;
+    const int g = flat_grid(n4 > 0 ? n4 : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(cmul_real_kernel<float>, dim3(g), dim3(256), 0, st, (const cx<float>*)k, (const float*)f,
+                                (cx<float>*)out, n4, n),
+             hipLaunchKernelGGL(cmul_real_kernel<double>, dim3(g), dim3(256), 0, st, (const cx<double>*)k, (const double*)f,
+                                (cx<double>*)out, n4, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_mul_real(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
+    OA_REQUIRE(a && b && out && n >= 0, "oa_mul_real: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long n4 = n / EW;
+    const int g = flat_grid(n4 > 0 ? n4 : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(axpby_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out,
+                                0.f, 0.f, 1, n4, n),
+             hipLaunchKernelGGL(axpby_kernel<double>, dim3(g), dim3(256), 0, st, (const double*)a, (const double*)b,
+                                (double*)out, 0., 0., 1, n4, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_axpby_real(int dtype, const void* a, const void* b, void* out, double alpha, double beta, long n, void* stream) {
+    OA_REQUIRE(a && b && out && n >= 0, "oa_axpby_real: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const long n4 = n / EW;
+    const int g = flat_grid(n4 > 0 ? n4 : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(axpby_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out,
+                                (float)alpha, (float)beta, 0, n4, n),
+             hipLaunchKernelGGL(axpby_kernel<double>, dim3(g), dim3(256), 0, st, (const double*)a, (const double*)b,
+                                (double*)out, alpha, beta, 0, n4, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_rot2(int dtype, const void* c, const void* s, const void* i1, const void* i2, void* o1, void* o2, long n,
+            void* stream) {
+    OA_REQUIRE(c && s && i1 && i2 && o1 && o2 && n >= 0, "oa_rot2: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = flat_grid(n > 0 ? n : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(rot2_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)c, (const float*)s,
+                                (const cx<float>*)i1, (const cx<float>*)i2, (cx<float>*)o1, (cx<float>*)o2, n),
+             hipLaunchKernelGGL(rot2_kernel<double>, dim3(g), dim3(256), 0, st, (const double*)c, (const double*)s,
+                                (const cx<double>*)i1, (const cx<double>*)i2, (cx<double>*)o1, (cx<double>*)o2, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_stack_add(int dtype, const void* x, double* acc, long n, void* stream) {
+    OA_REQUIRE(x && acc && n >= 0, "oa_stack_add: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = flat_grid(n > 0 ? n : 1);
+    DISPATCH(dtype, hipLaunchKernelGGL(stack_add_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, acc, n),
+             hipLaunchKernelGGL(stack_add_kernel<double>, dim3(g), dim3(256), 0, st, (const double*)x, acc, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+#define PLANE_GRID(p, w) dim3(((w) + 255) / 256, (p)->ny)
+
+int oa_hc_to_full(oa_plan* p, const void* hc, void* full, void* stream) {
+    OA_REQUIRE(p && hc && full, "oa_hc_to_full: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(hc_to_full_kernel<float>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const cx<float>*)hc,
+                                (cx<float>*)full, p->ny, p->nx, p->kp),
+             hipLaunchKernelGGL(hc_to_full_kernel<double>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const cx<double>*)hc,
+                                (cx<double>*)full, p->ny, p->nx, p->kp));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_full_to_hc(oa_plan* p, const void* full, void* hc, void* stream) {
+    OA_REQUIRE(p && hc && full, "oa_full_to_hc: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(full_to_hc_kernel<float>, PLANE_GRID(p, p->nx / 2 + 1), dim3(256), 0, st,
+                                (const cx<float>*)full, (cx<float>*)hc, p->ny, p->nx, p->kp),
+             hipLaunchKernelGGL(full_to_hc_kernel<double>, PLANE_GRID(p, p->nx / 2 + 1), dim3(256), 0, st,
+                                (const cx<double>*)full, (cx<double>*)hc, p->ny, p->nx, p->kp));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_hcreal_to_full(oa_plan* p, const void* hc, void* full, void* stream) {
+    OA_REQUIRE(p && hc && full, "oa_hcreal_to_full: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(hcreal_to_full_kernel<float>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const float*)hc,
+                                (float*)full, p->ny, p->nx, p->kp),
+             hipLaunchKernelGGL(hcreal_to_full_kernel<double>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const double*)hc,
+                                (double*)full, p->ny, p->nx, p->kp));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_fullreal_to_hc(oa_plan* p, const void* full, void* hc, void* stream) {
+    OA_REQUIRE(p && hc && full, "oa_fullreal_to_hc: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(fullreal_to_hc_kernel<float>, PLANE_GRID(p, (int)p->kp), dim3(256), 0, st, (const float*)full,
+                                (float*)hc, p->ny, p->nx, p->kp),
+             hipLaunchKernelGGL(fullreal_to_hc_kernel<double>, PLANE_GRID(p, (int)p->kp), dim3(256), 0, st,
+                                (const double*)full, (double*)hc, p->ny, p->nx, p->kp));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_qe_legs(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* Gx, void* Gy, void* H,
+               int phase_g, int phase_h, int h_times_i, void* stream) {
+    OA_REQUIRE(p && kX && kY && FG && FH && Gx && Gy && H, "oa_qe_legs: NULL argument");
+    OA_REQUIRE(p->have_laxes, "oa_qe_legs: call oa_plan_set_laxes first");
+    hipStream_t st = (hipStream_t)stream;
+    const int nxh = p->nx / 2;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(qe_legs_kernel<float>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<float>*)kX,
+                                (const cx<float>*)kY, (const float*)FG, (const float*)FH, (cx<float>*)Gx, (cx<float>*)Gy,
+                                (cx<float>*)H, (const float*)p->lx, (const float*)p->ly, nxh, p->kp, phase_g, phase_h,
+                                h_times_i),
+             hipLaunchKernelGGL(qe_legs_kernel<double>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<double>*)kX,
+                                (const cx<double>*)kY, (const double*)FG, (const double*)FH, (cx<double>*)Gx,
+                                (cx<double>*)Gy, (cx<double>*)H, (const double*)p->lx, (const double*)p->ly, nxh, p->kp,
+                                phase_g, phase_h, h_times_i));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_qe_div(oa_plan* p, const void* Px, const void* Py, const void* Fnorm, void* out, int accumulate, void* stream) {
+    OA_REQUIRE(p && Px && Py && Fnorm && out, "oa_qe_div: NULL argument");
+    OA_REQUIRE(p->have_laxes, "oa_qe_div: call oa_plan_set_laxes first");
+    hipStream_t st = (hipStream_t)stream;
+    const int nxh = p->nx / 2;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(qe_div_kernel<float>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<float>*)Px,
+                                (const cx<float>*)Py, (const float*)Fnorm, (cx<float>*)out, (const float*)p->lx,
+                                (const float*)p->ly, nxh, p->kp, accumulate),
+             hipLaunchKernelGGL(qe_div_kernel<double>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<double>*)Px,
+                                (const cx<double>*)Py, (const double*)Fnorm, (cx<double>*)out, (const double*)p->lx,
+                                (const double*)p->ly, nxh, p->kp, accumulate));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

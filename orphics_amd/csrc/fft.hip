@@ -1,0 +1,124 @@
+// HIP launchers for the LDS-staged 2-D FFT passes (K1) + oa_fft_* entry points.
+#include "common.hpp"
+#include "fft_plan.hpp"
+
+namespace oa {
+
+struct GpuCtx {
+    char* sm;
+    OA_D int tid() const { return threadIdx.x; }
+    OA_D int bid_x() const { return blockIdx.x; }
+    OA_D int bid_y() const { return blockIdx.y; }
+    OA_D void sync() const { __syncthreads(); }
+    OA_D void* smem() const { return sm; }
+};
+
+extern __shared__ __attribute__((aligned(16))) char oa_dyn_smem[];
+
+template <typename T, int MAXNT>
+__global__ __launch_bounds__(MAXNT) void row_fft_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_fft_body<T>(c, a);
+}
+
+template <typename T, int MAXNT>
+__global__ __launch_bounds__(MAXNT) void col_fft_kernel(ColArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_fft_body<T>(c, a);
+}
+
+constexpr size_t LDS_MAX = 160 * 1024;
+
+struct HipLauncher {
+    hipStream_t st;
+    int rc = 0;
+
+    template <class K, class A>
+    void go(K kern, dim3 grid, int nt, size_t smem, const A& a) {
+        if (rc) return;
+        if (smem > LDS_MAX || nt > 1024 || nt < 1) {
+            rc = fail("fft: transform size exceeds the LDS / workgroup budget for this dtype");
+            return;
+        }
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
+        }
+        hipLaunchKernelGGL(kern, grid, dim3(nt), smem, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+    }
+
+    template <typename T>
+    void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (nt <= 256) go(row_fft_kernel<T, 256>, dim3(grid), nt, smem, a);
+        else if (nt <= 512) go(row_fft_kernel<T, 512>, dim3(grid), nt, smem, a);
+        else go(row_fft_kernel<T, 1024>, dim3(grid), nt, smem, a);
+    }
+    template <typename T>
+    void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
+        if (nt <= 256) go(col_fft_kernel<T, 256>, dim3(gx, gy), nt, smem, a);
+        else if (nt <= 512) go(col_fft_kernel<T, 512>, dim3(gx, gy), nt, smem, a);
+        else go(col_fft_kernel<T, 1024>, dim3(gx, gy), nt, smem, a);
+    }
+};
+
+template <typename T>
+static Fft2dPlan<T> view(const oa_plan* p) {
+    Fft2dPlan<T> f;
+    f.ny = p->ny; f.nx = p->nx; f.logNy = p->logNy; f.logNx = p->logNx; f.kp = p->kp;
+    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y;
+    return f;
+}
+
+template <typename T>
+static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, hipStream_t st) {
+    if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->kp * sizeof(cx<T>))) return rc;
+    HipLauncher q{st};
+    view<T>(p).r2c(q, (const T*)in, (cx<T>*)out, (cx<T>*)p->scratch, (T)scale);
+    return q.rc;
+}
+template <typename T>
+static int c2r_impl(oa_plan* p, const void* in, void* out, double scale, hipStream_t st) {
+    if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->kp * sizeof(cx<T>))) return rc;
+    HipLauncher q{st};
+    view<T>(p).c2r(q, (const cx<T>*)in, (T*)out, (cx<T>*)p->scratch, (T)scale);
+    return q.rc;
+}
+template <typename T>
+static int c2c_impl(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st) {
+    if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->nx * sizeof(cx<T>))) return rc;
+    HipLauncher q{st};
+    view<T>(p).c2c(q, (const cx<T>*)in, (cx<T>*)out, (cx<T>*)p->scratch, inverse != 0, (T)scale);
+    return q.rc;
+}
+
+}  // namespace oa
+
+using namespace oa;
+
+extern "C" {
+
+int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, void* stream) {
+    OA_REQUIRE(p && real_in && hc_out, "oa_fft_r2c: NULL argument");
+    OA_REQUIRE(real_in != hc_out, "oa_fft_r2c: in-place not supported");
+    return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, (hipStream_t)stream)
+                              : r2c_impl<double>(p, real_in, hc_out, scale, (hipStream_t)stream);
+}
+
+int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, void* stream) {
+    OA_REQUIRE(p && hc_in && real_out, "oa_fft_c2r: NULL argument");
+    OA_REQUIRE(hc_in != real_out, "oa_fft_c2r: in-place not supported");
+    return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, (hipStream_t)stream)
+                              : c2r_impl<double>(p, hc_in, real_out, scale, (hipStream_t)stream);
+}
+
+int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream) {
+    OA_REQUIRE(p && full_in && full_out, "oa_fft_c2c: NULL argument");
+    OA_REQUIRE(full_in != full_out, "oa_fft_c2c: in-place not supported");
+    return p->dtype == OA_F32 ? c2c_impl<float>(p, full_in, full_out, inverse, scale, (hipStream_t)stream)
+                              : c2c_impl<double>(p, full_in, full_out, inverse, scale, (hipStream_t)stream);
+}
+
+}  // extern "C"

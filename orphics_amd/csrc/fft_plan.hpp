@@ -1,0 +1,114 @@
+// Host-side decomposition of a 2-D power-of-two FFT into row / column passes.
+// Shared by the HIP launcher (fft.hip) and the CPU emulator (tests/emul).
+#pragma once
+#include <cmath>
+#include <vector>
+#include "fft_kernels.hpp"
+
+namespace oa {
+
+inline Stages make_stages(int logL) {
+    Stages s{};
+    int rem = logL;
+    while (rem >= 4) { s.radix[s.n++] = 16; rem -= 4; }
+    if (rem) s.radix[s.n++] = 1 << rem;
+    return s;
+}
+
+template <typename T>
+inline std::vector<cx<T>> make_twiddles(int M) {
+    std::vector<cx<T>> t((size_t)M);
+    const long double tau = 6.283185307179586476925286766559005768L;
+    for (int k = 0; k < M; ++k) {
+        long double a = tau * (long double)k / (long double)M;
+        t[(size_t)k].x = (T)cosl(a);
+        t[(size_t)k].y = (T)(-sinl(a));
+    }
+    return t;
+}
+
+inline long kpitch_for(int nx) { return nx / 2 + 16; }
+
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// Geometry + device tables of one (ny, nx) transform.
+template <typename T>
+struct Fft2dPlan {
+    int ny = 0, nx = 0, logNy = 0, logNx = 0;
+    long kp = 0;                 // half-complex pitch (complex elements)
+    const cx<T>* tw_x = nullptr; // W_nx^k, k < nx
+    const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
+    static constexpr int COLC = 5;  // log2 columns per column tile
+
+    // ---- row passes -------------------------------------------------------
+    template <class Launcher>
+    void rows(Launcher& q, int mode, const void* in, long in_pitch, void* out, long out_pitch, T scale) const {
+        RowArgs<T> a{};
+        const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R);
+        a.logL = real_mode ? logNx - 1 : logNx;
+        const int L = 1 << a.logL;
+        int C = 4096 / L;
+        if (C < 1) C = 1;
+        if (C > ny) C = ny;
+        a.logC = ilog2(C);
+        a.NT = (L * C) / EPT;
+        if (a.NT < 1) a.NT = 1;
+        a.rowStride = L + (L >> 4) + 2;
+        a.st = make_stages(a.logL);
+        a.tw = tw_x;
+        a.logTw = logNx;
+        a.scale = scale;
+        a.mode = mode;
+        a.in = in; a.out = out; a.in_pitch = in_pitch; a.out_pitch = out_pitch;
+        q.row(ny / C, a.NT, (size_t)C * a.rowStride * sizeof(cx<T>), a);
+    }
+
+    // ---- full column transform of `width` columns (two passes) -------------
+    // in -> out (out != in), result in natural order in `out`.
+    template <class Launcher>
+    void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
+              T scale) const {
+        const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
+        const long N1 = 1L << logN1, N2 = 1L << logN2;
+        const int C = 1 << COLC;
+        const int tiles = (width + C - 1) / C;
+        ColArgs<T> a{};
+        a.width = width; a.logC = COLC; a.tw = tw_y; a.logTw = logNy; a.inverse = inverse ? 1 : 0;
+        // pass 1: length N1 over y1 (stride N2), twiddle, write block-transposed
+        a.in = in; a.in_pitch = in_pitch; a.out = out; a.out_pitch = out_pitch;
+        a.logL = logN1; a.NT = (int)((N1 * C) / EPT); a.st = make_stages(logN1);
+        a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
+        a.twiddle = (logN2 > 0) ? 1 : 0;
+        a.scale = (logN2 > 0) ? (T)1 : scale;
+        q.col(tiles, (int)N2, a.NT, (size_t)N1 * C * sizeof(cx<T>), a);
+        if (logN2 == 0) return;
+        // pass 2: length N2 over y2 (stride N1), in place, natural order out
+        a.in = out; a.in_pitch = out_pitch;
+        a.logL = logN2; a.NT = (int)((N2 * C) / EPT); a.st = make_stages(logN2);
+        if (a.NT < 1) a.NT = 1;
+        a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;
+        a.twiddle = 0; a.scale = scale;
+        q.col(tiles, (int)N1, a.NT, (size_t)N2 * C * sizeof(cx<T>), a);
+    }
+
+    // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane
+    template <class Launcher>
+    void r2c(Launcher& q, const T* in, cx<T>* out, cx<T>* tmp, T scale) const {
+        rows(q, ROW_R2C, in, nx / 2, tmp, kp, (T)1);
+        cols(q, tmp, kp, out, kp, nx / 2 + 1, false, scale);
+    }
+    // half-complex -> real; input preserved; tmp: two hc planes (tmp, tmp2)
+    template <class Launcher>
+    void c2r(Launcher& q, const cx<T>* in, T* out, cx<T>* tmp, T scale) const {
+        cols(q, in, kp, tmp, kp, nx / 2 + 1, true, (T)1);
+        rows(q, ROW_C2R, tmp, kp, out, nx / 2, scale);
+    }
+    // full complex (ny,nx) contiguous; tmp: one full plane; out != in
+    template <class Launcher>
+    void c2c(Launcher& q, const cx<T>* in, cx<T>* out, cx<T>* tmp, bool inverse, T scale) const {
+        rows(q, inverse ? ROW_C2C_I : ROW_C2C_F, in, nx, tmp, nx, (T)1);
+        cols(q, tmp, nx, out, nx, nx, inverse, scale);
+    }
+};
+
+}  // namespace oa

@@ -1,0 +1,146 @@
+// K8: on-device Gaussian random fields (Philox4x32-10 counter RNG + Box-Muller)
+// K9: device-side moment accumulation for Monte-Carlo ensembles.
+#include "common.hpp"
+
+namespace oa {
+
+struct U4 { uint32_t x, y, z, w; };
+
+OA_D U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        U4 n;
+        n.x = hi1 ^ ctr.y ^ k0;
+        n.y = lo1;
+        n.z = hi0 ^ ctr.w ^ k1;
+        n.w = lo0;
+        ctr = n;
+        k0 += W0;
+        k1 += W1;
+    }
+    return ctr;
+}
+
+// two N(0,1) from two 32-bit words
+OA_D void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;  // (0,1]
+    const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincospif(2.0f * u2, &s, &c);
+    n0 = r * c;
+    n1 = r * s;
+}
+
+// 4 normals for counter index `idx` of stream (seed, sid)
+OA_D void normals4(uint64_t seed, uint64_t sid, uint64_t idx, float* n) {
+    U4 c;
+    c.x = (uint32_t)idx; c.y = (uint32_t)(idx >> 32); c.z = (uint32_t)sid; c.w = (uint32_t)(sid >> 32);
+    const U4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    box_muller(r.x, r.y, n[0], n[1]);
+    box_muller(r.z, r.w, n[2], n[3]);
+}
+
+// Hermitian-consistent unit white noise on the hc grid, times covsqrt.
+// One Philox call serves 2 modes: (row y', column pair p) -> columns 2p, 2p+1.
+template <typename T>
+__global__ __launch_bounds__(256) void grf_hc_kernel(uint64_t seed, uint64_t sid, const T* __restrict__ cs,
+                                                     cx<T>* __restrict__ out, int ny, int nx, long kp) {
+    const int nxh = nx / 2;
+    const int npair = nxh / 2 + 1;  // pairs cover columns 0..nxh(+1)
+    const int pr = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (pr >= npair) return;
+    const T rs2 = (T)0.70710678118654752440;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = 2 * pr + j;
+        if (x > nxh) break;
+        // self-conjugate columns: rows y and ny-y must be conjugates
+        const bool edgecol = (x == 0 || x == nxh);
+        int ys = y;
+        bool cj = false;
+        if (edgecol && y > ny / 2) { ys = ny - y; cj = true; }
+        float n[4];
+        normals4(seed, sid, (uint64_t)ys * (uint64_t)npair + (uint64_t)pr, n);
+        T re = (T)n[2 * j], im = (T)n[2 * j + 1];
+        if (edgecol && (ys == 0 || ys == ny / 2)) { im = (T)0; }  // real mode, variance 1
+        else { re *= rs2; im *= rs2; }
+        if (cj) im = -im;
+        const long i = (long)y * kp + x;
+        const T s = cs ? cs[i] : (T)1;
+        out[i] = mk<T>(re * s, im * s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void randn_kernel(uint64_t seed, uint64_t sid, T* __restrict__ out, long n) {
+    const long n4 = (n + 3) / 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float v[4];
+        normals4(seed, sid, (uint64_t)i, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * i + j < n) out[4 * i + j] = (T)v[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void moments_add_kernel(const double* __restrict__ x, int d, int64_t* __restrict__ n,
+                                                          double* __restrict__ S, double* __restrict__ C) {
+    const long tot = (long)d * d;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long i = gid; i < tot; i += stride) {
+        const int a = (int)(i / d), b = (int)(i % d);
+        C[i] += x[a] * x[b];
+    }
+    for (long i = gid; i < d; i += stride) S[i] += x[i];
+    if (gid == 0) n[0] += 1;
+}
+
+}  // namespace oa
+
+using namespace oa;
+
+extern "C" {
+
+int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream) {
+    OA_REQUIRE(p && hc_out, "oa_grf_hc: NULL argument");
+    const int npair = p->nx / 4 + 1;
+    dim3 grid((npair + 255) / 256, p->ny);
+    if (p->dtype == OA_F32)
+        hipLaunchKernelGGL(grf_hc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, seed, stream_id,
+                           (const float*)covsqrt_hc, (cx<float>*)hc_out, p->ny, p->nx, p->kp);
+    else
+        hipLaunchKernelGGL(grf_hc_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, seed, stream_id,
+                           (const double*)covsqrt_hc, (cx<double>*)hc_out, p->ny, p->nx, p->kp);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, void* stream) {
+    OA_REQUIRE(out && n >= 0, "oa_randn: bad argument");
+    const int g = flat_grid((n + 3) / 4 > 0 ? (n + 3) / 4 : 1);
+    if (dtype == OA_F32)
+        hipLaunchKernelGGL(randn_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, seed, stream_id, (float*)out, n);
+    else if (dtype == OA_F64)
+        hipLaunchKernelGGL(randn_kernel<double>, dim3(g), dim3(256), 0, (hipStream_t)stream, seed, stream_id, (double*)out, n);
+    else
+        return fail("oa_randn: bad dtype");
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_moments_add(const double* x, int d, int64_t* n, double* S, double* C, void* stream) {
+    OA_REQUIRE(x && n && S && C && d >= 1, "oa_moments_add: bad argument");
+    const int g = flat_grid((long)d * d, 256, 64);
+    hipLaunchKernelGGL(moments_add_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, d, n, S, C);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

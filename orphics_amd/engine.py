@@ -1,0 +1,282 @@
+"""Thin device layer: one :class:`Engine` = one C-ABI plan (geometry, dtype,
+GPU) + typed wrappers that validate tensor shapes on the host before any kernel
+is launched.  torch is used only for device memory and streams."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import OA_F32, OA_F64, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_RDT = {"f32": torch.float32, "f64": torch.float64}
+_CDT = {"f32": torch.complex64, "f64": torch.complex128}
+_CODE = {"f32": OA_F32, "f64": OA_F64}
+
+
+def precision_of(x, default="f64"):
+    """dtype follows the data: float32/complex64 -> 'f32', float64/complex128 -> 'f64'."""
+    dt = getattr(x, "dtype", None)
+    if dt in (np.float32, np.complex64, torch.float32, torch.complex64):
+        return "f32"
+    if dt in (np.float64, np.complex128, torch.float64, torch.complex128):
+        return "f64"
+    return default
+
+
+class Engine(object):
+    _cache = {}
+
+    @classmethod
+    def get(cls, ny, nx, prec):
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+        key = (int(ny), int(nx), prec, dev)
+        e = cls._cache.get(key)
+        if e is None:
+            e = cls(ny, nx, prec)
+            cls._cache[key] = e
+        return e
+
+    def __init__(self, ny, nx, prec="f32"):
+        self.lib = _lib.load()
+        _lib.require_gpu()
+        if not torch.cuda.is_available():
+            raise _lib.OrphicsAmdError("orphics_amd: torch sees no GPU; device memory cannot be allocated")
+        self.ny, self.nx, self.prec = int(ny), int(nx), prec
+        self.code = _CODE[prec]
+        self.rdt, self.cdt = _RDT[prec], _CDT[prec]
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        h = ctypes.c_void_p()
+        check(self.lib.oa_plan_create(self.ny, self.nx, self.code, ctypes.byref(h)))
+        self.plan = h
+        self.kp = int(self.lib.oa_plan_kpitch(h))
+        self.nxh = self.nx // 2
+        self.npix = self.ny * self.nx
+        self._laxes = None
+        self._bin_scratch = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.oa_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ---- allocation -------------------------------------------------------
+    def real(self, *lead):
+        return torch.empty(tuple(lead) + (self.ny, self.nx), dtype=self.rdt, device=self.device)
+
+    def hc(self, *lead):
+        return torch.zeros(tuple(lead) + (self.ny, self.kp), dtype=self.cdt, device=self.device)
+
+    def hcreal(self, *lead):
+        return torch.zeros(tuple(lead) + (self.ny, self.kp), dtype=self.rdt, device=self.device)
+
+    def full(self, *lead):
+        return torch.empty(tuple(lead) + (self.ny, self.nx), dtype=self.cdt, device=self.device)
+
+    def to_real(self, a):
+        t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+        return t.to(device=self.device, dtype=self.rdt).contiguous()
+
+    def to_complex(self, a):
+        t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+        return t.to(device=self.device, dtype=self.cdt).contiguous()
+
+    # ---- validation ---------------------------------------------------------
+    def _chk(self, t, kind):
+        shp = {"real": (self.ny, self.nx), "hc": (self.ny, self.kp), "hcreal": (self.ny, self.kp),
+               "full": (self.ny, self.nx)}[kind]
+        dt = self.rdt if kind in ("real", "hcreal") else self.cdt
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise TypeError("expected a CUDA tensor for %s plane" % kind)
+        if tuple(t.shape) != shp or t.dtype != dt or not t.is_contiguous():
+            raise ValueError("%s plane must be contiguous %s of shape %s, got %s %s" % (kind, dt, shp, t.dtype, tuple(t.shape)))
+        return t
+
+    # ---- FFTs ------------------------------------------------------------------
+    def rfft(self, x, scale=1.0, out=None):
+        """real (ny,nx) -> hc; unnormalised forward (maps.py:1636)."""
+        self._chk(x, "real")
+        out = self.hc() if out is None else self._chk(out, "hc")
+        check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), _stream()))
+        return out
+
+    def irfft(self, k, scale=None, out=None):
+        """hc -> real; default scale 1/Npix (pixell fft.ifft normalize=True, maps.py:1633)."""
+        self._chk(k, "hc")
+        out = self.real() if out is None else self._chk(out, "real")
+        if scale is None:
+            scale = 1.0 / self.npix
+        check(self.lib.oa_fft_c2r(self.plan, _ptr(k), _ptr(out), float(scale), _stream()))
+        return out
+
+    def cfft(self, z, inverse=False, scale=1.0, out=None):
+        self._chk(z, "full")
+        out = self.full() if out is None else self._chk(out, "full")
+        check(self.lib.oa_fft_c2c(self.plan, _ptr(z), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
+        return out
+
+    # ---- layouts ----------------------------------------------------------------
+    def hc_to_full(self, k):
+        self._chk(k, "hc")
+        out = self.full()
+        check(self.lib.oa_hc_to_full(self.plan, _ptr(k), _ptr(out), _stream()))
+        return out
+
+    def full_to_hc(self, z):
+        self._chk(z, "full")
+        out = self.hc()
+        check(self.lib.oa_full_to_hc(self.plan, _ptr(z), _ptr(out), _stream()))
+        return out
+
+    def hcreal_to_full(self, f):
+        self._chk(f, "hcreal")
+        out = self.real()
+        check(self.lib.oa_hcreal_to_full(self.plan, _ptr(f), _ptr(out), _stream()))
+        return out
+
+    def fullreal_to_hc(self, f):
+        self._chk(f, "real")
+        out = self.hcreal()
+        check(self.lib.oa_fullreal_to_hc(self.plan, _ptr(f), _ptr(out), _stream()))
+        return out
+
+    # ---- flat elementwise ---------------------------------------------------------
+    def _same(self, *ts):
+        n = ts[0].numel()
+        for t in ts:
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous() and t.numel() == n):
+                raise ValueError("elementwise operands must be contiguous CUDA tensors of equal size")
+        return n
+
+    def f2power(self, k1, k2, norm, out=None):
+        n = self._same(k1, k2)
+        if k1.dtype != self.cdt or k2.dtype != self.cdt:
+            raise ValueError("f2power: complex dtype mismatch")
+        out = torch.empty(k1.shape, dtype=self.rdt, device=self.device) if out is None else out
+        check(self.lib.oa_f2power(self.code, _ptr(k1), _ptr(k2), _ptr(out), float(norm), n, _stream()))
+        return out
+
+    def cmul_real(self, k, f, out=None):
+        n = self._same(k, f)
+        if k.dtype != self.cdt or f.dtype != self.rdt:
+            raise ValueError("cmul_real: dtype mismatch")
+        out = torch.empty_like(k) if out is None else out
+        check(self.lib.oa_cmul_real(self.code, _ptr(k), _ptr(f), _ptr(out), n, _stream()))
+        return out
+
+    def mul_real(self, a, b, out=None):
+        n = self._same(a, b)
+        if a.dtype != self.rdt or b.dtype != self.rdt:
+            raise ValueError("mul_real: dtype mismatch")
+        out = torch.empty_like(a) if out is None else out
+        check(self.lib.oa_mul_real(self.code, _ptr(a), _ptr(b), _ptr(out), n, _stream()))
+        return out
+
+    def axpby(self, a, b, alpha, beta, out=None):
+        n = self._same(a, b)
+        if a.dtype != self.rdt or b.dtype != self.rdt:
+            raise ValueError("axpby: dtype mismatch")
+        out = torch.empty_like(a) if out is None else out
+        check(self.lib.oa_axpby_real(self.code, _ptr(a), _ptr(b), _ptr(out), float(alpha), float(beta), n, _stream()))
+        return out
+
+    def rot2(self, c, s, i1, i2):
+        n = self._same(c, s, i1, i2)
+        if c.dtype != self.rdt or i1.dtype != self.cdt or i2.dtype != self.cdt or s.dtype != self.rdt:
+            raise ValueError("rot2: dtype mismatch")
+        o1, o2 = torch.empty_like(i1), torch.empty_like(i2)
+        check(self.lib.oa_rot2(self.code, _ptr(c), _ptr(s), _ptr(i1), _ptr(i2), _ptr(o1), _ptr(o2), n, _stream()))
+        return o1, o2
+
+    # ---- QE legs --------------------------------------------------------------------
+    def set_laxes(self, ly, lx):
+        ly = np.ascontiguousarray(ly, dtype=np.float64)
+        lx = np.ascontiguousarray(lx, dtype=np.float64)
+        if ly.shape != (self.ny,) or lx.shape != (self.nx,):
+            raise ValueError("laxes must have shapes (ny,), (nx,)")
+        check(self.lib.oa_plan_set_laxes(self.plan, ly.ctypes.data_as(ctypes.c_void_p), lx.ctypes.data_as(ctypes.c_void_p)))
+        self._laxes = (ly, lx)
+
+    def qe_legs(self, kX, kY, FG, FH, phase_g=0, phase_h=0, h_times_i=False, out=None):
+        self._chk(kX, "hc"); self._chk(kY, "hc"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
+        if out is None:
+            out = (self.hc(), self.hc(), self.hc())
+        Gx, Gy, H = out
+        check(self.lib.oa_qe_legs(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(Gx), _ptr(Gy), _ptr(H),
+                                  int(phase_g), int(phase_h), 1 if h_times_i else 0, _stream()))
+        return Gx, Gy, H
+
+    def qe_div(self, Px, Py, Fnorm, out=None, accumulate=False):
+        self._chk(Px, "hc"); self._chk(Py, "hc"); self._chk(Fnorm, "hcreal")
+        out = self.hc() if out is None else self._chk(out, "hc")
+        check(self.lib.oa_qe_div(self.plan, _ptr(Px), _ptr(Py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, _stream()))
+        return out
+
+    # ---- binning -----------------------------------------------------------------------
+    def digitize(self, x64, edges64):
+        if x64.dtype != torch.float64 or edges64.dtype != torch.float64:
+            raise ValueError("digitize operates on float64")
+        x64 = x64.contiguous()
+        ids = torch.empty(x64.shape, dtype=torch.int32, device=self.device)
+        check(self.lib.oa_digitize(_ptr(x64), x64.numel(), _ptr(edges64), edges64.numel(), _ptr(ids), _stream()))
+        return ids
+
+    def modl_digitize(self, edges64, half=False, want_modl=False):
+        if self._laxes is None:
+            raise RuntimeError("set_laxes first")
+        ly = torch.as_tensor(self._laxes[0], device=self.device)
+        lx = torch.as_tensor(self._laxes[1], device=self.device)
+        pitch, width = (self.kp, self.nxh + 1) if half else (self.nx, self.nx)
+        ids = torch.empty((self.ny, pitch), dtype=torch.int32, device=self.device)
+        modl = torch.empty((self.ny, pitch), dtype=torch.float64, device=self.device) if want_modl else None
+        check(self.lib.oa_modl_digitize(_ptr(ly), _ptr(lx), self.ny, self.nx, pitch, width, _ptr(edges64),
+                                        edges64.numel(), _ptr(ids), _ptr(modl), _stream()))
+        return (ids, modl) if want_modl else ids
+
+    def bin(self, data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, herm=False):
+        """Returns (sums f64[nids], counts int64[nids] | wsums f64[nids])."""
+        n = data.numel()
+        if ids.numel() != n or ids.dtype != torch.int32 or not ids.is_contiguous() or not data.is_contiguous():
+            raise ValueError("bin: ids must be contiguous int32 with one entry per data element")
+        prec = precision_of(data)
+        if weights is not None and (weights.dtype != data.dtype or weights.numel() != n or not weights.is_contiguous()):
+            raise ValueError("bin: weights must match data")
+        if aux is not None and (aux.dtype != torch.float64 or aux.numel() != nids):
+            raise ValueError("bin: aux must be float64[nids]")
+        need = int(self.lib.oa_bin_scratch_bytes(nids))
+        if need < 0:
+            raise ValueError("bin: bad nids")
+        if self._bin_scratch is None or self._bin_scratch.numel() < need:
+            self._bin_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        sums = torch.empty(nids, dtype=torch.float64, device=self.device)
+        counts = torch.empty(nids, dtype=torch.int64, device=self.device) if weights is None else None
+        wsums = torch.empty(nids, dtype=torch.float64, device=self.device) if weights is not None else None
+        check(self.lib.oa_bin(_CODE[prec], _ptr(data), _ptr(ids), _ptr(weights), _ptr(aux), n, int(nids), int(mode),
+                              1 if skip_nan else 0, self.kp if herm else 0, self.nxh if herm else -1, _ptr(sums),
+                              _ptr(counts), _ptr(wsums), _ptr(self._bin_scratch), _stream()))
+        return sums, (counts if weights is None else wsums)
+
+    # ---- random fields / accumulators ---------------------------------------------------
+    def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):
+        if covsqrt_hc is not None:
+            self._chk(covsqrt_hc, "hcreal")
+        out = self.hc() if out is None else self._chk(out, "hc")
+        check(self.lib.oa_grf_hc(self.plan, int(seed), int(stream_id), _ptr(covsqrt_hc), _ptr(out), _stream()))
+        return out
+
+    def randn(self, seed, stream_id, shape=None):
+        out = torch.empty(shape if shape is not None else (self.ny, self.nx), dtype=self.rdt, device=self.device)
+        check(self.lib.oa_randn(self.code, int(seed), int(stream_id), _ptr(out), out.numel(), _stream()))
+        return out

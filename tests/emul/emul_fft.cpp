@@ -1,0 +1,95 @@
+// CPU thread emulator for the FFT pass kernels (TEST INFRASTRUCTURE).
+// Runs the exact kernel bodies of orphics_amd/csrc/fft_kernels.hpp with one
+// std::thread per GPU thread and std::barrier for __syncthreads(), so the
+// index math / pass decomposition is validated in the GPU-less container.
+#include <barrier>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+#include "../../orphics_amd/csrc/fft_plan.hpp"
+
+using namespace oa;
+
+struct EmuCtx {
+    int tid_, bx_, by_;
+    std::barrier<>* bar;
+    char* sm;
+    int tid() const { return tid_; }
+    int bid_x() const { return bx_; }
+    int bid_y() const { return by_; }
+    void sync() const { bar->arrive_and_wait(); }
+    void* smem() const { return sm; }
+};
+
+struct EmuLauncher {
+    template <class F>
+    void run(int gx, int gy, int nt, size_t smem, F body) {
+        std::vector<char> sm(smem + 64);
+        std::barrier<> bar(nt);
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t]() {
+                for (int by = 0; by < gy; ++by)
+                    for (int bx = 0; bx < gx; ++bx) {
+                        EmuCtx c{t, bx, by, &bar, sm.data()};
+                        body(c);
+                        bar.arrive_and_wait();
+                    }
+            });
+        for (auto& x : th) x.join();
+    }
+    template <typename T> void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T>(c, a); });
+    }
+    template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
+        run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fft_body<T>(c, a); });
+    }
+};
+
+template <typename T>
+struct Holder {
+    std::vector<cx<T>> twx, twy;
+    Fft2dPlan<T> p;
+    Holder(int ny, int nx) {
+        twx = make_twiddles<T>(nx);
+        twy = make_twiddles<T>(ny);
+        p.ny = ny; p.nx = nx; p.logNy = ilog2(ny); p.logNx = ilog2(nx);
+        p.kp = kpitch_for(nx); p.tw_x = twx.data(); p.tw_y = twy.data();
+    }
+};
+
+template <typename T>
+static int do_r2c(int ny, int nx, const T* in, cx<T>* out, double scale) {
+    Holder<T> h(ny, nx);
+    std::vector<cx<T>> tmp((size_t)ny * h.p.kp);
+    EmuLauncher q;
+    h.p.r2c(q, in, out, tmp.data(), (T)scale);
+    return 0;
+}
+template <typename T>
+static int do_c2r(int ny, int nx, const cx<T>* in, T* out, double scale) {
+    Holder<T> h(ny, nx);
+    std::vector<cx<T>> tmp((size_t)ny * h.p.kp);
+    EmuLauncher q;
+    h.p.c2r(q, in, out, tmp.data(), (T)scale);
+    return 0;
+}
+template <typename T>
+static int do_c2c(int ny, int nx, const cx<T>* in, cx<T>* out, int inverse, double scale) {
+    Holder<T> h(ny, nx);
+    std::vector<cx<T>> tmp((size_t)ny * nx);
+    EmuLauncher q;
+    h.p.c2c(q, in, out, tmp.data(), inverse != 0, (T)scale);
+    return 0;
+}
+
+extern "C" {
+long emu_kpitch(int nx) { return kpitch_for(nx); }
+int emu_r2c_f32(int ny, int nx, const float* in, void* out, double s) { return do_r2c<float>(ny, nx, in, (cx<float>*)out, s); }
+int emu_r2c_f64(int ny, int nx, const double* in, void* out, double s) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s); }
+int emu_c2r_f32(int ny, int nx, const void* in, float* out, double s) { return do_c2r<float>(ny, nx, (const cx<float>*)in, out, s); }
+int emu_c2r_f64(int ny, int nx, const void* in, double* out, double s) { return do_c2r<double>(ny, nx, (const cx<double>*)in, out, s); }
+int emu_c2c_f32(int ny, int nx, const void* in, void* out, int inv, double s) { return do_c2c<float>(ny, nx, (const cx<float>*)in, (cx<float>*)out, inv, s); }
+int emu_c2c_f64(int ny, int nx, const void* in, void* out, int inv, double s) { return do_c2c<double>(ny, nx, (const cx<double>*)in, (cx<double>*)out, inv, s); }
+}
