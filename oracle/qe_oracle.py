@@ -50,6 +50,14 @@ class QEOracleTT(object):
         self.LY = self.ly[:, None] * np.ones((1, Nx))
         self.LX = np.ones((Ny, 1)) * self.lx[None, :]
         self.modl = np.sqrt(self.LY ** 2 + self.LX ** 2)
+        # derivative axes: the self-conjugate Nyquist frequency of a real field has no odd
+        # (i*l) component -- exactly what np.real(ifft2(1j*l*F)) discards -- so spectral
+        # derivatives use l = 0 there (keeps every returned FT Hermitian).
+        lyd, lxd = self.ly.copy(), self.lx.copy()
+        lyd[Ny // 2] = 0.0
+        lxd[Nx // 2] = 0.0
+        self.LYd = lyd[:, None] * np.ones((1, Nx))
+        self.LXd = np.ones((Ny, 1)) * lxd[None, :]
         kmask = np.asarray(kmask, dtype=np.float64)
         gmask = kmask.copy()
         if grad_cut is not None:
@@ -71,7 +79,7 @@ class QEOracleTT(object):
 
     def _response(self, wg, wh, cr):
         """R(L) = (1/a) sum_jk L_j L_k DFT[ alpha_jk beta + gamma_j delta_k ](L)."""
-        l = (self.LX, self.LY)
+        l = (self.LXd, self.LYd)
         beta = _ifftn(wh)
         R = np.zeros(self.shape)
         for j in range(2):
@@ -84,10 +92,10 @@ class QEOracleTT(object):
 
     def unnormalized_ft(self, kX, kY):
         """i (lx DFT[gx h] + ly DFT[gy h]) on full-plane DFTs kX (gradient leg), kY."""
-        gx = _ifftn(1j * self.LX * self.Wg * kX).real
-        gy = _ifftn(1j * self.LY * self.Wg * kX).real
+        gx = _ifftn(1j * self.LXd * self.Wg * kX).real
+        gy = _ifftn(1j * self.LYd * self.Wg * kX).real
         h = _ifftn(self.Wh * kY).real
-        return 1j * (self.LX * _fft(gx * h) + self.LY * _fft(gy * h))
+        return 1j * (self.LXd * _fft(gx * h) + self.LYd * _fft(gy * h))
 
     def kappa_ft(self, kX, kY=None):
         """DFT of the reconstructed kappa map (same convention as fc.fft(kappa))."""

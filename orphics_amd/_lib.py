@@ -70,6 +70,9 @@ def load():
         raise OrphicsAmdError(
             "orphics_amd: HIP extension %s not built; run __graft_entry__.build() "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own libamdhip64.so.7; import it FIRST so this library binds to the same HIP
+    # runtime instance (device pointers and streams are shared with torch).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -54,6 +54,8 @@ struct oa_plan {
     size_t scratch_bytes;
     void* ly;        // T[ny]
     void* lx;        // T[nx]
+    void* lyd;       // T[ny]  derivative axis: Nyquist entry zeroed
+    void* lxd;       // T[nx]
     double* ly64;    // double[ny]
     double* lx64;    // double[nx]
     bool have_laxes;

@@ -144,7 +144,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void qe_legs_kernel(const cx<T>* __restrict__ kX, const cx<T>* __restrict__ kY,
                                                       const T* __restrict__ FG, const T* __restrict__ FH,
                                                       cx<T>* __restrict__ Gx, cx<T>* __restrict__ Gy, cx<T>* __restrict__ H,
-                                                      const T* __restrict__ lxv, const T* __restrict__ lyv, int nxh, long kp,
+                                                      const T* __restrict__ lxv, const T* __restrict__ lyv,
+                                                      const T* __restrict__ lxd, const T* __restrict__ lyd, int nxh, long kp,
                                                       int phase_g, int phase_h, int h_times_i) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void qe_legs_kernel(const cx<T>* __restrict__ 
     if (phase_g) g = g * phase2<T>(lx, ly, phase_g);
     if (phase_h) h = h * phase2<T>(lx, ly, phase_h);
     if (h_times_i) h = mul_pi(h);
-    Gx[i] = mul_pi(g) * lx;
-    Gy[i] = mul_pi(g) * ly;
+    Gx[i] = mul_pi(g) * lxd[x];
+    Gy[i] = mul_pi(g) * lyd[y];
     H[i] = h;
 }
 
@@ -322,11 +323,13 @@ int oa_qe_legs(oa_plan* p, const void* kX, const void* kY, const void* FG, const
     DISPATCH(p->dtype,
              hipLaunchKernelGGL(qe_legs_kernel<float>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<float>*)kX,
                                 (const cx<float>*)kY, (const float*)FG, (const float*)FH, (cx<float>*)Gx, (cx<float>*)Gy,
-                                (cx<float>*)H, (const float*)p->lx, (const float*)p->ly, nxh, p->kp, phase_g, phase_h,
+                                (cx<float>*)H, (const float*)p->lx, (const float*)p->ly, (const float*)p->lxd,
+                                (const float*)p->lyd, nxh, p->kp, phase_g, phase_h,
                                 h_times_i),
              hipLaunchKernelGGL(qe_legs_kernel<double>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<double>*)kX,
                                 (const cx<double>*)kY, (const double*)FG, (const double*)FH, (cx<double>*)Gx,
-                                (cx<double>*)Gy, (cx<double>*)H, (const double*)p->lx, (const double*)p->ly, nxh, p->kp,
+                                (cx<double>*)Gy, (cx<double>*)H, (const double*)p->lx, (const double*)p->ly,
+                                (const double*)p->lxd, (const double*)p->lyd, nxh, p->kp,
                                 phase_g, phase_h, h_times_i));
     OA_LAUNCH_CHECK();
     return 0;
@@ -339,11 +342,11 @@ int oa_qe_div(oa_plan* p, const void* Px, const void* Py, const void* Fnorm, voi
     const int nxh = p->nx / 2;
     DISPATCH(p->dtype,
              hipLaunchKernelGGL(qe_div_kernel<float>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<float>*)Px,
-                                (const cx<float>*)Py, (const float*)Fnorm, (cx<float>*)out, (const float*)p->lx,
-                                (const float*)p->ly, nxh, p->kp, accumulate),
+                                (const cx<float>*)Py, (const float*)Fnorm, (cx<float>*)out, (const float*)p->lxd,
+                                (const float*)p->lyd, nxh, p->kp, accumulate),
              hipLaunchKernelGGL(qe_div_kernel<double>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<double>*)Px,
-                                (const cx<double>*)Py, (const double*)Fnorm, (cx<double>*)out, (const double*)p->lx,
-                                (const double*)p->ly, nxh, p->kp, accumulate));
+                                (const cx<double>*)Py, (const double*)Fnorm, (cx<double>*)out, (const double*)p->lxd,
+                                (const double*)p->lyd, nxh, p->kp, accumulate));
     OA_LAUNCH_CHECK();
     return 0;
 }

@@ -78,6 +78,8 @@ int oa_plan_destroy(oa_plan* p) {
     if (p->scratch) (void)hipFree(p->scratch);
     if (p->ly) (void)hipFree(p->ly);
     if (p->lx) (void)hipFree(p->lx);
+    if (p->lyd) (void)hipFree(p->lyd);
+    if (p->lxd) (void)hipFree(p->lxd);
     if (p->ly64) (void)hipFree(p->ly64);
     if (p->lx64) (void)hipFree(p->lx64);
     delete p;
@@ -94,20 +96,31 @@ int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx) 
     if (!p->ly) {
         OA_HIP(hipMalloc(&p->ly, p->ny * es));
         OA_HIP(hipMalloc(&p->lx, p->nx * es));
+        OA_HIP(hipMalloc(&p->lyd, p->ny * es));
+        OA_HIP(hipMalloc(&p->lxd, p->nx * es));
         OA_HIP(hipMalloc((void**)&p->ly64, p->ny * sizeof(double)));
         OA_HIP(hipMalloc((void**)&p->lx64, p->nx * sizeof(double)));
     }
     OA_HIP(hipMemcpy(p->ly64, host_ly, p->ny * sizeof(double), hipMemcpyHostToDevice));
     OA_HIP(hipMemcpy(p->lx64, host_lx, p->nx * sizeof(double), hipMemcpyHostToDevice));
+    // derivative axes: the self-conjugate Nyquist frequency carries no odd (i*l) component of a
+    // real field (what np.real() of the reference's full-plane C2C inverse discards)
+    std::vector<double> dy(host_ly, host_ly + p->ny), dx(host_lx, host_lx + p->nx);
+    dy[p->ny / 2] = 0.0;
+    dx[p->nx / 2] = 0.0;
     if (p->dtype == OA_F32) {
-        std::vector<float> a(p->ny), b(p->nx);
-        for (int i = 0; i < p->ny; ++i) a[i] = (float)host_ly[i];
-        for (int i = 0; i < p->nx; ++i) b[i] = (float)host_lx[i];
+        std::vector<float> a(p->ny), b(p->nx), c(p->ny), d(p->nx);
+        for (int i = 0; i < p->ny; ++i) { a[i] = (float)host_ly[i]; c[i] = (float)dy[i]; }
+        for (int i = 0; i < p->nx; ++i) { b[i] = (float)host_lx[i]; d[i] = (float)dx[i]; }
         OA_HIP(hipMemcpy(p->ly, a.data(), p->ny * es, hipMemcpyHostToDevice));
         OA_HIP(hipMemcpy(p->lx, b.data(), p->nx * es, hipMemcpyHostToDevice));
+        OA_HIP(hipMemcpy(p->lyd, c.data(), p->ny * es, hipMemcpyHostToDevice));
+        OA_HIP(hipMemcpy(p->lxd, d.data(), p->nx * es, hipMemcpyHostToDevice));
     } else {
         OA_HIP(hipMemcpy(p->ly, host_ly, p->ny * es, hipMemcpyHostToDevice));
         OA_HIP(hipMemcpy(p->lx, host_lx, p->nx * es, hipMemcpyHostToDevice));
+        OA_HIP(hipMemcpy(p->lyd, dy.data(), p->ny * es, hipMemcpyHostToDevice));
+        OA_HIP(hipMemcpy(p->lxd, dx.data(), p->nx * es, hipMemcpyHostToDevice));
     }
     p->have_laxes = true;
     return 0;

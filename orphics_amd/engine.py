@@ -33,6 +33,59 @@ def precision_of(x, default="f64"):
     return default
 
 
+_BIN_SCRATCH = {}
+
+
+def cuda_device():
+    _lib.require_gpu()
+    if not torch.cuda.is_available():
+        raise _lib.OrphicsAmdError("orphics_amd: torch sees no GPU; device memory cannot be allocated")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def dev_digitize(x64, edges64):
+    """np.digitize(x, edges, right=True) on device (float64, bit-exact); plan-free."""
+    lib = _lib.load()
+    if x64.dtype != torch.float64 or edges64.dtype != torch.float64 or not x64.is_cuda or not edges64.is_cuda:
+        raise ValueError("digitize operates on float64 CUDA tensors")
+    x64 = x64.contiguous()
+    ids = torch.empty(x64.shape, dtype=torch.int32, device=x64.device)
+    check(lib.oa_digitize(_ptr(x64), x64.numel(), _ptr(edges64.contiguous()), edges64.numel(), _ptr(ids), _stream()))
+    return ids
+
+
+def dev_bin(data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, herm_pitch=0, herm_nxh=-1):
+    """Streaming histogram (oa_bin); returns (sums f64[nids], counts int64[nids] | wsums f64[nids])."""
+    lib = _lib.load()
+    n = data.numel()
+    if not (data.is_cuda and ids.is_cuda):
+        raise TypeError("bin: CUDA tensors required")
+    if ids.numel() != n or ids.dtype != torch.int32 or not ids.is_contiguous() or not data.is_contiguous():
+        raise ValueError("bin: ids must be contiguous int32 with one entry per data element")
+    prec = precision_of(data, default=None)
+    if prec is None:
+        raise ValueError("bin: data must be float32 or float64")
+    if weights is not None and (weights.dtype != data.dtype or weights.numel() != n or not weights.is_contiguous()):
+        raise ValueError("bin: weights must match data")
+    if aux is not None and (aux.dtype != torch.float64 or aux.numel() != nids):
+        raise ValueError("bin: aux must be float64[nids]")
+    need = int(lib.oa_bin_scratch_bytes(int(nids)))
+    if need < 0:
+        raise ValueError("bin: bad nids")
+    key = data.device.index
+    scr = _BIN_SCRATCH.get(key)
+    if scr is None or scr.numel() < need:
+        scr = torch.empty(need, dtype=torch.uint8, device=data.device)
+        _BIN_SCRATCH[key] = scr
+    sums = torch.empty(nids, dtype=torch.float64, device=data.device)
+    counts = torch.empty(nids, dtype=torch.int64, device=data.device) if weights is None else None
+    wsums = torch.empty(nids, dtype=torch.float64, device=data.device) if weights is not None else None
+    check(lib.oa_bin(_CODE[prec], _ptr(data), _ptr(ids), _ptr(weights), _ptr(aux), n, int(nids), int(mode),
+                     1 if skip_nan else 0, int(herm_pitch), int(herm_nxh), _ptr(sums), _ptr(counts), _ptr(wsums),
+                     _ptr(scr), _stream()))
+    return sums, (counts if weights is None else wsums)
+
+
 class Engine(object):
     _cache = {}
 
@@ -86,11 +139,15 @@ class Engine(object):
         return torch.empty(tuple(lead) + (self.ny, self.nx), dtype=self.cdt, device=self.device)
 
     def to_real(self, a):
-        t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+        if isinstance(a, np.ndarray):
+            a = np.require(a, requirements=["C", "W"]) if a.flags.writeable else np.array(a, order="C")
+        t = torch.as_tensor(a)
         return t.to(device=self.device, dtype=self.rdt).contiguous()
 
     def to_complex(self, a):
-        t = torch.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a)
+        if isinstance(a, np.ndarray):
+            a = np.require(a, requirements=["C", "W"]) if a.flags.writeable else np.array(a, order="C")
+        t = torch.as_tensor(a)
         return t.to(device=self.device, dtype=self.cdt).contiguous()
 
     # ---- validation ---------------------------------------------------------
@@ -226,12 +283,7 @@ class Engine(object):
 
     # ---- binning -----------------------------------------------------------------------
     def digitize(self, x64, edges64):
-        if x64.dtype != torch.float64 or edges64.dtype != torch.float64:
-            raise ValueError("digitize operates on float64")
-        x64 = x64.contiguous()
-        ids = torch.empty(x64.shape, dtype=torch.int32, device=self.device)
-        check(self.lib.oa_digitize(_ptr(x64), x64.numel(), _ptr(edges64), edges64.numel(), _ptr(ids), _stream()))
-        return ids
+        return dev_digitize(x64, edges64)
 
     def modl_digitize(self, edges64, half=False, want_modl=False):
         if self._laxes is None:
@@ -246,27 +298,8 @@ class Engine(object):
         return (ids, modl) if want_modl else ids
 
     def bin(self, data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, herm=False):
-        """Returns (sums f64[nids], counts int64[nids] | wsums f64[nids])."""
-        n = data.numel()
-        if ids.numel() != n or ids.dtype != torch.int32 or not ids.is_contiguous() or not data.is_contiguous():
-            raise ValueError("bin: ids must be contiguous int32 with one entry per data element")
-        prec = precision_of(data)
-        if weights is not None and (weights.dtype != data.dtype or weights.numel() != n or not weights.is_contiguous()):
-            raise ValueError("bin: weights must match data")
-        if aux is not None and (aux.dtype != torch.float64 or aux.numel() != nids):
-            raise ValueError("bin: aux must be float64[nids]")
-        need = int(self.lib.oa_bin_scratch_bytes(nids))
-        if need < 0:
-            raise ValueError("bin: bad nids")
-        if self._bin_scratch is None or self._bin_scratch.numel() < need:
-            self._bin_scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-        sums = torch.empty(nids, dtype=torch.float64, device=self.device)
-        counts = torch.empty(nids, dtype=torch.int64, device=self.device) if weights is None else None
-        wsums = torch.empty(nids, dtype=torch.float64, device=self.device) if weights is not None else None
-        check(self.lib.oa_bin(_CODE[prec], _ptr(data), _ptr(ids), _ptr(weights), _ptr(aux), n, int(nids), int(mode),
-                              1 if skip_nan else 0, self.kp if herm else 0, self.nxh if herm else -1, _ptr(sums),
-                              _ptr(counts), _ptr(wsums), _ptr(self._bin_scratch), _stream()))
-        return sums, (counts if weights is None else wsums)
+        return dev_bin(data, ids, nids, weights=weights, aux=aux, mode=mode, skip_nan=skip_nan,
+                       herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1)
 
     # ---- random fields / accumulators ---------------------------------------------------
     def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):

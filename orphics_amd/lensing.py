@@ -1,0 +1,336 @@
+"""Flat-sky lensing quadratic estimator + sim harness on MI355X.
+
+``Estimator`` / ``qest`` reproduce the call contract that survives in the
+reference (``qest.kappa_from_map``, lensing.py:973-976; constructor keywords
+from tutorials/tt_verification.ipynb cell 3).  The class itself is absent from
+the reference snapshot: the estimator is the Hu & Okamoto (2002)
+one in the real-space form of Hu, DeDeo & Vale (2007); oracle/qe_oracle.py is
+the float64 NumPy statement it is tested against.
+
+Per reconstruction (TT): 1 fused leg-filter kernel, 3 C2R FFTs, 2 real
+products, 2 R2C FFTs, 1 divergence/normalisation kernel -- all HIP, all on the
+half-plane layout.
+"""
+import numpy as np
+
+from . import maps
+from .cosmology import power_from_theory
+from .geometry import as_geometry
+from .stats import HalfPlane
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _half(a, nxh):
+    """Full-plane (Ny,Nx) host array -> the non-redundant half (Ny,Nx/2+1)."""
+    a = np.asarray(a)
+    return np.ascontiguousarray(a[:, :nxh + 1])
+
+
+def _safe_div(num, den):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out = num / den
+    out[~np.isfinite(out)] = 0
+    return out
+
+
+class Estimator(object):
+    """Flat-sky QE.  Keywords follow the reference's ``lensing.qest`` call
+    (tt_verification.ipynb cell 3):
+
+    theory  : object with lCl/uCl(spec, ell) (cosmology.TheorySpectra)
+    noise2d : (Ny,Nx) T noise power (not beam-deconvolved), beam2d the beam
+              transfer, kmask the 0/1 T mask; *_P the polarisation versions;
+    kmask_K : 0/1 mask applied to the reconstructed kappa modes
+    grad_cut: zero the gradient leg above this ell
+    unlensed_equals_lensed: use the lensed spectra in the gradient leg/response
+    dtype   : "f32" (fast path) or "f64" (parity mode) for the per-map kernels;
+              the one-off normalisation is always computed with the f64 kernels.
+    """
+
+    def __init__(self, shape, wcs, theory, noise2d=None, beam2d=None, kmask=None, noise2d_P=None, kmask_P=None,
+                 kmask_K=None, pol=False, grad_cut=None, unlensed_equals_lensed=False, bigell=9000, dtype="f32",
+                 theory_norm=None):
+        self.shape = tuple(shape)
+        self.wcs = wcs
+        self.geom = as_geometry(shape, wcs)
+        self.prec = dtype
+        self.pol = pol
+        self.eng = maps._engine(self.shape, dtype)
+        self.eng64 = maps._engine(self.shape, "f64")
+        Ny, Nx = self.shape[-2:]
+        self.nxh = Nx // 2
+        ly, lx = self.geom.laxes()
+        self.eng.set_laxes(ly, lx)
+        self.eng64.set_laxes(ly, lx)
+        self.ly, self.lxh = ly, lx[:self.nxh + 1]
+        self.modl_h = np.sqrt(ly[:, None] ** 2 + self.lxh[None, :] ** 2)
+        ones = np.ones((Ny, self.nxh + 1))
+        ml = np.where(self.modl_h <= bigell, self.modl_h, -1.0)  # theory is 0 beyond bigell
+        cfun_g = theory.lCl if unlensed_equals_lensed else theory.uCl
+        self.noise = {"T": _half(noise2d, self.nxh) if noise2d is not None else 0 * ones}
+        self.beam = _half(beam2d, self.nxh) if beam2d is not None else ones
+        self.mask = {"T": _half(kmask, self.nxh).astype(np.float64) if kmask is not None else ones}
+        self.mask_K = _half(kmask_K, self.nxh).astype(np.float64) if kmask_K is not None else ones
+        self.grad_cut = grad_cut
+        self.cl_grad = {"TT": np.where(ml >= 0, cfun_g("TT", np.abs(ml)), 0.0)}
+        self.cl_len = {"TT": np.where(ml >= 0, theory.lCl("TT", np.abs(ml)), 0.0)}
+        self.AL, self.Nlkk, self._F = {}, {}, {}
+        self._work = None
+        self._setup_tt()
+
+    # ---- filters / normalisation --------------------------------------------------
+    def _hcreal(self, eng, a_half):
+        """(Ny, Nx/2+1) host plane -> padded hc-layout device plane."""
+        torch = _torch()
+        t = eng.hcreal()
+        t[:, :self.nxh + 1] = torch.as_tensor(np.ascontiguousarray(a_half), dtype=eng.rdt, device=eng.device)
+        return t
+
+    def _setup_tt(self):
+        gmask = self.mask["T"].copy()
+        if self.grad_cut is not None:
+            gmask[self.modl_h > self.grad_cut] = 0
+        ct = self.cl_len["TT"] + _safe_div(self.noise["T"], self.beam ** 2)
+        wg = _safe_div(self.cl_grad["TT"], ct) * gmask          # on the deconvolved field
+        wh = _safe_div(np.ones_like(ct), ct) * self.mask["T"]
+        Wg = _safe_div(wg, self.beam)                            # on the observed (beam-convolved) field
+        Wh = _safe_div(wh, self.beam)
+        R = self._response_tt(wg, wh, self.cl_grad["TT"])
+        AL = _safe_div(np.ones_like(R), R)
+        L = self.modl_h
+        Fnorm = -(L * (L + 1.) / 2.) * AL * self.mask_K
+        self.AL["TT"] = AL
+        self.Nlkk["TT"] = (L * (L + 1.)) ** 2 / 4. * AL
+        self.R_TT = R
+        self._F["TT"] = (self._hcreal(self.eng, Wg), self._hcreal(self.eng, Wh), self._hcreal(self.eng, Fnorm))
+
+    def _response_tt(self, wg, wh, cr):
+        """R(L) = (1/a) sum_jk L_j L_k DFT[alpha_jk beta - gt_j dt_k](L) evaluated with
+        the f64 kernels (one-off): alpha_jk = IDFT[l_j l_k wg C], beta = IDFT[wh],
+        gt_j = IDFT[i l_j wg], dt_k = IDFT[i l_k wh C]  (oracle/qe_oracle.py)."""
+        torch = _torch()
+        e = self.eng64
+        one_k = e.hc()
+        one_k[:, :self.nxh + 1] = 1.0
+        F_wg, F_wh = self._hcreal(e, wg), self._hcreal(e, wh)
+        F_wgc, F_whc = self._hcreal(e, wg * cr), self._hcreal(e, wh * cr)
+        F_one = self._hcreal(e, np.ones_like(wg))
+        # first-derivative legs
+        kgx, kgy, kb = e.qe_legs(one_k, one_k, F_wg, F_wh)          # i lx wg, i ly wg, wh
+        kdx, kdy, _ = e.qe_legs(one_k, one_k, F_whc, F_wh)          # i lx wh C, i ly wh C
+        kax, kay, _ = e.qe_legs(one_k, one_k, F_wgc, F_wh)          # i lx wg C, i ly wg C
+        kaxx, kaxy, _ = e.qe_legs(kax, one_k, F_one, F_wh)          # -lx lx wgC, -lx ly wgC
+        _, kayy, _ = e.qe_legs(kay, one_k, F_one, F_wh)             # -ly ly wgC
+        beta = e.irfft(kb)
+        gx, gy = e.irfft(kgx), e.irfft(kgy)
+        dx, dy = e.irfft(kdx), e.irfft(kdy)
+        axx, axy, ayy = e.irfft(kaxx), e.irfft(kaxy), e.irfft(kayy)   # = -alpha_jk
+        # S_jk = alpha_jk beta - gt_j dt_k  ->  -S_jk = axx*beta + gx*dx
+        sxx = e.axpby(e.mul_real(axx, beta), e.mul_real(gx, dx), 1.0, 1.0)
+        syy = e.axpby(e.mul_real(ayy, beta), e.mul_real(gy, dy), 1.0, 1.0)
+        sxy = e.axpby(e.mul_real(axy, beta), e.axpby(e.mul_real(gx, dy), e.mul_real(gy, dx), 0.5, 0.5), 1.0, 1.0)
+        A, B, C2 = e.rfft(sxx), e.rfft(syy), e.rfft(sxy)             # = -DFT[S_xx], -DFT[S_yy], -DFT[S_xy]/2... (sxy is the half cross term)
+        # lx^2 A' + ly^2 B' + 2 lx ly C'  with two divergence passes: i l.(i l.M) = -l.M.l
+        ux = e.qe_div(A, C2, F_one)
+        uy = e.qe_div(C2, B, F_one)
+        tot = e.qe_div(ux, uy, F_one)                                # = -(lx^2 A + 2 lx ly C2 + ly^2 B)
+        Rk = e.f2power(tot, one_k, 1.0 / self.geom.pixarea)          # real part / a ; signs: (-1)*(-1) = +
+        return Rk.cpu().numpy()[:, :self.nxh + 1].astype(np.float64)
+
+    # ---- data plumbing -----------------------------------------------------------------
+    def _as_hc(self, x, alreadyFTed):
+        """Map / FT in any accepted container -> hc tensor of the run precision."""
+        torch = _torch()
+        e = self.eng
+        if isinstance(x, HalfPlane):
+            t = x.t
+            if t.dtype != e.cdt:
+                t = t.to(e.cdt)
+            return t.contiguous(), "half"
+        if alreadyFTed:
+            kind = "np" if isinstance(x, np.ndarray) else "torch"
+            return e.full_to_hc(e.to_complex(x)), kind
+        kind = "np" if isinstance(x, np.ndarray) else "torch"
+        return e.rfft(e.to_real(x)), kind
+
+    def _buffers(self):
+        if self._work is None:
+            e = self.eng
+            self._work = dict(G=(e.hc(), e.hc(), e.hc()), r=(e.real(), e.real(), e.real()), P=(e.hc(), e.hc()))
+        return self._work
+
+    def reconstruct_tt_hc(self, kX, kY=None, out=None):
+        """Device-native TT reconstruction: hc tensors in, kappa_hat DFT (hc) out."""
+        e = self.eng
+        kY = kX if kY is None else kY
+        FG, FH, Fn = self._F["TT"]
+        w = self._buffers()
+        Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
+        gx, gy, h = w["r"]
+        e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
+        e.mul_real(gx, h, out=gx)
+        e.mul_real(gy, h, out=gy)
+        Px, Py = w["P"]
+        e.rfft(gx, out=Px); e.rfft(gy, out=Py)
+        return e.qe_div(Px, Py, Fn, out=out)
+
+    def kappa_from_map(self, XY, T2DData, E2DData=None, B2DData=None, T2DDataY=None, E2DDataY=None, B2DDataY=None,
+                       alreadyFTed=False, returnFt=False):
+        """qest.kappa_from_map (lensing.py:973-976; notebook cell 4).  The X
+        (gradient) and Y legs may be different maps (SplitLensing)."""
+        if XY != "TT":
+            raise NotImplementedError("estimator %s: only TT is implemented in this round" % XY)
+        kX, kind = self._as_hc(T2DData, alreadyFTed)
+        kY = kX if T2DDataY is None else self._as_hc(T2DDataY, alreadyFTed)[0]
+        kft = self.reconstruct_tt_hc(kX, kY)
+        e = self.eng
+        if returnFt:
+            if kind == "half":
+                return HalfPlane(kft, e)
+            full = e.hc_to_full(kft)
+            return full.cpu().numpy() if kind == "np" else full
+        rec = e.irfft(kft)
+        return rec.cpu().numpy() if kind == "np" else rec
+
+    # full-plane views of the normalisation (host, float64)
+    def _full(self, half):
+        Ny, Nx = self.shape[-2:]
+        out = np.empty((Ny, Nx))
+        out[:, :self.nxh + 1] = half
+        idx = (-np.arange(Ny)) % Ny
+        out[:, self.nxh + 1:] = half[idx][:, 1:self.nxh][:, ::-1]
+        return out
+
+    def N_kappa(self, XY="TT"):
+        return self._full(self.Nlkk[XY])
+
+
+def qest(shape, wcs, theory, **kwargs):
+    """``lensing.qest(...)`` constructor name used by the reference notebooks."""
+    return Estimator(shape, wcs, theory, **kwargs)
+
+
+class SplitLensing(object):
+    """lensing.py:959-1003: split-based 4-point estimator built from QE calls
+    with distinct X / Y legs."""
+
+    def __init__(self, shape, wcs, qest, XY="TT"):
+        self.fc = maps.FourierCalc(shape, wcs)
+        self.qest = qest
+        self.est = XY
+
+    def qpower(self, k1, k2):
+        return self.fc.f2power(k1, k2)
+
+    def qfrag(self, a, b):
+        if self.est == 'TT':
+            return self.qest.kappa_from_map(self.est, T2DData=a, T2DDataY=b, alreadyFTed=True, returnFt=True)
+        raise NotImplementedError("SplitLensing: the reference's EE branch is marked wrong (lensing.py:975)")
+
+    def cross_estimator(self, ksplits):
+        """lensing.py:980-1003."""
+        torch = _torch()
+        if isinstance(ksplits, HalfPlane):
+            splits = [ksplits[i] for i in range(ksplits.t.shape[0])]
+            mean = HalfPlane(ksplits.t.mean(dim=0), ksplits.eng)
+            wrap = lambda t: t  # noqa: E731
+            arith = "half"
+        else:
+            arr = np.asanyarray(ksplits)
+            splits = [arr[i] for i in range(arr.shape[0])]
+            mean = np.mean(arr, axis=0)
+            arith = "np"
+        insplits = len(splits)
+        nsplits = float(insplits)
+
+        def val(x):
+            return x.t if isinstance(x, HalfPlane) else x
+
+        def mk(t, like):
+            return HalfPlane(t, like.eng) if isinstance(like, HalfPlane) else t
+
+        s = mean
+        k = self.qfrag(s, s)
+        kiisum = 0.
+        psum = 0.
+        psum2 = 0.
+        for i in range(insplits):
+            mi = splits[i]
+            ki = mk((val(self.qfrag(mi, s)) + val(self.qfrag(s, mi))) / 2., k)
+            kii = self.qfrag(mi, mi)
+            kiisum = kiisum + val(kii)
+            kic = mk(val(ki) - (1. / nsplits) * val(kii), k)
+            psum = psum + val(self.qpower(kic, kic))
+            for j in range(i + 1, int(insplits)):
+                mj = splits[j]
+                kij = mk((val(self.qfrag(mi, mj)) + val(self.qfrag(mj, mi))) / 2., k)
+                psum2 = psum2 + val(self.qpower(kij, kij))
+        kc = mk(val(k) - (1. / nsplits ** 2.) * kiisum, k)
+        res = (nsplits ** 4. * val(self.qpower(kc, kc)) - 4. * nsplits ** 2. * psum + 4. * psum2) \
+            / nsplits / (nsplits - 1.) / (nsplits - 2.) / (nsplits - 3.)
+        return mk(res, self.qpower(kc, kc)) if arith == "half" else res
+
+
+class FlatLensingSims(object):
+    """lensing.py:458-521: CMB / kappa / noise GRF generators, Gaussian beam,
+    white noise.  The lensing operation itself (pixell displace_map) is the
+    SURVEY.md section 8f-1 'next' row; ``get_sim(skip_lensing=True)`` is the
+    Gaussian (N0 / mean-field) simulation used by the Monte-Carlo driver."""
+
+    def __init__(self, shape, wcs, theory, beam_arcmin, noise_uk_arcmin, noise_e_uk_arcmin=None, noise_b_uk_arcmin=None,
+                 pol=False, fixed_lens_kappa=None, dtype="f32"):
+        if len(shape) < 3 and pol:
+            shape = (3,) + tuple(shape)
+        self.shape = tuple(shape)
+        self.wcs = wcs
+        self.geom = as_geometry(shape, wcs)
+        if noise_e_uk_arcmin is None:
+            noise_e_uk_arcmin = np.sqrt(2.) * noise_uk_arcmin
+        if noise_b_uk_arcmin is None:
+            noise_b_uk_arcmin = noise_e_uk_arcmin
+        self.modlmap = self.geom.modlmap()
+        Ny, Nx = self.shape[-2:]
+        ps_cmb = power_from_theory(self.modlmap, theory, lensed=False, pol=pol)
+        self.mgen = maps.MapGen(self.shape, wcs, ps_cmb, dtype=dtype)
+        ps_kk = theory.gCl('kk', self.modlmap).reshape((1, 1, Ny, Nx))
+        self.kgen = maps.MapGen(self.shape[-2:], wcs, ps_kk, dtype=dtype)
+        self.ps_kk = ps_kk
+        self.kbeam = maps.gauss_beam(self.modlmap, beam_arcmin)
+        ncomp = 3 if pol else 1
+        ps_noise = np.zeros((ncomp, ncomp, Ny, Nx))
+        ps_noise[0, 0] = (noise_uk_arcmin * np.pi / 180. / 60.) ** 2.
+        if pol:
+            ps_noise[1, 1] = (noise_e_uk_arcmin * np.pi / 180. / 60.) ** 2.
+            ps_noise[2, 2] = (noise_b_uk_arcmin * np.pi / 180. / 60.) ** 2.
+        self.ngen = maps.MapGen(self.shape, wcs, ps_noise, dtype=dtype)
+        self.ps_noise = ps_noise
+        self._fixed = fixed_lens_kappa is not None
+        self.kappa = fixed_lens_kappa
+
+    def get_unlensed(self, seed=None):
+        return self.mgen.get_map(seed=seed)
+
+    def get_kappa(self, seed=None):
+        return self.kgen.get_map(seed=seed, scalar=True)
+
+    def get_sim(self, seed_cmb=None, seed_kappa=None, seed_noise=None, lens_order=5, return_intermediate=False,
+                skip_lensing=False, cfrac=None):
+        """lensing.py:499-521."""
+        torch = _torch()
+        unlensed = self.get_unlensed(seed_cmb)
+        if skip_lensing:
+            lensed = unlensed
+            kappa = torch.zeros_like(lensed if lensed.ndim == 2 else lensed[0])
+        else:
+            raise NotImplementedError("map lensing (pixell displace_map) is SURVEY.md section 8f-1, not built yet; "
+                                      "use skip_lensing=True")
+        beamed = maps.filter_map(lensed, self.kbeam)
+        noise_map = self.ngen.get_map(seed=seed_noise)
+        observed = beamed + noise_map
+        if return_intermediate:
+            return [unlensed, kappa, lensed, beamed, noise_map, observed]
+        return observed

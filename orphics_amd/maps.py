@@ -1,0 +1,509 @@
+"""orphics.maps hot-path surface on MI355X: FourierCalc, MapGen, filter_map,
+gauss_beam, mask_kspace, tapers, binned_power.
+
+Signatures mirror /root/reference/orphics/maps.py (cited per function).  The
+FFT / per-mode arithmetic runs in the HIP kernels behind include/orphics_amd.h;
+there is no CPU fallback.
+
+Data conventions
+----------------
+* NumPy in -> NumPy out, full-plane float64/complex128 like the reference
+  (precision of the plan follows the input dtype: float32 maps use the f32
+  kernels, float64 the f64 kernels).
+* CUDA tensors in -> CUDA tensors out (full-plane).
+* ``FourierCalc(..., layout="half")``: Fourier-space results are
+  :class:`~orphics_amd.stats.HalfPlane` objects (non-redundant half plane of a
+  real field, the device-native fast path); every method also accepts them.
+"""
+import numpy as np
+
+from .geometry import FlatGeometry, as_geometry, rect_geometry  # noqa: F401
+from .stats import HalfPlane
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _is_tensor(x):
+    torch = _torch()
+    return isinstance(x, torch.Tensor)
+
+
+def _engine(shape, prec):
+    from .engine import Engine
+    Ny, Nx = shape[-2:]
+    if Ny < 32 or Nx < 32 or (Ny & (Ny - 1)) or (Nx & (Nx - 1)):
+        raise NotImplementedError("orphics_amd FFTs need power-of-two map sides >= 32, got %dx%d" % (Ny, Nx))
+    return Engine.get(Ny, Nx, prec)
+
+
+def _prec(x):
+    from .engine import precision_of
+    if isinstance(x, HalfPlane):
+        return x.eng.prec
+    return precision_of(x)
+
+
+def _ret(t, like):
+    """Return ``t`` (device tensor) in the container kind of ``like``."""
+    if isinstance(like, np.ndarray) or not (_is_tensor(like) or isinstance(like, HalfPlane)):
+        return t.cpu().numpy()
+    return t
+
+
+def _planes(x):
+    """Flatten leading dims: (..., Ny, Nx) -> list of 2-D slices + lead shape."""
+    lead = tuple(x.shape[:-2])
+    flat = x.reshape((-1,) + tuple(x.shape[-2:]))
+    return [flat[i] for i in range(flat.shape[0])], lead
+
+
+def gauss_beam(ell, fwhm):
+    """maps.py:1925-1927."""
+    tht_fwhm = np.deg2rad(fwhm / 60.)
+    return np.exp(-(tht_fwhm ** 2.) * (ell ** 2.) / (16. * np.log(2.)))
+
+
+def sigma_from_fwhm(fwhm):
+    return fwhm / 2. / np.sqrt(2. * np.log(2.))
+
+
+def fwhm_from_sigma(sigma):
+    return 2. * np.sqrt(2. * np.log(2.)) * sigma
+
+
+def mask_kspace(shape, wcs, lxcut=None, lycut=None, lmin=None, lmax=None):
+    """maps.py:1936-1948: int ones/zeros; zero where ell<=lmin, ell>=lmax,
+    |lx|<lxcut, |ly|<lycut."""
+    geom = as_geometry(shape, wcs)
+    output = np.ones(shape[-2:], dtype=int)
+    if (lmin is not None) or (lmax is not None):
+        modlmap = geom.modlmap()
+    if (lxcut is not None) or (lycut is not None):
+        ly, lx = geom.laxes()
+    if lmin is not None:
+        output[np.where(modlmap <= lmin)] = 0
+    if lmax is not None:
+        output[np.where(modlmap >= lmax)] = 0
+    if lxcut is not None:
+        output[:, np.where(np.abs(lx) < lxcut)] = 0
+    if lycut is not None:
+        output[np.where(np.abs(ly) < lycut), :] = 0
+    return output
+
+
+def cosine_window(Ny, Nx, lenApodY=30, lenApodX=30, padY=0, padX=0):
+    """maps.py:1891-1920 (host-side, one-off)."""
+    win = np.ones((Ny, Nx))
+    i = np.arange(Nx)
+    j = np.arange(Ny)
+    ii, jj = np.meshgrid(i, j)
+    if lenApodX > 0:
+        r = ii.astype(float) - padX
+        sel = np.where(ii <= (lenApodX + padX))
+        win[sel] = 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodX))
+        sel = np.where(ii >= ((Nx - 1) - lenApodX - padX))
+        r = ((Nx - 1) - ii - padX).astype(float)
+        win[sel] = 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodX))
+    if lenApodY > 0:
+        r = jj.astype(float) - padY
+        sel = np.where(jj <= (lenApodY + padY))
+        win[sel] *= 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodY))
+        sel = np.where(jj >= ((Ny - 1) - lenApodY - padY))
+        r = ((Ny - 1) - jj - padY).astype(float)
+        win[sel] *= 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodY))
+    win[0:padY, :] = 0
+    win[:, 0:padX] = 0
+    win[Ny - padY:, :] = 0
+    win[:, Nx - padX:] = 0
+    return win
+
+
+def get_taper(shape, wcs=None, taper_percent=12.0, pad_percent=3.0, weight=None):
+    """maps.py:1873-1878: returns (taper, mean(taper^2))."""
+    Ny, Nx = shape[-2:]
+    if weight is None:
+        weight = np.ones(shape[-2:])
+    n = min(Ny, Nx)
+    taper = cosine_window(Ny, Nx, lenApodY=int(taper_percent * n / 100.), lenApodX=int(taper_percent * n / 100.),
+                          padY=int(pad_percent * n / 100.), padX=int(pad_percent * n / 100.)) * weight
+    return taper, np.mean(taper ** 2.)
+
+
+def get_taper_deg(shape, wcs, taper_width_degrees=1.0, pad_width_degrees=0., weight=None, only_y=False):
+    """maps.py:1880-1888."""
+    Ny, Nx = shape[-2:]
+    if weight is None:
+        weight = np.ones(shape[-2:])
+    res = abs(as_geometry(shape, wcs).step_y)
+    pix_apod = int(taper_width_degrees * np.pi / 180. / res)
+    pix_pad = int(pad_width_degrees * np.pi / 180. / res)
+    taper = cosine_window(Ny, Nx, lenApodY=pix_apod, lenApodX=pix_apod if not only_y else 0, padY=pix_pad,
+                          padX=pix_pad if not only_y else 0) * weight
+    return taper, np.mean(taper ** 2.)
+
+
+def queb_rotmat(lmap, inverse=False, iau=False, spin=2):
+    """pixell enmap.queb_rotmat as used by maps.py:1607."""
+    sgn = 1 if iau else -1
+    a = sgn * spin * np.arctan2(-lmap[1], lmap[0])
+    c, s = np.cos(a), np.sin(a)
+    if inverse:
+        s = -s
+    return np.array([[c, -s], [s, c]])
+
+
+class FourierCalc(object):
+    """maps.py:1594-1677."""
+
+    def __init__(self, shape, wcs, iau=False, layout="full"):
+        self.shape = tuple(shape)
+        self.wcs = wcs
+        self.geom = as_geometry(shape, wcs)
+        self.layout = layout
+        assert layout in ("full", "half")
+        self.normfact = self.geom.area / np.prod(self.shape[-2:]) ** 2.
+        self.iau = iau
+        self._rot_dev = {}
+        if len(shape) > 2 and shape[-3] > 1:
+            self.rot = queb_rotmat(self.geom.lmap(), iau=iau)
+
+    # ---- helpers --------------------------------------------------------------
+    def _eng(self, x):
+        return _engine(self.shape, _prec(x))
+
+    def _rot_planes(self, eng, half):
+        key = (eng.prec, half)
+        if key not in self._rot_dev:
+            c = eng.to_real(self.rot[0, 0])
+            s = eng.to_real(self.rot[1, 0])
+            if half:
+                c, s = eng.fullreal_to_hc(c), eng.fullreal_to_hc(s)
+            self._rot_dev[key] = (c, s)
+        return self._rot_dev[key]
+
+    def _fft_real_planes(self, emap, eng, scale):
+        """list of hc tensors, one per 2-D slice of the real map ``emap``."""
+        torch = _torch()
+        if isinstance(emap, np.ndarray) and np.iscomplexobj(emap) or (_is_tensor(emap) and emap.is_complex()):
+            raise TypeError("complex maps go through the C2C path")
+        x = eng.to_real(emap)
+        planes, lead = _planes(x)
+        return [eng.rfft(p.contiguous(), scale=scale) for p in planes], lead
+
+    def _to_half(self, k, eng):
+        """Any k-space input -> HalfPlane (assumes Hermitian symmetry for full inputs)."""
+        if isinstance(k, HalfPlane):
+            return k
+        torch = _torch()
+        z = eng.to_complex(k)
+        planes, lead = _planes(z)
+        hs = [eng.full_to_hc(p.contiguous()) for p in planes]
+        return HalfPlane(torch.stack(hs).reshape(lead + (eng.ny, eng.kp)), eng)
+
+    def _to_full(self, k, eng):
+        if isinstance(k, HalfPlane):
+            return k.full()
+        return eng.to_complex(k)
+
+    def _wrap_k(self, hs, lead, eng, like):
+        """hc plane list -> output in the configured layout / container kind."""
+        torch = _torch()
+        t = torch.stack(hs).reshape(lead + (eng.ny, eng.kp))
+        hp = HalfPlane(t, eng)
+        if self.layout == "half":
+            return hp
+        return _ret(hp.full(), like)
+
+    # ---- reference API ----------------------------------------------------------
+    def iqu2teb(self, emap, nthread=0, normalize=True, rot=True):
+        """maps.py:1609-1617: 2-D FFT (enmap.fft normalize=True is 1/sqrt(Npix)),
+        then per-mode Q,U -> E,B rotation of the last two components."""
+        torch = _torch()
+        eng = self._eng(emap)
+        scale = 1.0 / np.sqrt(eng.npix) if normalize else 1.0
+        hs, lead = self._fft_real_planes(emap, eng, scale)
+        dorot = len(lead) >= 1 and lead[-1] > 1 and rot
+        if not dorot:
+            return self._wrap_k(hs, lead, eng, emap)
+        ncomp = lead[-1]
+        if self.layout == "half":
+            # Hermitian convention at the self-conjugate Nyquist modes
+            c, s = self._rot_planes(eng, True)
+            for b in range(0, len(hs), ncomp):
+                hs[b + ncomp - 2], hs[b + ncomp - 1] = eng.rot2(c, s, hs[b + ncomp - 2], hs[b + ncomp - 1])
+            return self._wrap_k(hs, lead, eng, emap)
+        # full layout: rotate on the full plane with the full-plane matrix, exactly like
+        # enmap.map_mul(self.rot, ...) (maps.py:1614-1615), Nyquist modes included
+        c, s = self._rot_planes(eng, False)
+        fs = [eng.hc_to_full(h) for h in hs]
+        for b in range(0, len(fs), ncomp):
+            fs[b + ncomp - 2], fs[b + ncomp - 1] = eng.rot2(c, s, fs[b + ncomp - 2], fs[b + ncomp - 1])
+        return _ret(torch.stack(fs).reshape(lead + (eng.ny, eng.nx)), emap)
+
+    def f2power(self, kmap1, kmap2, pixel_units=False):
+        """maps.py:1620-1624: Re(conj(k1) k2) * norm."""
+        torch = _torch()
+        norm = 1. if pixel_units else self.normfact
+        if isinstance(kmap1, HalfPlane) or isinstance(kmap2, HalfPlane):
+            eng = kmap1.eng if isinstance(kmap1, HalfPlane) else kmap2.eng
+            a, b = self._to_half(kmap1, eng), self._to_half(kmap2, eng)
+            return HalfPlane(eng.f2power(a.t.contiguous(), b.t.contiguous(), norm), eng)
+        eng = self._eng(kmap1)
+        a, b = eng.to_complex(kmap1), eng.to_complex(kmap2)
+        return _ret(eng.f2power(a, b, norm), kmap1)
+
+    def f1power(self, map1, kmap2, pixel_units=False, nthread=0):
+        """maps.py:1626-1630."""
+        kmap1 = self.iqu2teb(map1, nthread, normalize=False)
+        return self.f2power(kmap1, kmap2, pixel_units), kmap1
+
+    def ifft(self, kmap):
+        """maps.py:1632-1633: inverse C2C divided by Npix; returns complex like
+        the reference (HalfPlane input -> real map via C2R, the imaginary part is
+        identically zero there)."""
+        torch = _torch()
+        if isinstance(kmap, HalfPlane):
+            eng = kmap.eng
+            planes, lead = _planes(kmap.t)
+            outs = [eng.irfft(p.contiguous()) for p in planes]
+            return torch.stack(outs).reshape(lead + (eng.ny, eng.nx))
+        eng = self._eng(kmap)
+        z = eng.to_complex(kmap)
+        planes, lead = _planes(z)
+        outs = [eng.cfft(p.contiguous(), inverse=True, scale=1.0 / eng.npix) for p in planes]
+        return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), kmap)
+
+    def fft(self, emap):
+        """maps.py:1635-1636: unnormalised forward transform."""
+        torch = _torch()
+        cplx = (isinstance(emap, np.ndarray) and np.iscomplexobj(emap)) or (_is_tensor(emap) and emap.is_complex())
+        if cplx:
+            eng = self._eng(emap)
+            z = eng.to_complex(emap)
+            planes, lead = _planes(z)
+            outs = [eng.cfft(p.contiguous()) for p in planes]
+            return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), emap)
+        eng = self._eng(emap)
+        hs, lead = self._fft_real_planes(emap, eng, 1.0)
+        return self._wrap_k(hs, lead, eng, emap)
+
+    def power2d(self, emap=None, emap2=None, nthread=0, pixel_units=False, skip_cross=False, rot=True, kmap=None,
+                kmap2=None, dtype=None):
+        """maps.py:1639-1677."""
+        torch = _torch()
+        if kmap is not None:
+            lteb1 = kmap
+            ndim = len(kmap.shape)
+            if ndim > 2:
+                ncomp = kmap.shape[-3]
+        else:
+            lteb1 = self.iqu2teb(emap, nthread, normalize=False, rot=rot)
+            ndim = emap.ndim
+            if ndim > 2:
+                ncomp = emap.shape[-3]
+        if kmap2 is not None:
+            lteb2 = kmap2
+        else:
+            lteb2 = self.iqu2teb(emap2, nthread, normalize=False, rot=rot) if emap2 is not None else lteb1
+        assert tuple(lteb1.shape) == tuple(lteb2.shape)
+        if ndim > 2 and ncomp > 1:
+            pw = {}
+            for i in range(ncomp):
+                pw[(i, i)] = self.f2power(lteb1[i], lteb2[i], pixel_units)
+            if not skip_cross:
+                for i in range(ncomp):
+                    for j in range(i + 1, ncomp):
+                        pw[(i, j)] = self.f2power(lteb1[i], lteb2[j], pixel_units)
+                        pw[(j, i)] = pw[(i, j)]
+            first = pw[(0, 0)]
+            if isinstance(first, HalfPlane):
+                eng = first.eng
+                ret = torch.zeros((ncomp, ncomp, eng.ny, eng.kp), dtype=first.t.dtype, device=first.t.device)
+                for (i, j), v in pw.items():
+                    ret[i, j] = v.t
+                retpow = HalfPlane(ret, eng)
+            elif isinstance(first, np.ndarray):
+                retpow = np.zeros((ncomp, ncomp) + first.shape[-2:], dtype=dtype)
+                for (i, j), v in pw.items():
+                    retpow[i, j] = v
+            else:
+                retpow = torch.zeros((ncomp, ncomp) + tuple(first.shape[-2:]), dtype=first.dtype, device=first.device)
+                for (i, j), v in pw.items():
+                    retpow[i, j] = v
+            return retpow, lteb1, lteb2
+        if len(lteb1.shape) > 2:
+            lteb1 = lteb1[0]
+        if len(lteb2.shape) > 2:
+            lteb2 = lteb2[0]
+        p2d = self.f2power(lteb1, lteb2, pixel_units)
+        return p2d, lteb1, lteb2
+
+
+def filter_map(imap, kfilter):
+    """maps.py:1922-1923: Re(IFFT(FFT(m) * F)), IFFT / Npix.  ``kfilter`` is a
+    real (or int) full-plane (Ny,Nx) array; an even-symmetric filter keeps the
+    result exactly real and allows the half-plane R2C/C2R path, a general real
+    filter takes the C2C path like the reference."""
+    torch = _torch()
+    from .engine import precision_of
+    shape = tuple(imap.shape)
+    eng = _engine(shape, precision_of(imap))
+    x = eng.to_real(imap)
+    f = kfilter
+    if isinstance(f, np.ndarray) and np.iscomplexobj(f):
+        raise NotImplementedError("complex k-space filters are outside the reference's hot path")
+    fdev = eng.to_real(np.broadcast_to(np.asarray(f, dtype=np.float64), shape[-2:]) if not _is_tensor(f) else f)
+    planes, lead = _planes(x)
+    # even-symmetry test decides the fast path
+    flipped = torch.roll(torch.flip(fdev, dims=(0, 1)), shifts=(1, 1), dims=(0, 1))
+    if torch.equal(fdev, flipped):
+        fh = eng.fullreal_to_hc(fdev)
+        outs = []
+        for p in planes:
+            k = eng.rfft(p.contiguous())
+            k = eng.cmul_real(k, fh, out=k)
+            outs.append(eng.irfft(k))
+    else:
+        outs = []
+        for p in planes:
+            k = eng.hc_to_full(eng.rfft(p.contiguous()))
+            k = eng.cmul_real(k, fdev, out=k)
+            outs.append(torch.real(eng.cfft(k, inverse=True, scale=1.0 / eng.npix)).contiguous())
+    return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), imap)
+
+
+def multi_pow(cov, exp):
+    """pixell enmap.multi_pow (host, one-off per MapGen)."""
+    nc = cov.shape[0]
+    if nc == 1:
+        return np.abs(cov) ** exp
+    m = np.moveaxis(cov.reshape(nc, nc, -1), -1, 0)
+    w, v = np.linalg.eigh(m)
+    w = np.where(w > 0, w, 0.0) ** exp
+    res = np.einsum("pab,pb,pcb->pac", v, w, v)
+    return np.moveaxis(res, 0, -1).reshape(cov.shape)
+
+
+class MapGen(object):
+    """maps.py:1553-1587.  ``cov`` must be the 4-D per-mode covariance
+    (ncomp,ncomp,Ny,Nx); the 3-D (ncomp,ncomp,lmax) form relies on
+    pixell.spec2flat's interpolation -- use :func:`spec1d_to_2d` first.
+
+    ``get_map`` draws on the device (Philox; the reference's global
+    Mersenne-Twister stream cannot and need not be reproduced);
+    ``get_map_from_rand`` applies the reference arithmetic to caller-supplied
+    white noise (the parity entry point)."""
+
+    def __init__(self, shape, wcs, cov=None, covsqrt=None, pixel_units=False, smooth="auto", ndown=None, order=1,
+                 dtype="f32"):
+        self.shape = tuple(shape)
+        self.wcs = wcs
+        self.geom = as_geometry(shape, wcs)
+        self.prec = dtype
+        if covsqrt is not None:
+            self.covsqrt = np.asarray(covsqrt)
+        else:
+            assert cov is not None and cov.ndim >= 3, \
+                "Power spectra have to be of shape (ncomp,ncomp,lmax) or (ncomp,ncomp,Ny,Nx)."
+            if cov.ndim != 4:
+                raise NotImplementedError("pass a 4-D (ncomp,ncomp,Ny,Nx) covariance (see maps.spec1d_to_2d)")
+            if ndown:
+                raise NotImplementedError("downsample_power is outside the hot path")
+            if not pixel_units:
+                cov = cov * np.prod(self.shape[-2:]) / self.geom.area
+            self.covsqrt = multi_pow(cov, 0.5)
+        self.ncomp = self.covsqrt.shape[0]
+        self._cs_dev = {}
+        self._calls = 0
+
+    def _covsqrt_hc(self, eng):
+        key = eng.prec
+        if key not in self._cs_dev:
+            nc = self.ncomp
+            self._cs_dev[key] = [[eng.fullreal_to_hc(eng.to_real(self.covsqrt[i, j])) for j in range(nc)] for i in range(nc)]
+        return self._cs_dev[key]
+
+    def get_map(self, seed=None, scalar=False, iau=False, real=False, harm=False):
+        """maps.py:1576-1587 semantics with an on-device Hermitian draw:
+        C2R of covsqrt * (Hermitian unit white noise) with the unitary scale is
+        statistically identical to ``enmap.ifft(covsqrt * rand_gauss_harm).real``."""
+        torch = _torch()
+        eng = _engine(self.shape, self.prec)
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        elif isinstance(seed, (tuple, list)):
+            seed = int(np.random.SeedSequence(list(seed)).generate_state(1, dtype=np.uint64)[0] >> 1)
+        cs = self._covsqrt_hc(eng)
+        nc = self.ncomp
+        white = [eng.grf_hc(seed, c) for c in range(nc)]
+        ks = []
+        for i in range(nc):
+            acc = None
+            for j in range(nc):
+                if not np.any(self.covsqrt[i, j]):
+                    continue
+                term = eng.cmul_real(white[j], cs[i][j])
+                acc = term if acc is None else acc + term
+            ks.append(acc if acc is not None else eng.hc())
+        if harm:
+            return HalfPlane(torch.stack(ks) if len(self.shape) > 2 else ks[0], eng)
+        if not scalar and nc == 3:
+            # harm2map: E,B -> Q,U by the inverse rotation, then inverse FFT
+            rot = queb_rotmat(self.geom.lmap(), inverse=True, iau=iau)
+            c = eng.fullreal_to_hc(eng.to_real(rot[0, 0]))
+            s = eng.fullreal_to_hc(eng.to_real(rot[1, 0]))
+            ks[1], ks[2] = eng.rot2(c, s, ks[1], ks[2])
+        outs = [eng.irfft(k, scale=1.0 / np.sqrt(eng.npix)) for k in ks]
+        if len(self.shape) > 2:
+            return torch.stack(outs)
+        return outs[0]
+
+    def get_map_from_rand(self, rand, scalar=False, iau=False, harm=False):
+        """Reference arithmetic (maps.py:1579-1587) on a caller-supplied complex
+        white-noise array ``rand`` (what pixell.rand_gauss_harm would return):
+        covsqrt * rand, unitary inverse C2C, real part."""
+        torch = _torch()
+        from .engine import precision_of
+        eng = _engine(self.shape, precision_of(rand))
+        z = eng.to_complex(rand)
+        planes, lead = _planes(z)
+        nc = self.ncomp
+        cs = [[eng.to_real(self.covsqrt[i, j]) for j in range(nc)] for i in range(nc)]
+        ks = []
+        for i in range(nc):
+            acc = None
+            for j in range(nc):
+                term = eng.cmul_real(planes[j].contiguous(), cs[i][j])
+                acc = term if acc is None else acc + term
+            ks.append(acc)
+        if harm:
+            return _ret(torch.stack(ks).reshape(lead + (eng.ny, eng.nx)), rand)
+        if not scalar and nc == 3:
+            rot = queb_rotmat(self.geom.lmap(), inverse=True, iau=iau)
+            ks[1], ks[2] = eng.rot2(eng.to_real(rot[0, 0]), eng.to_real(rot[1, 0]), ks[1], ks[2])
+        outs = [torch.real(eng.cfft(k.contiguous(), inverse=True, scale=1.0 / np.sqrt(eng.npix))).contiguous() for k in ks]
+        return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), rand)
+
+
+def spec1d_to_2d(shape, wcs, ells, cls):
+    """Isotropic 1-D spectrum -> per-mode (Ny,Nx) plane by linear interpolation,
+    0 outside the table (SURVEY.md section 8d synthetic-input convention; the
+    reference's maps.spec1d_to_2d, maps.py:1590-1591, uses pixell.spec2flat)."""
+    ml = as_geometry(shape, wcs).modlmap()
+    return np.interp(ml, ells, cls, left=0.0, right=0.0)
+
+
+def binned_power(imap, bin_edges=None, binner=None, fc=None, modlmap=None, imap2=None, mask=1, wcs=None):
+    """maps.py:1350-1361 (``wcs`` is explicit because arrays carry none here)."""
+    from . import stats
+    shape = imap.shape
+    if fc is None:
+        fc = FourierCalc(shape, wcs)
+    modlmap = fc.geom.modlmap() if modlmap is None else modlmap
+    binner = stats.bin2D(modlmap, bin_edges) if binner is None else binner
+    p2d, _, _ = fc.power2d(imap * mask, imap2 * mask if imap2 is not None else None)
+    cents, p1d = binner.bin(p2d)
+    return cents, p1d / np.mean(mask ** 2.)

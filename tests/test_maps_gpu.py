@@ -1,0 +1,203 @@
+"""GPU parity of orphics_amd.maps / stats (through the C-ABI) vs the NumPy oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import maps_oracle as mo  # noqa: E402
+from oracle import stats_oracle as so  # noqa: E402
+
+RES = 2.0
+
+
+def geom(shape, res=RES):
+    from orphics_amd.geometry import FlatGeometry
+    return FlatGeometry.from_res(shape, res)
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - b).max() / np.abs(b).max()
+
+
+@pytest.mark.parametrize("dt,tol", [(np.float64, 1e-12), (np.float32, 5e-6)])
+def test_fouriercalc_scalar(dt, tol):
+    from orphics_amd import maps
+    shape = (128, 256)
+    g = geom(shape)
+    fc = maps.FourierCalc(shape, g)
+    fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+    assert fc.normfact == fo.normfact
+    rng = np.random.default_rng(0)
+    m1 = rng.standard_normal(shape).astype(dt)
+    m2 = rng.standard_normal(shape).astype(dt)
+    assert rel(fc.fft(m1), fo.fft(m1)) < tol
+    p, k1, k2 = fc.power2d(m1, m2)
+    po, k1o, k2o = fo.power2d(m1.astype(np.float64), m2.astype(np.float64))
+    assert isinstance(p, np.ndarray) and p.shape == shape and k1.shape == shape
+    assert rel(p, po) < 20 * tol and rel(k1, k1o) < tol and rel(k2, k2o) < tol
+    p2, _, _ = fc.power2d(kmap=k1, kmap2=k2)
+    assert rel(p2, po) < 20 * tol
+    pp, kk = fc.f1power(m1, k2)
+    assert rel(pp, po) < 20 * tol
+    assert rel(fc.f2power(k1, k2, pixel_units=True), fo.f2power(k1o, k2o, pixel_units=True)) < 20 * tol
+    z = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex128 if dt == np.float64 else np.complex64)
+    assert rel(fc.ifft(z), fo.ifft(z.astype(np.complex128))) < tol
+    assert rel(fc.iqu2teb(m1, normalize=True), fo.iqu2teb(m1.astype(np.float64), normalize=True)) < tol
+
+
+def test_fouriercalc_pol_and_half_layout():
+    from orphics_amd import maps
+    from orphics_amd.stats import HalfPlane
+    shape = (3, 64, 128)
+    g = geom(shape)
+    rng = np.random.default_rng(1)
+    m = rng.standard_normal(shape)
+    for iau in (False, True):
+        fc = maps.FourierCalc(shape, g, iau=iau)
+        fo = mo.FourierCalc(shape, g.step_y, g.step_x, iau=iau)
+        p, k1, _ = fc.power2d(m)
+        po, k1o, _ = fo.power2d(m)
+        assert p.shape == (3, 3, 64, 128)
+        assert rel(k1, k1o) < 1e-12 and rel(p, po) < 1e-11
+        ps, _, _ = fc.power2d(m, skip_cross=True)
+        assert np.all(ps[0, 1] == 0) and rel(ps[1, 1], po[1, 1]) < 1e-11
+    fh = maps.FourierCalc(shape, g, layout="half")
+    ph, kh, _ = fh.power2d(m)
+    assert isinstance(ph, HalfPlane) and isinstance(kh, HalfPlane)
+    # half layout follows the Hermitian convention at the self-conjugate Nyquist row/column
+    # (where the reference's full-plane E/B are not Hermitian); everything else is identical
+    pref = mo.FourierCalc(shape, g.step_y, g.step_x).power2d(m)[0]
+    got = ph.numpy()
+    keep = np.ones(shape[-2:], bool); keep[shape[-2] // 2, :] = False; keep[:, shape[-1] // 2] = False
+    assert rel(got[..., keep], pref[..., keep]) < 1e-11
+    back = fh.ifft(kh[0]).cpu().numpy()
+    assert rel(back, m[0]) < 1e-12
+
+
+def test_filter_map_beam_mask():
+    from orphics_amd import maps
+    shape = (128, 128)
+    g = geom(shape)
+    ml = g.modlmap()
+    rng = np.random.default_rng(2)
+    m = rng.standard_normal((2,) + shape)
+    kb = maps.gauss_beam(ml, 1.5)
+    assert np.array_equal(kb, mo.gauss_beam(ml, 1.5))
+    assert rel(maps.filter_map(m, kb), mo.filter_map(m, kb)) < 1e-12
+    assert np.allclose(maps.filter_map(m, np.ones(shape)), m, atol=1e-13)
+    for kw in (dict(lmin=300, lmax=2000), dict(lxcut=90, lycut=50), dict(lmin=100, lxcut=20)):
+        a = maps.mask_kspace(shape, g, **kw)
+        b = mo.mask_kspace(shape, g.step_y, g.step_x, **kw)
+        assert a.dtype == b.dtype and np.array_equal(a, b)
+    km = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    assert rel(maps.filter_map(m[0], km), mo.filter_map(m[0], km)) < 1e-12
+    # a non-symmetric real filter takes the general (C2C) path
+    f = rng.uniform(0, 1, shape)
+    assert rel(maps.filter_map(m[0], f), mo.filter_map(m[0], f)) < 1e-12
+    t, w2 = maps.get_taper(shape, g)
+    to, w2o = mo.get_taper(shape)
+    assert np.array_equal(t, to) and w2 == w2o
+
+
+def test_mapgen_parity_and_statistics():
+    from orphics_amd import maps
+    shape = (128, 128)
+    g = geom(shape)
+    ml = g.modlmap()
+    cov = (1.0 / (1 + (ml / 500.) ** 2)).reshape((1, 1) + shape)
+    mg = maps.MapGen(shape, g, cov, dtype="f64")
+    mgo = mo.MapGen(shape, g.step_y, g.step_x, cov)
+    assert np.allclose(mg.covsqrt, mgo.covsqrt)
+    rng = np.random.default_rng(3)
+    rand = rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+    assert rel(mg.get_map_from_rand(rand, scalar=True), mgo.get_map_from_rand(rand, scalar=True)) < 1e-12
+    # device draws: power of the realisations matches the input spectrum
+    fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+    acc = 0
+    for s in range(24):
+        acc = acc + fo.power2d(mg.get_map(seed=s, scalar=True).cpu().numpy())[0]
+    ratio = (acc / 24)[ml > 0] / cov[0, 0][ml > 0]
+    assert abs(ratio.mean() - 1) < 0.02
+    a = mg.get_map(seed=5, scalar=True); b = mg.get_map(seed=5, scalar=True); c = mg.get_map(seed=6, scalar=True)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    # polarised: TT/EE/TE spectra of the (T,Q,U) draw
+    shape3 = (3,) + shape
+    tt = 1.0 / (1 + (ml / 500.) ** 2); ee = 0.1 * tt; te = 0.15 * tt
+    cov3 = np.zeros((3, 3) + shape); cov3[0, 0] = tt; cov3[1, 1] = ee; cov3[0, 1] = cov3[1, 0] = te; cov3[2, 2] = 0.01 * tt
+    mg3 = maps.MapGen(shape3, geom(shape3), cov3, dtype="f64")
+    fo3 = mo.FourierCalc(shape3, g.step_y, g.step_x)
+    acc = 0
+    for s in range(24):
+        acc = acc + fo3.power2d(mg3.get_map(seed=100 + s).cpu().numpy())[0]
+    acc /= 24
+    sel = (ml > 200) & (ml < 3000)
+    assert abs(acc[0, 0][sel].sum() / tt[sel].sum() - 1) < 0.03
+    assert abs(acc[1, 1][sel].sum() / ee[sel].sum() - 1) < 0.03
+    assert abs(acc[0, 1][sel].sum() / te[sel].sum() - 1) < 0.06
+    assert abs(acc[2, 2][sel].sum() / (0.01 * tt)[sel].sum() - 1) < 0.03
+    rand3 = rng.standard_normal(shape3) + 1j * rng.standard_normal(shape3)
+    mgo3 = mo.MapGen(shape3, g.step_y, g.step_x, cov3)
+    assert rel(mg3.get_map_from_rand(rand3), mgo3.get_map_from_rand(rand3)) < 1e-11
+
+
+def test_bin2d_against_reference_golden(golden_dir):
+    """Product bin2D (HIP) vs the fixtures produced by the real orphics.stats.bin2D."""
+    from orphics_amd import stats
+    g = np.load(os.path.join(golden_dir, "bin2d_reference.npz"))
+    b = stats.bin2D(g["a_modlmap"], g["a_edges"])
+    assert np.array_equal(b.digitized, g["a_digitized"])
+    assert b.digitized.dtype == np.int64
+    c, r, cnt = b.bin(g["a_data"], get_count=True)
+    assert np.array_equal(c, g["a_cents"]) and np.array_equal(cnt, g["a_count"])
+    np.testing.assert_allclose(r, g["a_res"], rtol=1e-13)
+    np.testing.assert_allclose(b.bin(g["a_data"], weights=g["a_weights"])[1], g["a_res_w"], rtol=1e-13)
+    _, r, cnt = b.bin(g["a_data_nan"], mask_nan=True, get_count=True)
+    assert np.array_equal(cnt, g["a_count_nan"])
+    np.testing.assert_allclose(r, g["a_res_nan"], rtol=1e-13)
+    _, _, s = b.bin(g["a_data"], err=True)
+    np.testing.assert_allclose(s, so.bin2D(g["a_modlmap"], g["a_edges"]).bin(g["a_data"], err=True)[2], rtol=1e-10)
+    bt = stats.bin2D(g["t_modlmap"], g["t_edges"])
+    assert np.array_equal(bt.digitized, g["t_digitized"])  # exact ties on integer edges
+    _, r, cnt = bt.bin(g["t_data"], get_count=True)
+    assert np.array_equal(cnt, g["t_count"])
+    np.testing.assert_allclose(r, g["t_res"], rtol=1e-13)
+    b3 = stats.bin2D(g["h3_modrmap"], g["h3_edges"])  # H3 quirk reproduced
+    c3, r3 = b3.bin(g["h3_data"])
+    np.testing.assert_allclose(r3, g["h3_res"])
+    assert np.array_equal(stats.bin2D(g["tie_vals"], g["tie_edges"]).digitized, g["tie_digitized"])
+    c, r = stats.bin_in_annuli(g["a_data"], g["a_modlmap"], g["a_edges"])
+    np.testing.assert_allclose(r, g["a_res"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("N,res", [(1024, 2.0)])
+def test_config1_power2d_bin2d(N, res):
+    """BASELINE config 1: 1024^2 2' GRF auto-spectrum + bin2D, full- and half-plane paths."""
+    from orphics_amd import maps, stats
+    shape = (N, N)
+    g = geom(shape, res)
+    ml = g.modlmap()
+    rng = np.random.default_rng(0)
+    m = rng.standard_normal(shape)
+    edges = np.arange(100, 3000, 40.)
+    fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+    bo = so.bin2D(ml, edges)
+    co, ro = bo.bin(fo.power2d(m)[0])
+    binner = stats.bin2D(ml, edges)
+    assert np.array_equal(binner.digitized, bo.digitized)
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 1e-5)):
+        fc = maps.FourierCalc(shape, g)
+        p2d, _, _ = fc.power2d(m.astype(dt))
+        c, r, cnt = binner.bin(p2d, get_count=True)
+        assert np.array_equal(cnt, bo.bin(m, get_count=True)[2])
+        assert np.max(np.abs(r / ro - 1)) < tol
+        fh = maps.FourierCalc(shape, g, layout="half")
+        ph, _, _ = fh.power2d(torch.as_tensor(m.astype(dt)).cuda())
+        c2, r2, cnt2 = binner.bin(ph, get_count=True)
+        assert np.array_equal(cnt2, cnt)
+        assert np.max(np.abs(r2 / ro - 1)) < tol
+    assert abs(np.mean(ro) / g.pixarea - 1) < 0.02   # white noise -> pixel area
+    c3, r3 = maps.binned_power(m, bin_edges=edges, wcs=g)
+    assert np.max(np.abs(r3 / ro - 1)) < 1e-12

@@ -1,0 +1,173 @@
+"""CPU: the NumPy oracle against the golden vectors generated from the real
+reference (tests/golden/make_golden.py) and against analytic known answers."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import maps_oracle as mo
+from oracle import qe_oracle as qo
+from oracle import stats_oracle as so
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "bin2d_reference.npz"))
+
+
+def test_bin2d_indices_counts_bit_exact(g):
+    b = so.bin2D(g["a_modlmap"], g["a_edges"])
+    assert np.array_equal(b.digitized, g["a_digitized"])
+    c, r, cnt = b.bin(g["a_data"], get_count=True)
+    assert np.array_equal(cnt, g["a_count"])
+    assert np.array_equal(c, g["a_cents"])
+    np.testing.assert_allclose(r, g["a_res"], rtol=1e-15, atol=0)
+
+
+def test_bin2d_weighted_nan_err(g):
+    b = so.bin2D(g["a_modlmap"], g["a_edges"])
+    _, r = b.bin(g["a_data"], weights=g["a_weights"])
+    np.testing.assert_allclose(r, g["a_res_w"], rtol=1e-15)
+    _, r, cnt = b.bin(g["a_data_nan"], mask_nan=True, get_count=True)
+    assert np.array_equal(cnt, g["a_count_nan"])
+    np.testing.assert_allclose(r, g["a_res_nan"], rtol=1e-15)
+    with np.errstate(all="ignore"):
+        _, _, s = b.err_reference_shifted(g["a_data"])
+    np.testing.assert_allclose(s, g["a_err_ref_shifted"], rtol=1e-13)
+    # intended statistic: constant-within-bin data has zero scatter
+    const = b.digitized.reshape(g["a_data"].shape).astype(float)
+    _, _, s0 = b.bin(const, err=True)
+    assert np.allclose(s0, 0)
+
+
+def test_bin2d_exact_ties_and_quirks(g):
+    bt = so.bin2D(g["t_modlmap"], g["t_edges"])
+    assert np.array_equal(bt.digitized, g["t_digitized"])
+    _, r, cnt = bt.bin(g["t_data"], get_count=True)
+    assert np.array_equal(cnt, g["t_count"])
+    np.testing.assert_allclose(r, g["t_res"], rtol=1e-15)
+    b3 = so.bin2D(g["h3_modrmap"], g["h3_edges"])
+    c3, r3 = b3.bin(g["h3_data"])
+    assert c3.size == 3 and r3.size == g["h3_res"].size == 2  # H3: a real bin is dropped
+    np.testing.assert_allclose(r3, g["h3_res"])
+    assert np.array_equal(so.bin2D(g["tie_vals"], g["tie_edges"]).digitized, g["tie_digitized"])
+    assert list(g["tie_digitized"]) == [0, 1, 2, 3, 4]
+
+
+def test_get_stats_and_moments(golden_dir):
+    s = np.load(os.path.join(golden_dir, "stats_reference.npz"))
+    X = s["X"]
+    st = so.get_stats(X)
+    for k in ("mean", "cov", "covmean", "err", "errmean", "corr"):
+        np.testing.assert_allclose(st[k], s["gs_" + k], rtol=1e-13, atol=1e-15)
+    parts = [(10, X[:10].sum(0), X[:10].T @ X[:10]), (27, X[10:].sum(0), X[10:].T @ X[10:])]
+    n, S, C = so.moments_merge(parts)
+    mean, cov = so.moments_mean_cov(n, S, C)
+    np.testing.assert_allclose(mean, s["st_mean"], rtol=1e-13)
+    np.testing.assert_allclose(cov, s["st_cov"], rtol=1e-10, atol=1e-12)
+
+
+def test_mpi_distribute(golden_dir):
+    m = np.load(os.path.join(golden_dir, "mpi_reference.npz"))
+    for nt, nc in m["pairs"]:
+        num_each, dist = so.mpi_distribute(int(nt), int(nc))
+        assert np.array_equal(num_each, m[f"num_each_{nt}_{nc}"])
+        assert np.array_equal([d[0] for d in dist], m[f"first_{nt}_{nc}"])
+
+
+# ---- analytic known answers for the unpinned (pixell-boundary) pieces --------
+RES = 2.0 * np.pi / 180. / 60.
+
+
+def test_white_noise_power_is_pixel_area():
+    shape = (256, 256)
+    fc = mo.FourierCalc(shape, RES, -RES)
+    rng = np.random.default_rng(0)
+    p2d, _, _ = fc.power2d(rng.standard_normal(shape))
+    assert abs(p2d.mean() / RES ** 2 - 1) < 0.02
+
+
+def test_single_mode_delta_and_unit_filter():
+    shape = (64, 64)
+    fc = mo.FourierCalc(shape, RES, -RES)
+    y, x = np.mgrid[:64, :64]
+    m = np.cos(2 * np.pi * (3 * y + 5 * x) / 64.)
+    p2d, _, _ = fc.power2d(m)
+    nz = np.argwhere(p2d > 1e-12 * p2d.max())
+    assert {tuple(v) for v in nz} == {(3, 5), (61, 59)}
+    rng = np.random.default_rng(1)
+    z = rng.standard_normal(shape)
+    assert np.allclose(mo.filter_map(z, np.ones(shape)), z)
+    assert mo.mask_kspace(shape, RES, -RES, lmin=300, lmax=2000).dtype.kind == "i"
+
+
+def test_mapgen_power_matches_input():
+    shape = (128, 128)
+    ml = mo.modlmap(shape, RES, -RES)
+    cov = (1.0 / (1 + (ml / 500.) ** 2)).reshape((1, 1) + shape)
+    mg = mo.MapGen(shape, RES, -RES, cov)
+    fc = mo.FourierCalc(shape, RES, -RES)
+    acc = 0
+    for s in range(20):
+        m = mg.get_map(seed=s, scalar=True)
+        acc = acc + fc.power2d(m)[0]
+    ratio = (acc / 20)[ml > 0] / cov[0, 0][ml > 0]
+    assert abs(ratio.mean() - 1) < 0.02
+
+
+def _tt_setup(N=32, res_arcmin=4.0):
+    res = res_arcmin * np.pi / 180. / 60.
+    shape = (N, N)
+    ml = mo.modlmap(shape, res, -res)
+    cl = 1e3 / (1 + (ml / 300.) ** 3)
+    noise = np.full(shape, (10.0 * np.pi / 180. / 60.) ** 2)
+    beam = mo.gauss_beam(ml, 3.0)
+    kmask = mo.mask_kspace(shape, res, -res, lmin=100, lmax=1800)
+    return shape, res, ml, cl, noise, beam, kmask
+
+
+def test_qe_response_matches_brute_force():
+    shape, res, ml, cl, noise, beam, kmask = _tt_setup()
+    q = qo.QEOracleTT(shape, res, -res, cl, cl, noise, beam, kmask)
+    ct = cl + noise / beam ** 2
+    wg = cl / ct * kmask
+    wh = 1. / ct * kmask
+    ly, lx = mo.laxes(shape, res, -res)
+    for (yi, xi) in [(1, 0), (0, 2), (3, 29), (5, 5)]:
+        bf = qo.brute_force_response_tt(ly, lx, q.area, wg, wh, cl, yi, xi)
+        assert abs(q.R[yi, xi] / bf - 1) < 1e-10
+
+
+def test_qe_linear_response_recovers_injected_phi():
+    """T' = T + grad(phi).grad(T) to first order: <kappa_hat> must equal the
+    injected kappa mode (average over CMB realisations)."""
+    shape, res, ml, cl, noise, beam, kmask = _tt_setup(N=64, res_arcmin=3.0)
+    nonoise = noise * 0
+    q = qo.QEOracleTT(shape, res, -res, cl, cl, nonoise, np.ones(shape), kmask)
+    ly, lx = mo.laxes(shape, res, -res)
+    LY, LX = np.meshgrid(ly, lx, indexing="ij")
+    npix = shape[0] * shape[1]
+    phik = np.zeros(shape, complex)
+    yi, xi = 2, 3
+    amp = 1e-7 * npix
+    phik[yi, xi] = amp
+    phik[-yi, -xi] = amp
+    gpx = np.fft.ifft2(1j * LX * phik).real
+    gpy = np.fft.ifft2(1j * LY * phik).real
+    rng = np.random.default_rng(3)
+    acc = 0
+    nsim = 60
+    for i in range(nsim):
+        tk = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)) * np.sqrt(cl * npix / q.pixarea / 2.)
+        t = np.fft.ifft2(tk).real * np.sqrt(2.)
+        tkk = np.fft.fft2(t)
+        tx = np.fft.ifft2(1j * LX * tkk).real
+        ty = np.fft.ifft2(1j * LY * tkk).real
+        tl = t + gpx * tx + gpy * ty
+        # difference with the unlensed reconstruction removes the Gaussian (N0) noise exactly
+        acc = acc + (q.kappa_ft(np.fft.fft2(tl)) - q.kappa_ft(tkk))[yi, xi]
+    est = acc / nsim
+    L = ml[yi, xi]
+    expected = L * (L + 1) / 2. * amp
+    assert abs(est.real / expected - 1) < 0.05
+    assert abs(est.imag / expected) < 0.05
