@@ -68,6 +68,10 @@ int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx);
 int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, void* stream);
 int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, void* stream);
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream);
+/* One constituent pass of the transforms above, for per-kernel timing (bench.py roofline):
+ * pass_id 0 = R2C row pass (real in -> hc out), 1 = column pass 1 (hc -> hc, out != in),
+ * 2 = column pass 2 (in place on `out`; `in` ignored), 3 = C2R row pass (hc -> real). */
+int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of

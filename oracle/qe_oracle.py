@@ -77,6 +77,22 @@ class QEOracleTT(object):
             self.Fnorm = -(self.modl * (self.modl + 1.) / 2.) * self.AL * self.kmask_K
         self.Nlkk = (self.modl * (self.modl + 1.)) ** 2 / 4. * self.AL
 
+    @classmethod
+    def for_timing(cls, shape, step_y, step_x, Wg, Wh, Fnorm):
+        """Instance with caller-supplied filter planes and NO response computation
+        (bench.py cpu_baseline times only the per-map path)."""
+        self = cls.__new__(cls)
+        self.shape = tuple(shape[-2:])
+        Ny, Nx = self.shape
+        ly, lx = mo.laxes(shape, step_y, step_x)
+        lyd, lxd = ly.copy(), lx.copy()
+        lyd[Ny // 2] = 0.0
+        lxd[Nx // 2] = 0.0
+        self.LYd = lyd[:, None] * np.ones((1, Nx))
+        self.LXd = np.ones((Ny, 1)) * lxd[None, :]
+        self.Wg, self.Wh, self.Fnorm = Wg, Wh, Fnorm
+        return self
+
     def _response(self, wg, wh, cr):
         """R(L) = (1/a) sum_jk L_j L_k DFT[ alpha_jk beta + gamma_j delta_k ](L)."""
         l = (self.LXd, self.LYd)

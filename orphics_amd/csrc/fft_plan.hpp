@@ -65,25 +65,28 @@ struct Fft2dPlan {
 
     // ---- full column transform of `width` columns (two passes) -------------
     // in -> out (out != in), result in natural order in `out`.
+    // which: 0 = both passes, 1 = pass 1 only, 2 = pass 2 only (microbenchmarks)
     template <class Launcher>
     void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
-              T scale) const {
+              T scale, int which = 0) const {
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
         const int tiles = (width + C - 1) / C;
         ColArgs<T> a{};
         a.width = width; a.logC = COLC; a.tw = tw_y; a.logTw = logNy; a.inverse = inverse ? 1 : 0;
-        // pass 1: length N1 over y1 (stride N2), twiddle, write block-transposed
-        a.in = in; a.in_pitch = in_pitch; a.out = out; a.out_pitch = out_pitch;
-        a.logL = logN1; a.NT = (int)((N1 * C) / EPT); a.st = make_stages(logN1);
-        a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
-        a.twiddle = (logN2 > 0) ? 1 : 0;
-        a.scale = (logN2 > 0) ? (T)1 : scale;
-        q.col(tiles, (int)N2, a.NT, (size_t)N1 * C * sizeof(cx<T>), a);
-        if (logN2 == 0) return;
+        if (which != 2) {
+            // pass 1: length N1 over y1 (stride N2), twiddle, write block-transposed
+            a.in = in; a.in_pitch = in_pitch; a.out = out; a.out_pitch = out_pitch;
+            a.logL = logN1; a.NT = (int)((N1 * C) / EPT); a.st = make_stages(logN1);
+            a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
+            a.twiddle = (logN2 > 0) ? 1 : 0;
+            a.scale = (logN2 > 0) ? (T)1 : scale;
+            q.col(tiles, (int)N2, a.NT, (size_t)N1 * C * sizeof(cx<T>), a);
+        }
+        if (logN2 == 0 || which == 1) return;
         // pass 2: length N2 over y2 (stride N1), in place, natural order out
-        a.in = out; a.in_pitch = out_pitch;
+        a.in = out; a.in_pitch = out_pitch; a.out = out; a.out_pitch = out_pitch;
         a.logL = logN2; a.NT = (int)((N2 * C) / EPT); a.st = make_stages(logN2);
         if (a.NT < 1) a.NT = 1;
         a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;

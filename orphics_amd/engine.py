@@ -184,6 +184,10 @@ class Engine(object):
         check(self.lib.oa_fft_c2c(self.plan, _ptr(z), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
         return out
 
+    def fft_pass(self, pass_id, src, dst):
+        """Launch one constituent FFT pass (per-kernel timing in bench.py)."""
+        check(self.lib.oa_fft_pass(self.plan, int(pass_id), _ptr(src), _ptr(dst), _stream()))
+
     # ---- layouts ----------------------------------------------------------------
     def hc_to_full(self, k):
         self._chk(k, "hc")
