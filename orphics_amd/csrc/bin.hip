@@ -183,22 +183,33 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
     }
 }
 
+// one workgroup per id; fixed-order strided partial sums + fixed-order LDS tree -> deterministic
 __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict__ part_sum, const double* __restrict__ part_w,
                                                         const unsigned long long* __restrict__ part_cnt, int nblocks,
                                                         int nids, int weighted, double* __restrict__ sums,
                                                         int64_t* __restrict__ counts, double* __restrict__ wsums) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nids) return;
+    __shared__ double sh_s[256];
+    __shared__ double sh_q[256];
+    __shared__ unsigned long long sh_c[256];
+    const int i = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
     unsigned long long c = 0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = t; b < nblocks; b += 256) {
         s += part_sum[(long)b * nids + i];
         if (weighted) q += part_w[(long)b * nids + i];
         else c += part_cnt[(long)b * nids + i];
     }
-    sums[i] = s;
-    if (weighted) { if (wsums) wsums[i] = q; }
-    else if (counts) counts[i] = (int64_t)c;
+    sh_s[t] = s; sh_q[t] = q; sh_c[t] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) { sh_s[t] += sh_s[t + o]; sh_q[t] += sh_q[t + o]; sh_c[t] += sh_c[t + o]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sums[i] = sh_s[0];
+        if (weighted) { if (wsums) wsums[i] = sh_q[0]; }
+        else if (counts) counts[i] = (int64_t)sh_c[0];
+    }
 }
 
 template <typename T>
@@ -228,7 +239,7 @@ static int bin_impl(const void* data, const int32_t* ids, const void* weights, c
                            skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, part_sum, part_w, part_cnt);
     }
     OA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bin_final_kernel, dim3((nids + 255) / 256), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
+    hipLaunchKernelGGL(bin_final_kernel, dim3(nids), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
                        weighted ? 1 : 0, sums, counts, wsums);
     OA_LAUNCH_CHECK();
     return 0;

@@ -15,19 +15,32 @@ struct GpuCtx {
 
 extern __shared__ __attribute__((aligned(16))) char oa_dyn_smem[];
 
-template <typename T, int MAXNT>
-__global__ __launch_bounds__(MAXNT) void row_fft_kernel(RowArgs<T> a) {
-    GpuCtx c{oa_dyn_smem};
-    row_fft_body<T>(c, a);
-}
-
-template <typename T, int MAXNT>
-__global__ __launch_bounds__(MAXNT) void col_fft_kernel(ColArgs<T> a) {
-    GpuCtx c{oa_dyn_smem};
-    col_fft_body<T>(c, a);
-}
-
+#ifndef OA_WAVES_PER_EU
+#define OA_WAVES_PER_EU 4
+#endif
 constexpr size_t LDS_MAX = 160 * 1024;
+
+// workgroup size is a function of the transform length: NT = L*C/16, L*C = 4096 up to L = 4096
+template <class SEQ>
+constexpr int seq_logl() {
+    return Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+}
+template <class SEQ> constexpr int row_maxnt() { return seq_logl<SEQ>() <= 12 ? 256 : (seq_logl<SEQ>() == 13 ? 512 : 1024); }
+template <class SEQ> constexpr int col_maxnt() { return seq_logl<SEQ>() <= 7 ? 256 : 512; }
+// float kernels fit 128 VGPRs (4 waves/SIMD); double needs the 256-register budget
+template <typename T> constexpr int waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_WAVES_PER_EU; }
+
+template <typename T, int MODE, class SEQ>
+__global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_fft_body<T, MODE, SEQ>(c, a);
+}
+
+template <typename T, class SEQ>
+__global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_fft_kernel(ColArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_fft_body<T, SEQ>(c, a);
+}
 
 struct HipLauncher {
     hipStream_t st;
@@ -50,17 +63,36 @@ struct HipLauncher {
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
     }
 
+    template <typename T, int MODE, class S>
+    void row_mode(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
+        go(row_fft_kernel<T, MODE, S>, dim3(grid), nt, smem, a);
+    }
     template <typename T>
     void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
-        if (nt <= 256) go(row_fft_kernel<T, 256>, dim3(grid), nt, smem, a);
-        else if (nt <= 512) go(row_fft_kernel<T, 512>, dim3(grid), nt, smem, a);
-        else go(row_fft_kernel<T, 1024>, dim3(grid), nt, smem, a);
+        const bool ok = dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            switch (a.mode) {
+                case ROW_R2C: row_mode<T, ROW_R2C, S>(grid, nt, smem, a); break;
+                case ROW_C2R: row_mode<T, ROW_C2R, S>(grid, nt, smem, a); break;
+                case ROW_C2C_F: row_mode<T, ROW_C2C_F, S>(grid, nt, smem, a); break;
+                default: row_mode<T, ROW_C2C_I, S>(grid, nt, smem, a); break;
+            }
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported row length");
     }
     template <typename T>
     void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
-        if (nt <= 256) go(col_fft_kernel<T, 256>, dim3(gx, gy), nt, smem, a);
-        else if (nt <= 512) go(col_fft_kernel<T, 512>, dim3(gx, gy), nt, smem, a);
-        else go(col_fft_kernel<T, 1024>, dim3(gx, gy), nt, smem, a);
+        const bool ok = dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_logl<S>() <= 8) {
+                if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
+                go(col_fft_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+            } else {
+                if (!rc) rc = fail("fft: unsupported column sub-length");
+            }
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported column length");
     }
 };
 

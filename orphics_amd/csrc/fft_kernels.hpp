@@ -6,10 +6,15 @@
 // Design (DESIGN.md section "K1"):
 //  * every thread owns EPT=16 complex points per stage: one radix-16 butterfly
 //    or 16/R radix-R butterflies, register resident, fully unrolled;
-//  * a stage = LDS->regs, twiddle (table lookup, exact to 0.5 ulp), in-register
-//    DFT-R, barrier, regs->LDS at the Stockham (autosort) position, barrier;
-//  * row passes keep a whole row (or C short rows) in LDS, padded 1 element per
-//    16 so the stride-R first-stage writes are bank-conflict free;
+//  * the FIRST stage gathers its butterfly inputs straight from global memory
+//    (per t the lanes read consecutive addresses -> coalesced) and the LAST stage
+//    scatters straight to global memory: an L = R1*R2 transform costs ONE LDS
+//    round trip and ONE barrier; load/store are functors so filters, twiddles,
+//    scales and layout changes fuse into the pass;
+//  * twiddles: 4 table loads (w^1, w^2, w^4, w^8; exact to 0.5 ulp) + <= 3
+//    complex products each, instead of 15 scattered gathers;
+//  * row passes keep whole rows in LDS, padded 1 element per 16 so the
+//    stride-R first-stage writes are bank-conflict free;
 //  * column passes work on [L points][C=32 columns] tiles so every global
 //    access is a >=256-byte contiguous segment; a length-Ny column transform is
 //    split four-step style Ny = N1*N2 into two such passes (pass 1 applies the
@@ -94,13 +99,55 @@ OA_HD int lds_addr(int n, int c, int logC, int rowStride) {
     return (n << logC) + c;
 }
 
-// ---- one Stockham stage, part A: LDS -> regs, twiddle, DFT-R --------------
-template <typename T, int R, bool ROWMAJOR>
-OA_HD void stage_a(const cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC, int rowStride,
-                   int logNs, const cx<T>* tw, int logTw) {
+// multiply v[1..R-1] by w^t, w = tab[k << sh]; powers from 4 exact loads + products
+template <typename T, int R>
+OA_HD void apply_twiddles(cx<T>* v, const cx<T>* tw, int k, int sh) {
+    const cx<T> w1 = tw[k << sh];
+    v[1] = v[1] * w1;
+    if (R >= 4) {
+        const cx<T> w2 = tw[(2 * k) << sh];
+        const cx<T> w3 = w1 * w2;
+        v[2] = v[2] * w2;
+        v[3] = v[3] * w3;
+        if (R >= 8) {
+            const cx<T> w4 = tw[(4 * k) << sh];
+            v[4] = v[4] * w4;
+            v[5] = v[5] * (w4 * w1);
+            v[6] = v[6] * (w4 * w2);
+            const cx<T> w7 = w4 * w3;
+            v[7] = v[7] * w7;
+            if (R >= 16) {
+                const cx<T> w8 = tw[(8 * k) << sh];
+                v[8] = v[8] * w8;
+                v[9] = v[9] * (w8 * w1);
+                v[10] = v[10] * (w8 * w2);
+                v[11] = v[11] * (w8 * w3);
+                const cx<T> w12 = w8 * w4;
+                v[12] = v[12] * w12;
+                v[13] = v[13] * (w12 * w1);
+                v[14] = v[14] * (w12 * w2);
+                v[15] = v[15] * (w8 * w7);
+            }
+        }
+    }
+}
+
+struct NoLoad {
+    template <typename T> OA_HD cx<T> get(int, int) const { return cx<T>{}; }
+};
+struct NoStore {
+    template <typename T> OA_HD void put(int, int, cx<T>) const {}
+};
+
+// One Stockham stage of radix R for this thread's EPT/R butterflies.
+//   src: global functor (SRC_G) or LDS;  dst: global functor (DST_G) or LDS.
+template <typename T, int R, bool ROWMAJOR, bool SRC_G, bool DST_G, class Ctx, class Ld, class St>
+OA_HD void stage(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int rowStride, int logNs,
+                 const cx<T>* tw, int logTw, const Ld& ld, const St& st) {
     constexpr int LR = Log2c<R>::v;
     constexpr int NB = EPT / R;
     const int logLR = logL - LR;
+    cx<T> v[EPT];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -108,24 +155,15 @@ OA_HD void stage_a(const cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC
         if (ROWMAJOR) { j = b & ((1 << logLR) - 1); c = b >> logLR; }
         else { c = b & ((1 << logC) - 1); j = b >> logC; }
 #pragma unroll
-        for (int t = 0; t < R; ++t)
-            v[u * R + t] = s[lds_addr<ROWMAJOR>(j + (t << logLR), c, logC, rowStride)];
-        if (logNs > 0) {
-            const int k = j & ((1 << logNs) - 1);
-            const int sh = logTw - logNs - LR;
-#pragma unroll
-            for (int t = 1; t < R; ++t) v[u * R + t] = v[u * R + t] * tw[(t * k) << sh];
+        for (int t = 0; t < R; ++t) {
+            const int n = j + (t << logLR);
+            if (SRC_G) v[u * R + t] = ld.template get<T>(n, c);
+            else v[u * R + t] = s[lds_addr<ROWMAJOR>(n, c, logC, rowStride)];
         }
+        if (logNs > 0) apply_twiddles<T, R>(v + u * R, tw, j & ((1 << logNs) - 1), logTw - logNs - LR);
         Dft<T, R>::run(v + u * R);
     }
-}
-
-// ---- part B: regs -> LDS at the autosort position -------------------------
-template <typename T, int R, bool ROWMAJOR>
-OA_HD void stage_b(cx<T>* s, const cx<T>* v, int tid, int NT, int logL, int logC, int rowStride, int logNs) {
-    constexpr int LR = Log2c<R>::v;
-    constexpr int NB = EPT / R;
-    const int logLR = logL - LR;
+    if (!SRC_G && !DST_G) ctx.sync();  // in-place: every read of this stage precedes any write
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -135,35 +173,74 @@ OA_HD void stage_b(cx<T>* s, const cx<T>* v, int tid, int NT, int logL, int logC
         const int k = j & ((1 << logNs) - 1);
         const int base = ((j - k) << LR) + k;
 #pragma unroll
-        for (int t = 0; t < R; ++t)
-            s[lds_addr<ROWMAJOR>(base + (t << logNs), c, logC, rowStride)] = v[u * R + t];
+        for (int t = 0; t < R; ++t) {
+            const int n = base + (t << logNs);
+            if (DST_G) st.template put<T>(n, c, v[u * R + t]);
+            else s[lds_addr<ROWMAJOR>(n, c, logC, rowStride)] = v[u * R + t];
+        }
     }
 }
 
-// all stages of one batch of LDS-resident sequences (forward DFT, in place).
-// Entry: data in LDS, barrier already passed.  Exit: results in LDS, barrier passed.
-template <typename T, bool ROWMAJOR, class Ctx>
-OA_HD void lds_fft(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int rowStride,
-                   const Stages& st, const cx<T>* tw, int logTw) {
-    cx<T> v[EPT];
-    int logNs = 0;
-    for (int i = 0; i < st.n; ++i) {
-        const int R = st.radix[i];
-        switch (R) {
-            case 16: stage_a<T, 16, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs, tw, logTw); break;
-            case 8: stage_a<T, 8, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs, tw, logTw); break;
-            case 4: stage_a<T, 4, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs, tw, logTw); break;
-            default: stage_a<T, 2, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs, tw, logTw); break;
-        }
+// compile-time radix sequence (unused slots = 1)
+template <int A, int B = 1, int C = 1, int D = 1>
+struct Seq {
+    static constexpr int r0 = A, r1 = B, r2 = C, r3 = D;
+    static constexpr int n = (A > 1) + (B > 1) + (C > 1) + (D > 1);
+};
+
+template <int R> struct Log2x { static constexpr int v = Log2c<R>::v; };
+template <> struct Log2x<1> { static constexpr int v = 0; };
+
+// Forward DFT of the C sequences of this workgroup, radix sequence SEQ.
+//   SRC_G: the first stage reads ld.get(n,c); otherwise data is in LDS (caller synced).
+//   DST_G: the last stage writes st.put(k,c,v); otherwise results end in LDS (synced on exit).
+template <typename T, bool ROWMAJOR, bool SRC_G, bool DST_G, class SEQ, class Ctx, class Ld, class St>
+OA_HD void fft_pipeline(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int rowStride, const cx<T>* tw,
+                        int logTw, const Ld& ld, const St& st) {
+    constexpr int n = SEQ::n;
+    constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
+    if constexpr (n == 1) {
+        stage<T, SEQ::r0, ROWMAJOR, SRC_G, DST_G>(ctx, s, tid, NT, logL, logC, rowStride, 0, tw, logTw, ld, st);
+        if (!DST_G) ctx.sync();
+    } else {
+        stage<T, SEQ::r0, ROWMAJOR, SRC_G, false>(ctx, s, tid, NT, logL, logC, rowStride, 0, tw, logTw, ld, NoStore{});
         ctx.sync();
-        switch (R) {
-            case 16: stage_b<T, 16, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs); break;
-            case 8: stage_b<T, 8, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs); break;
-            case 4: stage_b<T, 4, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs); break;
-            default: stage_b<T, 2, ROWMAJOR>(s, v, tid, NT, logL, logC, rowStride, logNs); break;
+        if constexpr (n == 2) {
+            stage<T, SEQ::r1, ROWMAJOR, false, DST_G>(ctx, s, tid, NT, logL, logC, rowStride, l0, tw, logTw, NoLoad{}, st);
+        } else {
+            stage<T, SEQ::r1, ROWMAJOR, false, false>(ctx, s, tid, NT, logL, logC, rowStride, l0, tw, logTw, NoLoad{}, NoStore{});
+            ctx.sync();
+            if constexpr (n == 3) {
+                stage<T, SEQ::r2, ROWMAJOR, false, DST_G>(ctx, s, tid, NT, logL, logC, rowStride, l1, tw, logTw, NoLoad{}, st);
+            } else {
+                stage<T, SEQ::r2, ROWMAJOR, false, false>(ctx, s, tid, NT, logL, logC, rowStride, l1, tw, logTw, NoLoad{}, NoStore{});
+                ctx.sync();
+                stage<T, SEQ::r3, ROWMAJOR, false, DST_G>(ctx, s, tid, NT, logL, logC, rowStride, l2, tw, logTw, NoLoad{}, st);
+            }
         }
-        ctx.sync();
-        logNs += ilog2(R);
+        if (!DST_G) ctx.sync();
+    }
+}
+
+// host-side dispatch: logL -> radix sequence (greedy 16s, remainder last)
+template <class F>
+inline bool dispatch_seq(int logL, F&& f) {
+    switch (logL) {
+        case 1: f(Seq<2>{}); return true;
+        case 2: f(Seq<4>{}); return true;
+        case 3: f(Seq<8>{}); return true;
+        case 4: f(Seq<16>{}); return true;
+        case 5: f(Seq<16, 2>{}); return true;
+        case 6: f(Seq<16, 4>{}); return true;
+        case 7: f(Seq<16, 8>{}); return true;
+        case 8: f(Seq<16, 16>{}); return true;
+        case 9: f(Seq<16, 16, 2>{}); return true;
+        case 10: f(Seq<16, 16, 4>{}); return true;
+        case 11: f(Seq<16, 16, 8>{}); return true;
+        case 12: f(Seq<16, 16, 16>{}); return true;
+        case 13: f(Seq<16, 16, 16, 2>{}); return true;
+        case 14: f(Seq<16, 16, 16, 4>{}); return true;
+        default: return false;
     }
 }
 
@@ -186,7 +263,27 @@ struct RowArgs {
     int mode;
 };
 
-template <typename T, class Ctx>
+template <typename T, bool SWAP>
+struct RowLoad {
+    const cx<T>* in;
+    long pitch, r0;
+    template <typename U> OA_HD cx<U> get(int n, int c) const {
+        const cx<U> x = in[(r0 + c) * pitch + n];
+        return SWAP ? swp(x) : x;
+    }
+};
+template <typename T, bool SWAP>
+struct RowStore {
+    cx<T>* out;
+    long pitch, r0;
+    T scale;
+    template <typename U> OA_HD void put(int n, int c, cx<U> v) const {
+        if (SWAP) v = swp(v);
+        out[(r0 + c) * pitch + n] = v * scale;
+    }
+};
+
+template <typename T, int MODE, class SEQ, class Ctx>
 OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
@@ -194,47 +291,27 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     const long r0 = (long)ctx.bid_x() * C;
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
-    const bool inv = (a.mode == ROW_C2C_I);
 
-    // ---- global -> LDS
-    for (int i = tid; i < (C << logL); i += NT) {
-        const int c = i >> logL, n = i & (L - 1);
-        cx<T> x = in[(r0 + c) * a.in_pitch + n];
-        if (inv) x = swp(x);
-        s[lds_addr<true>(n, c, 0, RS)] = x;
+    if constexpr (MODE == ROW_C2C_F) {
+        fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
+                                               RowLoad<T, false>{in, a.in_pitch, r0},
+                                               RowStore<T, false>{out, a.out_pitch, r0, a.scale});
+        return;
     }
-    if (a.mode == ROW_C2R && tid < C)
-        s[lds_addr<true>(L, tid, 0, RS)] = in[(r0 + tid) * a.in_pitch + L];
-    ctx.sync();
-
-    if (a.mode == ROW_C2R) {
-        // Z'[k] = (X[k]+conj X[L-k]) + i W_N^{-k} (X[k]-conj X[L-k]), stored swapped
-        const int sh = a.logTw - (logL + 1);
+    if constexpr (MODE == ROW_C2C_I) {
+        fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
+                                               RowLoad<T, true>{in, a.in_pitch, r0},
+                                               RowStore<T, true>{out, a.out_pitch, r0, a.scale});
+        return;
+    }
+    const int sh = a.logTw - (logL + 1);
+    if constexpr (MODE == ROW_R2C) {
+        fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
+                                                RowLoad<T, false>{in, a.in_pitch, r0}, NoStore{});
+        // untangle straight to global: X[k] = E + W_N^k O ; X[L-k] = conj(E - W_N^k O)
         for (int i = tid; i < (C << (logL - 1)); i += NT) {
             const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
-            for (int rep = 0; rep < 2; ++rep) {
-                const int kk = rep ? (L >> 1) : k;
-                if (rep && k != 0) break;
-                const cx<T> A = s[lds_addr<true>(kk, c, 0, RS)];
-                const cx<T> B = s[lds_addr<true>(L - kk, c, 0, RS)];
-                const cx<T> w = a.tw[kk << sh];  // W_N^k
-                const cx<T> d1 = A - conj(B), d2 = B - conj(A);
-                const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
-                const cx<T> z2 = (B + conj(A)) - mul_pi(w * d2);
-                s[lds_addr<true>(kk, c, 0, RS)] = swp(z1);
-                if (kk != 0 && 2 * kk != L) s[lds_addr<true>(L - kk, c, 0, RS)] = swp(z2);
-            }
-        }
-        ctx.sync();
-    }
-
-    lds_fft<T, true>(ctx, s, tid, NT, logL, a.logC, RS, a.st, a.tw, a.logTw);
-
-    if (a.mode == ROW_R2C) {
-        // X[k] = E + W_N^k O ; X[L-k] = conj(E - W_N^k O)
-        const int sh = a.logTw - (logL + 1);
-        for (int i = tid; i < (C << (logL - 1)); i += NT) {
-            const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
+            cx<T>* row = out + (r0 + c) * a.out_pitch;
             for (int rep = 0; rep < 2; ++rep) {
                 const int kk = rep ? (L >> 1) : k;
                 if (rep && k != 0) break;
@@ -243,23 +320,33 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
                 const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
                 const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
                 const cx<T> wO = a.tw[kk << sh] * O;
-                s[lds_addr<true>(kk, c, 0, RS)] = E + wO;
-                s[lds_addr<true>(L - kk, c, 0, RS)] = conj(E - wO);
+                row[kk] = (E + wO) * a.scale;
+                row[L - kk] = conj(E - wO) * a.scale;
             }
         }
-        ctx.sync();
+        return;
     }
-
-    // ---- LDS -> global
-    const bool swap_out = (a.mode == ROW_C2C_I || a.mode == ROW_C2R);
-    for (int i = tid; i < (C << logL); i += NT) {
-        const int c = i >> logL, n = i & (L - 1);
-        cx<T> x = s[lds_addr<true>(n, c, 0, RS)];
-        if (swap_out) x = swp(x);
-        out[(r0 + c) * a.out_pitch + n] = x * a.scale;
+    if constexpr (MODE != ROW_C2R) return;
+    // ROW_C2R: Z'[k] = (X[k]+conj X[L-k]) + i W_N^{-k} (X[k]-conj X[L-k]), stored swapped in LDS
+    for (int i = tid; i < (C << (logL - 1)); i += NT) {
+        const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
+        const cx<T>* row = in + (r0 + c) * a.in_pitch;
+        for (int rep = 0; rep < 2; ++rep) {
+            const int kk = rep ? (L >> 1) : k;
+            if (rep && k != 0) break;
+            const cx<T> A = row[kk];
+            const cx<T> B = row[L - kk];
+            const cx<T> w = a.tw[kk << sh];  // W_N^k
+            const cx<T> d1 = A - conj(B), d2 = B - conj(A);
+            const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
+            const cx<T> z2 = (B + conj(A)) - mul_pi(w * d2);
+            s[lds_addr<true>(kk, c, 0, RS)] = swp(z1);
+            if (kk != 0 && 2 * kk != L) s[lds_addr<true>(L - kk, c, 0, RS)] = swp(z2);
+        }
     }
-    if (a.mode == ROW_R2C && tid < C)
-        out[(r0 + tid) * a.out_pitch + L] = s[lds_addr<true>(L, tid, 0, RS)] * a.scale;
+    ctx.sync();
+    fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw, NoLoad{},
+                                            RowStore<T, true>{out, a.out_pitch, r0, a.scale});
 }
 
 // ===========================================================================
@@ -283,34 +370,47 @@ struct ColArgs {
     T scale;
 };
 
-template <typename T, class Ctx>
+template <typename T>
+struct ColLoad {
+    const cx<T>* base;  // already offset to (group row origin, first column)
+    long nstride;       // elements between consecutive points n
+    int ncols;          // valid columns in this tile
+    bool inv;
+    template <typename U> OA_HD cx<U> get(int n, int c) const {
+        cx<U> x = mk<U>((U)0, (U)0);
+        if (c < ncols) x = base[n * nstride + c];
+        return inv ? swp(x) : x;
+    }
+};
+template <typename T>
+struct ColStore {
+    cx<T>* base;
+    long kstride;
+    int ncols;
+    bool inv;
+    const cx<T>* tw;  // inter-pass twiddle table or nullptr
+    long g;
+    T scale;
+    template <typename U> OA_HD void put(int k, int c, cx<U> v) const {
+        if (c >= ncols) return;
+        if (tw) v = v * tw[(int)(g * k)];
+        if (inv) v = swp(v);
+        base[k * kstride + c] = v * scale;
+    }
+};
+
+template <typename T, class SEQ, class Ctx>
 OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
-    const int tid = ctx.tid(), NT = a.NT;
-    const int logL = a.logL, logC = a.logC, C = 1 << logC;
-    const int c0 = ctx.bid_x() << logC;
+    const int tid = ctx.tid();
+    const int c0 = ctx.bid_x() << a.logC;
     const long g = ctx.bid_y();
-    const int tot = 1 << (logL + logC);
-
-    for (int i = tid; i < tot; i += NT) {
-        const int c = i & (C - 1), n = i >> logC;
-        cx<T> x = mk<T>((T)0, (T)0);
-        if (c0 + c < a.width) x = a.in[(g * a.in_gs + n * a.in_ns) * a.in_pitch + c0 + c];
-        if (a.inverse) x = swp(x);
-        s[i] = x;
-    }
-    ctx.sync();
-
-    lds_fft<T, false>(ctx, s, tid, NT, logL, logC, 0, a.st, a.tw, a.logTw);
-
-    for (int i = tid; i < tot; i += NT) {
-        const int c = i & (C - 1), k = i >> logC;
-        if (c0 + c >= a.width) continue;
-        cx<T> x = s[i];
-        if (a.twiddle) x = x * a.tw[(int)(g * k)];
-        if (a.inverse) x = swp(x);
-        a.out[(g * a.out_gs + k * a.out_ks) * a.out_pitch + c0 + c] = x * a.scale;
-    }
+    int ncols = a.width - c0;
+    if (ncols > (1 << a.logC)) ncols = 1 << a.logC;
+    const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, a.in_ns * a.in_pitch, ncols, a.inverse != 0};
+    const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, a.out_ks * a.out_pitch, ncols, a.inverse != 0,
+                         a.twiddle ? a.tw : nullptr, g, a.scale};
+    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, a.logL, a.logC, 0, a.tw, a.logTw, ld, st);
 }
 
 }  // namespace oa

@@ -40,10 +40,21 @@ struct EmuLauncher {
         for (auto& x : th) x.join();
     }
     template <typename T> void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
-        run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T>(c, a); });
+        dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            switch (a.mode) {
+                case ROW_R2C: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_R2C, S>(c, a); }); break;
+                case ROW_C2R: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2R, S>(c, a); }); break;
+                case ROW_C2C_F: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2C_F, S>(c, a); }); break;
+                default: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2C_I, S>(c, a); }); break;
+            }
+        });
     }
     template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
-        run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fft_body<T>(c, a); });
+        dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fft_body<T, S>(c, a); });
+        });
     }
 };
 
