@@ -73,6 +73,16 @@ int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, dou
  * 2 = column pass 2 (in place on `out`; `in` ignored), 3 = C2R row pass (hc -> real). */
 int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream);
 
+/* Column half of the transforms above on an hc plane (all ny-point column DFTs of the nx/2+1
+ * valid columns), out != in.  With oa_qe_rows it forms the fused estimator pipeline. */
+int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, void* stream);
+/* Fused QE row stage: inputs are the three leg planes AFTER their inverse column transforms
+ * (oa_fft_cols(..., inverse=1)); per row h = C2R(H), P_x = R2C(C2R(Gx) * h), P_y = R2C(C2R(Gy) * h),
+ * product scaled by `scale` (pass (1/(ny*nx))^2 for normalised inverses).  Outputs are row-transformed
+ * planes awaiting oa_fft_cols(..., inverse=0).  Replaces 3 x oa_fft_c2r rows + 2 x oa_mul_real +
+ * 2 x oa_fft_r2c rows: the real-space planes never touch HBM. */
+int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, void* stream);
+
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of
  * a real map holds, maps.py:1613) */

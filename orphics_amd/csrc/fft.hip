@@ -36,6 +36,17 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_k
     row_fft_body<T, MODE, SEQ>(c, a);
 }
 
+#ifndef OA_QE_WAVES_PER_EU
+#define OA_QE_WAVES_PER_EU 3
+#endif
+template <typename T> constexpr int qe_waves_per_eu() { return sizeof(T) == 8 ? 1 : OA_QE_WAVES_PER_EU; }
+
+template <typename T, class SEQ>
+__global__ __launch_bounds__(row_maxnt<SEQ>(), qe_waves_per_eu<T>()) void row_qe_kernel(RowQeArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_qe_body<T, SEQ>(c, a);
+}
+
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_fft_kernel(ColArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -77,6 +88,19 @@ struct HipLauncher {
                 case ROW_C2R: row_mode<T, ROW_C2R, S>(grid, nt, smem, a); break;
                 case ROW_C2C_F: row_mode<T, ROW_C2C_F, S>(grid, nt, smem, a); break;
                 default: row_mode<T, ROW_C2C_I, S>(grid, nt, smem, a); break;
+            }
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported row length");
+    }
+    template <typename T>
+    void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
+        const bool ok = dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_logl<S>() >= 4) {
+                if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
+                go(row_qe_kernel<T, S>, dim3(grid), nt, smem, a);
+            } else {
+                if (!rc) rc = fail("fft: unsupported row length");
             }
         });
         if (!ok && !rc) rc = fail("fft: unsupported row length");
@@ -140,11 +164,38 @@ static int pass_impl(oa_plan* p, int pass_id, const void* in, void* out, hipStre
     return q.rc;
 }
 
+template <typename T>
+static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st) {
+    HipLauncher q{st};
+    view<T>(p).cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, p->nx / 2 + 1, inverse != 0, (T)scale);
+    return q.rc;
+}
+template <typename T>
+static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
+                        hipStream_t st) {
+    HipLauncher q{st};
+    view<T>(p).rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale);
+    return q.rc;
+}
+
 }  // namespace oa
 
 using namespace oa;
 
 extern "C" {
+
+int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, void* stream) {
+    OA_REQUIRE(p && hc_in && hc_out, "oa_fft_cols: NULL argument");
+    OA_REQUIRE(hc_in != hc_out, "oa_fft_cols: in-place not supported");
+    return p->dtype == OA_F32 ? cols_impl<float>(p, hc_in, hc_out, inverse, scale, (hipStream_t)stream)
+                              : cols_impl<double>(p, hc_in, hc_out, inverse, scale, (hipStream_t)stream);
+}
+
+int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, void* stream) {
+    OA_REQUIRE(p && gx && gy && h && px && py, "oa_qe_rows: NULL argument");
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, (hipStream_t)stream)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, (hipStream_t)stream);
+}
 
 int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream) {
     OA_REQUIRE(p && in && out, "oa_fft_pass: NULL argument");

@@ -133,21 +133,22 @@ OA_HD void apply_twiddles(cx<T>* v, const cx<T>* tw, int k, int sh) {
 }
 
 struct NoLoad {
+    static constexpr bool reads_lds = false;
     template <typename T> OA_HD cx<T> get(int, int) const { return cx<T>{}; }
 };
 struct NoStore {
     template <typename T> OA_HD void put(int, int, cx<T>) const {}
 };
 
-// One Stockham stage of radix R for this thread's EPT/R butterflies.
-//   src: global functor (SRC_G) or LDS;  dst: global functor (DST_G) or LDS.
-template <typename T, int R, bool ROWMAJOR, bool SRC_G, bool DST_G, class Ctx, class Ld, class St>
-OA_HD void stage(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int rowStride, int logNs,
-                 const cx<T>* tw, int logTw, const Ld& ld, const St& st) {
+// One Stockham stage of radix R for this thread's EPT/R butterflies, in two halves:
+//   stage_in : gather inputs (global functor or LDS), twiddle, in-register DFT-R
+//   stage_out: scatter to the autosort position (global functor or LDS)
+template <typename T, int R, bool ROWMAJOR, bool SRC_G, class Ld>
+OA_HD void stage_in(const cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC, int rowStride, int logNs,
+                    const cx<T>* tw, int logTw, const Ld& ld) {
     constexpr int LR = Log2c<R>::v;
     constexpr int NB = EPT / R;
     const int logLR = logL - LR;
-    cx<T> v[EPT];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -163,7 +164,14 @@ OA_HD void stage(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int ro
         if (logNs > 0) apply_twiddles<T, R>(v + u * R, tw, j & ((1 << logNs) - 1), logTw - logNs - LR);
         Dft<T, R>::run(v + u * R);
     }
-    if (!SRC_G && !DST_G) ctx.sync();  // in-place: every read of this stage precedes any write
+}
+
+template <typename T, int R, bool ROWMAJOR, bool DST_G, class St>
+OA_HD void stage_out(cx<T>* s, const cx<T>* v, int tid, int NT, int logL, int logC, int rowStride, int logNs,
+                     const St& st) {
+    constexpr int LR = Log2c<R>::v;
+    constexpr int NB = EPT / R;
+    const int logLR = logL - LR;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -181,12 +189,28 @@ OA_HD void stage(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int ro
     }
 }
 
+template <typename T, int R, bool ROWMAJOR, bool SRC_G, bool DST_G, class Ctx, class Ld, class St>
+OA_HD void stage(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int rowStride, int logNs,
+                 const cx<T>* tw, int logTw, const Ld& ld, const St& st) {
+    cx<T> v[EPT];
+    stage_in<T, R, ROWMAJOR, SRC_G>(s, v, tid, NT, logL, logC, rowStride, logNs, tw, logTw, ld);
+    if ((!SRC_G || Ld::reads_lds) && !DST_G) ctx.sync();  // in-place: every read of this stage precedes any write
+    stage_out<T, R, ROWMAJOR, DST_G>(s, v, tid, NT, logL, logC, rowStride, logNs, st);
+}
+
 // compile-time radix sequence (unused slots = 1)
 template <int A, int B = 1, int C = 1, int D = 1>
 struct Seq {
     static constexpr int r0 = A, r1 = B, r2 = C, r3 = D;
     static constexpr int n = (A > 1) + (B > 1) + (C > 1) + (D > 1);
+    static constexpr int get(int i) { return i == 0 ? A : (i == 1 ? B : (i == 2 ? C : D)); }
+    // radix of stage i of the REVERSED sequence and the log2 of the product of the stages before it
+    static constexpr int rget(int i) { return get(n - 1 - i); }
 };
+
+constexpr int clog2(int r) { return r >= 16 ? 4 : (r >= 8 ? 3 : (r >= 4 ? 2 : (r >= 2 ? 1 : 0))); }
+template <class SEQ> constexpr int fwd_logns(int i) { int a = 0; for (int m = 0; m < i; ++m) a += clog2(SEQ::get(m)); return a; }
+template <class SEQ> constexpr int rev_logns(int i) { int a = 0; for (int m = 0; m < i; ++m) a += clog2(SEQ::rget(m)); return a; }
 
 template <int R> struct Log2x { static constexpr int v = Log2c<R>::v; };
 template <> struct Log2x<1> { static constexpr int v = 0; };
@@ -265,6 +289,7 @@ struct RowArgs {
 
 template <typename T, bool SWAP>
 struct RowLoad {
+    static constexpr bool reads_lds = false;
     const cx<T>* in;
     long pitch, r0;
     template <typename U> OA_HD cx<U> get(int n, int c) const {
@@ -283,11 +308,59 @@ struct RowStore {
     }
 };
 
+// C2R prologue: half-complex rows (global) -> packed Z'[k] = (X[k]+conj X[L-k]) + i W_N^{-k} (X[k]-conj X[L-k]),
+// stored SWAPPED in LDS (the inverse runs as a forward transform of the swapped data).  Caller syncs.
+template <typename T, class Ctx>
+OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
+                        const cx<T>* tw, int logTw) {
+    const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
+    const int sh = logTw - (logL + 1);
+    for (int i = tid; i < (C << (logL - 1)); i += NT) {
+        const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
+        const cx<T>* row = in + (r0 + c) * pitch;
+        for (int rep = 0; rep < 2; ++rep) {
+            const int kk = rep ? (L >> 1) : k;
+            if (rep && k != 0) break;
+            const cx<T> A = row[kk];
+            const cx<T> B = row[L - kk];
+            const cx<T> w = tw[kk << sh];  // W_N^k
+            const cx<T> d1 = A - conj(B), d2 = B - conj(A);
+            const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
+            const cx<T> z2 = (B + conj(A)) - mul_pi(w * d2);
+            s[lds_addr<true>(kk, c, 0, RS)] = swp(z1);
+            if (kk != 0 && 2 * kk != L) s[lds_addr<true>(L - kk, c, 0, RS)] = swp(z2);
+        }
+    }
+}
+
+// R2C epilogue: packed transform Z in LDS -> X[k] = E + W_N^k O, X[L-k] = conj(E - W_N^k O), straight to global.
+template <typename T, class Ctx>
+OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
+                        const cx<T>* tw, int logTw, T scale) {
+    const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
+    const int sh = logTw - (logL + 1);
+    for (int i = tid; i < (C << (logL - 1)); i += NT) {
+        const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
+        cx<T>* row = out + (r0 + c) * pitch;
+        for (int rep = 0; rep < 2; ++rep) {
+            const int kk = rep ? (L >> 1) : k;
+            if (rep && k != 0) break;
+            const cx<T> Zk = s[lds_addr<true>(kk, c, 0, RS)];
+            const cx<T> Zm = s[lds_addr<true>((L - kk) & (L - 1), c, 0, RS)];
+            const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
+            const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
+            const cx<T> wO = tw[kk << sh] * O;
+            row[kk] = (E + wO) * scale;
+            row[L - kk] = conj(E - wO) * scale;
+        }
+    }
+}
+
 template <typename T, int MODE, class SEQ, class Ctx>
 OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
-    const int logL = a.logL, L = 1 << logL, C = 1 << a.logC, RS = a.rowStride;
+    const int logL = a.logL, C = 1 << a.logC, RS = a.rowStride;
     const long r0 = (long)ctx.bid_x() * C;
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
@@ -296,57 +369,105 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
         fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
                                                RowLoad<T, false>{in, a.in_pitch, r0},
                                                RowStore<T, false>{out, a.out_pitch, r0, a.scale});
-        return;
-    }
-    if constexpr (MODE == ROW_C2C_I) {
+    } else if constexpr (MODE == ROW_C2C_I) {
         fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
                                                RowLoad<T, true>{in, a.in_pitch, r0},
                                                RowStore<T, true>{out, a.out_pitch, r0, a.scale});
-        return;
-    }
-    const int sh = a.logTw - (logL + 1);
-    if constexpr (MODE == ROW_R2C) {
+    } else if constexpr (MODE == ROW_R2C) {
         fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
                                                 RowLoad<T, false>{in, a.in_pitch, r0}, NoStore{});
-        // untangle straight to global: X[k] = E + W_N^k O ; X[L-k] = conj(E - W_N^k O)
-        for (int i = tid; i < (C << (logL - 1)); i += NT) {
-            const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
-            cx<T>* row = out + (r0 + c) * a.out_pitch;
-            for (int rep = 0; rep < 2; ++rep) {
-                const int kk = rep ? (L >> 1) : k;
-                if (rep && k != 0) break;
-                const cx<T> Zk = s[lds_addr<true>(kk, c, 0, RS)];
-                const cx<T> Zm = s[lds_addr<true>((L - kk) & (L - 1), c, 0, RS)];
-                const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
-                const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
-                const cx<T> wO = a.tw[kk << sh] * O;
-                row[kk] = (E + wO) * a.scale;
-                row[L - kk] = conj(E - wO) * a.scale;
-            }
-        }
-        return;
+        r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale);
+    } else {
+        c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw);
+        ctx.sync();
+        fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw, NoLoad{},
+                                                RowStore<T, true>{out, a.out_pitch, r0, a.scale});
     }
-    if constexpr (MODE != ROW_C2R) return;
-    // ROW_C2R: Z'[k] = (X[k]+conj X[L-k]) + i W_N^{-k} (X[k]-conj X[L-k]), stored swapped in LDS
-    for (int i = tid; i < (C << (logL - 1)); i += NT) {
-        const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
-        const cx<T>* row = in + (r0 + c) * a.in_pitch;
-        for (int rep = 0; rep < 2; ++rep) {
-            const int kk = rep ? (L >> 1) : k;
-            if (rep && k != 0) break;
-            const cx<T> A = row[kk];
-            const cx<T> B = row[L - kk];
-            const cx<T> w = a.tw[kk << sh];  // W_N^k
-            const cx<T> d1 = A - conj(B), d2 = B - conj(A);
-            const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
-            const cx<T> z2 = (B + conj(A)) - mul_pi(w * d2);
-            s[lds_addr<true>(kk, c, 0, RS)] = swp(z1);
-            if (kk != 0 && 2 * kk != L) s[lds_addr<true>(L - kk, c, 0, RS)] = swp(z2);
-        }
-    }
+}
+
+// ===========================================================================
+// Fused QE row stage (TT and every other estimator term): for each row
+//   h = C2R(H),  for leg in (Gx, Gy):  P_leg = R2C( C2R(leg) * h )
+// 3 half-complex planes in, 2 out; the real-space planes never touch HBM.
+// LDS: one padded work row set + one unpadded real row set (h).
+// ===========================================================================
+template <typename T>
+struct RowQeArgs {
+    const cx<T>* gx; const cx<T>* gy; const cx<T>* h;
+    cx<T>* px; cx<T>* py;
+    long pitch;
+    int logL, logC, NT, rowStride;
+    const cx<T>* tw;
+    int logTw;
+    T scale;      // product scale: (1/Npix)^2 for two normalised inverse transforms
+    int accumulate;  // reserved
+};
+
+// LDS -> LDS stage I of the reversed (inverse) / forward sequence
+template <typename T, class SEQ, int I, bool REV, class Ctx>
+OA_HD void lds_stage(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int RS, const cx<T>* tw, int logTw) {
+    constexpr int R = REV ? SEQ::rget(I) : SEQ::get(I);
+    constexpr int lns = REV ? rev_logns<SEQ>(I) : fwd_logns<SEQ>(I);
+    stage<T, R, true, false, false>(ctx, s, tid, NT, logL, logC, RS, lns, tw, logTw, NoLoad{}, NoStore{});
     ctx.sync();
-    fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw, NoLoad{},
-                                            RowStore<T, true>{out, a.out_pitch, r0, a.scale});
+}
+
+// inverse stages 0..n-2 of the reversed sequence (the last one is left to the caller)
+template <typename T, class SEQ, class Ctx>
+OA_HD void inverse_head(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int RS, const cx<T>* tw, int logTw) {
+    if constexpr (SEQ::n >= 2) lds_stage<T, SEQ, 0, true>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
+    if constexpr (SEQ::n >= 3) lds_stage<T, SEQ, 1, true>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
+    if constexpr (SEQ::n >= 4) lds_stage<T, SEQ, 2, true>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
+}
+// forward stages 1..n-1 (stage 0 is done in registers by the caller)
+template <typename T, class SEQ, class Ctx>
+OA_HD void forward_tail(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int RS, const cx<T>* tw, int logTw) {
+    if constexpr (SEQ::n >= 2) lds_stage<T, SEQ, 1, false>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
+    if constexpr (SEQ::n >= 3) lds_stage<T, SEQ, 2, false>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
+    if constexpr (SEQ::n >= 4) lds_stage<T, SEQ, 3, false>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
+}
+
+// The inverse transforms run the REVERSED radix sequence, so their last stage has radix R0 and leaves
+// point n = j + t*(L/R0) in register t of thread j -- exactly the operand layout of the forward
+// transform's first (twiddle-free) stage.  h therefore stays in 16 registers per thread, the
+// real-space product is a register multiply, and the only LDS is one padded work row set.
+template <typename T, class SEQ, class Ctx>
+OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
+    cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
+    const int tid = ctx.tid(), NT = a.NT;
+    const int logL = a.logL, logC = a.logC, C = 1 << logC, RS = a.rowStride;
+    const long r0 = (long)ctx.bid_x() * C;
+    constexpr int R0 = SEQ::get(0);
+    constexpr int lastns = rev_logns<SEQ>(SEQ::n - 1);
+    cx<T> hreg[EPT], v[EPT];
+
+    c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw);
+    ctx.sync();
+    inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
+    stage_in<T, R0, true, false>(work, hreg, tid, NT, logL, logC, RS, lastns, a.tw, a.logTw, NoLoad{});
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) hreg[t] = mk<T>(hreg[t].y * a.scale, hreg[t].x * a.scale);  // unswap -> (h[2n], h[2n+1])
+    ctx.sync();
+    for (int leg = 0; leg < 2; ++leg) {
+        const cx<T>* src = leg ? a.gy : a.gx;
+        cx<T>* dst = leg ? a.py : a.px;
+        c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw);
+        ctx.sync();
+        inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
+        stage_in<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, lastns, a.tw, a.logTw, NoLoad{});
+        // v holds the swapped C2R result: (im, re) = (x[2n+1], x[2n]); product with h, repacked for R2C
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].x, v[t].x * hreg[t].y);
+        // forward stage 0 (no twiddles) straight from registers
+#pragma unroll
+        for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
+        ctx.sync();
+        stage_out<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, 0, NoStore{});
+        ctx.sync();
+        forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
+        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1);
+        ctx.sync();
+    }
 }
 
 // ===========================================================================
@@ -372,6 +493,7 @@ struct ColArgs {
 
 template <typename T>
 struct ColLoad {
+    static constexpr bool reads_lds = false;
     const cx<T>* base;  // already offset to (group row origin, first column)
     long nstride;       // elements between consecutive points n
     int ncols;          // valid columns in this tile

@@ -63,6 +63,24 @@ struct Fft2dPlan {
         q.row(ny / C, a.NT, (size_t)C * a.rowStride * sizeof(cx<T>), a);
     }
 
+    // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
+    template <class Launcher>
+    void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale) const {
+        RowQeArgs<T> a{};
+        a.logL = logNx - 1;
+        const int L = 1 << a.logL;
+        int C = 4096 / L;
+        if (C < 1) C = 1;
+        if (C > ny) C = ny;
+        a.logC = ilog2(C);
+        a.NT = (L * C) / EPT;
+        if (a.NT < 1) a.NT = 1;
+        a.rowStride = L + (L >> 4) + 2;
+        a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
+        a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py;
+        q.row_qe(ny / C, a.NT, (size_t)C * a.rowStride * sizeof(cx<T>), a);
+    }
+
     // ---- full column transform of `width` columns (two passes) -------------
     // in -> out (out != in), result in natural order in `out`.
     // which: 0 = both passes, 1 = pass 1 only, 2 = pass 2 only (microbenchmarks)

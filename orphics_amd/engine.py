@@ -184,6 +184,22 @@ class Engine(object):
         check(self.lib.oa_fft_c2c(self.plan, _ptr(z), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
         return out
 
+    def fft_cols(self, k, inverse=False, scale=1.0, out=None):
+        """Column transforms only (hc -> hc, out != in)."""
+        self._chk(k, "hc")
+        out = self.hc() if out is None else self._chk(out, "hc")
+        check(self.lib.oa_fft_cols(self.plan, _ptr(k), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
+        return out
+
+    def qe_rows(self, gx, gy, h, px, py, scale=None):
+        """Fused row stage: P = R2C(C2R(G) * C2R(H)) for G in (gx, gy)."""
+        for t in (gx, gy, h, px, py):
+            self._chk(t, "hc")
+        if scale is None:
+            scale = 1.0 / float(self.npix) ** 2
+        check(self.lib.oa_qe_rows(self.plan, _ptr(gx), _ptr(gy), _ptr(h), _ptr(px), _ptr(py), float(scale), _stream()))
+        return px, py
+
     def fft_pass(self, pass_id, src, dst):
         """Launch one constituent FFT pass (per-kernel timing in bench.py)."""
         check(self.lib.oa_fft_pass(self.plan, int(pass_id), _ptr(src), _ptr(dst), _stream()))

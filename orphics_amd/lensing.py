@@ -160,17 +160,37 @@ class Estimator(object):
     def _buffers(self):
         if self._work is None:
             e = self.eng
-            self._work = dict(G=(e.hc(), e.hc(), e.hc()), r=(e.real(), e.real(), e.real()), P=(e.hc(), e.hc()))
+            self._work = dict(G=(e.hc(), e.hc(), e.hc()), C=(e.hc(), e.hc(), e.hc()), P=(e.hc(), e.hc()))
         return self._work
 
-    def reconstruct_tt_hc(self, kX, kY=None, out=None):
-        """Device-native TT reconstruction: hc tensors in, kappa_hat DFT (hc) out."""
+    def _real_buffers(self):
+        if getattr(self, "_rwork", None) is None:
+            e = self.eng
+            self._rwork = (e.real(), e.real(), e.real())
+        return self._rwork
+
+    def reconstruct_tt_hc(self, kX, kY=None, out=None, fused=True):
+        """Device-native TT reconstruction: hc tensors in, kappa_hat DFT (hc) out.
+
+        fused=True (default): legs -> 3 inverse column transforms -> ONE fused row-stage kernel
+        (3 C2R + 2 products + 2 R2C in LDS, oa_qe_rows) -> 2 forward column transforms -> divergence.
+        fused=False: the modular sequence of public C-ABI calls (3 C2R, 2 products, 2 R2C)."""
         e = self.eng
         kY = kX if kY is None else kY
         FG, FH, Fn = self._F["TT"]
         w = self._buffers()
         Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
-        gx, gy, h = w["r"]
+        if fused:
+            cx, cy, ch = w["C"]
+            e.fft_cols(Gx, inverse=True, out=cx)
+            e.fft_cols(Gy, inverse=True, out=cy)
+            e.fft_cols(H, inverse=True, out=ch)
+            e.qe_rows(cx, cy, ch, Gx, Gy)          # Gx, Gy reused as the row-transformed products
+            Px, Py = w["P"]
+            e.fft_cols(Gx, inverse=False, out=Px)
+            e.fft_cols(Gy, inverse=False, out=Py)
+            return e.qe_div(Px, Py, Fn, out=out)
+        gx, gy, h = self._real_buffers()
         e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
         e.mul_real(gx, h, out=gx)
         e.mul_real(gy, h, out=gy)

@@ -50,6 +50,12 @@ struct EmuLauncher {
             }
         });
     }
+    template <typename T> void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
+        dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_body<T, S>(c, a); });
+        });
+    }
     template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
         dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
@@ -95,7 +101,21 @@ static int do_c2c(int ny, int nx, const cx<T>* in, cx<T>* out, int inverse, doub
     return 0;
 }
 
+template <typename T>
+static int do_qe_rows(int ny, int nx, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, double s) {
+    Holder<T> hd(ny, nx);
+    EmuLauncher q;
+    hd.p.rows_qe(q, gx, gy, h, px, py, (T)s);
+    return 0;
+}
+
 extern "C" {
+int emu_qe_rows_f32(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s) {
+    return do_qe_rows<float>(ny, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s);
+}
+int emu_qe_rows_f64(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s) {
+    return do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s);
+}
 long emu_kpitch(int nx) { return kpitch_for(nx); }
 int emu_r2c_f32(int ny, int nx, const float* in, void* out, double s) { return do_r2c<float>(ny, nx, in, (cx<float>*)out, s); }
 int emu_r2c_f64(int ny, int nx, const double* in, void* out, double s) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s); }

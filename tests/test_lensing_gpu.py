@@ -134,3 +134,20 @@ def test_split_lensing_cross_estimator_matches_numpy():
     kc = k - kiisum / n ** 2
     ref = (n ** 4 * fo.f2power(kc, kc) - 4 * n ** 2 * psum + 4 * psum2) / n / (n - 1) / (n - 2) / (n - 3)
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-8
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 2e-5)])
+@pytest.mark.parametrize("N", [64, 512, 2048])
+def test_fused_pipeline_equals_modular(N, prec, tol):
+    """oa_fft_cols + oa_qe_rows (fused row stage) == the modular C2R / product / R2C sequence."""
+    from orphics_amd import lensing
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, 1.0 * 512 / N if N < 512 else 1.0, seed=3)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask,
+                     unlensed_equals_lensed=True, dtype=prec)
+    e = q.eng
+    k1 = e.rfft(e.to_real(t1)); k2 = e.rfft(e.to_real(t2))
+    a = q.reconstruct_tt_hc(k1, k2, fused=True).clone()
+    b = q.reconstruct_tt_hc(k1, k2, fused=False).clone()
+    w = N // 2 + 1
+    a, b = a.cpu().numpy()[:, :w], b.cpu().numpy()[:, :w]
+    assert np.abs(a - b).max() / np.abs(b).max() < tol

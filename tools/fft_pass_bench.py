@@ -34,7 +34,8 @@ def t(fn):
     return a.elapsed_time(b) / reps * 1e-3
 
 
-for name, fn, nb in [("row_r2c", lambda: e.fft_pass(0, r1, s1), A + Ah), ("col_pass1", lambda: e.fft_pass(1, s1, s2), 2 * Ah),
+s3, s4, s5 = e.hc(), e.hc(), e.hc()
+for name, fn, nb in [("qe_rows", lambda: e.qe_rows(s1, s2, s3, s4, s5), 5 * Ah), ("row_r2c", lambda: e.fft_pass(0, r1, s1), A + Ah), ("col_pass1", lambda: e.fft_pass(1, s1, s2), 2 * Ah),
                      ("col_pass2", lambda: e.fft_pass(2, s1, s2), 2 * Ah), ("row_c2r", lambda: e.fft_pass(3, s1, r1), A + Ah)]:
     dt = t(fn)
     print("%-10s N=%d %s  %.1f us  %.0f GB/s (algorithmic)" % (name, N, prec, dt * 1e6, nb / dt / 1e9))
