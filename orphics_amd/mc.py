@@ -1,0 +1,100 @@
+"""Monte-Carlo driver: Gaussian realisations -> TT reconstruction -> bandpowers,
+sharded over GPUs with the reference's task split and ONE all-reduce at the end.
+
+This is the north-star loop of tutorials/tt_verification.ipynb cell 4 /
+SURVEY.md section 3.4 for the Gaussian (N0 / mean-field) case: every realisation
+is independent, so ranks never talk until ``Statistics.allreduce`` time
+(stats.py:1184-1232): n (int64), sum (d,), cross (d,d) and, optionally, the
+mean-field stack (Ny, kp, 2) are summed over ranks with RCCL (gloo in CPU tests).
+"""
+import numpy as np
+
+from . import mpi as _mpi
+from .stats import Statistics
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def allreduce_tensors(tensors, comm):
+    """SUM all-reduce of device (or CPU) tensors in place over a TorchComm; no-op
+    for a single rank / fake comm.  One collective per tensor, issued once per run."""
+    if comm is None or comm.Get_size() == 1 or not hasattr(comm, "dist"):
+        return tensors
+    for t in tensors:
+        comm.dist.all_reduce(t, op=comm.dist.ReduceOp.SUM, group=comm.group)
+    return tensors
+
+
+class GaussianN0MonteCarlo(object):
+    """N0 bias / mean-field Monte Carlo on Gaussian maps with total power
+    C_l^TT B_l^2 + N_l, generated on the device in harmonic space
+    (MapGen semantics, maps.py:1576-1587, with the Philox stream (base_seed, sim index))."""
+
+    def __init__(self, qest, total_power_half, bin_edges, comm=None, base_seed=1234, mean_field=False):
+        """qest: lensing.Estimator; total_power_half: (Ny, Nx/2+1) host array of the
+        observed-map power (C B^2 + N); bin_edges: kappa bandpower edges."""
+        torch = _torch()
+        self.q = qest
+        self.eng = qest.eng
+        self.comm = comm if comm is not None else _mpi.get_world()
+        self.base_seed = int(base_seed)
+        self.mean_field = mean_field
+        e = self.eng
+        geom = qest.geom
+        # unnormalised DFT of a unit-pixel-variance white map has |k|^2 = Npix; power p -> k = sqrt(p Npix^2/area) w
+        amp = np.sqrt(np.asarray(total_power_half, dtype=np.float64) * float(e.npix) ** 2 / geom.area)
+        self.cs = qest._hcreal(e, amp)
+        self.edges = np.asarray(bin_edges, dtype=np.float64)
+        self.ids = e.modl_digitize(torch.as_tensor(self.edges, device=e.device), half=True)
+        self.nids = self.edges.size + 1
+        self.d = self.nids - 2
+        self.norm = geom.area / float(e.npix) ** 2
+        self.n = torch.zeros(1, dtype=torch.int64, device=e.device)
+        self.S = torch.zeros(self.d, dtype=torch.float64, device=e.device)
+        self.C = torch.zeros(self.d, self.d, dtype=torch.float64, device=e.device)
+        self.mf = torch.zeros((e.ny, e.kp, 2), dtype=torch.float64, device=e.device) if mean_field else None
+        self.mf_count = torch.zeros(1, dtype=torch.int64, device=e.device)
+        self._kT, self._kk, self._p = e.hc(), e.hc(), e.hcreal()
+
+    def run_local(self, sims):
+        """Process the given global sim indices on this rank's GPU."""
+        torch = _torch()
+        from ._lib import check
+        from .engine import _ptr, _stream
+        e, q = self.eng, self.q
+        for i in sims:
+            e.grf_hc(self.base_seed, int(i), self.cs, out=self._kT)
+            q.reconstruct_tt_hc(self._kT, out=self._kk)
+            e.f2power(self._kk, self._kk, self.norm, out=self._p)
+            sums, counts = e.bin(self._p, self.ids, self.nids, herm=True)
+            p1d = (sums[1:-1] / counts[1:-1].to(torch.float64)).contiguous()
+            check(e.lib.oa_moments_add(_ptr(p1d), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))
+            if self.mean_field:
+                ri = torch.view_as_real(self._kk)  # (ny, kp, 2)
+                check(e.lib.oa_stack_add(e.code, _ptr(ri), _ptr(self.mf), ri.numel(), _stream()))
+                self.mf_count += 1
+        return self
+
+    def run(self, nsims):
+        """Shard ``nsims`` with mpi.mpi_distribute (mpi.py:78-91), run, reduce once;
+        returns a reduced :class:`Statistics` (label 'n0' = kappa auto bandpowers,
+        stack 'mf' = interleaved (re,im) sum of kappa_hat DFTs if mean_field)."""
+        comm = self.comm
+        size, rank = comm.Get_size(), comm.Get_rank()
+        _, tasks = _mpi.mpi_distribute(nsims, size, allow_empty=True)
+        self.run_local(tasks[rank])
+        tens = [self.n, self.S, self.C] + ([self.mf, self.mf_count] if self.mean_field else [])
+        allreduce_tensors(tens, comm)
+        st = Statistics(comm=None)
+        st.add_moments("n0", int(self.n.item()), self.S.cpu().numpy(), self.C.cpu().numpy())
+        if self.mean_field:
+            st.add_stack_sum("mf", self.mf.cpu().numpy(), int(self.mf_count.item()))
+        st.allreduce()
+        return st
+
+    @property
+    def centers(self):
+        return (self.edges[1:] + self.edges[:-1]) / 2.

@@ -151,3 +151,31 @@ def test_fused_pipeline_equals_modular(N, prec, tol):
     w = N // 2 + 1
     a, b = a.cpu().numpy()[:, :w], b.cpu().numpy()[:, :w]
     assert np.abs(a - b).max() / np.abs(b).max() < tol
+
+
+def test_mc_driver_n0_and_mean_field():
+    """GaussianN0MonteCarlo: device GRFs -> TT QE -> bandpower moments (+ mean-field stack);
+    the MC N0 equals the analytic N_L^kk, moments equal a host recomputation."""
+    from orphics_amd import lensing, mc, stats
+    N, res = 256, 2.0
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, res, seed=2)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask,
+                     unlensed_equals_lensed=True, dtype="f32")
+    tot_h = (cl * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(100, 3000, 12)
+    drv = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=77, mean_field=True)
+    st = drv.run(48)
+    assert st.count("n0") == 48 and st.stack_count("mf") == 48
+    _, nl = stats.bin2D(ml, edges).bin(q.N_kappa("TT"))
+    assert np.max(np.abs(st.mean("n0") / nl - 1)) < 0.08
+    assert st.cov("n0").shape == (11, 11) and np.all(np.diag(st.cov("n0")) > 0)
+    # same seeds -> identical moments (counter-based RNG, deterministic binning)
+    st2 = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=77).run(48)
+    np.testing.assert_allclose(st2.mean("n0"), st.mean("n0"), rtol=0, atol=0)
+    # mean field of Gaussian sims is consistent with zero: |<kappa_hat>|^2 ~ N0 / nsims
+    mf = st.stack_sum("mf")
+    mfk = (mf[..., 0] + 1j * mf[..., 1])[:, :N // 2 + 1] / 48.0
+    p_mf = np.abs(mfk) ** 2 * (g.area / float(N * N) ** 2)
+    sel = (ml[:, :N // 2 + 1] > 300) & (ml[:, :N // 2 + 1] < 2500)
+    ratio = p_mf[sel].mean() / (q.N_kappa("TT")[:, :N // 2 + 1][sel].mean() / 48.0)
+    assert 0.7 < ratio < 1.3
