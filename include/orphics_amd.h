@@ -80,8 +80,11 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
  * (oa_fft_cols(..., inverse=1)); per row h = C2R(H), P_x = R2C(C2R(Gx) * h), P_y = R2C(C2R(Gy) * h),
  * product scaled by `scale` (pass (1/(ny*nx))^2 for normalised inverses).  Outputs are row-transformed
  * planes awaiting oa_fft_cols(..., inverse=0).  Replaces 3 x oa_fft_c2r rows + 2 x oa_mul_real +
- * 2 x oa_fft_r2c rows: the real-space planes never touch HBM. */
-int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, void* stream);
+ * 2 x oa_fft_r2c rows: the real-space planes never touch HBM.  accumulate != 0 adds the result to
+ * the existing px, py (estimators whose weight is a sum of separable terms: cos/sin spin-2 pieces;
+ * `scale` carries the sign). */
+int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
+               int accumulate, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of

@@ -34,7 +34,7 @@ SIGNATURES = {
     "oa_fft_c2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_fft_pass": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "oa_fft_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
-    "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_void_p]),
+    "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_int, c_void_p]),
     "oa_hc_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

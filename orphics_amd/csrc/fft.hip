@@ -172,9 +172,9 @@ static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double 
 }
 template <typename T>
 static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-                        hipStream_t st) {
+                        int accumulate, hipStream_t st) {
     HipLauncher q{st};
-    view<T>(p).rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale);
+    view<T>(p).rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate);
     return q.rc;
 }
 
@@ -191,10 +191,11 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
                               : cols_impl<double>(p, hc_in, hc_out, inverse, scale, (hipStream_t)stream);
 }
 
-int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, void* stream) {
+int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
+               int accumulate, void* stream) {
     OA_REQUIRE(p && gx && gy && h && px && py, "oa_qe_rows: NULL argument");
-    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, (hipStream_t)stream)
-                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, (hipStream_t)stream)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, (hipStream_t)stream);
 }
 
 int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream) {

@@ -336,7 +336,7 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
 // R2C epilogue: packed transform Z in LDS -> X[k] = E + W_N^k O, X[L-k] = conj(E - W_N^k O), straight to global.
 template <typename T, class Ctx>
 OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
-                        const cx<T>* tw, int logTw, T scale) {
+                        const cx<T>* tw, int logTw, T scale, bool accumulate = false) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
@@ -350,8 +350,13 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
             const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
             const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
             const cx<T> wO = tw[kk << sh] * O;
-            row[kk] = (E + wO) * scale;
-            row[L - kk] = conj(E - wO) * scale;
+            cx<T> o1 = (E + wO) * scale, o2 = conj(E - wO) * scale;
+            if (accumulate) {
+                o1 = o1 + row[kk];
+                if (2 * kk != L) o2 = o2 + row[L - kk]; else o2 = o1;
+            }
+            row[kk] = o1;
+            row[L - kk] = o2;
         }
     }
 }
@@ -400,7 +405,7 @@ struct RowQeArgs {
     const cx<T>* tw;
     int logTw;
     T scale;      // product scale: (1/Npix)^2 for two normalised inverse transforms
-    int accumulate;  // reserved
+    int accumulate;  // != 0: add the (scaled) result to the existing contents of px, py
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -465,7 +470,7 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
         stage_out<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, 0, NoStore{});
         ctx.sync();
         forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
-        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1);
+        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0);
         ctx.sync();
     }
 }

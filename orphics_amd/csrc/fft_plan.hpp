@@ -65,7 +65,8 @@ struct Fft2dPlan {
 
     // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
     template <class Launcher>
-    void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale) const {
+    void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
+                 int accumulate = 0) const {
         RowQeArgs<T> a{};
         a.logL = logNx - 1;
         const int L = 1 << a.logL;
@@ -77,7 +78,7 @@ struct Fft2dPlan {
         if (a.NT < 1) a.NT = 1;
         a.rowStride = L + (L >> 4) + 2;
         a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
-        a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py;
+        a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
         q.row_qe(ny / C, a.NT, (size_t)C * a.rowStride * sizeof(cx<T>), a);
     }
 

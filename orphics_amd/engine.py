@@ -191,13 +191,14 @@ class Engine(object):
         check(self.lib.oa_fft_cols(self.plan, _ptr(k), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
         return out
 
-    def qe_rows(self, gx, gy, h, px, py, scale=None):
+    def qe_rows(self, gx, gy, h, px, py, scale=None, accumulate=False):
         """Fused row stage: P = R2C(C2R(G) * C2R(H)) for G in (gx, gy)."""
         for t in (gx, gy, h, px, py):
             self._chk(t, "hc")
         if scale is None:
             scale = 1.0 / float(self.npix) ** 2
-        check(self.lib.oa_qe_rows(self.plan, _ptr(gx), _ptr(gy), _ptr(h), _ptr(px), _ptr(py), float(scale), _stream()))
+        check(self.lib.oa_qe_rows(self.plan, _ptr(gx), _ptr(gy), _ptr(h), _ptr(px), _ptr(py), float(scale),
+                                  1 if accumulate else 0, _stream()))
         return px, py
 
     def fft_pass(self, pass_id, src, dst):

@@ -81,6 +81,16 @@ class Estimator(object):
         self.AL, self.Nlkk, self._F = {}, {}, {}
         self._work = None
         self._setup_tt()
+        if pol:
+            for sp in ("EE", "BB", "TE"):
+                self.cl_grad[sp] = np.where(ml >= 0, cfun_g(sp, np.abs(ml)), 0.0)
+                self.cl_len[sp] = np.where(ml >= 0, theory.lCl(sp, np.abs(ml)), 0.0)
+            self.noise["P"] = _half(noise2d_P, self.nxh) if noise2d_P is not None else 2.0 * self.noise["T"]
+            self.mask["P"] = _half(kmask_P, self.nxh).astype(np.float64) if kmask_P is not None else self.mask["T"]
+            sgn = 1 if getattr(self, "iau", False) else -1
+            lyg, lxg = np.meshgrid(self.ly, self.lxh, indexing="ij")
+            self.ang_h = sgn * 2 * np.arctan2(-lxg, lyg)       # pixell queb_rotmat angle (maps.py:1607)
+            self._gen = {}
 
     # ---- filters / normalisation --------------------------------------------------
     def _hcreal(self, eng, a_half):
@@ -202,11 +212,17 @@ class Estimator(object):
                        alreadyFTed=False, returnFt=False):
         """qest.kappa_from_map (lensing.py:973-976; notebook cell 4).  The X
         (gradient) and Y legs may be different maps (SplitLensing)."""
-        if XY != "TT":
-            raise NotImplementedError("estimator %s: only TT is implemented in this round" % XY)
-        kX, kind = self._as_hc(T2DData, alreadyFTed)
-        kY = kX if T2DDataY is None else self._as_hc(T2DDataY, alreadyFTed)[0]
-        kft = self.reconstruct_tt_hc(kX, kY)
+        fields = {"T": (T2DData, T2DDataY), "E": (E2DData, E2DDataY), "B": (B2DData, B2DDataY)}
+        X, Y = XY[0], XY[1]
+        if fields[X][0] is None or (fields[Y][0] is None and fields[Y][1] is None):
+            raise ValueError("estimator %s needs the %s and %s data" % (XY, X, Y))
+        kX, kind = self._as_hc(fields[X][0], alreadyFTed)
+        ysrc = fields[Y][1] if fields[Y][1] is not None else fields[Y][0]
+        kY = kX if (ysrc is fields[X][0]) else self._as_hc(ysrc, alreadyFTed)[0]
+        if XY == "TT":
+            kft = self.reconstruct_tt_hc(kX, kY)
+        else:
+            kft = self.reconstruct_hc(XY, kX, kY)
         e = self.eng
         if returnFt:
             if kind == "half":
@@ -215,6 +231,233 @@ class Estimator(object):
             return full.cpu().numpy() if kind == "np" else full
         rec = e.irfft(kft)
         return rec.cpu().numpy() if kind == "np" else rec
+
+    # ---- general separable estimators (TE, EE, EB, TB; TT also available for cross-checks) -------
+    # term = (coef, p, A, B, trig): coef * (L.l_p) * A(l1) * B(l2) * trig(a2 - a1)   (oracle/qe_oracle.py)
+    @staticmethod
+    def _terms(XY):
+        if XY == "TT":
+            return ([(1., 1, "wTT", "iT", "1")], [(1., 1, "cTT", "1", "1"), (1., 2, "1", "cTT", "1")])
+        if XY == "EE":
+            return ([(1., 1, "wEE", "iE", "cos")], [(1., 1, "cEE", "1", "cos"), (1., 2, "1", "cEE", "cos")])
+        if XY == "EB":
+            return ([(1., 1, "wEE", "iB", "sin")], [(1., 1, "cEE", "1", "sin"), (1., 2, "1", "cBB", "sin")])
+        if XY == "TB":
+            return ([(1., 1, "wTE", "iB", "sin")], [(1., 1, "cTE", "1", "sin")])
+        if XY == "TE":
+            return ([(1., 1, "wTE", "iE", "cos"), (1., 2, "iT", "wET", "1")],
+                    [(1., 1, "cTE", "1", "cos"), (1., 2, "1", "cTE", "1")])
+        raise ValueError("unknown estimator %r" % (XY,))
+
+    @staticmethod
+    def _trig_product(t1, t2):
+        key = tuple(sorted((t1, t2)))
+        return {("1", "1"): [(1., 0, "1")], ("1", "cos"): [(1., 1, "cos")], ("1", "sin"): [(1., 1, "sin")],
+                ("cos", "cos"): [(.5, 0, "1"), (.5, 2, "cos")], ("sin", "sin"): [(.5, 0, "1"), (-.5, 2, "cos")],
+                ("cos", "sin"): [(.5, 2, "sin")]}[key]
+
+    def _planes(self):
+        """Host half-plane filter / spectrum planes by name (beam-deconvolved field weights)."""
+        if getattr(self, "_P", None) is None:
+            b2 = self.beam ** 2
+            ct = {"T": self.cl_len["TT"] + _safe_div(self.noise["T"], b2),
+                  "E": self.cl_len["EE"] + _safe_div(self.noise["P"], b2),
+                  "B": self.cl_len["BB"] + _safe_div(self.noise["P"], b2)}
+            m = {"T": self.mask["T"], "E": self.mask["P"], "B": self.mask["P"]}
+            P = {"1": np.ones_like(self.modl_h)}
+            for X in "TEB":
+                P["i" + X] = _safe_div(np.ones_like(ct[X]), ct[X]) * m[X]
+            gm = {X: m[X].copy() for X in "TEB"}
+            if self.grad_cut is not None:
+                for X in "TEB":
+                    gm[X][self.modl_h > self.grad_cut] = 0
+            P["wTT"] = _safe_div(self.cl_grad["TT"], ct["T"]) * gm["T"]
+            P["wEE"] = _safe_div(self.cl_grad["EE"], ct["E"]) * gm["E"]
+            P["wTE"] = _safe_div(self.cl_grad["TE"], ct["T"]) * gm["T"]
+            P["wET"] = _safe_div(self.cl_grad["TE"], ct["E"]) * gm["E"]
+            for k in ("TT", "EE", "BB", "TE"):
+                P["c" + k] = self.cl_grad[k]
+            self._P, self._ct = P, ct
+        return self._P
+
+    def _real_of(self, U_herm, cache, key):
+        """irfft (f64 kernels) of a Hermitian half-plane host array, cached by description."""
+        torch = _torch()
+        if key in cache:
+            return cache[key]
+        e = self.eng64
+        k = e.hc()
+        k[:, :self.nxh + 1] = torch.as_tensor(np.ascontiguousarray(U_herm), dtype=e.cdt, device=e.device)
+        r = e.irfft(k)
+        cache[key] = r
+        return r
+
+    def _sum_gf(self, gterms, fterms):
+        """(1/Area) sum_l1 g(l1,l2) f(l1,l2) on the half plane via real-space products (f64 kernels).
+        Every factor carries exactly two l-components in total, each written as (i l_j) so all planes are
+        Hermitian: conv = i^-2 DFT[u v]/a = -DFT[u v]/a; products accumulate per (j,k) class."""
+        torch = _torch()
+        e = self.eng64
+        P = self._planes()
+        lyd, lxd = self.ly.copy(), self.lxh.copy()
+        lyd[e.ny // 2] = 0.0
+        if self.nxh < lxd.size:
+            lxd[self.nxh] = 0.0
+        comp = (lxd[None, :] * np.ones((e.ny, 1)), lyd[:, None] * np.ones((1, self.nxh + 1)))
+        cache = {}
+        S = {"xx": None, "yy": None, "xy": None}
+
+        def plane(name_or_arr):
+            return P[name_or_arr] if isinstance(name_or_arr, str) else name_or_arr
+
+        def tag(x):
+            return x if isinstance(x, str) else ("arr", id(x))
+
+        def add(cls, coef, u, v):
+            prod = e.mul_real(u, v)
+            S[cls] = e.axpby(prod, prod, coef, 0.0) if S[cls] is None else e.axpby(S[cls], prod, 1.0, coef)
+
+        for (cg, p, Ag, Bg, tg) in gterms:
+            for (cf, q, Af, Bf, tf) in fterms:
+                A = plane(Ag) * plane(Af)
+                B = plane(Bg) * plane(Bf)
+                kA, kB = (tag(Ag), tag(Af)), (tag(Bg), tag(Bf))
+                for (ct_, mh, kind) in self._trig_product(tg, tf):
+                    for j in range(2):
+                        for k in range(2):
+                            cls = "xx" if (j, k) == (0, 0) else ("yy" if (j, k) == (1, 1) else "xy")
+                            fu, fv = [], []
+                            (fu if p == 1 else fv).append(j)
+                            (fu if q == 1 else fv).append(k)
+
+                            def build(base, comps, trig, which):
+                                arr = base.astype(np.complex128)
+                                for cidx in comps:
+                                    arr = arr * (1j * comp[cidx])
+                                if trig is not None:
+                                    arr = arr * (np.cos(mh * self.ang_h) if trig == "c" else np.sin(mh * self.ang_h))
+                                return arr
+
+                            coef = -cg * cf * ct_   # i^-2
+                            if kind == "1":
+                                u = self._real_of(build(A, fu, None, 0), cache, (kA, tuple(fu), None, 0))
+                                v = self._real_of(build(B, fv, None, 1), cache, (kB, tuple(fv), None, 0))
+                                add(cls, coef, u, v)
+                            else:
+                                uc = self._real_of(build(A, fu, "c", 0), cache, (kA, tuple(fu), "c", mh))
+                                us = self._real_of(build(A, fu, "s", 0), cache, (kA, tuple(fu), "s", mh))
+                                vc = self._real_of(build(B, fv, "c", 1), cache, (kB, tuple(fv), "c", mh))
+                                vs = self._real_of(build(B, fv, "s", 1), cache, (kB, tuple(fv), "s", mh))
+                                if kind == "cos":      # cos(m(a2-a1)) = c1 c2 + s1 s2
+                                    add(cls, coef, uc, vc); add(cls, coef, us, vs)
+                                else:                  # sin(m(a2-a1)) = s2 c1 - c2 s1
+                                    add(cls, coef, uc, vs); add(cls, -coef, us, vc)
+        zero = torch.zeros((e.ny, e.nx), dtype=e.rdt, device=e.device)
+        A_, B_, C_ = [e.rfft(S[c] if S[c] is not None else zero) for c in ("xx", "yy", "xy")]
+        C2 = e.hc()
+        C2.copy_(C_ * 0.5)
+        one_k = e.hc()
+        one_k[:, :self.nxh + 1] = 1.0
+        F_one = self._hcreal(e, np.ones_like(self.modl_h))
+        ux = e.qe_div(A_, C2, F_one)
+        uy = e.qe_div(C2, B_, F_one)
+        tot = e.qe_div(ux, uy, F_one)           # = -(lx^2 A + lx ly C + ly^2 B)
+        Rk = e.f2power(tot, one_k, -1.0 / self.geom.pixarea)
+        return Rk.cpu().numpy()[:, :self.nxh + 1].astype(np.float64)
+
+    def _setup_general(self, XY):
+        if XY in self._gen:
+            return self._gen[XY]
+        if not self.pol and XY != "TT":
+            raise ValueError("construct the estimator with pol=True for %s" % XY)
+        P = self._planes()
+        g, f = self._terms(XY)
+        R = self._sum_gf(g, f)
+        AL = _safe_div(np.ones_like(R), R)
+        L = self.modl_h
+        X, Y = XY[0], XY[1]
+        cross = {"TT": self._ct["T"], "EE": self._ct["E"], "BB": self._ct["B"], "TE": self.cl_len["TE"]}
+        cXY = cross.get(X + Y, cross.get(Y + X, np.zeros_like(L)))
+        gp = [(c, p, P[A] * self._ct[X] if p == 1 else P[A] * self._ct[X], P[B] * self._ct[Y], t) for (c, p, A, B, t) in g]
+        gs = [(c * (-1. if t == "sin" else 1.), 3 - p, P[B] * cXY, P[A] * cXY, t) for (c, p, A, B, t) in g]
+        n1 = self._sum_gf(g, gp)
+        n2 = self._sum_gf(g, gs) if np.any(cXY) else 0.0
+        self.AL[XY] = AL
+        self.Nlkk[XY] = (L * (L + 1.)) ** 2 / 4. * AL ** 2 * (n1 + n2)
+        Fnorm = -(L * (L + 1.) / 2.) * AL * self.mask_K
+        # device filter planes per weight term and trig piece: (sign, FG, FH, swap_legs)
+        c, s_ = np.cos(self.ang_h), np.sin(self.ang_h)
+        pieces = []
+        for (cg, p, A, B, trig) in g:
+            FGh, FHh = (P[A], P[B]) if p == 1 else (P[B], P[A])
+            FGh, FHh = _safe_div(FGh, self.beam), _safe_div(FHh, self.beam)
+            if trig == "1":
+                tl = [(1., None, None)]
+            elif trig == "cos":
+                tl = [(1., c, c), (1., s_, s_)]
+            else:  # sin(a2 - a1): gradient leg at l1 (p==1) or at l2 (p==2)
+                tl = [(1., c, s_), (-1., s_, c)] if p == 1 else [(1., s_, c), (-1., c, s_)]
+            for (sg, tg, th) in tl:
+                fg = FGh if tg is None else FGh * tg
+                fh = FHh if th is None else FHh * th
+                pieces.append((cg * sg, self._hcreal(self.eng, fg), self._hcreal(self.eng, fh), p == 2))
+        self._gen[XY] = dict(pieces=pieces, Fnorm=self._hcreal(self.eng, Fnorm), R=R)
+        return self._gen[XY]
+
+    def reconstruct_hc(self, XY, kX, kY, out=None, norm=None, accumulate=False):
+        """General estimator on hc tensors: kX = DFT of field XY[0], kY = DFT of field XY[1].
+        ``norm`` overrides the divergence/normalisation plane (MV weights), ``accumulate`` adds into ``out``."""
+        e = self.eng
+        G = self._setup_general(XY)
+        w = self._buffers()
+        Gx, Gy, H = w["G"]
+        cx, cy, ch = w["C"]
+        if getattr(self, "_acc", None) is None:
+            self._acc = (e.hc(), e.hc())
+        ax, ay = self._acc
+        scale0 = 1.0 / float(e.npix) ** 2
+        for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
+            kg, kh = (kY, kX) if swap else (kX, kY)
+            e.qe_legs(kg, kh, FG, FH, out=(Gx, Gy, H))
+            e.fft_cols(Gx, inverse=True, out=cx)
+            e.fft_cols(Gy, inverse=True, out=cy)
+            e.fft_cols(H, inverse=True, out=ch)
+            e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0))
+        Px, Py = w["P"]
+        e.fft_cols(ax, inverse=False, out=Px)
+        e.fft_cols(ay, inverse=False, out=Py)
+        return e.qe_div(Px, Py, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate)
+
+    # ---- minimum-variance combination (BASELINE config 3) -------------------------------------------
+    def mv_weights(self, estimators=("TT", "TE", "EE", "EB", "TB")):
+        """Per-mode inverse-noise weights w_a = N_a^-1 / sum_b N_b^-1 (diagonal approximation: the
+        cross-estimator covariances are neglected, as in the reference notebooks' MV curves) and the
+        resulting N_L^kk,MV = 1 / sum_b N_b^-1."""
+        for XY in estimators:
+            self._setup_general(XY) if XY != "TT" or XY not in self.Nlkk else None
+        inv = {XY: _safe_div(np.ones_like(self.modl_h), self.Nlkk[XY]) for XY in estimators}
+        tot = sum(inv.values())
+        w = {XY: _safe_div(inv[XY], tot) for XY in estimators}
+        self.Nlkk["MV"] = _safe_div(np.ones_like(tot), tot)
+        return w
+
+    def reconstruct_mv_hc(self, kT, kE, kB, estimators=("TT", "TE", "EE", "EB", "TB"), out=None):
+        """kappa_hat^MV = sum_a w_a kappa_hat^a, accumulated in the divergence kernel."""
+        e = self.eng
+        key = tuple(estimators)
+        if getattr(self, "_mv", None) is None or self._mv[0] != key:
+            w = self.mv_weights(estimators)
+            L = self.modl_h
+            planes = {}
+            for XY in estimators:
+                AL = self.AL[XY]
+                planes[XY] = self._hcreal(e, -(L * (L + 1.) / 2.) * AL * self.mask_K * w[XY])
+            self._mv = (key, planes)
+        out = e.hc() if out is None else out
+        f = {"T": kT, "E": kE, "B": kB}
+        for i, XY in enumerate(estimators):
+            self.reconstruct_hc(XY, f[XY[0]], f[XY[1]], out=out, norm=self._mv[1][XY], accumulate=(i > 0))
+        return out
 
     # full-plane views of the normalisation (host, float64)
     def _full(self, half):

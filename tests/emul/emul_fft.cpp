@@ -105,7 +105,7 @@ template <typename T>
 static int do_qe_rows(int ny, int nx, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, double s) {
     Holder<T> hd(ny, nx);
     EmuLauncher q;
-    hd.p.rows_qe(q, gx, gy, h, px, py, (T)s);
+    hd.p.rows_qe(q, gx, gy, h, px, py, (T)s, 0);
     return 0;
 }
 

@@ -179,3 +179,79 @@ def test_mc_driver_n0_and_mean_field():
     sel = (ml[:, :N // 2 + 1] > 300) & (ml[:, :N // 2 + 1] < 2500)
     ratio = p_mf[sel].mean() / (q.N_kappa("TT")[:, :N // 2 + 1][sel].mean() / 48.0)
     assert 0.7 < ratio < 1.3
+
+
+def pol_setup(N, res_arcmin, seed=0):
+    from orphics_amd import cosmology, maps
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res_arcmin)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    nT = np.full(shape, cosmology.white_noise_power(1.0))
+    nP = 2 * nT
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3000)
+    cl = {k: th.lCl(k, ml) for k in ("TT", "EE", "BB", "TE")}
+    rng = np.random.default_rng(seed)
+    sc = 1.0 / np.sqrt(g.pixarea)
+    # correlated T,E + independent B Gaussian observed fields (beam-convolved + noise), as DFTs
+    w1, w2, w3 = (np.fft.fft2(rng.standard_normal(shape)) for _ in range(3))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.nan_to_num(cl["TE"] / np.sqrt(cl["TT"] * cl["EE"]))
+    kT = w1 * np.sqrt(cl["TT"]) * beam * sc + np.fft.fft2(rng.standard_normal(shape)) * np.sqrt(nT) * sc
+    kE = (r * w1 + np.sqrt(1 - r ** 2) * w2) * np.sqrt(cl["EE"]) * beam * sc + np.fft.fft2(rng.standard_normal(shape)) * np.sqrt(nP) * sc
+    kB = w3 * np.sqrt(cl["BB"]) * beam * sc + np.fft.fft2(rng.standard_normal(shape)) * np.sqrt(nP) * sc
+    return shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, dict(T=kT, E=kE, B=kB)
+
+
+@pytest.mark.parametrize("XY", ["TT", "EE", "EB", "TE", "TB"])
+def test_pol_estimators_match_oracle(XY):
+    """Device general estimators (f64 kernels) vs oracle.QEOracle: response, N0 and kappa_hat DFT;
+    f32 kernels: kappa bandpowers within 1e-5."""
+    from orphics_amd import lensing, maps, stats
+    N, res = 128, 2.0
+    shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup(N, res, seed=4)
+    qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)
+    qr.setup(XY)
+    X, Y = XY[0], XY[1]
+    kref = qr.kappa_ft(XY, k[X], k[Y])
+    kw = dict(noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask, pol=True,
+              unlensed_equals_lensed=True)
+    q = lensing.qest(shape, g, th, dtype="f64", **kw)
+    args = dict(T2DData=k["T"], E2DData=k["E"], B2DData=k["B"], alreadyFTed=True, returnFt=True)
+    got = q.kappa_from_map(XY, **args)
+    sel = (ml > 40) & (ml < 2900) & (qr.R[XY] != 0)
+    Rf = q._full(q._gen[XY]["R"]) if XY != "TT" else q._full(q.R_TT)
+    assert np.max(np.abs(Rf[sel] / qr.R[XY][sel] - 1)) < 1e-8
+    assert np.max(np.abs(q.N_kappa(XY)[sel] / qr.Nlkk[XY][sel] - 1)) < 1e-7
+    assert np.abs(got - kref)[sel].max() / np.abs(kref[sel]).max() < 1e-8
+    q32 = lensing.qest(shape, g, th, dtype="f32", **kw)
+    got32 = q32.kappa_from_map(XY, **{kk: (v.astype(np.complex64) if isinstance(v, np.ndarray) else v) for kk, v in args.items()})
+    edges = np.linspace(40, 2900, 16)
+    bo = so.bin2D(ml, edges)
+    fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+    _, pref = bo.bin(fo.f2power(kref, kref))
+    _, p32 = stats.bin2D(ml, edges).bin(maps.FourierCalc(shape, g).f2power(got32.astype(np.complex128), got32.astype(np.complex128)))
+    assert np.max(np.abs(p32 / pref - 1)) < 1e-5
+
+
+def test_mv_combination_matches_oracle():
+    """BASELINE config 3 shape (TT/EE/EB/TE/TB minimum-variance combination) at test size."""
+    from orphics_amd import lensing
+    N, res = 128, 2.0
+    shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup(N, res, seed=9)
+    qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)
+    ref = qr.kappa_mv_ft(k)
+    for prec, tol in (("f64", 1e-8), ("f32", 3e-4)):
+        q = lensing.qest(shape, g, th, noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask,
+                         pol=True, unlensed_equals_lensed=True, dtype=prec)
+        e = q.eng
+        hk = {X: e.full_to_hc(e.to_complex(k[X])) for X in "TEB"}
+        got = e.hc_to_full(q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"])).cpu().numpy()
+        sel = (ml > 40) & (ml < 2900)
+        assert np.abs(got - ref)[sel].max() / np.abs(ref[sel]).max() < tol
+        nmv = q._full(q.Nlkk["MV"])
+        assert np.max(np.abs(nmv[sel & (qr.Nlkk["MV"] > 0)] / qr.Nlkk["MV"][sel & (qr.Nlkk["MV"] > 0)] - 1)) < 1e-6
+        assert np.all(nmv[sel] <= q.N_kappa("TT")[sel] * (1 + 1e-9))   # MV is never noisier than TT

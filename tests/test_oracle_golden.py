@@ -171,3 +171,81 @@ def test_qe_linear_response_recovers_injected_phi():
     expected = L * (L + 1) / 2. * amp
     assert abs(est.real / expected - 1) < 0.05
     assert abs(est.imag / expected) < 0.05
+
+
+def _pol_setup(N=48, res_arcmin=3.0):
+    res = res_arcmin * np.pi / 180. / 60.
+    shape = (N, N)
+    ml = mo.modlmap(shape, res, -res)
+    tt = 1e3 / (1 + (ml / 300.) ** 3)
+    cl = dict(TT=tt, EE=0.05 * tt, BB=0.0 * tt, TE=0.12 * tt * np.cos(ml / 400.))
+    w = (2.0 * np.pi / 180. / 60.) ** 2
+    noise = dict(T=np.full(shape, w), P=np.full(shape, 2 * w))   # filters only (maps are noise-free)
+    mk = mo.mask_kspace(shape, res, -res, lmin=100, lmax=1800)
+    return shape, res, ml, cl, noise, mk
+
+
+def test_general_estimators_response_matches_brute_force():
+    shape, res, ml, cl, noise, mk = _pol_setup(N=24, res_arcmin=5.0)
+    cl = dict(cl, BB=0.002 * cl["TT"])
+    q = qo.QEOracle(shape, res, -res, cl, noise, np.ones(shape), dict(T=mk, P=mk))
+    for XY in ("TT", "EE", "EB", "TE", "TB"):
+        g, f = qo.estimator_terms(XY)
+        q.setup(XY)
+        for (yi, xi) in [(1, 2), (3, 22)]:
+            bf = qo.brute_force_gf(q, g, f, yi, xi)
+            assert abs(q.R[XY][yi, xi] / bf - 1) < 1e-10
+
+
+@pytest.mark.parametrize("XY", ["TT", "EE", "EB", "TE", "TB"])
+def test_general_estimators_recover_injected_phi(XY):
+    """First-order lensed T,Q,U (scalar remapping) -> E,B by the reference rotation
+    (maps.py:1614-1615) -> every estimator returns the injected kappa mode."""
+    shape, res, ml, cl, noise, mk = _pol_setup()
+    q = qo.QEOracle(shape, res, -res, cl, noise, np.ones(shape), dict(T=mk, P=mk))
+    q.setup(XY)
+    ly, lx = mo.laxes(shape, res, -res)
+    LY, LX = np.meshgrid(ly, lx, indexing="ij")
+    npix = shape[0] * shape[1]
+    rot = mo.queb_rotmat(mo.lmap(shape, res, -res))
+    irot = mo.queb_rotmat(mo.lmap(shape, res, -res), inverse=True)
+    phik = np.zeros(shape, complex)
+    yi, xi = 2, 3
+    amp = 1e-7 * npix
+    phik[yi, xi] = amp
+    phik[-yi, -xi] = amp
+    gpx = np.fft.ifft2(1j * LX * phik).real
+    gpy = np.fft.ifft2(1j * LY * phik).real
+    rng = np.random.default_rng(5)
+    # correlated T,E Gaussian modes; B = 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.nan_to_num(cl["TE"] / np.sqrt(cl["TT"] * cl["EE"]))
+
+    def lens(m):
+        k = np.fft.fft2(m)
+        return m + gpx * np.fft.ifft2(1j * LX * k).real + gpy * np.fft.ifft2(1j * LY * k).real
+
+    acc = 0
+    nsim = 40
+    for i in range(nsim):
+        w1 = np.fft.fft2(rng.standard_normal(shape))
+        w2 = np.fft.fft2(rng.standard_normal(shape))
+        sc = np.sqrt(1.0 / q.pixarea)
+        kT = w1 * np.sqrt(cl["TT"]) * sc
+        kE = (r * w1 + np.sqrt(1 - r ** 2) * w2) * np.sqrt(cl["EE"]) * sc
+        kB = 0 * kE
+        qu = mo.map_mul(irot, np.array([kE, kB]))
+        T, Q, U = np.fft.ifft2(kT).real, np.fft.ifft2(qu[0]).real, np.fft.ifft2(qu[1]).real
+        f0 = {"T": np.fft.fft2(T)}
+        eb = mo.map_mul(rot, np.array([np.fft.fft2(Q), np.fft.fft2(U)]))
+        f0["E"], f0["B"] = eb[0], eb[1]
+        f1 = {"T": np.fft.fft2(lens(T))}
+        eb = mo.map_mul(rot, np.array([np.fft.fft2(lens(Q)), np.fft.fft2(lens(U))]))
+        f1["E"], f1["B"] = eb[0], eb[1]
+        X, Y = XY[0], XY[1]
+        acc = acc + (q.kappa_ft(XY, f1[X], f1[Y]) - q.kappa_ft(XY, f0[X], f0[Y]))[yi, xi]
+    est = acc / nsim
+    L = ml[yi, xi]
+    expected = L * (L + 1) / 2. * amp
+    assert abs(est.real / expected - 1) < 0.08, (XY, est / expected)
+    assert abs(est.imag / expected) < 0.08
