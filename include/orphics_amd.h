@@ -86,6 +86,17 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
                int accumulate, void* stream);
 
+/* Fused estimator column stages (the fast path of lensing.Estimator.reconstruct_*):
+ *  oa_qe_legs_cols : oa_qe_legs + oa_fft_cols(inverse) of the three leg planes in one go -- kX, kY and the
+ *                    filters are read once per column tile, the filtered legs never exist in HBM
+ *                    (outputs feed oa_qe_rows);
+ *  oa_qe_cols_div  : oa_fft_cols(forward) of the two oa_qe_rows outputs + oa_qe_div in one go:
+ *                    out (+)= Fnorm * (i lx FFT[Px] + i ly FFT[Py]). */
+int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                    void* stream);
+int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
+                   void* stream);
+
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of
  * a real map holds, maps.py:1613) */

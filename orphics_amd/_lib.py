@@ -35,6 +35,8 @@ SIGNATURES = {
     "oa_fft_pass": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "oa_fft_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_int, c_void_p]),
+    "oa_qe_legs_cols": (c_int, [c_void_p] * 9),
+    "oa_qe_cols_div": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     "oa_hc_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

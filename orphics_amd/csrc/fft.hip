@@ -47,6 +47,20 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), qe_waves_per_eu<T>()) void row_qe
     row_qe_body<T, SEQ>(c, a);
 }
 
+template <typename T> constexpr int fused_col_waves_per_eu() { return sizeof(T) == 8 ? 1 : 2; }
+
+template <typename T, class SEQ>
+__global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_legs_kernel(ColLegsArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_legs_body<T, SEQ>(c, a);
+}
+
+template <typename T, class SEQ>
+__global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_div_kernel(ColDivArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_div_body<T, SEQ>(c, a);
+}
+
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_fft_kernel(ColArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -104,6 +118,28 @@ struct HipLauncher {
             }
         });
         if (!ok && !rc) rc = fail("fft: unsupported row length");
+    }
+    template <typename T>
+    void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
+        const bool ok = dispatch_seq(logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_logl<S>() <= 8) {
+                if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
+                go(col_legs_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+            } else if (!rc) rc = fail("fft: unsupported column sub-length");
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported column length");
+    }
+    template <typename T>
+    void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
+        const bool ok = dispatch_seq(logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_logl<S>() <= 8) {
+                if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
+                go(col_div_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+            } else if (!rc) rc = fail("fft: unsupported column sub-length");
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported column length");
     }
     template <typename T>
     void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
@@ -178,11 +214,49 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
     return q.rc;
 }
 
+template <typename T>
+static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy,
+                          void* h, hipStream_t st) {
+    HipLauncher q{st};
+    view<T>(p).legs_cols(q, (const cx<T>*)kX, (const cx<T>*)kY, (const T*)FG, (const T*)FH, (const T*)p->lxd,
+                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h);
+    return q.rc;
+}
+template <typename T>
+static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
+                         hipStream_t st) {
+    const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
+    if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
+    HipLauncher q{st};
+    cx<T>* tA = (cx<T>*)p->scratch;
+    cx<T>* tB = tA + (size_t)p->ny * p->kp;
+    view<T>(p).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
+                        (cx<T>*)out, tA, tB, accumulate);
+    return q.rc;
+}
+
 }  // namespace oa
 
 using namespace oa;
 
 extern "C" {
+
+int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                    void* stream) {
+    OA_REQUIRE(p && kX && kY && FG && FH && gx && gy && h, "oa_qe_legs_cols: NULL argument");
+    OA_REQUIRE(p->have_laxes, "oa_qe_legs_cols: call oa_plan_set_laxes first");
+    OA_REQUIRE(gx != kX && gy != kX && h != kX && gx != kY && gy != kY && h != kY, "oa_qe_legs_cols: outputs alias inputs");
+    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, (hipStream_t)stream)
+                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, (hipStream_t)stream);
+}
+
+int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
+                   void* stream) {
+    OA_REQUIRE(p && px_rows && py_rows && Fnorm && out, "oa_qe_cols_div: NULL argument");
+    OA_REQUIRE(p->have_laxes, "oa_qe_cols_div: call oa_plan_set_laxes first");
+    return p->dtype == OA_F32 ? cols_div_impl<float>(p, px_rows, py_rows, Fnorm, out, accumulate, (hipStream_t)stream)
+                              : cols_div_impl<double>(p, px_rows, py_rows, Fnorm, out, accumulate, (hipStream_t)stream);
+}
 
 int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, void* stream) {
     OA_REQUIRE(p && hc_in && hc_out, "oa_fft_cols: NULL argument");

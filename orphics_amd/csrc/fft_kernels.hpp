@@ -526,6 +526,191 @@ struct ColStore {
     }
 };
 
+// ---- column pipelines that start from / end in registers (fused estimator passes) ----------------
+// v holds this thread's first-stage inputs (element u*R0+t <-> point j_u + t*L/R0); results go to `st`.
+template <typename T, class SEQ, class Ctx, class St>
+OA_HD void col_pipeline_from_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logC, const cx<T>* tw, int logTw,
+                                  const St& st) {
+    constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+    constexpr int R0 = SEQ::get(0);
+#pragma unroll
+    for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
+    if constexpr (SEQ::n == 1) {
+        stage_out<T, R0, false, true>(s, v, tid, NT, logL, logC, 0, 0, st);
+    } else {
+        stage_out<T, R0, false, false>(s, v, tid, NT, logL, logC, 0, 0, NoStore{});
+        ctx.sync();
+        constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
+        if constexpr (SEQ::n == 2) {
+            stage<T, SEQ::r1, false, false, true>(ctx, s, tid, NT, logL, logC, 0, l0, tw, logTw, NoLoad{}, st);
+        } else {
+            stage<T, SEQ::r1, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l0, tw, logTw, NoLoad{}, NoStore{});
+            ctx.sync();
+            if constexpr (SEQ::n == 3) {
+                stage<T, SEQ::r2, false, false, true>(ctx, s, tid, NT, logL, logC, 0, l1, tw, logTw, NoLoad{}, st);
+            } else {
+                stage<T, SEQ::r2, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l1, tw, logTw, NoLoad{}, NoStore{});
+                ctx.sync();
+                stage<T, SEQ::r3, false, false, true>(ctx, s, tid, NT, logL, logC, 0, l2, tw, logTw, NoLoad{}, st);
+            }
+        }
+    }
+}
+
+// full pipeline from a global load functor whose LAST stage stays in registers:
+// v[u*RL + t] = bin (base_u + t*Ns) of the transform, RL = last radix, Ns = L/RL.
+template <typename T, class SEQ, class Ctx, class Ld>
+OA_HD void col_pipeline_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logC, const cx<T>* tw, int logTw,
+                                const Ld& ld) {
+    constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+    constexpr int n = SEQ::n;
+    constexpr int RL = SEQ::get(n - 1);
+    if constexpr (n == 1) {
+        stage_in<T, RL, false, true>(s, v, tid, NT, logL, logC, 0, 0, tw, logTw, ld);
+    } else {
+        stage<T, SEQ::r0, false, true, false>(ctx, s, tid, NT, logL, logC, 0, 0, tw, logTw, ld, NoStore{});
+        ctx.sync();
+        constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
+        if constexpr (n >= 3) {
+            stage<T, SEQ::r1, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l0, tw, logTw, NoLoad{}, NoStore{});
+            ctx.sync();
+        }
+        if constexpr (n >= 4) {
+            stage<T, SEQ::r2, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l1, tw, logTw, NoLoad{}, NoStore{});
+            ctx.sync();
+        }
+        constexpr int ll = (n == 2) ? l0 : ((n == 3) ? l1 : l2);
+        stage_in<T, RL, false, false>(s, v, tid, NT, logL, logC, 0, ll, tw, logTw, NoLoad{});
+    }
+}
+
+// ===========================================================================
+// (A) leg filters fused into the inverse column pass 1: kX, kY are read ONCE per tile and the three
+//     leg planes  Gx = i lx FG kX,  Gy = i ly FG kX,  H = FH kY  leave as pass-1 outputs.
+// ===========================================================================
+template <typename T>
+struct ColLegsArgs {
+    const cx<T>* kX; const cx<T>* kY;
+    const T* FG; const T* FH;
+    const T* lxd; const T* lyd;
+    cx<T>* gx; cx<T>* gy; cx<T>* h;
+    long pitch;
+    int width, logC, NT;
+    const cx<T>* tw;
+    int logTw;
+    long in_gs, in_ns, out_gs, out_ks;
+    int twiddle;
+};
+
+template <typename T, class SEQ, class Ctx>
+OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+    constexpr int R0 = SEQ::get(0), LR = Log2x<R0>::v, NB = EPT / R0;
+    const int tid = ctx.tid(), NT = a.NT, logC = a.logC;
+    const int c0 = ctx.bid_x() << logC;
+    const long g = ctx.bid_y();
+    int ncols = a.width - c0;
+    if (ncols > (1 << logC)) ncols = 1 << logC;
+    cx<T> gv[EPT], hv[EPT], v[EPT];
+    T lyv[EPT];
+    T lxv[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b & ((1 << logC) - 1), j = b >> logC;
+        const bool ok = c < ncols;
+        lxv[u] = ok ? a.lxd[c0 + c] : (T)0;
+#pragma unroll
+        for (int t = 0; t < R0; ++t) {
+            const int n = j + (t << (logL - LR));
+            const long y = g * a.in_gs + n * a.in_ns;
+            const long i = y * a.pitch + c0 + c;
+            cx<T> kx = mk<T>((T)0, (T)0), ky = kx;
+            T fg = 0, fh = 0;
+            if (ok) { kx = a.kX[i]; ky = a.kY[i]; fg = a.FG[i]; fh = a.FH[i]; }
+            gv[u * R0 + t] = kx * fg;
+            hv[u * R0 + t] = ky * fh;
+            lyv[u * R0 + t] = a.lyd[y];
+        }
+    }
+    for (int leg = 0; leg < 3; ++leg) {
+        // inverse transform = forward transform of the swapped data
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+#pragma unroll
+            for (int t = 0; t < R0; ++t) {
+                const int e = u * R0 + t;
+                cx<T> x;
+                if (leg == 0) x = mul_pi(gv[e]) * lxv[u];
+                else if (leg == 1) x = mul_pi(gv[e]) * lyv[e];
+                else x = hv[e];
+                v[e] = swp(x);
+            }
+        cx<T>* dst = leg == 0 ? a.gx : (leg == 1 ? a.gy : a.h);
+        const ColStore<T> st{dst + g * a.out_gs * a.pitch + c0, a.out_ks * a.pitch, ncols, true,
+                             a.twiddle ? a.tw : nullptr, g, (T)1};
+        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
+        ctx.sync();
+    }
+}
+
+// ===========================================================================
+// (B) divergence * normalisation fused into the forward column pass 2:
+//     out = Fn * (i lx FFTcol[A] + i ly FFTcol[B])   (+ out if accumulate)
+// ===========================================================================
+template <typename T>
+struct ColDivArgs {
+    const cx<T>* A; const cx<T>* B;
+    const T* Fn;
+    const T* lxd; const T* lyd;
+    cx<T>* out;
+    long pitch;
+    int width, logC, NT;
+    const cx<T>* tw;
+    int logTw;
+    long in_gs, in_ns, out_gs, out_ks;
+    int accumulate;
+};
+
+template <typename T, class SEQ, class Ctx>
+OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+    constexpr int n = SEQ::n;
+    constexpr int RL = SEQ::get(n - 1), LRL = Log2x<RL>::v, NB = EPT / RL;
+    constexpr int logNs = logL - LRL;
+    const int tid = ctx.tid(), NT = a.NT, logC = a.logC;
+    const int c0 = ctx.bid_x() << logC;
+    const long g = ctx.bid_y();
+    int ncols = a.width - c0;
+    if (ncols > (1 << logC)) ncols = 1 << logC;
+    cx<T> va[EPT], vb[EPT];
+    const ColLoad<T> la{a.A + g * a.in_gs * a.pitch + c0, a.in_ns * a.pitch, ncols, false};
+    const ColLoad<T> lb{a.B + g * a.in_gs * a.pitch + c0, a.in_ns * a.pitch, ncols, false};
+    col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, a.tw, a.logTw, la);
+    ctx.sync();
+    col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, a.tw, a.logTw, lb);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b & ((1 << logC) - 1), j = b >> logC;
+        if (c >= ncols) continue;
+        const int kq = j & ((1 << logNs) - 1);
+        const int base = ((j - kq) << LRL) + kq;
+        const T lx = a.lxd[c0 + c];
+#pragma unroll
+        for (int t = 0; t < RL; ++t) {
+            const int k = base + (t << logNs);
+            const long y = g * a.out_gs + k * a.out_ks;
+            const long i = y * a.pitch + c0 + c;
+            cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y]) * a.Fn[i];
+            if (a.accumulate) d = d + a.out[i];
+            a.out[i] = d;
+        }
+    }
+}
+
 template <typename T, class SEQ, class Ctx>
 OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());

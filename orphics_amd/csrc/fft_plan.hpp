@@ -113,6 +113,43 @@ struct Fft2dPlan {
         q.col(tiles, (int)N1, a.NT, (size_t)N2 * C * sizeof(cx<T>), a);
     }
 
+    // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
+    template <class Launcher>
+    void legs_cols(Launcher& q, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
+                   cx<T>* gx, cx<T>* gy, cx<T>* h) const {
+        const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
+        const long N1 = 1L << logN1, N2 = 1L << logN2;
+        const int C = 1 << COLC;
+        const int width = nx / 2 + 1;
+        const int tiles = (width + C - 1) / C;
+        ColLegsArgs<T> a{};
+        a.kX = kX; a.kY = kY; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
+        a.pitch = kp; a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
+        a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
+        q.col_legs(tiles, (int)N2, a.NT, (size_t)N1 * C * sizeof(cx<T>), logN1, a);
+        cx<T>* outs[3] = {gx, gy, h};
+        for (int i = 0; i < 3; ++i) cols(q, outs[i], kp, outs[i], kp, width, true, (T)1, 2);
+    }
+
+    // (B) forward column transforms of two row-transformed planes + divergence * Fnorm
+    //     tmpA, tmpB: two hc scratch planes
+    template <class Launcher>
+    void cols_div(Launcher& q, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
+                  cx<T>* tmpA, cx<T>* tmpB, int accumulate) const {
+        const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
+        const long N1 = 1L << logN1, N2 = 1L << logN2;
+        const int C = 1 << COLC;
+        const int width = nx / 2 + 1;
+        const int tiles = (width + C - 1) / C;
+        cols(q, pa, kp, tmpA, kp, width, false, (T)1, 1);
+        cols(q, pb, kp, tmpB, kp, width, false, (T)1, 1);
+        ColDivArgs<T> a{};
+        a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = kp; a.width = width;
+        a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
+        a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
+        q.col_div(tiles, (int)N1, a.NT, (size_t)N2 * C * sizeof(cx<T>), logN2, a);
+    }
+
     // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane
     template <class Launcher>
     void r2c(Launcher& q, const T* in, cx<T>* out, cx<T>* tmp, T scale) const {

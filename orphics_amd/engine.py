@@ -201,6 +201,22 @@ class Engine(object):
                                   1 if accumulate else 0, _stream()))
         return px, py
 
+    def qe_legs_cols(self, kX, kY, FG, FH, out):
+        """Fused leg filters + inverse column transforms (3 planes out, ready for qe_rows)."""
+        self._chk(kX, "hc"); self._chk(kY, "hc"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
+        gx, gy, h = out
+        for t in out:
+            self._chk(t, "hc")
+        check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), _stream()))
+        return out
+
+    def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False):
+        """Fused forward column transforms + divergence * normalisation."""
+        self._chk(px, "hc"); self._chk(py, "hc"); self._chk(Fnorm, "hcreal")
+        out = self.hc() if out is None else self._chk(out, "hc")
+        check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, _stream()))
+        return out
+
     def fft_pass(self, pass_id, src, dst):
         """Launch one constituent FFT pass (per-kernel timing in bench.py)."""
         check(self.lib.oa_fft_pass(self.plan, int(pass_id), _ptr(src), _ptr(dst), _stream()))

@@ -189,17 +189,15 @@ class Estimator(object):
         kY = kX if kY is None else kY
         FG, FH, Fn = self._F["TT"]
         w = self._buffers()
-        Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
         if fused:
-            cx, cy, ch = w["C"]
-            e.fft_cols(Gx, inverse=True, out=cx)
-            e.fft_cols(Gy, inverse=True, out=cy)
-            e.fft_cols(H, inverse=True, out=ch)
-            e.qe_rows(cx, cy, ch, Gx, Gy)          # Gx, Gy reused as the row-transformed products
-            Px, Py = w["P"]
-            e.fft_cols(Gx, inverse=False, out=Px)
-            e.fft_cols(Gy, inverse=False, out=Py)
-            return e.qe_div(Px, Py, Fn, out=out)
+            # legs+inverse columns (1 fused pass + 3 in-place passes) -> fused row stage -> forward
+            # columns + divergence (2 passes + 1 fused pass): the filtered legs, the real-space planes
+            # and the pre-divergence planes never exist in HBM
+            cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"])
+            Gx, Gy, _ = w["G"]
+            e.qe_rows(cx, cy, ch, Gx, Gy)
+            return e.qe_cols_div(Gx, Gy, Fn, out=out)
+        Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
         gx, gy, h = self._real_buffers()
         e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
         e.mul_real(gx, h, out=gx)
@@ -418,15 +416,9 @@ class Estimator(object):
         scale0 = 1.0 / float(e.npix) ** 2
         for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
             kg, kh = (kY, kX) if swap else (kX, kY)
-            e.qe_legs(kg, kh, FG, FH, out=(Gx, Gy, H))
-            e.fft_cols(Gx, inverse=True, out=cx)
-            e.fft_cols(Gy, inverse=True, out=cy)
-            e.fft_cols(H, inverse=True, out=ch)
+            e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch))
             e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0))
-        Px, Py = w["P"]
-        e.fft_cols(ax, inverse=False, out=Px)
-        e.fft_cols(ay, inverse=False, out=Py)
-        return e.qe_div(Px, Py, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate)
+        return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate)
 
     # ---- minimum-variance combination (BASELINE config 3) -------------------------------------------
     def mv_weights(self, estimators=("TT", "TE", "EE", "EB", "TB")):

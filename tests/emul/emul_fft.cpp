@@ -56,6 +56,18 @@ struct EmuLauncher {
             run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_body<T, S>(c, a); });
         });
     }
+    template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
+        dispatch_seq(logL, [&](auto seq) {
+            using S = decltype(seq);
+            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_legs_body<T, S>(c, a); });
+        });
+    }
+    template <typename T> void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
+        dispatch_seq(logL, [&](auto seq) {
+            using S = decltype(seq);
+            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_div_body<T, S>(c, a); });
+        });
+    }
     template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
         dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
@@ -109,7 +121,33 @@ static int do_qe_rows(int ny, int nx, const cx<T>* gx, const cx<T>* gy, const cx
     return 0;
 }
 
+template <typename T>
+static int do_legs_cols(int ny, int nx, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
+                        cx<T>* gx, cx<T>* gy, cx<T>* h) {
+    Holder<T> hd(ny, nx);
+    EmuLauncher q;
+    hd.p.legs_cols(q, kX, kY, FG, FH, lxd, lyd, gx, gy, h);
+    return 0;
+}
+template <typename T>
+static int do_cols_div(int ny, int nx, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out) {
+    Holder<T> hd(ny, nx);
+    std::vector<cx<T>> tA((size_t)ny * hd.p.kp), tB((size_t)ny * hd.p.kp);
+    EmuLauncher q;
+    hd.p.cols_div(q, pa, pb, Fn, lxd, lyd, out, tA.data(), tB.data(), 0);
+    return 0;
+}
+
 extern "C" {
+int emu_legs_cols_f64(int ny, int nx, const void* kX, const void* kY, const double* FG, const double* FH, const double* lxd,
+                      const double* lyd, void* gx, void* gy, void* h) {
+    return do_legs_cols<double>(ny, nx, (const cx<double>*)kX, (const cx<double>*)kY, FG, FH, lxd, lyd, (cx<double>*)gx,
+                                (cx<double>*)gy, (cx<double>*)h);
+}
+int emu_cols_div_f64(int ny, int nx, const void* pa, const void* pb, const double* Fn, const double* lxd, const double* lyd,
+                     void* out) {
+    return do_cols_div<double>(ny, nx, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out);
+}
 int emu_qe_rows_f32(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s) {
     return do_qe_rows<float>(ny, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s);
 }
