@@ -162,6 +162,13 @@ int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights,
            int nids, int mode, int skip_nan, long herm_pitch, int herm_nxh, double* sums, int64_t* counts,
            double* wsums, void* scratch, void* stream);
 
+/* oa_bin_power: FourierCalc.f2power (maps.py:1620-1624) fused into oa_bin: the binned value is
+ * Re(conj(k1[i]) k2[i]) * norm for complex planes k1, k2 (k1 == k2 for auto spectra); the 2-D power
+ * plane is never written.  Same ids / multiplicity / determinism contract as oa_bin (mode 0). */
+int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const int32_t* ids, const void* weights, long n,
+                 int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
+                 void* stream);
+
 /* ---- Gaussian random fields (MapGen.get_map, maps.py:1576-1587) --------------
  * Fills an hc plane with Hermitian-consistent complex white noise of unit
  * variance per full-plane mode, scaled per mode by the real hc-layout plane

@@ -320,3 +320,43 @@ def interp_spectrum(ells, cls, ell2d):
     """Linear interpolation of a 1-D C_ell onto a 2-D |ell| grid, 0 outside
     (SURVEY.md section 8d synthetic-input convention)."""
     return np.interp(ell2d, ells, cls, left=0.0, right=0.0)
+
+
+def matched_filter(imap, fwhm_arcmin, step_y, step_x, cls, noise_uk_arcmin=None, taper_per=12.0):
+    """maps.py:677-699 (unitary fft/ifft pair == fft2/ifft2)."""
+    shape = imap.shape
+    taper = 1.0
+    if taper_per is not None:
+        taper, _ = get_taper(shape[-2:], taper_percent=taper_per)
+    ml = modlmap(shape, step_y, step_x)
+    p2d = gauss_beam(ml, fwhm_arcmin)
+    s2d = np.interp(ml, np.arange(cls.size), cls, left=0.0, right=0.0)
+    n2d = 0. if noise_uk_arcmin is None else (noise_uk_arcmin * np.pi / 180. / 60.) ** 2.
+    with np.errstate(divide="ignore", invalid="ignore"):
+        filt2d = p2d / (s2d + n2d)
+    filt2d[~np.isfinite(filt2d)] = 0.
+    return _ifft2(_fft2(imap * taper) * filt2d).real
+
+
+def kspace_coadd(kmaps, kbeams, kncovs, fkbeam=1):
+    """maps.py:1098-1114."""
+    kmaps, kbeams, kncovs = np.asarray(kmaps), np.asarray(kbeams), np.asarray(kncovs)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        numer = np.sum(kmaps * kbeams * fkbeam / kncovs, axis=0)
+        numer[~np.isfinite(numer)] = 0
+        denom = np.sum(kbeams ** 2 / kncovs, axis=0)
+        f = numer / denom
+    f[~np.isfinite(f)] = 0
+    return f
+
+
+def matched_filter_apply(ktemp, kmap, n2d, normfact, kmask=None):
+    """MatchedFilter.apply, maps.py:2587-2604."""
+    if kmask is None:
+        kmask = 1.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        in2d = 1. / n2d
+    in2d[~np.isfinite(in2d)] = 0
+    phi_un = np.sum(ktemp.conj() * kmap * normfact * kmask * in2d).real
+    phi_var = 1. / np.sum(ktemp.conj() * ktemp * normfact * kmask * in2d).real
+    return phi_un * phi_var, phi_var

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborphics_amd.so")
+LIB_PATH = os.environ.get("ORPHICS_AMD_LIB", os.path.join(_HERE, "liborphics_amd.so"))  # override: tuning builds only
 
 OA_F32 = 0
 OA_F64 = 1
@@ -53,6 +53,8 @@ SIGNATURES = {
     "oa_bin_scratch_bytes": (c_long, [c_int]),
     "oa_bin": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_long, c_int,
                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_bin_power": (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_long, c_int, c_long, c_int,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_grf_hc": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
     "oa_randn": (c_int, [c_int, c_u64, c_u64, c_void_p, c_long, c_void_p]),
     "oa_moments_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -92,8 +92,11 @@ OA_D void wave_accum(bool valid, int id, double v, double cw, int ci, double* ro
     }
 }
 
-template <typename T, bool WEIGHTED>
-__global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ data, const int32_t* __restrict__ ids,
+// POWER: `data`/`data2` are complex planes and the binned value is Re(conj(k1) k2) * pnorm
+// (FourierCalc.f2power fused into the histogram: the 2-D power plane never exists in HBM)
+template <typename T, bool WEIGHTED, bool POWER>
+__global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ data, const T* __restrict__ data2, double pnorm,
+                                                        const int32_t* __restrict__ ids,
                                                         const T* __restrict__ w, const double* __restrict__ aux, long n,
                                                         int nids, int mode, int skip_nan, unsigned hp, int nxh,
                                                         double* __restrict__ part_sum, double* __restrict__ part_w,
@@ -119,17 +122,32 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
         bool ok[4];
         if (c < nchunks && i0 + 3 < n) {
             const Arr<int32_t, 4> I = reinterpret_cast<const Arr<int32_t, 4>*>(ids)[c];
-            const Arr<T, 4> D = reinterpret_cast<const Arr<T, 4>*>(data)[c];
             Arr<T, 4> W;
             if (WEIGHTED) W = reinterpret_cast<const Arr<T, 4>*>(w)[c];
+            if (POWER) {
+                const Arr<T, 8> K1 = reinterpret_cast<const Arr<T, 8>*>(data)[c];
+                const Arr<T, 8> K2 = (data2 == data) ? K1 : reinterpret_cast<const Arr<T, 8>*>(data2)[c];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { id[j] = I.v[j]; v[j] = (double)D.v[j]; cw[j] = WEIGHTED ? (double)W.v[j] : 1.0; ok[j] = true; }
+                for (int j = 0; j < 4; ++j)
+                    v[j] = (double)((K1.v[2 * j] * K2.v[2 * j] + K1.v[2 * j + 1] * K2.v[2 * j + 1]) * (T)pnorm);
+            } else {
+                const Arr<T, 4> D = reinterpret_cast<const Arr<T, 4>*>(data)[c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (double)D.v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { id[j] = I.v[j]; cw[j] = WEIGHTED ? (double)W.v[j] : 1.0; ok[j] = true; }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ok[j] = (c < nchunks) && (i0 + j < n);
                 id[j] = ok[j] ? ids[i0 + j] : -1;
-                v[j] = ok[j] ? (double)data[i0 + j] : 0.0;
+                if (POWER) {
+                    const long e = 2 * (i0 + j);
+                    v[j] = ok[j] ? (double)((data[e] * data2[e] + data[e + 1] * data2[e + 1]) * (T)pnorm) : 0.0;
+                } else {
+                    v[j] = ok[j] ? (double)data[i0 + j] : 0.0;
+                }
                 cw[j] = (WEIGHTED && ok[j]) ? (double)w[i0 + j] : 1.0;
             }
         }
@@ -213,7 +231,8 @@ __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict
 }
 
 template <typename T>
-static int bin_impl(const void* data, const int32_t* ids, const void* weights, const double* aux, long n, int nids, int mode,
+static int bin_impl(const void* data, const void* data2, double pnorm, bool power, const int32_t* ids, const void* weights,
+                    const double* aux, long n, int nids, int mode,
                     int skip_nan, long hp, int nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
                     hipStream_t st) {
     const long nchunks = (n + 3) / 4;
@@ -225,19 +244,21 @@ static int bin_impl(const void* data, const int32_t* ids, const void* weights, c
     unsigned long long* part_cnt = reinterpret_cast<unsigned long long*>(part_w);
     const size_t smem = (size_t)2 * BIN_WAVES * nids * sizeof(double);
     const bool weighted = weights != nullptr;
-    if (weighted) {
-        auto k = bin_kernel<T, true>;
-        if (smem > 48 * 1024)
-            OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, ids, (const T*)weights, aux, n, nids, mode,
-                           skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, part_sum, part_w, part_cnt);
-    } else {
-        auto k = bin_kernel<T, false>;
-        if (smem > 48 * 1024)
-            OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, ids, (const T*)nullptr, aux, n, nids, mode,
-                           skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, part_sum, part_w, part_cnt);
+#define OA_BIN_LAUNCH(W, P)                                                                                          \
+    {                                                                                                                \
+        auto k = bin_kernel<T, W, P>;                                                                                \
+        if (smem > 48 * 1024)                                                                                        \
+            OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)smem));                                                                  \
+        hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, (const T*)data2, pnorm, ids,       \
+                           (const T*)weights, aux, n, nids, mode, skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh,        \
+                           part_sum, part_w, part_cnt);                                                              \
     }
+    if (weighted && power) OA_BIN_LAUNCH(true, true)
+    else if (weighted) OA_BIN_LAUNCH(true, false)
+    else if (power) OA_BIN_LAUNCH(false, true)
+    else OA_BIN_LAUNCH(false, false)
+#undef OA_BIN_LAUNCH
     OA_LAUNCH_CHECK();
     hipLaunchKernelGGL(bin_final_kernel, dim3(nids), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
                        weighted ? 1 : 0, sums, counts, wsums);
@@ -287,12 +308,28 @@ int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights,
     OA_REQUIRE(weights ? (wsums != nullptr) : (counts != nullptr), "oa_bin: counts (unweighted) / wsums (weighted) required");
     if (herm_nxh >= 0) OA_REQUIRE(herm_pitch > 0 && herm_pitch % 4 == 0, "oa_bin: herm_pitch must be a positive multiple of 4");
     if (dtype == OA_F32)
-        return bin_impl<float>(data, ids, weights, aux, n, nids, mode, skip_nan, herm_pitch, herm_nxh, sums, counts, wsums,
-                               scratch, (hipStream_t)stream);
+        return bin_impl<float>(data, data, 1.0, false, ids, weights, aux, n, nids, mode, skip_nan, herm_pitch, herm_nxh, sums,
+                               counts, wsums, scratch, (hipStream_t)stream);
     if (dtype == OA_F64)
-        return bin_impl<double>(data, ids, weights, aux, n, nids, mode, skip_nan, herm_pitch, herm_nxh, sums, counts, wsums,
-                                scratch, (hipStream_t)stream);
+        return bin_impl<double>(data, data, 1.0, false, ids, weights, aux, n, nids, mode, skip_nan, herm_pitch, herm_nxh, sums,
+                                counts, wsums, scratch, (hipStream_t)stream);
     return fail("oa_bin: bad dtype");
+}
+
+int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const int32_t* ids, const void* weights, long n,
+                 int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
+                 void* stream) {
+    OA_REQUIRE(k1 && k2 && ids && sums && scratch && n >= 0, "oa_bin_power: bad argument");
+    OA_REQUIRE(nids >= 1 && nids <= BIN_MAX_IDS, "oa_bin_power: nids (= nedges+1) must be in [1,1024]");
+    OA_REQUIRE(weights ? (wsums != nullptr) : (counts != nullptr), "oa_bin_power: counts (unweighted) / wsums (weighted) required");
+    if (herm_nxh >= 0) OA_REQUIRE(herm_pitch > 0 && herm_pitch % 4 == 0, "oa_bin_power: herm_pitch must be a positive multiple of 4");
+    if (dtype == OA_F32)
+        return bin_impl<float>(k1, k2, norm, true, ids, weights, nullptr, n, nids, 0, 0, herm_pitch, herm_nxh, sums, counts,
+                               wsums, scratch, (hipStream_t)stream);
+    if (dtype == OA_F64)
+        return bin_impl<double>(k1, k2, norm, true, ids, weights, nullptr, n, nids, 0, 0, herm_pitch, herm_nxh, sums, counts,
+                                wsums, scratch, (hipStream_t)stream);
+    return fail("oa_bin_power: bad dtype");
 }
 
 }  // extern "C"

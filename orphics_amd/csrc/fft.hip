@@ -47,7 +47,10 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), qe_waves_per_eu<T>()) void row_qe
     row_qe_body<T, SEQ>(c, a);
 }
 
-template <typename T> constexpr int fused_col_waves_per_eu() { return sizeof(T) == 8 ? 1 : 2; }
+#ifndef OA_FUSED_COL_WAVES
+#define OA_FUSED_COL_WAVES 3
+#endif
+template <typename T> constexpr int fused_col_waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_FUSED_COL_WAVES; }
 
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_legs_kernel(ColLegsArgs<T> a) {

@@ -290,21 +290,21 @@ struct RowArgs {
 template <typename T, bool SWAP>
 struct RowLoad {
     static constexpr bool reads_lds = false;
-    const cx<T>* in;
-    long pitch, r0;
+    const cx<T>* in;   // pre-offset to the first row of this workgroup
+    unsigned pitch;
     template <typename U> OA_HD cx<U> get(int n, int c) const {
-        const cx<U> x = in[(r0 + c) * pitch + n];
+        const cx<U> x = in[(unsigned)c * pitch + (unsigned)n];
         return SWAP ? swp(x) : x;
     }
 };
 template <typename T, bool SWAP>
 struct RowStore {
-    cx<T>* out;
-    long pitch, r0;
+    cx<T>* out;        // pre-offset to the first row of this workgroup
+    unsigned pitch;
     T scale;
     template <typename U> OA_HD void put(int n, int c, cx<U> v) const {
         if (SWAP) v = swp(v);
-        out[(r0 + c) * pitch + n] = v * scale;
+        out[(unsigned)c * pitch + (unsigned)n] = v * scale;
     }
 };
 
@@ -317,7 +317,7 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
         const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
-        const cx<T>* row = in + (r0 + c) * pitch;
+        const cx<T>* row = in + r0 * pitch + (unsigned)c * (unsigned)pitch;
         for (int rep = 0; rep < 2; ++rep) {
             const int kk = rep ? (L >> 1) : k;
             if (rep && k != 0) break;
@@ -341,7 +341,7 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
         const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
-        cx<T>* row = out + (r0 + c) * pitch;
+        cx<T>* row = out + r0 * pitch + (unsigned)c * (unsigned)pitch;
         for (int rep = 0; rep < 2; ++rep) {
             const int kk = rep ? (L >> 1) : k;
             if (rep && k != 0) break;
@@ -372,21 +372,21 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
 
     if constexpr (MODE == ROW_C2C_F) {
         fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
-                                               RowLoad<T, false>{in, a.in_pitch, r0},
-                                               RowStore<T, false>{out, a.out_pitch, r0, a.scale});
+                                               RowLoad<T, false>{in + r0 * a.in_pitch, (unsigned)a.in_pitch},
+                                               RowStore<T, false>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     } else if constexpr (MODE == ROW_C2C_I) {
         fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
-                                               RowLoad<T, true>{in, a.in_pitch, r0},
-                                               RowStore<T, true>{out, a.out_pitch, r0, a.scale});
+                                               RowLoad<T, true>{in + r0 * a.in_pitch, (unsigned)a.in_pitch},
+                                               RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     } else if constexpr (MODE == ROW_R2C) {
         fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
-                                                RowLoad<T, false>{in, a.in_pitch, r0}, NoStore{});
+                                                RowLoad<T, false>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
         r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale);
     } else {
         c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw);
         ctx.sync();
         fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw, NoLoad{},
-                                                RowStore<T, true>{out, a.out_pitch, r0, a.scale});
+                                                RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     }
 }
 
@@ -500,29 +500,29 @@ template <typename T>
 struct ColLoad {
     static constexpr bool reads_lds = false;
     const cx<T>* base;  // already offset to (group row origin, first column)
-    long nstride;       // elements between consecutive points n
+    unsigned nstride;   // elements between consecutive points n (32-bit: planes hold < 2^31 elements)
     int ncols;          // valid columns in this tile
     bool inv;
     template <typename U> OA_HD cx<U> get(int n, int c) const {
         cx<U> x = mk<U>((U)0, (U)0);
-        if (c < ncols) x = base[n * nstride + c];
+        if (c < ncols) x = base[(unsigned)n * nstride + (unsigned)c];
         return inv ? swp(x) : x;
     }
 };
 template <typename T>
 struct ColStore {
     cx<T>* base;
-    long kstride;
+    unsigned kstride;
     int ncols;
     bool inv;
     const cx<T>* tw;  // inter-pass twiddle table or nullptr
-    long g;
+    unsigned g;
     T scale;
     template <typename U> OA_HD void put(int k, int c, cx<U> v) const {
         if (c >= ncols) return;
-        if (tw) v = v * tw[(int)(g * k)];
+        if (tw) v = v * tw[g * (unsigned)k];
         if (inv) v = swp(v);
-        base[k * kstride + c] = v * scale;
+        base[(unsigned)k * kstride + (unsigned)c] = v * scale;
     }
 };
 
@@ -612,46 +612,60 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
     if (ncols > (1 << logC)) ncols = 1 << logC;
-    cx<T> gv[EPT], hv[EPT], v[EPT];
-    T lyv[EPT];
-    T lxv[NB];
+    // register budget: gv (kept across the three pipelines) + v (pipeline operand) only
+    cx<T> gv[EPT], v[EPT];
+    const long org = g * a.in_gs * a.pitch + c0;   // scalar tile origin; per-element offsets are 32-bit
+    const cx<T>* kXb = a.kX + org; const cx<T>* kYb = a.kY + org;
+    const T* FGb = a.FG + org; const T* FHb = a.FH + org;
+    const unsigned nstr = (unsigned)(a.in_ns * a.pitch);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
         const int c = b & ((1 << logC) - 1), j = b >> logC;
         const bool ok = c < ncols;
-        lxv[u] = ok ? a.lxd[c0 + c] : (T)0;
 #pragma unroll
         for (int t = 0; t < R0; ++t) {
             const int n = j + (t << (logL - LR));
-            const long y = g * a.in_gs + n * a.in_ns;
-            const long i = y * a.pitch + c0 + c;
+            const unsigned i = (unsigned)n * nstr + (unsigned)c;
             cx<T> kx = mk<T>((T)0, (T)0), ky = kx;
             T fg = 0, fh = 0;
-            if (ok) { kx = a.kX[i]; ky = a.kY[i]; fg = a.FG[i]; fh = a.FH[i]; }
+            if (ok) { kx = kXb[i]; ky = kYb[i]; fg = FGb[i]; fh = FHb[i]; }
             gv[u * R0 + t] = kx * fg;
-            hv[u * R0 + t] = ky * fh;
-            lyv[u * R0 + t] = a.lyd[y];
+            v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
     }
-    for (int leg = 0; leg < 3; ++leg) {
-        // inverse transform = forward transform of the swapped data
-#pragma unroll
-        for (int u = 0; u < NB; ++u)
-#pragma unroll
-            for (int t = 0; t < R0; ++t) {
-                const int e = u * R0 + t;
-                cx<T> x;
-                if (leg == 0) x = mul_pi(gv[e]) * lxv[u];
-                else if (leg == 1) x = mul_pi(gv[e]) * lyv[e];
-                else x = hv[e];
-                v[e] = swp(x);
-            }
-        cx<T>* dst = leg == 0 ? a.gx : (leg == 1 ? a.gy : a.h);
-        const ColStore<T> st{dst + g * a.out_gs * a.pitch + c0, a.out_ks * a.pitch, ncols, true,
-                             a.twiddle ? a.tw : nullptr, g, (T)1};
+    {   // H = FH kY
+        const ColStore<T> st{a.h + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
+                             a.twiddle ? a.tw : nullptr, (unsigned)g, (T)1};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
         ctx.sync();
+    }
+    {   // Gx = i lx FG kX   (lx is constant along a column)
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = (tid + u * NT) & ((1 << logC) - 1);
+            const T lx = (c < ncols) ? a.lxd[c0 + c] : (T)0;
+#pragma unroll
+            for (int t = 0; t < R0; ++t) v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * lx);
+        }
+        const ColStore<T> st{a.gx + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
+                             a.twiddle ? a.tw : nullptr, (unsigned)g, (T)1};
+        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
+        ctx.sync();
+    }
+    {   // Gy = i ly FG kX   (ly follows the input row of each tap)
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int j = (tid + u * NT) >> logC;
+#pragma unroll
+            for (int t = 0; t < R0; ++t) {
+                const unsigned y = (unsigned)(g * a.in_gs) + (unsigned)(j + (t << (logL - LR))) * (unsigned)a.in_ns;
+                v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * a.lyd[y]);
+            }
+        }
+        const ColStore<T> st{a.gy + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
+                             a.twiddle ? a.tw : nullptr, (unsigned)g, (T)1};
+        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
     }
 }
 
@@ -686,11 +700,15 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     int ncols = a.width - c0;
     if (ncols > (1 << logC)) ncols = 1 << logC;
     cx<T> va[EPT], vb[EPT];
-    const ColLoad<T> la{a.A + g * a.in_gs * a.pitch + c0, a.in_ns * a.pitch, ncols, false};
-    const ColLoad<T> lb{a.B + g * a.in_gs * a.pitch + c0, a.in_ns * a.pitch, ncols, false};
+    const ColLoad<T> la{a.A + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
+    const ColLoad<T> lb{a.B + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, a.tw, a.logTw, la);
     ctx.sync();
     col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, a.tw, a.logTw, lb);
+    const long oorg = g * a.out_gs * a.pitch + c0;
+    const T* Fnb = a.Fn + oorg;
+    cx<T>* outb = a.out + oorg;
+    const unsigned ostr = (unsigned)(a.out_ks * a.pitch);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -702,11 +720,11 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
 #pragma unroll
         for (int t = 0; t < RL; ++t) {
             const int k = base + (t << logNs);
-            const long y = g * a.out_gs + k * a.out_ks;
-            const long i = y * a.pitch + c0 + c;
-            cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y]) * a.Fn[i];
-            if (a.accumulate) d = d + a.out[i];
-            a.out[i] = d;
+            const unsigned y = (unsigned)(g * a.out_gs) + (unsigned)k * (unsigned)a.out_ks;
+            const unsigned i = (unsigned)k * ostr + (unsigned)c;
+            cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y]) * Fnb[i];
+            if (a.accumulate) d = d + outb[i];
+            outb[i] = d;
         }
     }
 }
@@ -719,9 +737,9 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
     if (ncols > (1 << a.logC)) ncols = 1 << a.logC;
-    const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, a.in_ns * a.in_pitch, ncols, a.inverse != 0};
-    const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, a.out_ks * a.out_pitch, ncols, a.inverse != 0,
-                         a.twiddle ? a.tw : nullptr, g, a.scale};
+    const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
+    const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
+                         a.twiddle ? a.tw : nullptr, (unsigned)g, a.scale};
     fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, a.logL, a.logC, 0, a.tw, a.logTw, ld, st);
 }
 

@@ -86,6 +86,28 @@ def dev_bin(data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, her
     return sums, (counts if weights is None else wsums)
 
 
+def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1):
+    """Binned Re(conj k1 k2)*norm without materialising the 2-D power (oa_bin_power)."""
+    lib = _lib.load()
+    n = k1.numel()
+    if not (k1.is_cuda and k2.is_cuda and ids.is_cuda and k1.is_complex() and k2.dtype == k1.dtype):
+        raise TypeError("bin_power: complex CUDA tensors of equal dtype required")
+    if k2.numel() != n or ids.numel() != n or ids.dtype != torch.int32 or not (ids.is_contiguous() and k1.is_contiguous() and k2.is_contiguous()):
+        raise ValueError("bin_power: operands must be contiguous with one int32 id per mode")
+    prec = precision_of(k1, default=None)
+    need = int(lib.oa_bin_scratch_bytes(int(nids)))
+    key = k1.device.index
+    scr = _BIN_SCRATCH.get(key)
+    if scr is None or scr.numel() < need:
+        scr = torch.empty(need, dtype=torch.uint8, device=k1.device)
+        _BIN_SCRATCH[key] = scr
+    sums = torch.empty(nids, dtype=torch.float64, device=k1.device)
+    counts = torch.empty(nids, dtype=torch.int64, device=k1.device)
+    check(lib.oa_bin_power(_CODE[prec], _ptr(k1), _ptr(k2), float(norm), _ptr(ids), None, n, int(nids), int(herm_pitch),
+                           int(herm_nxh), _ptr(sums), _ptr(counts), None, _ptr(scr), _stream()))
+    return sums, counts
+
+
 class Engine(object):
     _cache = {}
 
@@ -337,6 +359,9 @@ class Engine(object):
     def bin(self, data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, herm=False):
         return dev_bin(data, ids, nids, weights=weights, aux=aux, mode=mode, skip_nan=skip_nan,
                        herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1)
+
+    def bin_power(self, k1, k2, norm, ids, nids, herm=True):
+        return dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1)
 
     # ---- random fields / accumulators ---------------------------------------------------
     def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):

@@ -507,3 +507,100 @@ def binned_power(imap, bin_edges=None, binner=None, fc=None, modlmap=None, imap2
     p2d, _, _ = fc.power2d(imap * mask, imap2 * mask if imap2 is not None else None)
     cents, p1d = binner.bin(p2d)
     return cents, p1d / np.mean(mask ** 2.)
+
+
+# ---- Wiener / inverse-variance per-mode filters -----------------------
+def matched_filter(imap, fwhm_arcmin, cls=None, noise_uk_arcmin=None, taper_per=12.0, wcs=None):
+    """maps.py:677-699: taper -> FFT -> beam/(S+N) (non-finite -> 0) -> inverse FFT, real part.
+    ``wcs`` is explicit (arrays carry no geometry here)."""
+    from . import cosmology
+    geom = as_geometry(imap.shape, wcs)
+    taper = 1.0
+    if taper_per is not None:
+        taper, _ = get_taper(imap.shape[-2:], geom, taper_percent=taper_per)
+    modlmap = geom.modlmap()
+    p2d = gauss_beam(modlmap, fwhm_arcmin)
+    if cls is None:
+        s2d = cosmology.default_theory().lCl('TT', modlmap) * p2d ** 2.
+    else:
+        s2d = np.interp(modlmap, np.arange(cls.size), cls, left=0.0, right=0.0)
+    n2d = 0.
+    if noise_uk_arcmin is not None:
+        n2d = (noise_uk_arcmin * np.pi / 180. / 60.) ** 2.
+    with np.errstate(divide="ignore", invalid="ignore"):
+        filt2d = p2d / (s2d + n2d)
+    filt2d[~np.isfinite(filt2d)] = 0.
+    # enmap.fft / enmap.ifft (both unitary) bracket the multiply == filter_map's unnormalised/normalised pair
+    return filter_map(imap * taper, filt2d)
+
+
+def kspace_coadd(kmaps, kbeams, kncovs, fkbeam=1):
+    """maps.py:1098-1114: f = sum_i k_i b_i fk / n_i  /  sum_i b_i^2 / n_i per mode (non-finite -> 0).
+    The per-mode weights are real one-off planes; the complex accumulation runs on the device."""
+    torch = _torch()
+    from .engine import precision_of
+    kmaps_in = kmaps
+    kbeams = np.asarray(kbeams, dtype=np.float64)
+    kncovs = np.asarray(kncovs, dtype=np.float64)
+    first = kmaps[0]
+    eng = _engine(first.shape, precision_of(first))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = kbeams * fkbeam / kncovs
+        denom = np.sum(kbeams ** 2 / kncovs, axis=0)
+        w[~np.isfinite(w)] = 0            # numer[~finite] = 0 mode by mode
+        inv = 1.0 / denom
+        inv[~np.isfinite(inv)] = 0
+    acc = None
+    for i in range(len(kmaps)):
+        k = eng.to_complex(kmaps[i])
+        wi = eng.to_real(np.broadcast_to(w[i], k.shape))
+        term = eng.cmul_real(k, wi)
+        if acc is None:
+            acc = term
+        else:
+            ar, tr = torch.view_as_real(acc), torch.view_as_real(term)
+            eng.axpby(ar, tr, 1.0, 1.0, out=ar)
+    out = eng.cmul_real(acc, eng.to_real(np.broadcast_to(inv, acc.shape)))
+    return _ret(out, kmaps_in[0] if not isinstance(kmaps_in, np.ndarray) else kmaps_in)
+
+
+class MatchedFilter(object):
+    """maps.py:2576-2604: amplitude of a template in a map with noise power n2d:
+    phi = sum conj(t) k norm mask / n  /  sum |t|^2 norm mask / n  (two global reductions,
+    done by the deterministic histogram kernel with a single bin)."""
+
+    def __init__(self, shape, wcs, template=None, noise_power=None):
+        self.shape = tuple(shape[-2:])
+        self.geom = as_geometry(self.shape, wcs)
+        self.fc = FourierCalc(self.shape, self.geom)
+        self.normfact = self.geom.area / (np.prod(self.shape)) ** 2
+        if noise_power is not None:
+            self.n2d = noise_power
+        if template is not None:
+            self.ktemp = self.fc.fft(np.asarray(template, dtype=np.float64))
+
+    def apply(self, imap=None, kmap=None, template=None, ktemplate=None, noise_power=None, kmask=None):
+        torch = _torch()
+        from .engine import dev_bin
+        if kmap is None:
+            kmap = self.fc.fft(np.asarray(imap, dtype=np.float64))
+        else:
+            assert imap is None
+        n2d = self.n2d if noise_power is None else noise_power
+        if ktemplate is None:
+            ktemp = self.ktemp if template is None else self.fc.fft(np.asarray(template, dtype=np.float64))
+        else:
+            ktemp = ktemplate
+        with np.errstate(divide="ignore", invalid="ignore"):
+            in2d = 1. / np.asarray(n2d, dtype=np.float64)
+        in2d[~np.isfinite(in2d)] = 0
+        w = in2d if kmask is None else in2d * np.real(np.asarray(kmask))
+        eng = _engine(self.shape, "f64")
+        kt, km = eng.to_complex(ktemp), eng.to_complex(kmap)
+        wd = eng.to_real(w)
+        ids = torch.zeros(kt.numel(), dtype=torch.int32, device=eng.device)
+        s_un, _ = dev_bin(eng.f2power(kt, km, self.normfact).reshape(-1), ids, 1, weights=wd.reshape(-1))
+        s_tt, _ = dev_bin(eng.f2power(kt, kt, self.normfact).reshape(-1), ids, 1, weights=wd.reshape(-1))
+        phi_un = float(s_un[0].item())
+        phi_var = 1. / float(s_tt[0].item())
+        return phi_un * phi_var, phi_var

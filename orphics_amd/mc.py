@@ -68,8 +68,7 @@ class GaussianN0MonteCarlo(object):
         for i in sims:
             e.grf_hc(self.base_seed, int(i), self.cs, out=self._kT)
             q.reconstruct_tt_hc(self._kT, out=self._kk)
-            e.f2power(self._kk, self._kk, self.norm, out=self._p)
-            sums, counts = e.bin(self._p, self.ids, self.nids, herm=True)
+            sums, counts = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True)
             p1d = (sums[1:-1] / counts[1:-1].to(torch.float64)).contiguous()
             check(e.lib.oa_moments_add(_ptr(p1d), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))
             if self.mean_field:

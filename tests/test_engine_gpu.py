@@ -189,3 +189,23 @@ def test_grf_statistics():
     assert kk[0, 0].imag == 0 and kk[ny // 2, nx // 2].imag == 0
     r = e.randn(7, 3).cpu().numpy()
     assert abs(r.mean()) < 0.02 and abs(r.std() - 1) < 0.02
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_bin_power_equals_f2power_then_bin(prec):
+    from orphics_amd.geometry import FlatGeometry
+    ny, nx = 128, 256
+    e = eng(ny, nx, prec)
+    g = FlatGeometry.from_res((ny, nx), 2.0)
+    e.set_laxes(*g.laxes())
+    ed = torch.as_tensor(np.arange(100., 3000., 200.), device=e.device)
+    rng = np.random.default_rng(3)
+    k1 = e.rfft(e.to_real(rng.standard_normal((ny, nx))))
+    k2 = e.rfft(e.to_real(rng.standard_normal((ny, nx))))
+    ids = e.modl_digitize(ed, half=True)
+    nids = ed.numel() + 1
+    for a, b in ((k1, k1), (k1, k2)):
+        s1, c1 = e.bin(e.f2power(a, b, 0.37), ids, nids, herm=True)
+        s2, c2 = e.bin_power(a, b, 0.37, ids, nids, herm=True)
+        assert torch.equal(c1, c2)
+        np.testing.assert_allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-12 if prec == "f64" else 1e-6)

@@ -201,3 +201,32 @@ def test_config1_power2d_bin2d(N, res):
     assert abs(np.mean(ro) / g.pixarea - 1) < 0.02   # white noise -> pixel area
     c3, r3 = maps.binned_power(m, bin_edges=edges, wcs=g)
     assert np.max(np.abs(r3 / ro - 1)) < 1e-12
+
+
+def test_matched_filter_coadd_and_template_amplitude():
+    """matched_filter, kspace_coadd, MatchedFilter.apply vs the oracle."""
+    from orphics_amd import maps
+    shape = (128, 128)
+    g = geom(shape)
+    ml = g.modlmap()
+    rng = np.random.default_rng(12)
+    m = rng.standard_normal(shape)
+    cls = 1e3 / (1 + (np.arange(8000) / 300.) ** 3)
+    got = maps.matched_filter(m, 1.5, cls=cls, noise_uk_arcmin=10.0, wcs=g)
+    ref = mo.matched_filter(m, 1.5, g.step_y, g.step_x, cls, noise_uk_arcmin=10.0)
+    assert rel(got, ref) < 1e-12
+    kmaps = np.array([np.fft.fft2(rng.standard_normal(shape)) for _ in range(3)])
+    kbeams = np.array([maps.gauss_beam(ml, f) for f in (1.4, 2.2, 5.0)])
+    kncovs = np.array([np.full(shape, v) for v in (1e-5, 3e-5, 0.0)])   # a zero-noise map -> non-finite -> 0 rule
+    kncovs[2][ml > 2000] = 2e-5
+    got = maps.kspace_coadd(kmaps, kbeams, kncovs, fkbeam=kbeams[0])
+    ref = mo.kspace_coadd(kmaps, kbeams, kncovs, fkbeam=kbeams[0])
+    assert rel(got, ref) < 1e-12
+    templ = np.exp(-0.5 * (g.modlmap() * 0 + np.hypot(*np.meshgrid(np.arange(128) - 64, np.arange(128) - 64))) ** 2 / 25.)
+    n2d = 1e-4 * (1 + (ml / 1000.) ** 2)
+    data = 3.7 * templ + 0.01 * rng.standard_normal(shape)
+    mf = maps.MatchedFilter(shape, g, template=templ, noise_power=n2d)
+    amp, var = mf.apply(imap=data)
+    ramp, rvar = mo.matched_filter_apply(np.fft.fft2(templ), np.fft.fft2(data), n2d, g.area / (128 * 128) ** 2)
+    assert abs(amp / ramp - 1) < 1e-12 and abs(var / rvar - 1) < 1e-12
+    assert abs(amp - 3.7) < 0.05

@@ -35,7 +35,14 @@ def t(fn):
 
 
 s3, s4, s5 = e.hc(), e.hc(), e.hc()
-for name, fn, nb in [("qe_rows", lambda: e.qe_rows(s1, s2, s3, s4, s5), 5 * Ah), ("row_r2c", lambda: e.fft_pass(0, r1, s1), A + Ah), ("col_pass1", lambda: e.fft_pass(1, s1, s2), 2 * Ah),
+import numpy as np
+from orphics_amd.geometry import FlatGeometry
+ly, lx = FlatGeometry.from_res((N, N), 0.5).laxes()
+e.set_laxes(ly, lx)
+f1 = torch.rand(N, e.kp, device="cuda", dtype=e.rdt); f2 = torch.rand(N, e.kp, device="cuda", dtype=e.rdt)
+for name, fn, nb in [("legs_cols", lambda: e.qe_legs_cols(s1, s1, f1, f2, out=(s3, s4, s5)), 5 * Ah),
+                     ("cols_div", lambda: e.qe_cols_div(s3, s4, f1, out=s5), 3.5 * Ah),
+                     ("qe_rows", lambda: e.qe_rows(s1, s2, s3, s4, s5), 5 * Ah), ("row_r2c", lambda: e.fft_pass(0, r1, s1), A + Ah), ("col_pass1", lambda: e.fft_pass(1, s1, s2), 2 * Ah),
                      ("col_pass2", lambda: e.fft_pass(2, s1, s2), 2 * Ah), ("row_c2r", lambda: e.fft_pass(3, s1, r1), A + Ah)]:
     dt = t(fn)
     print("%-10s N=%d %s  %.1f us  %.0f GB/s (algorithmic)" % (name, N, prec, dt * 1e6, nb / dt / 1e9))
