@@ -28,6 +28,9 @@
 
 namespace oa {
 
+#ifndef OA_PE_UNROLL
+#define OA_PE_UNROLL 4         // unroll of the real<->half-complex (un)tangle loops (register pressure vs MLP)
+#endif
 constexpr int EPT = 16;        // complex points per thread per stage
 constexpr int MAX_STAGES = 8;
 
@@ -315,6 +318,7 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
                         const cx<T>* tw, int logTw) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
+#pragma unroll OA_PE_UNROLL
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
         const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
         const cx<T>* row = in + r0 * pitch + (unsigned)c * (unsigned)pitch;
@@ -339,6 +343,7 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
                         const cx<T>* tw, int logTw, T scale, bool accumulate = false) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
+#pragma unroll OA_PE_UNROLL
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
         const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
         cx<T>* row = out + r0 * pitch + (unsigned)c * (unsigned)pitch;
