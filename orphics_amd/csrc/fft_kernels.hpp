@@ -102,25 +102,42 @@ OA_HD int lds_addr(int n, int c, int logC, int rowStride) {
     return (n << logC) + c;
 }
 
-// multiply v[1..R-1] by w^t, w = tab[k << sh]; powers from 4 exact loads + products
+// Stage twiddles come from a tiny two-level table in LDS (no global gathers on the critical path):
+//   tab[0 .. 2^h)            = W_L^i          (low digits)
+//   tab[2^h .. 2^h + L/2^h)  = W_L^(q 2^h)    (high digits),   h = (logL+1)/2
+//   W_L^e = tab[2^h + (e >> h)] * tab[e & (2^h - 1)]           (1 product, ~1 ulp)
+template <typename T>
+OA_HD cx<T> tw_lds(const cx<T>* tab, int h, int e) {
+    return tab[(1 << h) + (e >> h)] * tab[e & ((1 << h) - 1)];
+}
+OA_HD int tw_lds_h(int logL) { return (logL + 1) >> 1; }
+OA_HD int tw_lds_size(int logL) { return (1 << tw_lds_h(logL)) + (1 << (logL - tw_lds_h(logL))); }
+
+template <typename T, class Ctx>
+OA_HD void tw_lds_fill(Ctx& ctx, cx<T>* tab, const cx<T>* gtw, int logG, int logL, int NT) {
+    const int h = tw_lds_h(logL), nlo = 1 << h, nhi = 1 << (logL - h), sh = logG - logL;
+    for (int i = ctx.tid(); i < nlo + nhi; i += NT) tab[i] = gtw[(i < nlo ? i : ((i - nlo) << h)) << sh];
+}
+
+// multiply v[1..R-1] by w^t, w = W_L^(k << sh); base powers w^1,w^2,w^4,w^8 from the LDS table, rest by products
 template <typename T, int R>
-OA_HD void apply_twiddles(cx<T>* v, const cx<T>* tw, int k, int sh) {
-    const cx<T> w1 = tw[k << sh];
+OA_HD void apply_twiddles(cx<T>* v, const cx<T>* tab, int k, int sh, int h) {
+    const cx<T> w1 = tw_lds(tab, h, k << sh);
     v[1] = v[1] * w1;
     if (R >= 4) {
-        const cx<T> w2 = tw[(2 * k) << sh];
+        const cx<T> w2 = tw_lds(tab, h, (2 * k) << sh);
         const cx<T> w3 = w1 * w2;
         v[2] = v[2] * w2;
         v[3] = v[3] * w3;
         if (R >= 8) {
-            const cx<T> w4 = tw[(4 * k) << sh];
+            const cx<T> w4 = tw_lds(tab, h, (4 * k) << sh);
             v[4] = v[4] * w4;
             v[5] = v[5] * (w4 * w1);
             v[6] = v[6] * (w4 * w2);
             const cx<T> w7 = w4 * w3;
             v[7] = v[7] * w7;
             if (R >= 16) {
-                const cx<T> w8 = tw[(8 * k) << sh];
+                const cx<T> w8 = tw_lds(tab, h, (8 * k) << sh);
                 v[8] = v[8] * w8;
                 v[9] = v[9] * (w8 * w1);
                 v[10] = v[10] * (w8 * w2);
@@ -164,7 +181,7 @@ OA_HD void stage_in(const cx<T>* s, cx<T>* v, int tid, int NT, int logL, int log
             if (SRC_G) v[u * R + t] = ld.template get<T>(n, c);
             else v[u * R + t] = s[lds_addr<ROWMAJOR>(n, c, logC, rowStride)];
         }
-        if (logNs > 0) apply_twiddles<T, R>(v + u * R, tw, j & ((1 << logNs) - 1), logTw - logNs - LR);
+        if (logNs > 0) apply_twiddles<T, R>(v + u * R, tw, j & ((1 << logNs) - 1), logL - logNs - LR, tw_lds_h(logL));
         Dft<T, R>::run(v + u * R);
     }
 }
@@ -374,23 +391,26 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     const long r0 = (long)ctx.bid_x() * C;
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
+    cx<T>* twl = s + C * RS;                      // two-level stage-twiddle table (LDS)
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    ctx.sync();
 
     if constexpr (MODE == ROW_C2C_F) {
-        fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
+        fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL,
                                                RowLoad<T, false>{in + r0 * a.in_pitch, (unsigned)a.in_pitch},
                                                RowStore<T, false>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     } else if constexpr (MODE == ROW_C2C_I) {
-        fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
+        fft_pipeline<T, true, true, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL,
                                                RowLoad<T, true>{in + r0 * a.in_pitch, (unsigned)a.in_pitch},
                                                RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     } else if constexpr (MODE == ROW_R2C) {
-        fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw,
+        fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL,
                                                 RowLoad<T, false>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
         r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale);
     } else {
         c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw);
         ctx.sync();
-        fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, a.tw, a.logTw, NoLoad{},
+        fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{},
                                                 RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     }
 }
@@ -450,11 +470,13 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     constexpr int R0 = SEQ::get(0);
     constexpr int lastns = rev_logns<SEQ>(SEQ::n - 1);
     cx<T> hreg[EPT], v[EPT];
+    cx<T>* twl = work + C * RS;                   // two-level stage-twiddle table (LDS)
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
 
     c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw);
     ctx.sync();
-    inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
-    stage_in<T, R0, true, false>(work, hreg, tid, NT, logL, logC, RS, lastns, a.tw, a.logTw, NoLoad{});
+    inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
+    stage_in<T, R0, true, false>(work, hreg, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = mk<T>(hreg[t].y * a.scale, hreg[t].x * a.scale);  // unswap -> (h[2n], h[2n+1])
     ctx.sync();
@@ -463,8 +485,8 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
         cx<T>* dst = leg ? a.py : a.px;
         c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw);
         ctx.sync();
-        inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
-        stage_in<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, lastns, a.tw, a.logTw, NoLoad{});
+        inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
+        stage_in<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
         // v holds the swapped C2R result: (im, re) = (x[2n+1], x[2n]); product with h, repacked for R2C
 #pragma unroll
         for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].x, v[t].x * hreg[t].y);
@@ -474,7 +496,7 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
         ctx.sync();
         stage_out<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, 0, NoStore{});
         ctx.sync();
-        forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, a.tw, a.logTw);
+        forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
         r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0);
         ctx.sync();
     }
@@ -520,12 +542,12 @@ struct ColStore {
     unsigned kstride;
     int ncols;
     bool inv;
-    const cx<T>* tw;  // inter-pass twiddle table or nullptr
+    const cx<T>* tw;  // LDS table of the inter-pass twiddles W_N^(g k), k < L, or nullptr
     unsigned g;
     T scale;
     template <typename U> OA_HD void put(int k, int c, cx<U> v) const {
         if (c >= ncols) return;
-        if (tw) v = v * tw[g * (unsigned)k];
+        if (tw) v = v * tw[k];
         if (inv) v = swp(v);
         base[(unsigned)k * kstride + (unsigned)c] = v * scale;
     }
@@ -619,6 +641,11 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     if (ncols > (1 << logC)) ncols = 1 << logC;
     // register budget: gv (kept across the three pipelines) + v (pipeline operand) only
     cx<T> gv[EPT], v[EPT];
+    cx<T>* twl = s + (1 << (logL + logC));        // stage twiddles, then the inter-pass twiddles W_N^(g k)
+    cx<T>* ti = twl + tw_lds_size(logL);
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    for (int i = tid; i < (1 << logL); i += NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
+    ctx.sync();
     const long org = g * a.in_gs * a.pitch + c0;   // scalar tile origin; per-element offsets are 32-bit
     const cx<T>* kXb = a.kX + org; const cx<T>* kYb = a.kY + org;
     const T* FGb = a.FG + org; const T* FHb = a.FH + org;
@@ -641,8 +668,8 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     }
     {   // H = FH kY
         const ColStore<T> st{a.h + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
-                             a.twiddle ? a.tw : nullptr, (unsigned)g, (T)1};
-        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
+                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1};
+        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
     }
     {   // Gx = i lx FG kX   (lx is constant along a column)
@@ -654,8 +681,8 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             for (int t = 0; t < R0; ++t) v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * lx);
         }
         const ColStore<T> st{a.gx + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
-                             a.twiddle ? a.tw : nullptr, (unsigned)g, (T)1};
-        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
+                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1};
+        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
     }
     {   // Gy = i ly FG kX   (ly follows the input row of each tap)
@@ -669,8 +696,8 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             }
         }
         const ColStore<T> st{a.gy + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
-                             a.twiddle ? a.tw : nullptr, (unsigned)g, (T)1};
-        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, a.tw, a.logTw, st);
+                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1};
+        col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
     }
 }
 
@@ -705,11 +732,14 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     int ncols = a.width - c0;
     if (ncols > (1 << logC)) ncols = 1 << logC;
     cx<T> va[EPT], vb[EPT];
+    cx<T>* twl = s + (1 << (logL + logC));
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    ctx.sync();
     const ColLoad<T> la{a.A + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     const ColLoad<T> lb{a.B + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
-    col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, a.tw, a.logTw, la);
+    col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL, la);
     ctx.sync();
-    col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, a.tw, a.logTw, lb);
+    col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL, lb);
     const long oorg = g * a.out_gs * a.pitch + c0;
     const T* Fnb = a.Fn + oorg;
     cx<T>* outb = a.out + oorg;
@@ -742,10 +772,16 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
     if (ncols > (1 << a.logC)) ncols = 1 << a.logC;
+    cx<T>* twl = s + (1 << (a.logL + a.logC));
+    cx<T>* ti = twl + tw_lds_size(a.logL);
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, a.logL, a.NT);
+    if (a.twiddle)
+        for (int i = tid; i < (1 << a.logL); i += a.NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
+    ctx.sync();
     const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
     const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
-                         a.twiddle ? a.tw : nullptr, (unsigned)g, a.scale};
-    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, a.logL, a.logC, 0, a.tw, a.logTw, ld, st);
+                         a.twiddle ? ti : nullptr, (unsigned)g, a.scale};
+    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, a.logL, a.logC, 0, twl, a.logL, ld, st);
 }
 
 }  // namespace oa

@@ -60,7 +60,7 @@ struct Fft2dPlan {
         a.scale = scale;
         a.mode = mode;
         a.in = in; a.out = out; a.in_pitch = in_pitch; a.out_pitch = out_pitch;
-        q.row(ny / C, a.NT, (size_t)C * a.rowStride * sizeof(cx<T>), a);
+        q.row(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
 
     // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
@@ -79,7 +79,7 @@ struct Fft2dPlan {
         a.rowStride = L + (L >> 4) + 2;
         a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
         a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
-        q.row_qe(ny / C, a.NT, (size_t)C * a.rowStride * sizeof(cx<T>), a);
+        q.row_qe(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
 
     // ---- full column transform of `width` columns (two passes) -------------
@@ -101,7 +101,7 @@ struct Fft2dPlan {
             a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
             a.twiddle = (logN2 > 0) ? 1 : 0;
             a.scale = (logN2 > 0) ? (T)1 : scale;
-            q.col(tiles, (int)N2, a.NT, (size_t)N1 * C * sizeof(cx<T>), a);
+            q.col(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), a);
         }
         if (logN2 == 0 || which == 1) return;
         // pass 2: length N2 over y2 (stride N1), in place, natural order out
@@ -110,7 +110,7 @@ struct Fft2dPlan {
         if (a.NT < 1) a.NT = 1;
         a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;
         a.twiddle = 0; a.scale = scale;
-        q.col(tiles, (int)N1, a.NT, (size_t)N2 * C * sizeof(cx<T>), a);
+        q.col(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), a);
     }
 
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
@@ -126,7 +126,7 @@ struct Fft2dPlan {
         a.kX = kX; a.kY = kY; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
         a.pitch = kp; a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
-        q.col_legs(tiles, (int)N2, a.NT, (size_t)N1 * C * sizeof(cx<T>), logN1, a);
+        q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
         cx<T>* outs[3] = {gx, gy, h};
         for (int i = 0; i < 3; ++i) cols(q, outs[i], kp, outs[i], kp, width, true, (T)1, 2);
     }
@@ -147,7 +147,7 @@ struct Fft2dPlan {
         a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = kp; a.width = width;
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
         a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
-        q.col_div(tiles, (int)N1, a.NT, (size_t)N2 * C * sizeof(cx<T>), logN2, a);
+        q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a);
     }
 
     // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane
