@@ -135,6 +135,15 @@ int oa_qe_legs(oa_plan* p, const void* kX, const void* kY, const void* FG, const
                void* Gx, void* Gy, void* H, int phase_g, int phase_h, int h_times_i, void* stream);
 int oa_qe_div(oa_plan* p, const void* Px, const void* Py, const void* Fnorm, void* out, int accumulate, void* stream);
 
+/* ---- flat-sky lensing of simulated maps (lensing.flat_taylens, lensing.py:395-440) ------------------
+ * oa_lens_split  : shift[i] = rint(alpha[i]/step), delta[i] = alpha[i] - shift[i]*step (nearest pixel +
+ *                  sub-pixel remainder of a displacement component; lensing.py:420-424)
+ * oa_lens_gather : out[y,x] (+)= coef * src[(y+sy) mod ny, (x+sx) mod nx] * dx^pow_x * dy^pow_y
+ *                  (integer-pixel remap and one Taylor term, lensing.py:428-438) */
+int oa_lens_split(int dtype, const void* alpha, double step, int32_t* shift, void* delta, long n, void* stream);
+int oa_lens_gather(oa_plan* p, const void* src, const int32_t* shift_x, const int32_t* shift_y, const void* dx, const void* dy,
+                   int pow_x, int pow_y, double coef, void* out, int accumulate, void* stream);
+
 /* ---- radial binning (stats.bin2D, stats.py:782-811) ------------------------
  * oa_digitize : ids[i] = np.digitize(x[i], edges, right=True) (stats.py:786):
  *               e[id-1] < x <= e[id]; 0 = underflow, nedges = overflow. x, edges

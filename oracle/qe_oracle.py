@@ -367,3 +367,42 @@ def brute_force_gf(q, gterms, fterms, Lyi, Lxi):
             tot += val(gterms, y1, x1, y2, x2) * val(fterms, y1, x1, y2, x2)
     return tot / q.area
 
+
+
+# ---- flat-sky lensing of simulated maps (lensing.py:395-454, 651-665), signed-coordinate restatement -----
+def alpha_from_kappa(kappa, step_y, step_x):
+    shape = kappa.shape
+    ly, lx = mo.laxes(shape, step_y, step_x)
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[shape[0] // 2] = 0.0
+    lxd[shape[1] // 2] = 0.0
+    ml = np.sqrt(ly[:, None] ** 2 + lx[None, :] ** 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        f = np.nan_to_num(2. / ml / (ml + 1.))
+    f[ml < 2.] = 0.
+    fphi = _fft(kappa) * f
+    return _ifftn(1j * lyd[:, None] * fphi).real, _ifftn(1j * lxd[None, :] * fphi).real
+
+
+def flat_taylens(alpha, imap, step_y, step_x, taylor_order=5):
+    from math import factorial
+    ay, ax = alpha
+    Ny, Nx = imap.shape
+    ly, lx = mo.laxes(imap.shape, step_y, step_x)
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[Ny // 2] = 0.0
+    lxd[Nx // 2] = 0.0
+    sx = np.rint(ax / step_x).astype(int)
+    sy = np.rint(ay / step_y).astype(int)
+    dx = ax - sx * step_x
+    dy = ay - sy * step_y
+    iy, ix = np.mgrid[0:Ny, 0:Nx]
+    yy, xx = (iy + sy) % Ny, (ix + sx) % Nx
+    out = imap[yy, xx].copy()
+    kmap = _fft(imap)
+    for n in range(1, taylor_order):
+        for b in range(n + 1):
+            a = n - b
+            d = _ifftn((1j * lxd[None, :]) ** a * (1j * lyd[:, None]) ** b * kmap).real
+            out += d[yy, xx] * dx ** a * dy ** b / (factorial(a) * factorial(b))
+    return out

@@ -48,6 +48,8 @@ SIGNATURES = {
     "oa_rot2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_qe_legs": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "oa_qe_div": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "oa_lens_split": (c_int, [c_int, c_void_p, c_double, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_lens_gather": (c_int, [c_void_p] * 6 + [c_int, c_int, c_double, c_void_p, c_int, c_void_p]),
     "oa_digitize": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p]),
     "oa_modl_digitize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "oa_bin_scratch_bytes": (c_long, [c_int]),

@@ -175,6 +175,46 @@ __global__ __launch_bounds__(256) void qe_div_kernel(const cx<T>* __restrict__ P
     out[i] = accumulate ? out[i] + d : d;
 }
 
+// ---------------------------------------------------------------- flat-sky lensing op (lensing.py:395-440)
+// displacement (coordinate units) -> nearest-pixel shift + sub-pixel remainder
+template <typename T>
+__global__ __launch_bounds__(256) void lens_split_kernel(const T* __restrict__ alpha, T step, int* __restrict__ shift,
+                                                         T* __restrict__ delta, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T a = alpha[i];
+        const T r = rint(a / step);
+        shift[i] = (int)r;
+        delta[i] = a - r * step;
+    }
+}
+
+template <typename T>
+OA_D T ipow(T x, int p) {
+    T r = (T)1;
+    for (int i = 0; i < p; ++i) r *= x;
+    return r;
+}
+
+// out[y,x] (+)= coef * src[(y+sy)%ny, (x+sx)%nx] * dx^px * dy^py   (Taylens gather + Taylor term)
+template <typename T>
+__global__ __launch_bounds__(256) void lens_gather_kernel(const T* __restrict__ src, const int* __restrict__ sx,
+                                                          const int* __restrict__ sy, const T* __restrict__ dx,
+                                                          const T* __restrict__ dy, int px, int py, T coef,
+                                                          T* __restrict__ out, int ny, int nx, int accumulate) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const long i = (long)y * nx + x;
+    int xs = (x + sx[i]) % nx, ys = (y + sy[i]) % ny;
+    if (xs < 0) xs += nx;
+    if (ys < 0) ys += ny;
+    T v = coef * src[(long)ys * nx + xs];
+    if (px) v *= ipow(dx[i], px);
+    if (py) v *= ipow(dy[i], py);
+    out[i] = accumulate ? out[i] + v : v;
+}
+
 }  // namespace oa
 
 using namespace oa;
@@ -310,6 +350,36 @@ int oa_fullreal_to_hc(oa_plan* p, const void* full, void* hc, void* stream) {
                                 (float*)hc, p->ny, p->nx, p->kp),
              hipLaunchKernelGGL(fullreal_to_hc_kernel<double>, PLANE_GRID(p, (int)p->kp), dim3(256), 0, st,
                                 (const double*)full, (double*)hc, p->ny, p->nx, p->kp));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_lens_split(int dtype, const void* alpha, double step, int32_t* shift, void* delta, long n, void* stream) {
+    OA_REQUIRE(alpha && shift && delta && n >= 0 && step != 0.0, "oa_lens_split: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = flat_grid(n > 0 ? n : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(lens_split_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)alpha, (float)step, shift,
+                                (float*)delta, n),
+             hipLaunchKernelGGL(lens_split_kernel<double>, dim3(g), dim3(256), 0, st, (const double*)alpha, step, shift,
+                                (double*)delta, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_lens_gather(oa_plan* p, const void* src, const int32_t* shift_x, const int32_t* shift_y, const void* dx, const void* dy,
+                   int pow_x, int pow_y, double coef, void* out, int accumulate, void* stream) {
+    OA_REQUIRE(p && src && shift_x && shift_y && dx && dy && out, "oa_lens_gather: NULL argument");
+    OA_REQUIRE(pow_x >= 0 && pow_y >= 0 && pow_x + pow_y <= 16, "oa_lens_gather: bad Taylor powers");
+    OA_REQUIRE(src != out, "oa_lens_gather: in-place not supported");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(lens_gather_kernel<float>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const float*)src, shift_x,
+                                shift_y, (const float*)dx, (const float*)dy, pow_x, pow_y, (float)coef, (float*)out, p->ny,
+                                p->nx, accumulate),
+             hipLaunchKernelGGL(lens_gather_kernel<double>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const double*)src,
+                                shift_x, shift_y, (const double*)dx, (const double*)dy, pow_x, pow_y, coef, (double*)out,
+                                p->ny, p->nx, accumulate));
     OA_LAUNCH_CHECK();
     return 0;
 }

@@ -340,6 +340,22 @@ class Engine(object):
         check(self.lib.oa_qe_div(self.plan, _ptr(Px), _ptr(Py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, _stream()))
         return out
 
+    # ---- flat-sky lensing op ---------------------------------------------------------------
+    def lens_split(self, alpha, step):
+        self._chk(alpha, "real")
+        shift = torch.empty(alpha.shape, dtype=torch.int32, device=self.device)
+        delta = torch.empty_like(alpha)
+        check(self.lib.oa_lens_split(self.code, _ptr(alpha), float(step), _ptr(shift), _ptr(delta), alpha.numel(), _stream()))
+        return shift, delta
+
+    def lens_gather(self, src, sx, sy, dx, dy, px, py, coef, out, accumulate):
+        self._chk(src, "real"); self._chk(out, "real"); self._chk(dx, "real"); self._chk(dy, "real")
+        if sx.dtype != torch.int32 or sy.dtype != torch.int32 or sx.numel() != src.numel() or sy.numel() != src.numel():
+            raise ValueError("lens_gather: shifts must be int32 planes")
+        check(self.lib.oa_lens_gather(self.plan, _ptr(src), _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy), int(px), int(py),
+                                      float(coef), _ptr(out), 1 if accumulate else 0, _stream()))
+        return out
+
     # ---- binning -----------------------------------------------------------------------
     def digitize(self, x64, edges64):
         return dev_digitize(x64, edges64)

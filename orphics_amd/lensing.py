@@ -530,6 +530,78 @@ class SplitLensing(object):
         return mk(res, self.qpower(kc, kc)) if arith == "half" else res
 
 
+# ---- kappa -> phi -> deflection, flat-sky Taylens -------------------------------
+def _eng_for(x, shape):
+    from .engine import precision_of
+    return maps._engine(shape, precision_of(x, default="f32"))
+
+
+class FlatLenser(object):
+    """kappa_to_phi / alpha_from_kappa / flat_taylens (lensing.py:651-665, 443-454, 395-440) on the device.
+    Coordinates are signed (x decreases with pixel index for standard CAR), so the pixel shift of a
+    displacement component is alpha/step with the signed step."""
+
+    def __init__(self, shape, wcs, dtype="f32"):
+        self.shape = tuple(shape[-2:])
+        self.geom = as_geometry(self.shape, wcs)
+        self.eng = maps._engine(self.shape, dtype)
+        e = self.eng
+        ly, lx = self.geom.laxes()
+        e.set_laxes(ly, lx)
+        nxh = e.nxh
+        ml = np.sqrt(ly[:, None] ** 2 + lx[None, :nxh + 1] ** 2)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            f = np.nan_to_num(2. / ml / (ml + 1.))
+        f[ml < 2.] = 0.                                   # fkappa_to_fphi, lensing.py:662-665
+        torch = _torch()
+        self._fphi = e.hcreal(); self._fphi[:, :nxh + 1] = torch.as_tensor(f, dtype=e.rdt, device=e.device)
+        self._one = e.hcreal(); self._one[:, :nxh + 1] = 1.0
+
+    def alpha_from_kappa(self, kappa):
+        """grad(phi) with phi = IDFT[2 kappa_l/(l(l+1))]: returns (alpha_y, alpha_x) device maps."""
+        e = self.eng
+        kk = e.rfft(e.to_real(kappa))
+        gx, gy, _ = e.qe_legs(kk, kk, self._fphi, self._fphi)
+        return e.irfft(gy), e.irfft(gx)
+
+    def kappa_to_phi(self, kappa):
+        e = self.eng
+        return e.irfft(e.cmul_real(e.rfft(e.to_real(kappa)), self._fphi))
+
+    def lens(self, imap, alpha, taylor_order=5):
+        """flat_taylens: T(x + alpha) by nearest-pixel remap + Taylor series in FFT derivatives."""
+        from math import factorial
+        e = self.eng
+        ay, ax = alpha
+        sx, dx = e.lens_split(ax, self.geom.step_x)
+        sy, dy = e.lens_split(ay, self.geom.step_y)
+        src = e.to_real(imap)
+        out = e.real()
+        e.lens_gather(src, sx, sy, dx, dy, 0, 0, 1.0, out, False)
+        k0 = e.rfft(src)
+        # D[a][b] = (i lx)^a (i ly)^b k0, built incrementally with the derivative kernel
+        row = {(0, 0): k0}
+        for n in range(1, taylor_order):
+            for b in range(n + 1):
+                a = n - b
+                if (a, b) in row:
+                    continue
+                if a > 0:
+                    dxk, _, _ = e.qe_legs(row[(a - 1, b)], k0, self._one, self._one)
+                    row[(a, b)] = dxk
+                else:
+                    _, dyk, _ = e.qe_legs(row[(a, b - 1)], k0, self._one, self._one)
+                    row[(a, b)] = dyk
+            for b in range(n + 1):
+                a = n - b
+                d = e.irfft(row[(a, b)])
+                e.lens_gather(d, sx, sy, dx, dy, a, b, 1.0 / (factorial(a) * factorial(b)), out, True)
+            for key in [kk for kk in row if kk[0] + kk[1] < n]:   # only the previous order is needed to go on
+                if key != (0, 0):
+                    del row[key]
+        return out
+
+
 class FlatLensingSims(object):
     """lensing.py:458-521: CMB / kappa / noise GRF generators, Gaussian beam,
     white noise.  The lensing operation itself (pixell displace_map) is the
@@ -565,6 +637,8 @@ class FlatLensingSims(object):
         self.ps_noise = ps_noise
         self._fixed = fixed_lens_kappa is not None
         self.kappa = fixed_lens_kappa
+        self.lenser = FlatLenser(self.shape[-2:], wcs, dtype=dtype)
+        self.alpha = self.lenser.alpha_from_kappa(self.kappa) if self._fixed else None
 
     def get_unlensed(self, seed=None):
         return self.mgen.get_map(seed=seed)
@@ -581,8 +655,20 @@ class FlatLensingSims(object):
             lensed = unlensed
             kappa = torch.zeros_like(lensed if lensed.ndim == 2 else lensed[0])
         else:
-            raise NotImplementedError("map lensing (pixell displace_map) is SURVEY.md section 8f-1, not built yet; "
-                                      "use skip_lensing=True")
+            if not self._fixed:
+                kappa = self.get_kappa(seed_kappa)
+                self.kappa = kappa
+                self.alpha = self.lenser.alpha_from_kappa(kappa)
+            else:
+                kappa = None
+                assert seed_kappa is None
+            # the reference calls pixell.lensing.displace_map(order=lens_order) (lensing.py:512); here the
+            # FFT-only Taylens of lensing.py:395-440 is used (same Taylor order)
+            if unlensed.ndim == 2:
+                lensed = self.lenser.lens(unlensed, self.alpha, taylor_order=lens_order)
+            else:
+                lensed = torch.stack([self.lenser.lens(unlensed[i].contiguous(), self.alpha, taylor_order=lens_order)
+                                      for i in range(unlensed.shape[0])])
         beamed = maps.filter_map(lensed, self.kbeam)
         noise_map = self.ngen.get_map(seed=seed_noise)
         observed = beamed + noise_map

@@ -255,3 +255,64 @@ def test_mv_combination_matches_oracle():
         nmv = q._full(q.Nlkk["MV"])
         assert np.max(np.abs(nmv[sel & (qr.Nlkk["MV"] > 0)] / qr.Nlkk["MV"][sel & (qr.Nlkk["MV"] > 0)] - 1)) < 1e-6
         assert np.all(nmv[sel] <= q.N_kappa("TT")[sel] * (1 + 1e-9))   # MV is never noisier than TT
+
+
+def test_flat_lensing_op_matches_oracle_and_remaps():
+    """kappa -> phi -> alpha and the FFT-only Taylens (lensing.py:395-454,651-665) vs the NumPy restatement;
+    a constant one-pixel displacement is an exact roll."""
+    from orphics_amd import lensing
+    from orphics_amd.geometry import FlatGeometry
+    N = 128
+    g = FlatGeometry.from_res((N, N), 2.0)
+    rng = np.random.default_rng(21)
+    ml = g.modlmap()
+    kap = np.fft.ifft2(np.fft.fft2(rng.standard_normal((N, N))) * 1.5 / (1 + (ml / 200.) ** 2)).real
+    T = np.fft.ifft2(np.fft.fft2(rng.standard_normal((N, N))) / (1 + (ml / 400.) ** 2)).real
+    L = lensing.FlatLenser((N, N), g, dtype="f64")
+    ay, ax = L.alpha_from_kappa(kap)
+    ray, rax = qo.alpha_from_kappa(kap, g.step_y, g.step_x)
+    assert np.abs(ay.cpu().numpy() - ray).max() < 1e-12 * np.abs(ray).max() + 1e-18
+    assert np.abs(ax.cpu().numpy() - rax).max() < 1e-12 * np.abs(rax).max() + 1e-18
+    assert np.abs(ray).max() / abs(g.step_y) > 0.5        # a real multi-pixel test
+    lensed = L.lens(T, (ay, ax), taylor_order=5).cpu().numpy()
+    ref = qo.flat_taylens((ray, rax), T, g.step_y, g.step_x, taylor_order=5)
+    assert np.abs(lensed - ref).max() / np.abs(ref).max() < 1e-10
+    torch_ = torch
+    one_y = torch_.full((N, N), g.step_y, dtype=torch_.float64, device="cuda")
+    one_x = torch_.full((N, N), 2 * g.step_x, dtype=torch_.float64, device="cuda")
+    rolled = L.lens(T, (one_y, one_x)).cpu().numpy()
+    assert np.allclose(rolled, np.roll(np.roll(T, -1, axis=0), -2, axis=1), atol=1e-12)
+
+
+def test_tt_qe_is_unbiased_on_lensed_sims():
+    """tutorials/tt_verification.ipynb criterion: mean of (C^{kappa_hat kappa} - C^{kk})/C^{kk} over lensed
+    sims is consistent with 0 (here 1024^2 1' maps, 24 sims, |bias| < 6 % + 3 sigma for L < 1500)."""
+    from orphics_amd import cosmology, lensing, maps, stats
+    from orphics_amd.geometry import FlatGeometry
+    N, res = 1024, 1.0
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    sims = lensing.FlatLensingSims(shape, g, th, 1.5, 1.0, dtype="f32")
+    n2d = sims.ps_noise[0, 0]
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2500)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3000)
+    q = lensing.qest(shape, g, th, noise2d=n2d, beam2d=sims.kbeam, kmask=tmask, kmask_K=kmask,
+                     unlensed_equals_lensed=True, dtype="f32")
+    fc = maps.FourierCalc(shape, g, layout="half")
+    edges = np.linspace(40, 1500, 9)
+    binner = stats.bin2D(ml, edges)
+    st = stats.Stats()
+    for i in range(24):
+        unl, kappa, lensed, beamed, noise, obs = sims.get_sim(seed_cmb=(1, i), seed_kappa=(2, i), seed_noise=(3, i),
+                                                              return_intermediate=True)
+        kk_in = fc.fft(kappa)
+        rec = q.kappa_from_map("TT", fc.fft(obs), alreadyFTed=True, returnFt=True)
+        _, pc = binner.bin(fc.f2power(rec, kk_in))
+        _, pi = binner.bin(fc.f2power(kk_in, kk_in))
+        st.add_to_stats("ratio", (pc - pi) / pi)
+    st.get_stats(verbose=False)
+    y, e = st.stats["ratio"]["mean"], st.stats["ratio"]["errmean"]
+    assert np.all(np.abs(y) < 0.06 + 3 * e), (y, e)
+    assert abs(y.mean()) < 0.04
