@@ -604,3 +604,87 @@ class MatchedFilter(object):
         phi_un = float(s_un[0].item())
         phi_var = 1. / float(s_tt[0].item())
         return phi_un * phi_var, phi_var
+
+
+# ---- split-based signal / noise power (maps.py:2296-2411) --------------------
+def _hp_val(x):
+    return x.t if isinstance(x, HalfPlane) else x
+
+
+def _hp_like(t, like):
+    return HalfPlane(t, like.eng) if isinstance(like, HalfPlane) else t
+
+
+def split_calc(isplits, jsplits, icoadd, jcoadd, fourier_calc=None, alt=True, wcs=None):
+    """maps.py:2296-2333: (total, crosses, noise) power from Fourier transforms of splits.
+    ``isplits``/``jsplits``: (nsplits,Ny,Nx) complex arrays or lists of HalfPlane."""
+    i_list = [isplits[i] for i in range(len(isplits))]
+    j_list = [jsplits[i] for i in range(len(jsplits))]
+    fc = fourier_calc if fourier_calc is not None else FourierCalc(tuple(np.shape(icoadd))[-2:] if not isinstance(icoadd, HalfPlane) else icoadd.shape[-2:], wcs)
+    total = fc.f2power(icoadd, jcoadd)
+    insplits, jnsplits = len(i_list), len(j_list)
+    if alt:
+        assert insplits == jnsplits
+        noise = 0.
+        for i in range(insplits):
+            diff1 = _hp_like(_hp_val(i_list[i]) - _hp_val(icoadd), icoadd)
+            diff2 = _hp_like(_hp_val(j_list[i]) - _hp_val(jcoadd), jcoadd)
+            noise = noise + _hp_val(fc.f2power(diff1, diff2))
+        noise = noise / ((1. - 1. / insplits) * insplits ** 2)
+        crosses = _hp_val(total) - noise
+    else:
+        ncrosses = 0.
+        totcross = 0.
+        for i in range(insplits):
+            for j in range(jnsplits):
+                if i == j:
+                    continue
+                totcross = totcross + _hp_val(fc.f2power(i_list[i], j_list[j]))
+                ncrosses += 1.
+        crosses = totcross / ncrosses
+        noise = _hp_val(total) - crosses
+    return total, _hp_like(crosses, total), _hp_like(noise, total)
+
+
+def noise_from_splits(splits, fourier_calc=None, nthread=0, do_cross=True, wcs=None):
+    """maps.py:2338-2411: noise = (mean auto - mean cross)/Nsplits of I,Q,U split maps and, optionally,
+    the mean T,E,B cross power.  ``splits``: (nsplits,ncomp,Ny,Nx) or (nsplits,Ny,Nx) real maps."""
+    splits = np.asarray(splits).astype(np.float32)
+    assert splits.ndim == 3 or splits.ndim == 4
+    ndim = splits.ndim
+    if splits.ndim == 3:
+        splits = splits[:, None, :, :]
+    ncomp = splits.shape[1]
+    if fourier_calc is None:
+        shape = splits.shape[-3:] if do_cross else splits.shape[-2:]
+        fourier_calc = FourierCalc(shape, wcs)
+    fc = fourier_calc
+    Nsplits = splits.shape[0]
+    if do_cross:
+        assert ncomp == 3 or ncomp == 1
+    ksplits = [fc.iqu2teb(split, nthread=nthread, normalize=False, rot=False) for split in splits]
+    if do_cross:
+        kteb_splits = []
+        for split in splits:
+            # the reference only rotates when ndim==3 and ncomp==3, which can never hold (maps.py:2376-2378)
+            kteb_splits.append(fc.iqu2teb(split, nthread=nthread, normalize=False, rot=(ndim == 3 and ncomp == 3)))
+    auto = 0.
+    for ksplit in ksplits:
+        auto = auto + fc.power2d(kmap=ksplit)[0]
+    auto = auto / Nsplits
+    Ncrosses = (Nsplits * (Nsplits - 1) / 2)
+    cross = 0.
+    for i in range(len(ksplits)):
+        for j in range(i + 1, len(ksplits)):
+            cross = cross + fc.power2d(kmap=ksplits[i], kmap2=ksplits[j])[0]
+    cross = cross / Ncrosses
+    if do_cross:
+        cross_teb = 0.
+        for i in range(len(ksplits)):
+            for j in range(i + 1, len(ksplits)):
+                cross_teb = cross_teb + fc.power2d(kmap=kteb_splits[i], kmap2=kteb_splits[j])[0]
+        cross_teb = cross_teb / Ncrosses
+    else:
+        cross_teb = None
+    noise = (auto - cross) / Nsplits
+    return noise, cross_teb
