@@ -406,3 +406,16 @@ def flat_taylens(alpha, imap, step_y, step_x, taylor_order=5):
             d = _ifftn((1j * lxd[None, :]) ** a * (1j * lyd[:, None]) ** b * kmap).real
             out += d[yy, xx] * dx ** a * dy ** b / (factorial(a) * factorial(b))
     return out
+
+
+def lensed_bb_brute(ly, lx, area, ang, clee, clpp, yi, xi):
+    """Direct sum of C^BB(l) = (1/Area) sum_l1 [l1.l2]^2 sin^2(a1 - a) C^EE(l1) C^pp(l2) at one mode."""
+    Ny, Nx = clee.shape
+    tot = 0.0
+    for y1 in range(Ny):
+        y2 = (yi - y1) % Ny
+        for x1 in range(Nx):
+            x2 = (xi - x1) % Nx
+            dot = ly[y1] * ly[y2] + lx[x1] * lx[x2]
+            tot += dot ** 2 * np.sin(ang[y1, x1] - ang[yi, xi]) ** 2 * clee[y1, x1] * clpp[y2, x2]
+    return tot / area

@@ -104,3 +104,61 @@ def knox_cov(cl_tot, nmodes):
     """Gaussian bandpower variance 2 C_b^2 / N_modes (mode-count form of
     LensForecast.KnoxCov, cosmology.py:1054-1082, with N_modes from bin2D counts)."""
     return 2. * np.asarray(cl_tot) ** 2. / np.asarray(nmodes)
+
+
+class LensForecast(object):
+    """Gaussian bandpower covariance (cosmology.py:948-1094): only the pieces on the hot path's
+    output side -- loadKK / loadGenericCls, _bin_cls, KnoxCov, sigmaClSquared, sn."""
+
+    def __init__(self, theory=None):
+        self.theory = TheorySpectra() if theory is None else theory
+        self.Nls = {}
+
+    def loadKK(self, ellsCls, Cls, ellsNls, Nls, lpad=30000):
+        """cosmology.py:976-985: kk signal + reconstruction noise (inf outside the noise table)."""
+        ellsNls, Nls = np.asarray(ellsNls, float), np.asarray(Nls, float)
+        self.Nls['kk'] = lambda x: np.interp(np.asarray(x, float), ellsNls, Nls, left=np.inf, right=np.inf)
+        self.theory.loadGenericCls(ellsCls, Cls, 'kk', lpad=lpad)
+
+    def loadGenericCls(self, specType, ellsCls, Cls, ellsNls=None, Nls=None):
+        """cosmology.py:1034-1036."""
+        if Nls is not None:
+            e, n = np.asarray(ellsNls, float), np.asarray(Nls, float)
+            self.Nls[specType] = lambda x: np.interp(np.asarray(x, float), e, n, left=np.inf, right=np.inf)
+        self.theory.loadGenericCls(ellsCls, Cls, specType)
+
+    def _bin_cls(self, spec, ell_left, ell_right, noise=True, ntot=False):
+        """cosmology.py:1038-1052: ell-weighted mean of C_l (+N_l for autos) over [left, right]."""
+        a, b = spec
+        ells = np.arange(ell_left, ell_right + 1, 1)
+        cls = self.theory.gCl(spec, ells)
+        Noise = 0.
+        if noise:
+            Noise = self.Nls[spec](ells) if a == b else 0.
+        tot = Noise if (ntot and a == b and noise) else cls + Noise
+        return np.sum(ells * tot) / np.sum(ells)
+
+    def KnoxCov(self, specTypeXY, specTypeWZ, ellBinEdges, fsky, ntot=False):
+        """cosmology.py:1054-1082: cov(C^XY, C^WZ) = (C^XW C^YZ + C^XZ C^YW)/((2l+1) dl fsky)."""
+        X, Y = specTypeXY
+        W, Z = specTypeWZ
+        covs, sigs1, sigs2 = [], [], []
+        for ell_left, ell_right in zip(ellBinEdges[:-1], ellBinEdges[1:]):
+            ClSum = self._bin_cls(X + W, ell_left, ell_right, ntot=ntot) * self._bin_cls(Y + Z, ell_left, ell_right, ntot=ntot) \
+                + self._bin_cls(X + Z, ell_left, ell_right, ntot=ntot) * self._bin_cls(Y + W, ell_left, ell_right, ntot=ntot)
+            ellMid = (ell_right + ell_left) / 2.
+            ellWidth = ell_right - ell_left
+            var = ClSum / (2. * ellMid + 1.) / ellWidth / fsky
+            covs.append(var)
+            with np.errstate(divide="ignore"):
+                sigs1.append(self._bin_cls(specTypeXY, ell_left, ell_right, noise=False) ** 2. * np.nan_to_num(1. / var))
+                sigs2.append(self._bin_cls(specTypeWZ, ell_left, ell_right, noise=False) ** 2. * np.nan_to_num(1. / var))
+        return np.array(covs), np.array(sigs1), np.array(sigs2)
+
+    def sigmaClSquared(self, specType, ellBinEdges, fsky, ntot=False):
+        return self.KnoxCov(specType, specType, ellBinEdges, fsky, ntot=ntot)[0]
+
+    def sn(self, ellBinEdges, fsky, specType, ntot=False):
+        """cosmology.py:1087-1094."""
+        var, sigs1, _ = self.KnoxCov(specType, specType, ellBinEdges, fsky, ntot=ntot)
+        return np.sqrt(sigs1.sum()), np.sqrt(var)

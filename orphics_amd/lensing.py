@@ -675,3 +675,151 @@ class FlatLensingSims(object):
         if return_intermediate:
             return [unlensed, kappa, lensed, beamed, noise_map, observed]
         return observed
+
+
+# ---- analytic N_L / MV / iterative delensing ------------------------------------
+class NlGenerator(object):
+    """Call contract of the reference's ``lensing.NlGenerator`` as it survives in
+    tutorials/Lensing-noise-curves*.ipynb cell 3 (the class itself is absent from the snapshot):
+
+        nlgen = NlGenerator(shape, wcs, theory, bin_edges, lensedEqualsUnlensed=True)
+        nlgen.updateNoise(beamX=, noiseTX=, noisePX=, tellminX=, tellmaxX=, pellminX=, pellmaxX=)
+        ls, nls = nlgen.getNl('TT')
+        ls, nls, bells, nlbb, efficiency = nlgen.getNlIterative(polCombs, kmin, kmax, tellmax, pellmin, pellmax)
+
+    N_L^kk = L^2 (L+1)^2 A_L / 4 (legacy convention quoted in the notebooks' tracebacks); every 2-D
+    quantity is computed by FFT convolution with the f64 kernels and binned with bin2D.  ``TCMB`` converts
+    muK-arcmin noise to the theory's units (1 for muK^2 spectra, 2.7255e6 for dimensionless ones)."""
+
+    def __init__(self, shape, wcs, theorySpectra, bin_edges=None, gradCut=None, TCMB=1.0, bigell=9000,
+                 lensedEqualsUnlensed=False, unlensedEqualsLensed=True):
+        from . import stats
+        self.shape = tuple(shape[-2:])
+        self.wcs = wcs
+        self.geom = as_geometry(self.shape, wcs)
+        self.theory = theorySpectra
+        self.TCMB = TCMB
+        self.gradCut = gradCut
+        self.bigell = bigell
+        self.use_lensed = bool(lensedEqualsUnlensed or unlensedEqualsLensed)
+        self.modlmap = self.geom.modlmap()
+        self.bin_edges = None if bin_edges is None else np.asarray(bin_edges, dtype=np.float64)
+        self.binner = None if bin_edges is None else stats.bin2D(self.modlmap, self.bin_edges)
+        self.q = None
+
+    def updateBins(self, bin_edges):
+        from . import stats
+        self.bin_edges = np.asarray(bin_edges, dtype=np.float64)
+        self.binner = stats.bin2D(self.modlmap, self.bin_edges)
+
+    def updateNoise(self, beamX, noiseTX, noisePX, tellminX, tellmaxX, pellminX, pellmaxX, beamY=None, noiseTY=None,
+                    noisePY=None, tellminY=None, tellmaxY=None, pellminY=None, pellmaxY=None, **kwargs):
+        """White noise + Gaussian beam + ell ranges (the X and Y legs share one experiment here)."""
+        ml = self.modlmap
+        self.beam2d = maps.gauss_beam(ml, beamX)
+        self.nT = np.full(self.shape, (noiseTX * np.pi / 180. / 60. / self.TCMB) ** 2.)
+        self.nP = np.full(self.shape, (noisePX * np.pi / 180. / 60. / self.TCMB) ** 2.)
+        self.tmask = maps.mask_kspace(self.shape, self.geom, lmin=tellminX, lmax=tellmaxX)
+        self.pmask = maps.mask_kspace(self.shape, self.geom, lmin=pellminX, lmax=pellmaxX)
+        self.q = Estimator(self.shape, self.geom, self.theory, noise2d=self.nT, beam2d=self.beam2d, kmask=self.tmask,
+                           noise2d_P=self.nP, kmask_P=self.pmask, kmask_K=None, pol=True, grad_cut=self.gradCut,
+                           unlensed_equals_lensed=self.use_lensed, bigell=self.bigell, dtype="f64")
+        return self.nT, self.nP, self.nT, self.nP
+
+    def _N2d(self, polComb):
+        if polComb == "TT":
+            return self.q.N_kappa("TT")
+        self.q._setup_general(polComb)
+        return self.q.N_kappa(polComb)
+
+    def getNl(self, polComb='TT', halo=True):
+        """Binned N_L^kk of one estimator: (bin centers, N_L)."""
+        self.N2d = self._N2d(polComb)
+        cents, nl = self.binner.bin(self.N2d)
+        return cents, nl
+
+    def getNlMV(self, polCombs):
+        self.q.mv_weights(tuple(polCombs))
+        cents, nl = self.binner.bin(self.q._full(self.q.Nlkk["MV"]))
+        return cents, nl
+
+    # -- flat-sky lensing B-mode power by FFT convolution:
+    #    C^BB(l) = (1/Area) sum_l1 [l1.l2]^2 sin^2(a1 - a) C^EE(l1) C^pp(l2),  l2 = l - l1,  a = 2 x (mode angle)
+    def lensed_bb(self, clee_h, clpp_h):
+        q = self.q
+        e = q.eng64
+        lyd, lxd = q.ly.copy(), q.lxh.copy()
+        lyd[e.ny // 2] = 0.0
+        lxd[q.nxh] = 0.0
+        comp = (lxd[None, :] * np.ones((e.ny, 1)), lyd[:, None] * np.ones((1, q.nxh + 1)))
+        ang = q.ang_h
+        cache = {}
+        acc = {"1": None, "c": None, "s": None}
+        for j in range(2):
+            for k in range(j, 2):
+                mult = 1.0 if j == k else 2.0
+                v = q._real_of(-comp[j] * comp[k] * clpp_h + 0j, cache, ("v", j, k))       # (i l_j)(i l_k) C^pp
+                for key, trig in (("1", None), ("c", np.cos(2 * ang)), ("s", np.sin(2 * ang))):
+                    base = -comp[j] * comp[k] * clee_h * (1.0 if trig is None else trig)
+                    u = q._real_of(base + 0j, cache, ("u", j, k, key))
+                    prod = e.mul_real(u, v)
+                    acc[key] = e.axpby(prod, prod, mult, 0.0) if acc[key] is None else e.axpby(acc[key], prod, 1.0, mult)
+        out = {}
+        for key in acc:
+            out[key] = e.rfft(acc[key]).cpu().numpy()[:, :q.nxh + 1].real / self.geom.pixarea
+        bb = 0.5 * out["1"] - 0.5 * np.cos(2 * ang) * out["c"] - 0.5 * np.sin(2 * ang) * out["s"]
+        return bb
+
+    def getNlIterative(self, polCombs, kmin, kmax, tellmax, pellmin, pellmax, dell=20, halo=True, dTolPercentage=1.,
+                       verbose=False, plot=False, max_iterations=np.inf, eff_at=60, kappa_min=0, kappa_max=np.inf):
+        """Iterative EB delensing (Smith et al. 2012 style): N_L^EB -> Wiener phi -> residual lensing B power
+        C^BB_res = BB[C^EE, C^pp] - BB[C^EE W^E, C^pp W^phi] -> N_L^EB ..., until the binned N_L^EB moves by less
+        than dTolPercentage.  Returns (ls, N_L^MV over polCombs, bells, residual C^BB, efficiency %)."""
+        from . import stats
+        q = self.q
+        L = q.modl_h
+        with np.errstate(divide="ignore", invalid="ignore"):
+            k2p = np.nan_to_num(4. / (L * (L + 1.)) ** 2)
+        clkk = np.where(L <= self.bigell, self.theory.gCl("kk", L), 0.0)
+        clpp = clkk * k2p
+        clee = q.cl_grad["EE"]
+        nee = _safe_div(q.noise["P"], q.beam ** 2)
+        WE = _safe_div(clee, clee + nee) * ((L > pellmin) & (L < pellmax))
+        bb_len = self.lensed_bb(clee, clpp)
+        bb_res = bb_len.copy()
+        old = None
+        it = 0
+        bells = np.arange(2, min(pellmax, 4000), dell, dtype=np.float64)
+        bb_binner = stats.bin2D(self.modlmap, bells)
+        while True:
+            q.cl_len["BB"] = bb_res
+            q._P = None
+            q._gen.pop("EB", None)
+            q._setup_general("EB")
+            nkk = q.Nlkk["EB"]
+            cents, nl_eb = self.binner.bin(q._full(nkk))
+            it += 1
+            if verbose:
+                print("iteration", it, "N_L^EB[0..3] =", nl_eb[:3])
+            if old is not None:
+                change = np.nanmax(np.abs(nl_eb / old - 1.)) * 100.
+                if change < dTolPercentage:
+                    break
+            if it >= max_iterations:
+                break
+            old = nl_eb
+            npp = nkk * k2p
+            Wp = _safe_div(clpp, clpp + npp) * ((L > max(kmin, kappa_min)) & (L < min(kmax, kappa_max)))
+            bb_res = bb_len - self.lensed_bb(clee * WE, clpp * Wp)
+        # MV over the requested estimators with the delensed B power
+        for XY in polCombs:
+            if XY != "TT":
+                q._gen.pop(XY, None)
+        q._mv = None
+        w = q.mv_weights(tuple(polCombs))
+        ls, nls = self.binner.bin(q._full(q.Nlkk["MV"]))
+        bcents, nlbb = bb_binner.bin(q._full(bb_res))
+        _, lbb = bb_binner.bin(q._full(bb_len))
+        i = int(np.argmin(np.abs(bcents - eff_at)))
+        efficiency = (1. - nlbb[i] / lbb[i]) * 100.
+        return ls, nls, bcents, nlbb, efficiency

@@ -103,3 +103,24 @@ def test_mpi_distribute_and_fake_comm(golden_dir):
     assert c.Get_rank() == 0 and c.Get_size() == 1
     comm, rank, mine = mpi.distribute(7, verbose=False, comm=c)
     assert rank == 0 and mine == list(range(7))
+
+
+def test_lensforecast_knoxcov_formula():
+    """cosmology.py:1054-1082: per-bin var = 2 (C+N)^2 / ((2l+1) dl fsky) for an auto spectrum."""
+    from orphics_amd import cosmology
+    ells = np.arange(2, 3000)
+    clkk = 1e-7 * (ells / 100.) ** -1.2
+    nl = 2e-8 * np.ones_like(clkk) * (1 + (ells / 1500.) ** 2)
+    LF = cosmology.LensForecast()
+    LF.loadKK(ells, clkk, ells, nl)
+    edges = np.arange(100, 2000, 100)
+    var, s1, s2 = LF.KnoxCov("kk", "kk", edges, 0.4)
+    for i, (a, b) in enumerate(zip(edges[:-1], edges[1:])):
+        e = np.arange(a, b + 1)
+        tot = np.sum(e * (np.interp(e, ells, clkk) + np.interp(e, ells, nl))) / np.sum(e)
+        sig = np.sum(e * np.interp(e, ells, clkk)) / np.sum(e)
+        v = 2 * tot ** 2 / (2 * (a + b) / 2. + 1) / (b - a) / 0.4
+        assert abs(var[i] / v - 1) < 1e-12 and abs(s1[i] / (sig ** 2 / v) - 1) < 1e-12
+    sn, errs = LF.sn(edges, 0.4, "kk")
+    assert abs(sn - np.sqrt(s1.sum())) < 1e-12 and np.allclose(errs, np.sqrt(var))
+    assert np.allclose(cosmology.knox_cov(3.0, 50), 2 * 9. / 50)
