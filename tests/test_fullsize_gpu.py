@@ -1,0 +1,136 @@
+"""GPU, BASELINE.json full sizes: size-independent properties (round trips, Parseval, linearity, checksums of
+the bit-exact bin ids, f32-vs-f64 agreement) where the NumPy oracle would take minutes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def eng(n, prec):
+    from orphics_amd.engine import Engine
+    return Engine.get(n, n, prec)
+
+
+@pytest.mark.parametrize("N", [4096, 8192, 16384])
+def test_fft_round_trip_parseval_linearity(N):
+    e = eng(N, "f32")
+    x = e.randn(11, 0)
+    y = e.randn(11, 1)
+    kx = e.rfft(x)
+    back = e.irfft(kx)
+    err = (back - x).abs().max().item()
+    assert err < 2e-5, err                                   # encode -> decode
+    # Parseval with Hermitian multiplicities: sum |x|^2 = (1/Npix) sum_full |X|^2
+    w = kx[:, :N // 2 + 1].abs().double() ** 2
+    tot = 2 * w.sum() - w[:, 0].sum() - w[:, N // 2].sum()
+    assert abs(tot.item() / (N * N) / (x.double() ** 2).sum().item() - 1) < 1e-5
+    # linearity: F(2x - 3y) = 2F(x) - 3F(y)
+    ky = e.rfft(y)
+    kz = e.rfft(e.axpby(x, y, 2.0, -3.0))
+    ref = 2.0 * kx - 3.0 * ky
+    assert ((kz - ref)[:, :N // 2 + 1].abs().max() / ref[:, :N // 2 + 1].abs().max()).item() < 2e-6
+    # a single Fourier mode comes back as a delta
+    del kx, ky, kz, ref, back
+    k1 = e.hc()
+    k1[5, 7] = N * N / 2.0
+    m = e.irfft(k1)
+    yy = torch.arange(N, device=m.device, dtype=torch.float64)
+    expect = torch.cos(2 * np.pi * (5 * yy[:, None] + 7 * yy[None, :]) / N)
+    assert (m.double() - expect).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("N,res", [(4096, 0.5), (8192, 0.5)])
+def test_bin_ids_bit_exact_with_numpy_at_full_size(N, res):
+    """H2: Delta ell = 21600/4096 makes grid modes land exactly on integer edges; device ids must equal
+    np.digitize(right=True) of NumPy's modlmap everywhere, and counts must sum to Npix."""
+    from orphics_amd.geometry import FlatGeometry
+    e = eng(N, "f32")
+    g = FlatGeometry.from_res((N, N), res)
+    ly, lx = g.laxes()
+    e.set_laxes(ly, lx)
+    edges = np.arange(0., 12000., 5400. / 8)                 # integer edges hit exactly by on-axis modes
+    ed = torch.as_tensor(edges, device=e.device)
+    ids_h = e.modl_digitize(ed, half=True).cpu().numpy()[:, :N // 2 + 1]
+    ml_h = np.sqrt(ly[:, None] ** 2 + lx[None, :N // 2 + 1] ** 2)
+    ref = np.digitize(ml_h.reshape(-1), edges, right=True).reshape(ml_h.shape)
+    assert np.array_equal(ids_h, ref)
+    ties = np.isin(ml_h, edges).sum()
+    assert ties > 10                                        # the exact-tie cases are really exercised
+    data = torch.ones((N, e.kp), dtype=torch.float32, device=e.device)
+    sums, counts = e.bin(data, e.modl_digitize(ed, half=True), len(edges) + 1, herm=True)
+    assert int(counts.sum().item()) == N * N
+    assert torch.equal(counts.double(), sums)
+
+
+def test_config2_tt_qe_4096_f32_vs_f64():
+    """BASELINE config 2: 4096^2 0.5' TT QE, one realisation: f32 kernels vs f64 kernels (the f64 path is the one
+    pinned to the NumPy oracle at small sizes): kappa bandpowers within 1e-5, fused == modular."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N, res = 4096, 0.5
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    out = {}
+    for prec in ("f32", "f64"):
+        q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask,
+                         unlensed_equals_lensed=True, dtype=prec)
+        e = q.eng
+        t = e.randn(5, 0) if prec == "f32" else out["t"].double()
+        out["t"] = t if prec == "f32" else out["t"]
+        kT = e.rfft(t.contiguous())
+        kk = q.reconstruct_tt_hc(kT).clone()
+        km = q.reconstruct_tt_hc(kT, fused=False)
+        assert ((kk - km)[:, :N // 2 + 1].abs().max() / km[:, :N // 2 + 1].abs().max()).item() < (3e-5 if prec == "f32" else 1e-11)
+        ed = torch.as_tensor(np.linspace(20, 3500, 20), device=e.device)
+        s, c = e.bin_power(kk, kk, g.area / float(N * N) ** 2, e.modl_digitize(ed, half=True), 21, herm=True)
+        out[prec] = (s[1:-1] / c[1:-1].double()).cpu().numpy()
+        del q
+    assert np.max(np.abs(out["f32"] / out["f64"] - 1)) < 1e-5
+
+
+def test_config5_16384_tt_qe_runs_and_matches_knox_scatter():
+    """BASELINE config 5 (HBM-capacity stress): 16384^2 0.25' TT QE on one GPU; the Gaussian bandpower
+    scatter of N0 realisations agrees with the mode-count Knox variance 2 C_b^2 / N_modes."""
+    from orphics_amd import cosmology, lensing, maps, mc, stats
+    from orphics_amd.geometry import FlatGeometry
+    N, res = 16384, 0.25
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    nxh = N // 2
+    ly, lx = g.laxes()
+    ml_h = np.sqrt(ly[:, None] ** 2 + lx[None, :nxh + 1] ** 2)
+
+    def full(a_h):
+        o = np.empty(shape, dtype=a_h.dtype)
+        o[:, :nxh + 1] = a_h
+        o[:, nxh + 1:] = a_h[(-np.arange(N)) % N][:, 1:nxh][:, ::-1]
+        return o
+    beam_h = maps.gauss_beam(ml_h, 1.5)
+    noise_h = np.full(ml_h.shape, cosmology.white_noise_power(1.0))
+    q = lensing.qest(shape, g, th, noise2d=full(noise_h), beam2d=full(beam_h),
+                     kmask=full(((ml_h > 300) & (ml_h < 2000)).astype(np.int64)),
+                     kmask_K=full(((ml_h > 20) & (ml_h < 3500)).astype(np.int64)), unlensed_equals_lensed=True, dtype="f32")
+    tot_h = th.lCl("TT", ml_h) * beam_h ** 2 + noise_h
+    edges = np.linspace(200, 3000, 15)
+    drv = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=5)
+    st = drv.run(12)
+    mean, var = st.mean("n0"), st.var("n0")
+    e = q.eng
+    ed = torch.as_tensor(edges, device=e.device)
+    ones = torch.ones((N, e.kp), dtype=torch.float32, device=e.device)
+    _, counts = e.bin(ones, e.modl_digitize(ed, half=True), len(edges) + 1, herm=True)
+    nmodes = counts[1:-1].cpu().numpy() / 2.0              # independent modes of a real field
+    knox = cosmology.knox_cov(mean, nmodes)
+    ratio = var / knox
+    assert 0.3 < np.median(ratio) < 2.5, ratio             # 12 sims: chi^2_11 scatter on each variance
+    nl = q.Nlkk["TT"]
+    sel = (ml_h > 400) & (ml_h < 2800)
+    assert abs(mean.mean() / nl[sel].mean() - 1) < 0.25    # N0 level
