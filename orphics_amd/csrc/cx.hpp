@@ -32,6 +32,37 @@ template <typename T> OA_HD cx<T> mul_pi(cx<T> a) { return mk<T>(-a.y, a.x); }
 // re<->im swap: IDFT(x) = swap(DFT(swap(x)))
 template <typename T> OA_HD cx<T> swp(cx<T> a) { return mk<T>(a.y, a.x); }
 
+// a + (-i) b  and  a + (+i) b : the radix-4 building blocks of every butterfly
+template <typename T> OA_HD cx<T> add_mi(cx<T> a, cx<T> b) { return mk<T>(a.x + b.y, a.y - b.x); }
+template <typename T> OA_HD cx<T> add_pi(cx<T> a, cx<T> b) { return mk<T>(a.x - b.y, a.y + b.x); }
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_NO_PK_ASM)
+// gfx950 packed-f32 forms with operand swizzles / sign modifiers (op_sel, neg_lo/neg_hi) that hipcc
+// does not select on its own (it emits v_xor + v_mov + v_pk_* instead): 1 instruction for a +- i b,
+// 2 for a complex product.  Plain VALU -> hardware interlocked, no manual wait states needed.
+typedef float oa_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cx<float> add_mi(cx<float> a, cx<float> b) {
+    oa_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"
+        : "=v"(r) : "v"(__builtin_bit_cast(oa_f2, a)), "v"(__builtin_bit_cast(oa_f2, b)));
+    return __builtin_bit_cast(cx<float>, r);
+}
+__device__ __forceinline__ cx<float> add_pi(cx<float> a, cx<float> b) {
+    oa_f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=v"(r) : "v"(__builtin_bit_cast(oa_f2, a)), "v"(__builtin_bit_cast(oa_f2, b)));
+    return __builtin_bit_cast(cx<float>, r);
+}
+__device__ __forceinline__ cx<float> operator*(cx<float> a, cx<float> b) {
+    oa_f2 t, r;
+    const oa_f2 av = __builtin_bit_cast(oa_f2, a), bv = __builtin_bit_cast(oa_f2, b);
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));          // (a.x b.x, a.x b.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                  // (-a.y b.y, a.y b.x) + t
+        : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return __builtin_bit_cast(cx<float>, r);
+}
+#endif
+
 OA_HD int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

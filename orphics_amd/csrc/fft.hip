@@ -1,34 +1,7 @@
 // HIP launchers for the LDS-staged 2-D FFT passes (K1) + oa_fft_* entry points.
-#include "common.hpp"
-#include "fft_plan.hpp"
+#include "fft_launch.hpp"
 
 namespace oa {
-
-struct GpuCtx {
-    char* sm;
-    OA_D int tid() const { return threadIdx.x; }
-    OA_D int bid_x() const { return blockIdx.x; }
-    OA_D int bid_y() const { return blockIdx.y; }
-    OA_D void sync() const { __syncthreads(); }
-    OA_D void* smem() const { return sm; }
-};
-
-extern __shared__ __attribute__((aligned(16))) char oa_dyn_smem[];
-
-#ifndef OA_WAVES_PER_EU
-#define OA_WAVES_PER_EU 4
-#endif
-constexpr size_t LDS_MAX = 160 * 1024;
-
-// workgroup size is a function of the transform length: NT = L*C/16, L*C = 4096 up to L = 4096
-template <class SEQ>
-constexpr int seq_logl() {
-    return Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
-}
-template <class SEQ> constexpr int row_maxnt() { return seq_logl<SEQ>() <= 12 ? 256 : (seq_logl<SEQ>() == 13 ? 512 : 1024); }
-template <class SEQ> constexpr int col_maxnt() { return seq_logl<SEQ>() <= 7 ? 256 : 512; }
-// float kernels fit 128 VGPRs (4 waves/SIMD); double needs the 256-register budget
-template <typename T> constexpr int waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_WAVES_PER_EU; }
 
 template <typename T, int MODE, class SEQ>
 __global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_kernel(RowArgs<T> a) {
@@ -47,16 +20,6 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), qe_waves_per_eu<T>()) void row_qe
     row_qe_body<T, SEQ>(c, a);
 }
 
-#ifndef OA_FUSED_COL_WAVES
-#define OA_FUSED_COL_WAVES 3
-#endif
-template <typename T> constexpr int fused_col_waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_FUSED_COL_WAVES; }
-
-template <typename T, class SEQ>
-__global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_legs_kernel(ColLegsArgs<T> a) {
-    GpuCtx c{oa_dyn_smem};
-    col_legs_body<T, SEQ>(c, a);
-}
 
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_div_kernel(ColDivArgs<T> a) {
@@ -75,21 +38,7 @@ struct HipLauncher {
     int rc = 0;
 
     template <class K, class A>
-    void go(K kern, dim3 grid, int nt, size_t smem, const A& a) {
-        if (rc) return;
-        if (smem > LDS_MAX || nt > 1024 || nt < 1) {
-            rc = fail("fft: transform size exceeds the LDS / workgroup budget for this dtype");
-            return;
-        }
-        if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(nt), smem, st, a);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
-    }
+    void go(K kern, dim3 grid, int nt, size_t smem, const A& a) { launch_go(rc, st, kern, grid, nt, smem, a); }
 
     template <typename T, int MODE, class S>
     void row_mode(int grid, int nt, size_t smem, const RowArgs<T>& a) {
@@ -124,14 +73,8 @@ struct HipLauncher {
     }
     template <typename T>
     void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
-        const bool ok = dispatch_seq(logL, [&](auto seq) {
-            using S = decltype(seq);
-            if constexpr (seq_logl<S>() <= 8) {
-                if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
-                go(col_legs_kernel<T, S>, dim3(gx, gy), nt, smem, a);
-            } else if (!rc) rc = fail("fft: unsupported column sub-length");
-        });
-        if (!ok && !rc) rc = fail("fft: unsupported column length");
+        if (rc) return;
+        rc = launch_col_legs<T>(st, gx, gy, nt, smem, logL, a);   // separate translation unit (fft_legs.hip)
     }
     template <typename T>
     void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {

@@ -28,9 +28,6 @@
 
 namespace oa {
 
-#ifndef OA_PE_UNROLL
-#define OA_PE_UNROLL 4         // unroll of the real<->half-complex (un)tangle loops (register pressure vs MLP)
-#endif
 constexpr int EPT = 16;        // complex points per thread per stage
 constexpr int MAX_STAGES = 8;
 
@@ -73,12 +70,14 @@ struct Dft {
         Dft<T, R / 2>::run(o);
 #pragma unroll
         for (int k = 0; k < R / 2; ++k) {
-            cx<T> t;
-            if (k == 0) t = o[k];
-            else if (4 * k == R) t = mul_mi(o[k]);
-            else t = o[k] * w16<T>(k * (16 / R));
-            v[k] = e[k] + t;
-            v[k + R / 2] = e[k] - t;
+            if (4 * k == R) {   // twiddle -i: one swizzled add each, no product
+                v[k] = add_mi(e[k], o[k]);
+                v[k + R / 2] = add_pi(e[k], o[k]);
+            } else {
+                const cx<T> t = (k == 0) ? o[k] : o[k] * w16<T>(k * (16 / R));
+                v[k] = e[k] + t;
+                v[k + R / 2] = e[k] - t;
+            }
         }
     }
 };
@@ -335,7 +334,6 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
                         const cx<T>* tw, int logTw) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
-#pragma unroll OA_PE_UNROLL
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
         const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
         const cx<T>* row = in + r0 * pitch + (unsigned)c * (unsigned)pitch;
@@ -360,7 +358,6 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
                         const cx<T>* tw, int logTw, T scale, bool accumulate = false) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
-#pragma unroll OA_PE_UNROLL
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
         const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
         cx<T>* row = out + r0 * pitch + (unsigned)c * (unsigned)pitch;

@@ -1,0 +1,62 @@
+// Shared launch plumbing of the FFT translation units (fft.hip, fft_legs.hip).
+#pragma once
+#include "common.hpp"
+#include "fft_plan.hpp"
+
+namespace oa {
+
+struct GpuCtx {
+    char* sm;
+    OA_D int tid() const { return threadIdx.x; }
+    OA_D int bid_x() const { return blockIdx.x; }
+    OA_D int bid_y() const { return blockIdx.y; }
+    OA_D void sync() const { __syncthreads(); }
+    OA_D void* smem() const { return sm; }
+};
+
+extern __shared__ __attribute__((aligned(16))) char oa_dyn_smem[];
+
+#ifndef OA_WAVES_PER_EU
+#define OA_WAVES_PER_EU 4
+#endif
+constexpr size_t LDS_MAX = 160 * 1024;
+
+// workgroup size is a function of the transform length: NT = L*C/16, L*C = 4096 up to L = 4096
+template <class SEQ>
+constexpr int seq_logl() {
+    return Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+}
+template <class SEQ> constexpr int row_maxnt() { return seq_logl<SEQ>() <= 12 ? 256 : (seq_logl<SEQ>() == 13 ? 512 : 1024); }
+template <class SEQ> constexpr int col_maxnt() { return seq_logl<SEQ>() <= 7 ? 256 : 512; }
+// float kernels fit 128 VGPRs (4 waves/SIMD); double needs the 256-register budget
+template <typename T> constexpr int waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_WAVES_PER_EU; }
+
+
+#ifndef OA_FUSED_COL_WAVES
+#define OA_FUSED_COL_WAVES 3
+#endif
+template <typename T> constexpr int fused_col_waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_FUSED_COL_WAVES; }
+
+template <class K, class A>
+inline void launch_go(int& rc, hipStream_t st, K kern, dim3 grid, int nt, size_t smem, const A& a) {
+    if (rc) return;
+    if (smem > LDS_MAX || nt > 1024 || nt < 1) {
+        rc = fail("fft: transform size exceeds the LDS / workgroup budget for this dtype");
+        return;
+    }
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)smem);
+        if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(nt), smem, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+}
+
+// defined in fft_legs.hip (built WITHOUT the packed-asm complex operators: the leg kernel's many
+// independent global loads schedule better around compiler-visible arithmetic)
+template <typename T>
+int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a);
+
+}  // namespace oa

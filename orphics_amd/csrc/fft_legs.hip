@@ -1,0 +1,33 @@
+// Fused leg-filter + inverse column pass-1 kernel (own translation unit, see fft_launch.hpp).
+#define OA_NO_PK_ASM 1
+#include "fft_launch.hpp"
+
+namespace oa {
+
+template <typename T, class SEQ>
+__global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_legs_kernel(ColLegsArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_legs_body<T, SEQ>(c, a);
+}
+
+
+template <typename T>
+int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
+    int rc = 0;
+    const bool ok = dispatch_seq(logL, [&](auto seq) {
+        using S = decltype(seq);
+        if constexpr (seq_logl<S>() <= 8) {
+            if (nt > col_maxnt<S>()) { rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
+            launch_go(rc, st, col_legs_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+        } else {
+            rc = fail("fft: unsupported column sub-length");
+        }
+    });
+    if (!ok && !rc) rc = fail("fft: unsupported column length");
+    return rc;
+}
+
+template int launch_col_legs<float>(hipStream_t, int, int, int, size_t, int, const ColLegsArgs<float>&);
+template int launch_col_legs<double>(hipStream_t, int, int, int, size_t, int, const ColLegsArgs<double>&);
+
+}  // namespace oa
