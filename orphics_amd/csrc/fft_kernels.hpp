@@ -233,6 +233,7 @@ template <class SEQ> constexpr int rev_logns(int i) { int a = 0; for (int m = 0;
 
 template <int R> struct Log2x { static constexpr int v = Log2c<R>::v; };
 template <> struct Log2x<1> { static constexpr int v = 0; };
+template <class SEQ> constexpr int seq_total_log() { return clog2(SEQ::r0) + clog2(SEQ::r1) + clog2(SEQ::r2) + clog2(SEQ::r3); }
 
 // Forward DFT of the C sequences of this workgroup, radix sequence SEQ.
 //   SRC_G: the first stage reads ld.get(n,c); otherwise data is in LDS (caller synced).
@@ -384,7 +385,8 @@ template <typename T, int MODE, class SEQ, class Ctx>
 OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
-    const int logL = a.logL, C = 1 << a.logC, RS = a.rowStride;
+    constexpr int logL = seq_total_log<SEQ>();   // compile-time: LDS offsets of the 16 taps become immediates
+    const int C = 1 << a.logC, RS = a.rowStride;
     const long r0 = (long)ctx.bid_x() * C;
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
@@ -462,7 +464,8 @@ template <typename T, class SEQ, class Ctx>
 OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
-    const int logL = a.logL, logC = a.logC, C = 1 << logC, RS = a.rowStride;
+    constexpr int logL = seq_total_log<SEQ>();
+    const int logC = a.logC, C = 1 << logC, RS = a.rowStride;
     const long r0 = (long)ctx.bid_x() * C;
     constexpr int R0 = SEQ::get(0);
     constexpr int lastns = rev_logns<SEQ>(SEQ::n - 1);
@@ -769,16 +772,17 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
     if (ncols > (1 << a.logC)) ncols = 1 << a.logC;
-    cx<T>* twl = s + (1 << (a.logL + a.logC));
-    cx<T>* ti = twl + tw_lds_size(a.logL);
-    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, a.logL, a.NT);
+    constexpr int logL = seq_total_log<SEQ>();
+    cx<T>* twl = s + (1 << (logL + a.logC));
+    cx<T>* ti = twl + tw_lds_size(logL);
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, a.NT);
     if (a.twiddle)
-        for (int i = tid; i < (1 << a.logL); i += a.NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
+        for (int i = tid; i < (1 << logL); i += a.NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
     ctx.sync();
     const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
     const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
                          a.twiddle ? ti : nullptr, (unsigned)g, a.scale};
-    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, a.logL, a.logC, 0, twl, a.logL, ld, st);
+    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, logL, a.logC, 0, twl, logL, ld, st);
 }
 
 }  // namespace oa
