@@ -29,6 +29,7 @@
 namespace oa {
 
 constexpr int EPT = 16;        // complex points per thread per stage
+constexpr int COL_LOGC = 5;    // log2 columns per column tile (compile-time: index math folds to masks/shifts)
 constexpr int MAX_STAGES = 8;
 
 struct Stages {
@@ -634,7 +635,9 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
     constexpr int R0 = SEQ::get(0), LR = Log2x<R0>::v, NB = EPT / R0;
-    const int tid = ctx.tid(), NT = a.NT, logC = a.logC;
+    constexpr int logC = COL_LOGC;
+    constexpr int NT = ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) : 1;
+    const int tid = ctx.tid();
     const int c0 = ctx.bid_x() << logC;
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
@@ -726,7 +729,9 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     constexpr int n = SEQ::n;
     constexpr int RL = SEQ::get(n - 1), LRL = Log2x<RL>::v, NB = EPT / RL;
     constexpr int logNs = logL - LRL;
-    const int tid = ctx.tid(), NT = a.NT, logC = a.logC;
+    constexpr int logC = COL_LOGC;
+    constexpr int NT = ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) : 1;
+    const int tid = ctx.tid();
     const int c0 = ctx.bid_x() << logC;
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
@@ -768,21 +773,23 @@ template <typename T, class SEQ, class Ctx>
 OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid();
-    const int c0 = ctx.bid_x() << a.logC;
+    constexpr int CLC = COL_LOGC;
+    constexpr int CNT = ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) : 1;
+    const int c0 = ctx.bid_x() << CLC;
     const long g = ctx.bid_y();
     int ncols = a.width - c0;
-    if (ncols > (1 << a.logC)) ncols = 1 << a.logC;
+    if (ncols > (1 << CLC)) ncols = 1 << CLC;
     constexpr int logL = seq_total_log<SEQ>();
-    cx<T>* twl = s + (1 << (logL + a.logC));
+    cx<T>* twl = s + (1 << (logL + CLC));
     cx<T>* ti = twl + tw_lds_size(logL);
-    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, a.NT);
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, CNT);
     if (a.twiddle)
-        for (int i = tid; i < (1 << logL); i += a.NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
+        for (int i = tid; i < (1 << logL); i += CNT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
     ctx.sync();
     const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
     const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
                          a.twiddle ? ti : nullptr, (unsigned)g, a.scale};
-    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, a.NT, logL, a.logC, 0, twl, logL, ld, st);
+    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
 }
 
 }  // namespace oa

@@ -38,7 +38,7 @@ struct Fft2dPlan {
     long kp = 0;                 // half-complex pitch (complex elements)
     const cx<T>* tw_x = nullptr; // W_nx^k, k < nx
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
-    static constexpr int COLC = 5;  // log2 columns per column tile
+    static constexpr int COLC = COL_LOGC;  // log2 columns per column tile (kernels assume it at compile time)
 
     // ---- row passes -------------------------------------------------------
     template <class Launcher>
