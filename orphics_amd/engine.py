@@ -72,7 +72,7 @@ def dev_bin(data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, her
     need = int(lib.oa_bin_scratch_bytes(int(nids)))
     if need < 0:
         raise ValueError("bin: bad nids")
-    key = data.device.index
+    key = (data.device.index, torch.cuda.current_stream().cuda_stream)   # one scratch per stream: streams may overlap
     scr = _BIN_SCRATCH.get(key)
     if scr is None or scr.numel() < need:
         scr = torch.empty(need, dtype=torch.uint8, device=data.device)
@@ -96,7 +96,7 @@ def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1):
         raise ValueError("bin_power: operands must be contiguous with one int32 id per mode")
     prec = precision_of(k1, default=None)
     need = int(lib.oa_bin_scratch_bytes(int(nids)))
-    key = k1.device.index
+    key = (k1.device.index, torch.cuda.current_stream().cuda_stream)
     scr = _BIN_SCRATCH.get(key)
     if scr is None or scr.numel() < need:
         scr = torch.empty(need, dtype=torch.uint8, device=k1.device)

@@ -151,6 +151,20 @@ class Estimator(object):
         Rk = e.f2power(tot, one_k, 1.0 / self.geom.pixarea)          # real part / a ; signs: (-1)*(-1) = +
         return Rk.cpu().numpy()[:, :self.nxh + 1].astype(np.float64)
 
+    def fork(self):
+        """A second handle on the same estimator for use on ANOTHER HIP stream: shares the (read-only)
+        filter / normalisation planes, owns its own C-ABI plan (FFT scratch) and work buffers, so independent
+        realisations can be in flight concurrently (Monte-Carlo loops)."""
+        import copy
+        from .engine import Engine
+        other = copy.copy(self)
+        other.eng = Engine(self.eng.ny, self.eng.nx, self.prec)
+        other.eng.set_laxes(*self.geom.laxes())
+        other._work = None
+        other._rwork = None
+        other._acc = None
+        return other
+
     # ---- data plumbing -----------------------------------------------------------------
     def _as_hc(self, x, alreadyFTed):
         """Map / FT in any accepted container -> hc tensor of the run precision."""
