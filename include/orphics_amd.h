@@ -107,6 +107,13 @@ int oa_full_to_hc(oa_plan* p, const void* full_in, void* hc_out, void* stream);
 int oa_hcreal_to_full(oa_plan* p, const void* hcreal_in, void* fullreal_out, void* stream);
 int oa_fullreal_to_hc(oa_plan* p, const void* fullreal_in, void* hcreal_out, void* stream);
 
+/* Fourier-space regridding of an hc plane between two grids of the SAME patch (same delta-ell):
+ * out(l) = scale * in(l) for the modes both grids hold, 0 elsewhere; the smaller grid's Nyquist row /
+ * column is zeroed.  Crop = exact down-sampling of a band-limited field (enmap.downgrade_fft-like,
+ * lensing.py:106), embed = exact up-sampling. */
+int oa_hc_resample(int dtype, const void* in, int ny_in, int nx_in, long kp_in, void* out, int ny_out, int nx_out,
+                   long kp_out, double scale, void* stream);
+
 /* ---- flat elementwise kernels (n = number of elements) --------------------
  * oa_f2power    : out = Re(conj(k1)*k2)*norm        (FourierCalc.f2power, maps.py:1620-1624)
  * oa_cmul_real  : out = k * f (complex * real)      (filter_map's `* kfilter`, maps.py:1923;

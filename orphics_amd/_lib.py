@@ -41,6 +41,7 @@ SIGNATURES = {
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_fullreal_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_hc_resample": (c_int, [c_int, c_void_p, c_int, c_int, c_long, c_void_p, c_int, c_int, c_long, c_double, c_void_p]),
     "oa_f2power": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p]),
     "oa_cmul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_mul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),

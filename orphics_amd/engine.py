@@ -108,6 +108,17 @@ def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1):
     return sums, counts
 
 
+def hc_resample(src_eng, k, dst_eng, scale=1.0, out=None):
+    """Move an hc plane between two grids of the same patch (crop / zero-embed in Fourier space)."""
+    src_eng._chk(k, "hc")
+    if src_eng.prec != dst_eng.prec:
+        raise ValueError("hc_resample: precision mismatch")
+    out = dst_eng.hc() if out is None else dst_eng._chk(out, "hc")
+    check(src_eng.lib.oa_hc_resample(src_eng.code, _ptr(k), src_eng.ny, src_eng.nx, src_eng.kp, _ptr(out), dst_eng.ny,
+                                     dst_eng.nx, dst_eng.kp, float(scale), _stream()))
+    return out
+
+
 class Engine(object):
     _cache = {}
 

@@ -478,6 +478,75 @@ class Estimator(object):
         return self._full(self.Nlkk[XY])
 
 
+class BandlimitedEstimator(object):
+    """Exact reconstruction on a coarser internal grid for band-limited filters.
+
+    The legs are zero above the filter ell_max, so they -- and their real-space products (band limit
+    ell_max_X + ell_max_Y) -- are represented exactly on any grid whose Nyquist frequency exceeds that band
+    limit: the estimator can run on an (n_small x n_small) grid of the same patch, 1/(N/n_small)^2 of the work,
+    and returns the same kappa_hat modes (all L below the coarse Nyquist) up to rounding.  Opt-in: the default
+    ``Estimator`` path and bench.py always run at the full map resolution."""
+
+    def __init__(self, shape, wcs, theory, n_small=None, **kwargs):
+        from .engine import Engine
+        from .geometry import FlatGeometry
+        self.shape = tuple(shape[-2:])
+        self.geom = as_geometry(self.shape, wcs)
+        N = self.shape[0]
+        assert self.shape[0] == self.shape[1], "square maps only"
+        lnyq = np.pi / abs(self.geom.step_y)
+        lmaxs = []
+        for key in ("kmask", "kmask_P"):
+            m = kwargs.get(key)
+            if m is not None:
+                ml = self.geom.modlmap()
+                lmaxs.append(float(ml[np.asarray(m) > 0].max()))
+        if not lmaxs:
+            raise ValueError("band-limited mode needs a k-space mask (kmask / kmask_P) to bound the legs")
+        band = 2.0 * max(lmaxs)
+        if n_small is None:
+            n_small = N
+            while n_small // 2 >= 32 and lnyq * (n_small // 2) / N > band * 1.02:
+                n_small //= 2
+        self.n = int(n_small)
+        f = N // self.n
+        if lnyq / f <= band:
+            raise ValueError("n_small=%d aliases the leg products (band limit %.0f, coarse Nyquist %.0f)" % (self.n, band, lnyq / f))
+        self.gsmall = FlatGeometry((self.n, self.n), self.geom.step_y * f, self.geom.step_x * f, self.geom.area)
+
+        def crop(a):
+            if a is None:
+                return None
+            a = np.asarray(a)
+            h = self.n // 2
+            idx = np.r_[0:h, N - h:N]
+            return np.ascontiguousarray(a[np.ix_(idx, idx)])
+        kw = dict(kwargs)
+        for key in ("noise2d", "beam2d", "kmask", "noise2d_P", "kmask_P", "kmask_K"):
+            if kw.get(key) is not None:
+                kw[key] = crop(kw[key])
+        # no kappa above the coarse Nyquist: restrict the kappa mask accordingly
+        mlc = self.gsmall.modlmap()
+        km = np.ones((self.n, self.n)) if kw.get("kmask_K") is None else kw["kmask_K"].astype(np.float64)
+        kw["kmask_K"] = km * (mlc < lnyq / f)
+        self.q = Estimator((self.n, self.n), self.gsmall, theory, **kw)
+        self.big = maps._engine(self.shape, self.q.prec)
+        self.scale = (self.n / float(N)) ** 2          # DFT on the coarse grid = (n/N)^2 x the full-grid DFT
+        self._kc = self.q.eng.hc()
+
+    def reconstruct_tt_hc(self, kT_full, out=None):
+        """Full-resolution hc transform of the map in; kappa_hat DFT on the COARSE grid out (HalfPlane-able with
+        ``self.q.eng``); its bandpowers with ``self.gsmall`` equal the full-resolution ones."""
+        from .engine import hc_resample
+        hc_resample(self.big, kT_full, self.q.eng, self.scale, out=self._kc)
+        return self.q.reconstruct_tt_hc(self._kc, out=out)
+
+    def kappa_full_hc(self, kappa_small):
+        """Embed the coarse kappa_hat DFT into the full-resolution hc grid."""
+        from .engine import hc_resample
+        return hc_resample(self.q.eng, kappa_small, self.big, 1.0 / self.scale)
+
+
 def qest(shape, wcs, theory, **kwargs):
     """``lensing.qest(...)`` constructor name used by the reference notebooks."""
     return Estimator(shape, wcs, theory, **kwargs)

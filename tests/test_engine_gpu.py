@@ -209,3 +209,38 @@ def test_bin_power_equals_f2power_then_bin(prec):
         s2, c2 = e.bin_power(a, b, 0.37, ids, nids, herm=True)
         assert torch.equal(c1, c2)
         np.testing.assert_allclose(s2.cpu().numpy(), s1.cpu().numpy(), rtol=1e-12 if prec == "f64" else 1e-6)
+
+
+def test_error_behaviour_is_loud():
+    """Bad shapes / arguments are rejected on the host before any kernel is launched; the C-ABI returns non-zero
+    with oa_last_error() set and never throws."""
+    import ctypes
+    from orphics_amd import _lib, maps, stats
+    from orphics_amd.geometry import FlatGeometry
+    lib = _lib.load()
+    e = eng(64, 64, "f32")
+    with pytest.raises(ValueError):
+        e.rfft(torch.zeros(32, 64, device="cuda"))                      # wrong shape
+    with pytest.raises(ValueError):
+        e.rfft(torch.zeros(64, 64, device="cuda", dtype=torch.float64))  # wrong dtype for an f32 plan
+    with pytest.raises(TypeError):
+        e.rfft(np.zeros((64, 64), np.float32))                           # host memory is not a device plane
+    with pytest.raises(NotImplementedError):
+        maps.FourierCalc((100, 100), FlatGeometry.from_res((100, 100), 2.0)).fft(np.zeros((100, 100)))
+    with pytest.raises(ValueError):
+        stats.bin2D(np.ones((8, 8)), np.array([3., 2., 1.]))
+    with pytest.raises(TypeError):
+        stats.bin2D(np.ones((8, 8)), np.array([1., 2., 3.])).bin(np.ones((8, 8)) * 1j)
+    h = ctypes.c_void_p()
+    assert lib.oa_plan_create(100, 64, 0, ctypes.byref(h)) != 0 and b"powers of two" in lib.oa_last_error()
+    assert lib.oa_plan_create(16, 64, 0, ctypes.byref(h)) != 0 and b">= 32" in lib.oa_last_error()
+    assert lib.oa_plan_create(64, 64, 7, ctypes.byref(h)) != 0 and b"dtype" in lib.oa_last_error()
+    assert lib.oa_fft_r2c(e.plan, None, None, 1.0, None) != 0 and b"NULL" in lib.oa_last_error()
+    x = torch.zeros(64, 64, device="cuda")
+    assert lib.oa_bin(0, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), None, None, 10, 5000, 0, 0, 0, -1,
+                      ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(x.data_ptr()), None) != 0
+    assert b"nids" in lib.oa_last_error()
+    # legs need the multipole axes first
+    e2 = __import__("orphics_amd.engine", fromlist=["Engine"]).Engine(64, 64, "f32")
+    with pytest.raises(_lib.OrphicsAmdError):
+        e2.qe_legs(e2.hc(), e2.hc(), e2.hcreal(), e2.hcreal())
