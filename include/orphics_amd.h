@@ -65,8 +65,14 @@ int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx);
  *              with scale = 1/(ny*nx))
  * oa_fft_c2c : full -> full, forward (inverse=0) or inverse (inverse=1),
  *              out != in (MapGen non-Hermitian draws maps.py:1578-1587, pol legs). */
-int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, void* stream);
-int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, void* stream);
+/* ACTIVE COLUMNS (`width`, `win`, `wout` arguments below): band-limited filters (the k-space masks of
+ * lensing.Estimator, lensing.py:533-560) leave every hc plane on the estimator path exactly zero beyond some
+ * column kx >= width.  A transform told so neither reads nor produces those columns -- same arithmetic on
+ * the remaining ones, so results are unchanged; HBM traffic and column-pass work scale with width/(nx/2+1).
+ * width <= 0 (or > nx/2+1) means all columns.  r2c: only columns < width of hc_out are written;
+ * c2r / inverse cols: columns >= width of the input are taken as zero and never read. */
+int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, void* stream);
+int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream);
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream);
 /* One constituent pass of the transforms above, for per-kernel timing (bench.py roofline):
  * pass_id 0 = R2C row pass (real in -> hc out), 1 = column pass 1 (hc -> hc, out != in),
@@ -75,7 +81,7 @@ int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream
 
 /* Column half of the transforms above on an hc plane (all ny-point column DFTs of the nx/2+1
  * valid columns), out != in.  With oa_qe_rows it forms the fused estimator pipeline. */
-int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, void* stream);
+int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, int width, void* stream);
 /* Fused QE row stage: inputs are the three leg planes AFTER their inverse column transforms
  * (oa_fft_cols(..., inverse=1)); per row h = C2R(H), P_x = R2C(C2R(Gx) * h), P_y = R2C(C2R(Gy) * h),
  * product scaled by `scale` (pass (1/(ny*nx))^2 for normalised inverses).  Outputs are row-transformed
@@ -84,7 +90,7 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
  * the existing px, py (estimators whose weight is a sum of separable terms: cos/sin spin-2 pieces;
  * `scale` carries the sign). */
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-               int accumulate, void* stream);
+               int accumulate, int win, int wout, void* stream);
 
 /* Fused estimator column stages (the fast path of lensing.Estimator.reconstruct_*):
  *  oa_qe_legs_cols : oa_qe_legs + oa_fft_cols(inverse) of the three leg planes in one go -- kX, kY and the
@@ -93,9 +99,9 @@ int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* 
  *  oa_qe_cols_div  : oa_fft_cols(forward) of the two oa_qe_rows outputs + oa_qe_div in one go:
  *                    out (+)= Fnorm * (i lx FFT[Px] + i ly FFT[Py]). */
 int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                    void* stream);
+                    int width, void* stream);
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
-                   void* stream);
+                   int width, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of
@@ -180,9 +186,12 @@ int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights,
 
 /* oa_bin_power: FourierCalc.f2power (maps.py:1620-1624) fused into oa_bin: the binned value is
  * Re(conj(k1[i]) k2[i]) * norm for complex planes k1, k2 (k1 == k2 for auto spectra); the 2-D power
- * plane is never written.  Same ids / multiplicity / determinism contract as oa_bin (mode 0). */
+ * plane is never written.  Same ids / multiplicity / determinism contract as oa_bin (mode 0).
+ * active_cols > 0 (Hermitian mode only): only columns < active_cols of each row are visited (planes that
+ * vanish beyond them): sums are unchanged, COUNTS then cover the visited columns only -- take the
+ * data-independent counts from one full oa_bin_power / oa_bin call at plan time. */
 int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const int32_t* ids, const void* weights, long n,
-                 int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
+                 int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch, int active_cols,
                  void* stream);
 
 /* ---- Gaussian random fields (MapGen.get_map, maps.py:1576-1587) --------------
@@ -199,6 +208,9 @@ int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, vo
 /* ---- one-pass moment accumulation (Statistics.add, stats.py:1068-1090) ---------
  * n += 1 ; S += x ; C += x x^T  for a device vector x of length d (float64). */
 int oa_moments_add(const double* x, int d, int64_t* n, double* S, double* C, void* stream);
+/* Same with x_a = sums[a] / counts[a] (the bin means of stats.bin2D.bin, stats.py:1327-1343) formed in the
+ * kernel: feeds the interior slots of oa_bin / oa_bin_power output directly (pass sums+1, counts+1, d=nbins). */
+int oa_moments_add_binned(const double* sums, const int64_t* counts, int d, int64_t* n, double* S, double* C, void* stream);
 /* stack accumulation (Statistics.add_stack, stats.py:1124-1150): acc(f64) += x (dtype) */
 int oa_stack_add(int dtype, const void* x, double* acc, long n, void* stream);
 

@@ -98,7 +98,7 @@ template <typename T, bool WEIGHTED, bool POWER>
 __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ data, const T* __restrict__ data2, double pnorm,
                                                         const int32_t* __restrict__ ids,
                                                         const T* __restrict__ w, const double* __restrict__ aux, long n,
-                                                        int nids, int mode, int skip_nan, unsigned hp, int nxh,
+                                                        int nids, int mode, int skip_nan, unsigned hp, int nxh, unsigned wq,
                                                         double* __restrict__ part_sum, double* __restrict__ part_w,
                                                         unsigned long long* __restrict__ part_cnt) {
     extern __shared__ __attribute__((aligned(16))) char sm_raw[];
@@ -112,15 +112,19 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
     double* row_w = s_w + wv * nids;
     unsigned long long* row_cnt = s_cnt + wv * nids;
 
-    const long nchunks = (n + 3) / 4;
+    // wq > 0: visit only the first wq 4-element chunks of every row of pitch hp (active columns)
+    const long nchunks = wq ? (n / hp) * (long)wq : (n + 3) / 4;
     for (long base = (long)blockIdx.x * BIN_BLOCK; base < nchunks; base += (long)gridDim.x * BIN_BLOCK) {
-        const long c = base + tid;
+        const long cv = base + tid;      // virtual chunk index over the visited region
+        const bool cin = cv < nchunks;
+        long c = cv;
+        if (wq) { const long r = cv / wq; c = r * (long)(hp >> 2) + (cv - r * wq); }
         const long i0 = c * 4;
         int id[4];
         double v[4], cw[4];
         int ci[4];
         bool ok[4];
-        if (c < nchunks && i0 + 3 < n) {
+        if (cin && i0 + 3 < n) {
             const Arr<int32_t, 4> I = reinterpret_cast<const Arr<int32_t, 4>*>(ids)[c];
             Arr<T, 4> W;
             if (WEIGHTED) W = reinterpret_cast<const Arr<T, 4>*>(w)[c];
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ok[j] = (c < nchunks) && (i0 + j < n);
+                ok[j] = cin && (i0 + j < n);
                 id[j] = ok[j] ? ids[i0 + j] : -1;
                 if (POWER) {
                     const long e = 2 * (i0 + j);
@@ -234,8 +238,10 @@ template <typename T>
 static int bin_impl(const void* data, const void* data2, double pnorm, bool power, const int32_t* ids, const void* weights,
                     const double* aux, long n, int nids, int mode,
                     int skip_nan, long hp, int nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
-                    hipStream_t st) {
-    const long nchunks = (n + 3) / 4;
+                    hipStream_t st, int active_cols = 0) {
+    unsigned wq = 0;                                  // 4-element chunks visited per row (0 = whole rows)
+    if (active_cols > 0 && nxh >= 0 && hp > 0 && (long)active_cols < hp && n % hp == 0) wq = (unsigned)((active_cols + 3) / 4);
+    const long nchunks = wq ? (n / hp) * (long)wq : (n + 3) / 4;
     int G = (int)((nchunks + BIN_BLOCK - 1) / BIN_BLOCK);
     if (G < 1) G = 1;
     if (G > BIN_GMAX) G = BIN_GMAX;
@@ -251,7 +257,7 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
             OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)smem));                                                                  \
         hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, (const T*)data2, pnorm, ids,       \
-                           (const T*)weights, aux, n, nids, mode, skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh,        \
+                           (const T*)weights, aux, n, nids, mode, skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, wq,    \
                            part_sum, part_w, part_cnt);                                                              \
     }
     if (weighted && power) OA_BIN_LAUNCH(true, true)
@@ -318,17 +324,17 @@ int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights,
 
 int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const int32_t* ids, const void* weights, long n,
                  int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
-                 void* stream) {
+                 int active_cols, void* stream) {
     OA_REQUIRE(k1 && k2 && ids && sums && scratch && n >= 0, "oa_bin_power: bad argument");
     OA_REQUIRE(nids >= 1 && nids <= BIN_MAX_IDS, "oa_bin_power: nids (= nedges+1) must be in [1,1024]");
     OA_REQUIRE(weights ? (wsums != nullptr) : (counts != nullptr), "oa_bin_power: counts (unweighted) / wsums (weighted) required");
     if (herm_nxh >= 0) OA_REQUIRE(herm_pitch > 0 && herm_pitch % 4 == 0, "oa_bin_power: herm_pitch must be a positive multiple of 4");
     if (dtype == OA_F32)
         return bin_impl<float>(k1, k2, norm, true, ids, weights, nullptr, n, nids, 0, 0, herm_pitch, herm_nxh, sums, counts,
-                               wsums, scratch, (hipStream_t)stream);
+                               wsums, scratch, (hipStream_t)stream, active_cols);
     if (dtype == OA_F64)
         return bin_impl<double>(k1, k2, norm, true, ids, weights, nullptr, n, nids, 0, 0, herm_pitch, herm_nxh, sums, counts,
-                                wsums, scratch, (hipStream_t)stream);
+                                wsums, scratch, (hipStream_t)stream, active_cols);
     return fail("oa_bin_power: bad dtype");
 }
 

@@ -111,17 +111,17 @@ static Fft2dPlan<T> view(const oa_plan* p) {
 }
 
 template <typename T>
-static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, hipStream_t st) {
+static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, int width, hipStream_t st) {
     if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->kp * sizeof(cx<T>))) return rc;
     HipLauncher q{st};
-    view<T>(p).r2c(q, (const T*)in, (cx<T>*)out, (cx<T>*)p->scratch, (T)scale);
+    view<T>(p).r2c(q, (const T*)in, (cx<T>*)out, (cx<T>*)p->scratch, (T)scale, width);
     return q.rc;
 }
 template <typename T>
-static int c2r_impl(oa_plan* p, const void* in, void* out, double scale, hipStream_t st) {
+static int c2r_impl(oa_plan* p, const void* in, void* out, double scale, int width, hipStream_t st) {
     if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->kp * sizeof(cx<T>))) return rc;
     HipLauncher q{st};
-    view<T>(p).c2r(q, (const cx<T>*)in, (T*)out, (cx<T>*)p->scratch, (T)scale);
+    view<T>(p).c2r(q, (const cx<T>*)in, (T*)out, (cx<T>*)p->scratch, (T)scale, width);
     return q.rc;
 }
 template <typename T>
@@ -147,37 +147,40 @@ static int pass_impl(oa_plan* p, int pass_id, const void* in, void* out, hipStre
 }
 
 template <typename T>
-static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st) {
+static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double scale, int width, hipStream_t st) {
     HipLauncher q{st};
-    view<T>(p).cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, p->nx / 2 + 1, inverse != 0, (T)scale);
+    auto f = view<T>(p);
+    f.cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, f.clampw(width), inverse != 0, (T)scale);
     return q.rc;
 }
 template <typename T>
 static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-                        int accumulate, hipStream_t st) {
+                        int accumulate, int win, int wout, hipStream_t st) {
     HipLauncher q{st};
-    view<T>(p).rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate);
+    auto f = view<T>(p);
+    f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate,
+              f.clampw(win), f.clampw(wout));
     return q.rc;
 }
 
 template <typename T>
 static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy,
-                          void* h, hipStream_t st) {
+                          void* h, int width, hipStream_t st) {
     HipLauncher q{st};
     view<T>(p).legs_cols(q, (const cx<T>*)kX, (const cx<T>*)kY, (const T*)FG, (const T*)FH, (const T*)p->lxd,
-                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h);
+                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width);
     return q.rc;
 }
 template <typename T>
 static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
-                         hipStream_t st) {
+                         int width, hipStream_t st) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
     view<T>(p).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
-                        (cx<T>*)out, tA, tB, accumulate);
+                        (cx<T>*)out, tA, tB, accumulate, width);
     return q.rc;
 }
 
@@ -188,34 +191,34 @@ using namespace oa;
 extern "C" {
 
 int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                    void* stream) {
+                    int width, void* stream) {
     OA_REQUIRE(p && kX && kY && FG && FH && gx && gy && h, "oa_qe_legs_cols: NULL argument");
     OA_REQUIRE(p->have_laxes, "oa_qe_legs_cols: call oa_plan_set_laxes first");
     OA_REQUIRE(gx != kX && gy != kX && h != kX && gx != kY && gy != kY && h != kY, "oa_qe_legs_cols: outputs alias inputs");
-    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, (hipStream_t)stream)
-                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, (hipStream_t)stream)
+                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, (hipStream_t)stream);
 }
 
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
-                   void* stream) {
+                   int width, void* stream) {
     OA_REQUIRE(p && px_rows && py_rows && Fnorm && out, "oa_qe_cols_div: NULL argument");
     OA_REQUIRE(p->have_laxes, "oa_qe_cols_div: call oa_plan_set_laxes first");
-    return p->dtype == OA_F32 ? cols_div_impl<float>(p, px_rows, py_rows, Fnorm, out, accumulate, (hipStream_t)stream)
-                              : cols_div_impl<double>(p, px_rows, py_rows, Fnorm, out, accumulate, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? cols_div_impl<float>(p, px_rows, py_rows, Fnorm, out, accumulate, width, (hipStream_t)stream)
+                              : cols_div_impl<double>(p, px_rows, py_rows, Fnorm, out, accumulate, width, (hipStream_t)stream);
 }
 
-int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, void* stream) {
+int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, int width, void* stream) {
     OA_REQUIRE(p && hc_in && hc_out, "oa_fft_cols: NULL argument");
     OA_REQUIRE(hc_in != hc_out, "oa_fft_cols: in-place not supported");
-    return p->dtype == OA_F32 ? cols_impl<float>(p, hc_in, hc_out, inverse, scale, (hipStream_t)stream)
-                              : cols_impl<double>(p, hc_in, hc_out, inverse, scale, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? cols_impl<float>(p, hc_in, hc_out, inverse, scale, width, (hipStream_t)stream)
+                              : cols_impl<double>(p, hc_in, hc_out, inverse, scale, width, (hipStream_t)stream);
 }
 
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-               int accumulate, void* stream) {
+               int accumulate, int win, int wout, void* stream) {
     OA_REQUIRE(p && gx && gy && h && px && py, "oa_qe_rows: NULL argument");
-    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, (hipStream_t)stream)
-                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream);
 }
 
 int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream) {
@@ -224,18 +227,18 @@ int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream
                               : pass_impl<double>(p, pass_id, in, out, (hipStream_t)stream);
 }
 
-int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, void* stream) {
+int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, void* stream) {
     OA_REQUIRE(p && real_in && hc_out, "oa_fft_r2c: NULL argument");
     OA_REQUIRE(real_in != hc_out, "oa_fft_r2c: in-place not supported");
-    return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, (hipStream_t)stream)
-                              : r2c_impl<double>(p, real_in, hc_out, scale, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, width, (hipStream_t)stream)
+                              : r2c_impl<double>(p, real_in, hc_out, scale, width, (hipStream_t)stream);
 }
 
-int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, void* stream) {
+int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream) {
     OA_REQUIRE(p && hc_in && real_out, "oa_fft_c2r: NULL argument");
     OA_REQUIRE(hc_in != real_out, "oa_fft_c2r: in-place not supported");
-    return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, (hipStream_t)stream)
-                              : c2r_impl<double>(p, hc_in, real_out, scale, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, width, (hipStream_t)stream)
+                              : c2r_impl<double>(p, hc_in, real_out, scale, width, (hipStream_t)stream);
 }
 
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream) {

@@ -306,6 +306,7 @@ struct RowArgs {
     int logTw;
     T scale;
     int mode;
+    int wcols;                 // R2C: columns produced; C2R: columns read (the rest are zero).  >= L+1: all
 };
 
 template <typename T, bool SWAP>
@@ -333,7 +334,7 @@ struct RowStore {
 // stored SWAPPED in LDS (the inverse runs as a forward transform of the swapped data).  Caller syncs.
 template <typename T, class Ctx>
 OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
-                        const cx<T>* tw, int logTw) {
+                        const cx<T>* tw, int logTw, int win = 0x7fffffff) {   // columns >= win are zero and never read
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
@@ -342,8 +343,9 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
         for (int rep = 0; rep < 2; ++rep) {
             const int kk = rep ? (L >> 1) : k;
             if (rep && k != 0) break;
-            const cx<T> A = row[kk];
-            const cx<T> B = row[L - kk];
+            cx<T> A = mk<T>((T)0, (T)0), B = A;
+            if (kk < win) A = row[kk];
+            if (L - kk < win) B = row[L - kk];
             const cx<T> w = tw[kk << sh];  // W_N^k
             const cx<T> d1 = A - conj(B), d2 = B - conj(A);
             const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
@@ -357,7 +359,8 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
 // R2C epilogue: packed transform Z in LDS -> X[k] = E + W_N^k O, X[L-k] = conj(E - W_N^k O), straight to global.
 template <typename T, class Ctx>
 OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
-                        const cx<T>* tw, int logTw, T scale, bool accumulate = false) {
+                        const cx<T>* tw, int logTw, T scale, bool accumulate = false, int wout = 0x7fffffff) {
+    // only columns < wout are produced (the caller's consumers never look at the others)
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
@@ -366,6 +369,8 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
         for (int rep = 0; rep < 2; ++rep) {
             const int kk = rep ? (L >> 1) : k;
             if (rep && k != 0) break;
+            const bool w1 = kk < wout, w2 = (L - kk) < wout;
+            if (!w1 && !w2) continue;
             const cx<T> Zk = s[lds_addr<true>(kk, c, 0, RS)];
             const cx<T> Zm = s[lds_addr<true>((L - kk) & (L - 1), c, 0, RS)];
             const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
@@ -373,11 +378,11 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
             const cx<T> wO = tw[kk << sh] * O;
             cx<T> o1 = (E + wO) * scale, o2 = conj(E - wO) * scale;
             if (accumulate) {
-                o1 = o1 + row[kk];
-                if (2 * kk != L) o2 = o2 + row[L - kk]; else o2 = o1;
+                if (w1) o1 = o1 + row[kk];
+                if (2 * kk != L) { if (w2) o2 = o2 + row[L - kk]; } else o2 = o1;
             }
-            row[kk] = o1;
-            row[L - kk] = o2;
+            if (w1) row[kk] = o1;
+            if (w2) row[L - kk] = o2;
         }
     }
 }
@@ -406,9 +411,9 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     } else if constexpr (MODE == ROW_R2C) {
         fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL,
                                                 RowLoad<T, false>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
-        r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale);
+        r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale, false, a.wcols);
     } else {
-        c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw);
+        c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.wcols);
         ctx.sync();
         fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{},
                                                 RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
@@ -431,6 +436,7 @@ struct RowQeArgs {
     int logTw;
     T scale;      // product scale: (1/Npix)^2 for two normalised inverse transforms
     int accumulate;  // != 0: add the (scaled) result to the existing contents of px, py
+    int win, wout;   // leg columns >= win are zero (not read); only product columns < wout are written
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -474,7 +480,7 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* twl = work + C * RS;                   // two-level stage-twiddle table (LDS)
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
 
-    c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw);
+    c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
     ctx.sync();
     inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
     stage_in<T, R0, true, false>(work, hreg, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
@@ -484,7 +490,7 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? a.gy : a.gx;
         cx<T>* dst = leg ? a.py : a.px;
-        c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw);
+        c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
         ctx.sync();
         inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
         stage_in<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
@@ -498,7 +504,7 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
         stage_out<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, 0, NoStore{});
         ctx.sync();
         forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
-        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0);
+        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
         ctx.sync();
     }
 }

@@ -40,9 +40,13 @@ struct Fft2dPlan {
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
     static constexpr int COLC = COL_LOGC;  // log2 columns per column tile (kernels assume it at compile time)
 
+    // active-column count of an hc plane: <= 0 or too large means all nx/2+1 columns
+    int clampw(int w) const { return (w <= 0 || w > nx / 2 + 1) ? nx / 2 + 1 : w; }
+
     // ---- row passes -------------------------------------------------------
     template <class Launcher>
-    void rows(Launcher& q, int mode, const void* in, long in_pitch, void* out, long out_pitch, T scale) const {
+    void rows(Launcher& q, int mode, const void* in, long in_pitch, void* out, long out_pitch, T scale,
+              int wcols = 0x7fffffff) const {
         RowArgs<T> a{};
         const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R);
         a.logL = real_mode ? logNx - 1 : logNx;
@@ -59,6 +63,7 @@ struct Fft2dPlan {
         a.logTw = logNx;
         a.scale = scale;
         a.mode = mode;
+        a.wcols = wcols;
         a.in = in; a.out = out; a.in_pitch = in_pitch; a.out_pitch = out_pitch;
         q.row(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
@@ -66,7 +71,7 @@ struct Fft2dPlan {
     // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
     template <class Launcher>
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
-                 int accumulate = 0) const {
+                 int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff) const {
         RowQeArgs<T> a{};
         a.logL = logNx - 1;
         const int L = 1 << a.logL;
@@ -79,6 +84,7 @@ struct Fft2dPlan {
         a.rowStride = L + (L >> 4) + 2;
         a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
         a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
+        a.win = win; a.wout = wout;
         q.row_qe(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
 
@@ -116,11 +122,11 @@ struct Fft2dPlan {
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
     template <class Launcher>
     void legs_cols(Launcher& q, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
-                   cx<T>* gx, cx<T>* gy, cx<T>* h) const {
+                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff) const {
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
-        const int width = nx / 2 + 1;
+        const int width = clampw(wmax);
         const int tiles = (width + C - 1) / C;
         ColLegsArgs<T> a{};
         a.kX = kX; a.kY = kY; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
@@ -135,11 +141,11 @@ struct Fft2dPlan {
     //     tmpA, tmpB: two hc scratch planes
     template <class Launcher>
     void cols_div(Launcher& q, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
-                  cx<T>* tmpA, cx<T>* tmpB, int accumulate) const {
+                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff) const {
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
-        const int width = nx / 2 + 1;
+        const int width = clampw(wmax);
         const int tiles = (width + C - 1) / C;
         cols(q, pa, kp, tmpA, kp, width, false, (T)1, 1);
         cols(q, pb, kp, tmpB, kp, width, false, (T)1, 1);
@@ -152,15 +158,19 @@ struct Fft2dPlan {
 
     // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane
     template <class Launcher>
-    void r2c(Launcher& q, const T* in, cx<T>* out, cx<T>* tmp, T scale) const {
-        rows(q, ROW_R2C, in, nx / 2, tmp, kp, (T)1);
-        cols(q, tmp, kp, out, kp, nx / 2 + 1, false, scale);
+    // only the first `wmax` columns of `out` are produced when wmax is given
+    void r2c(Launcher& q, const T* in, cx<T>* out, cx<T>* tmp, T scale, int wmax = 0x7fffffff) const {
+        const int w = clampw(wmax);
+        rows(q, ROW_R2C, in, nx / 2, tmp, kp, (T)1, w);
+        cols(q, tmp, kp, out, kp, w, false, scale);
     }
     // half-complex -> real; input preserved; tmp: two hc planes (tmp, tmp2)
     template <class Launcher>
-    void c2r(Launcher& q, const cx<T>* in, T* out, cx<T>* tmp, T scale) const {
-        cols(q, in, kp, tmp, kp, nx / 2 + 1, true, (T)1);
-        rows(q, ROW_C2R, tmp, kp, out, nx / 2, scale);
+    // columns >= wmax of `in` are taken as zero (never read) when wmax is given
+    void c2r(Launcher& q, const cx<T>* in, T* out, cx<T>* tmp, T scale, int wmax = 0x7fffffff) const {
+        const int w = clampw(wmax);
+        cols(q, in, kp, tmp, kp, w, true, (T)1);
+        rows(q, ROW_C2R, tmp, kp, out, nx / 2, scale, w);
     }
     // full complex (ny,nx) contiguous; tmp: one full plane; out != in
     template <class Launcher>

@@ -102,6 +102,21 @@ __global__ __launch_bounds__(256) void moments_add_kernel(const double* __restri
     if (gid == 0) n[0] += 1;
 }
 
+// x_a = sums[a] / counts[a] formed on the fly: bin means (bin2D.bin) straight into the ensemble moments
+__global__ __launch_bounds__(256) void moments_add_binned_kernel(const double* __restrict__ sums, const int64_t* __restrict__ counts,
+                                                                 int d, int64_t* __restrict__ n, double* __restrict__ S,
+                                                                 double* __restrict__ C) {
+    const long tot = (long)d * d;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long i = gid; i < tot; i += stride) {
+        const int a = (int)(i / d), b = (int)(i % d);
+        C[i] += (sums[a] / (double)counts[a]) * (sums[b] / (double)counts[b]);
+    }
+    for (long i = gid; i < d; i += stride) S[i] += sums[i] / (double)counts[i];
+    if (gid == 0) n[0] += 1;
+}
+
 }  // namespace oa
 
 using namespace oa;
@@ -139,6 +154,14 @@ int oa_moments_add(const double* x, int d, int64_t* n, double* S, double* C, voi
     OA_REQUIRE(x && n && S && C && d >= 1, "oa_moments_add: bad argument");
     const int g = flat_grid((long)d * d, 256, 64);
     hipLaunchKernelGGL(moments_add_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, x, d, n, S, C);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_moments_add_binned(const double* sums, const int64_t* counts, int d, int64_t* n, double* S, double* C, void* stream) {
+    OA_REQUIRE(sums && counts && n && S && C && d >= 1, "oa_moments_add_binned: bad argument");
+    const int g = flat_grid((long)d * d, 256, 64);
+    hipLaunchKernelGGL(moments_add_binned_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, sums, counts, d, n, S, C);
     OA_LAUNCH_CHECK();
     return 0;
 }

@@ -86,8 +86,10 @@ def dev_bin(data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, her
     return sums, (counts if weights is None else wsums)
 
 
-def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1):
-    """Binned Re(conj k1 k2)*norm without materialising the 2-D power (oa_bin_power)."""
+def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1, active_cols=0):
+    """Binned Re(conj k1 k2)*norm without materialising the 2-D power (oa_bin_power).
+    ``active_cols`` > 0: visit only those leading columns of each row (planes that vanish beyond them);
+    the returned counts then cover the visited region only."""
     lib = _lib.load()
     n = k1.numel()
     if not (k1.is_cuda and k2.is_cuda and ids.is_cuda and k1.is_complex() and k2.dtype == k1.dtype):
@@ -104,7 +106,7 @@ def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1):
     sums = torch.empty(nids, dtype=torch.float64, device=k1.device)
     counts = torch.empty(nids, dtype=torch.int64, device=k1.device)
     check(lib.oa_bin_power(_CODE[prec], _ptr(k1), _ptr(k2), float(norm), _ptr(ids), None, n, int(nids), int(herm_pitch),
-                           int(herm_nxh), _ptr(sums), _ptr(counts), None, _ptr(scr), _stream()))
+                           int(herm_nxh), _ptr(sums), _ptr(counts), None, _ptr(scr), int(active_cols), _stream()))
     return sums, counts
 
 
@@ -195,20 +197,23 @@ class Engine(object):
         return t
 
     # ---- FFTs ------------------------------------------------------------------
-    def rfft(self, x, scale=1.0, out=None):
-        """real (ny,nx) -> hc; unnormalised forward (maps.py:1636)."""
+    def rfft(self, x, scale=1.0, out=None, width=0):
+        """real (ny,nx) -> hc; unnormalised forward (maps.py:1636).  ``width`` > 0: only the first ``width``
+        columns of ``out`` are produced (callers that filter with a band-limited mask; see ACTIVE COLUMNS in
+        include/orphics_amd.h) -- the rest of ``out`` is left untouched."""
         self._chk(x, "real")
         out = self.hc() if out is None else self._chk(out, "hc")
-        check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), _stream()))
+        check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), int(width), _stream()))
         return out
 
-    def irfft(self, k, scale=None, out=None):
-        """hc -> real; default scale 1/Npix (pixell fft.ifft normalize=True, maps.py:1633)."""
+    def irfft(self, k, scale=None, out=None, width=0):
+        """hc -> real; default scale 1/Npix (pixell fft.ifft normalize=True, maps.py:1633).
+        ``width`` > 0 asserts that columns >= width of ``k`` are zero (they are not read)."""
         self._chk(k, "hc")
         out = self.real() if out is None else self._chk(out, "real")
         if scale is None:
             scale = 1.0 / self.npix
-        check(self.lib.oa_fft_c2r(self.plan, _ptr(k), _ptr(out), float(scale), _stream()))
+        check(self.lib.oa_fft_c2r(self.plan, _ptr(k), _ptr(out), float(scale), int(width), _stream()))
         return out
 
     def cfft(self, z, inverse=False, scale=1.0, out=None):
@@ -217,37 +222,40 @@ class Engine(object):
         check(self.lib.oa_fft_c2c(self.plan, _ptr(z), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
         return out
 
-    def fft_cols(self, k, inverse=False, scale=1.0, out=None):
-        """Column transforms only (hc -> hc, out != in)."""
+    def fft_cols(self, k, inverse=False, scale=1.0, out=None, width=0):
+        """Column transforms only (hc -> hc, out != in); ``width`` > 0: first ``width`` columns only."""
         self._chk(k, "hc")
         out = self.hc() if out is None else self._chk(out, "hc")
-        check(self.lib.oa_fft_cols(self.plan, _ptr(k), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
+        check(self.lib.oa_fft_cols(self.plan, _ptr(k), _ptr(out), 1 if inverse else 0, float(scale), int(width), _stream()))
         return out
 
-    def qe_rows(self, gx, gy, h, px, py, scale=None, accumulate=False):
-        """Fused row stage: P = R2C(C2R(G) * C2R(H)) for G in (gx, gy)."""
+    def qe_rows(self, gx, gy, h, px, py, scale=None, accumulate=False, win=0, wout=0):
+        """Fused row stage: P = R2C(C2R(G) * C2R(H)) for G in (gx, gy).  ``win``: leg columns >= win are zero
+        (not read); ``wout``: only product columns < wout are written."""
         for t in (gx, gy, h, px, py):
             self._chk(t, "hc")
         if scale is None:
             scale = 1.0 / float(self.npix) ** 2
         check(self.lib.oa_qe_rows(self.plan, _ptr(gx), _ptr(gy), _ptr(h), _ptr(px), _ptr(py), float(scale),
-                                  1 if accumulate else 0, _stream()))
+                                  1 if accumulate else 0, int(win), int(wout), _stream()))
         return px, py
 
-    def qe_legs_cols(self, kX, kY, FG, FH, out):
-        """Fused leg filters + inverse column transforms (3 planes out, ready for qe_rows)."""
+    def qe_legs_cols(self, kX, kY, FG, FH, out, width=0):
+        """Fused leg filters + inverse column transforms (3 planes out, ready for qe_rows); ``width`` > 0:
+        the filters vanish for columns >= width, which are neither read nor produced."""
         self._chk(kX, "hc"); self._chk(kY, "hc"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
         gx, gy, h = out
         for t in out:
             self._chk(t, "hc")
-        check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), _stream()))
+        check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), int(width), _stream()))
         return out
 
-    def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False):
-        """Fused forward column transforms + divergence * normalisation."""
+    def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False, width=0):
+        """Fused forward column transforms + divergence * normalisation; ``width`` > 0: only the first
+        ``width`` columns of ``out`` are produced (Fnorm vanishes beyond them)."""
         self._chk(px, "hc"); self._chk(py, "hc"); self._chk(Fnorm, "hcreal")
         out = self.hc() if out is None else self._chk(out, "hc")
-        check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, _stream()))
+        check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, int(width), _stream()))
         return out
 
     def fft_pass(self, pass_id, src, dst):
@@ -387,8 +395,9 @@ class Engine(object):
         return dev_bin(data, ids, nids, weights=weights, aux=aux, mode=mode, skip_nan=skip_nan,
                        herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1)
 
-    def bin_power(self, k1, k2, norm, ids, nids, herm=True):
-        return dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1)
+    def bin_power(self, k1, k2, norm, ids, nids, herm=True, active_cols=0):
+        return dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1,
+                             active_cols=active_cols if herm else 0)
 
     # ---- random fields / accumulators ---------------------------------------------------
     def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):

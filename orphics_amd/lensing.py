@@ -11,6 +11,8 @@ Per reconstruction (TT): 1 fused leg-filter kernel, 3 C2R FFTs, 2 real
 products, 2 R2C FFTs, 1 divergence/normalisation kernel -- all HIP, all on the
 half-plane layout.
 """
+import weakref
+
 import numpy as np
 
 from . import maps
@@ -53,7 +55,11 @@ class Estimator(object):
 
     def __init__(self, shape, wcs, theory, noise2d=None, beam2d=None, kmask=None, noise2d_P=None, kmask_P=None,
                  kmask_K=None, pol=False, grad_cut=None, unlensed_equals_lensed=False, bigell=9000, dtype="f32",
-                 theory_norm=None):
+                 theory_norm=None, prune=True):
+        # prune: let the fused kernels skip the hc columns on which the (band-limited) filters vanish --
+        # same arithmetic on the remaining columns, identical results (include/orphics_amd.h, ACTIVE COLUMNS)
+        self.prune = bool(prune)
+        self._clean = {}                    # id -> weakref of output planes whose inactive columns are known zero
         self.shape = tuple(shape)
         self.wcs = wcs
         self.geom = as_geometry(shape, wcs)
@@ -78,7 +84,7 @@ class Estimator(object):
         self.grad_cut = grad_cut
         self.cl_grad = {"TT": np.where(ml >= 0, cfun_g("TT", np.abs(ml)), 0.0)}
         self.cl_len = {"TT": np.where(ml >= 0, theory.lCl("TT", np.abs(ml)), 0.0)}
-        self.AL, self.Nlkk, self._F = {}, {}, {}
+        self.AL, self.Nlkk, self._F, self._W = {}, {}, {}, {}
         self._work = None
         self._setup_tt()
         if pol:
@@ -117,6 +123,35 @@ class Estimator(object):
         self.Nlkk["TT"] = (L * (L + 1.)) ** 2 / 4. * AL
         self.R_TT = R
         self._F["TT"] = (self._hcreal(self.eng, Wg), self._hcreal(self.eng, Wh), self._hcreal(self.eng, Fnorm))
+        self._W["TT"] = (self._support_cols(Wg, Wh), self._support_cols(Fnorm))
+
+    def _support_cols(self, *planes):
+        """Number of leading hc columns outside which all the given half-plane filters vanish (0 = no pruning)."""
+        if not self.prune:
+            return 0
+        nz = np.zeros(self.nxh + 1, dtype=bool)
+        for a in planes:
+            nz |= np.any(np.asarray(a) != 0, axis=0)
+        w = int(np.nonzero(nz)[0].max()) + 1 if nz.any() else 1
+        return 0 if w >= self.nxh + 1 else w
+
+    def _is_clean(self, t):
+        r = self._clean.get(id(t))
+        if r is not None and r() is t:
+            return True
+        if len(self._clean) > 64:
+            self._clean = {k: v for k, v in self._clean.items() if v() is not None}
+        return False
+
+    @property
+    def leg_cols(self):
+        """Columns of the input transform the TT estimator reads (``Engine.rfft(..., width=q.leg_cols)``)."""
+        return self._W["TT"][0]
+
+    @property
+    def kappa_cols(self):
+        """Columns of kappa_hat that can be non-zero (``Engine.bin_power(..., active_cols=q.kappa_cols)``)."""
+        return self._W["TT"][1]
 
     def _response_tt(self, wg, wh, cr):
         """R(L) = (1/a) sum_jk L_j L_k DFT[alpha_jk beta - gt_j dt_k](L) evaluated with
@@ -163,6 +198,7 @@ class Estimator(object):
         other._work = None
         other._rwork = None
         other._acc = None
+        other._clean = {}
         return other
 
     # ---- data plumbing -----------------------------------------------------------------
@@ -198,7 +234,11 @@ class Estimator(object):
 
         fused=True (default): legs -> 3 inverse column transforms -> ONE fused row-stage kernel
         (3 C2R + 2 products + 2 R2C in LDS, oa_qe_rows) -> 2 forward column transforms -> divergence.
-        fused=False: the modular sequence of public C-ABI calls (3 C2R, 2 products, 2 R2C)."""
+        fused=False: the modular sequence of public C-ABI calls (3 C2R, 2 products, 2 R2C).
+
+        With ``prune`` (default) only the first ``leg_cols`` columns of kX / kY are read and only the first
+        ``kappa_cols`` columns of the result are computed; the remaining columns of ``out`` are zero (an ``out``
+        plane is zero-filled there the first time it is seen and must not be scribbled on afterwards)."""
         e = self.eng
         kY = kX if kY is None else kY
         FG, FH, Fn = self._F["TT"]
@@ -207,10 +247,16 @@ class Estimator(object):
             # legs+inverse columns (1 fused pass + 3 in-place passes) -> fused row stage -> forward
             # columns + divergence (2 passes + 1 fused pass): the filtered legs, the real-space planes
             # and the pre-divergence planes never exist in HBM
-            cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"])
+            wl, wk = self._W["TT"]
+            if out is None:
+                out = e.hc()                                   # zero-initialised
+            elif wk and not self._is_clean(out):
+                out[:, wk:] = 0                                # inactive columns: zeroed once per output plane
+                self._clean[id(out)] = weakref.ref(out)
+            cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"], width=wl)
             Gx, Gy, _ = w["G"]
-            e.qe_rows(cx, cy, ch, Gx, Gy)
-            return e.qe_cols_div(Gx, Gy, Fn, out=out)
+            e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk)
+            return e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk)
         Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
         gx, gy, h = self._real_buffers()
         e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)

@@ -69,8 +69,8 @@ class GaussianN0MonteCarlo(object):
             e.grf_hc(self.base_seed, int(i), self.cs, out=self._kT)
             q.reconstruct_tt_hc(self._kT, out=self._kk)
             sums, counts = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True)
-            p1d = (sums[1:-1] / counts[1:-1].to(torch.float64)).contiguous()
-            check(e.lib.oa_moments_add(_ptr(p1d), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))
+            # bin means sums/counts of the interior bins are formed inside the accumulation kernel
+            check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))
             if self.mean_field:
                 ri = torch.view_as_real(self._kk)  # (ny, kp, 2)
                 check(e.lib.oa_stack_add(e.code, _ptr(ri), _ptr(self.mf), ri.numel(), _stream()))

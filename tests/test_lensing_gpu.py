@@ -397,3 +397,46 @@ def test_bandlimited_estimator_is_exact():
         assert np.max(np.abs(ps / pf - 1)) < tol_band
     with pytest.raises(ValueError):
         lensing.BandlimitedEstimator(shape, g, th, n_small=256, **kw)   # would alias the leg products
+
+
+def test_active_column_pruning_is_exact():
+    """prune=True (default) skips the hc columns where the band-limited filters vanish: kappa_hat must equal the
+    unpruned pipeline's (same arithmetic on the surviving columns -> f64 ~1e-13, f32 ~1e-6 of the peak mode)
+    and stay zero elsewhere; width-limited rfft / irfft / bin_power agree with their full versions."""
+    from orphics_amd import lensing
+    N, res = 1024, 1.0
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, res, seed=8)
+    kw = dict(noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True)
+    for prec, tol in (("f64", 1e-12), ("f32", 2e-6)):
+        qp = lensing.qest(shape, g, th, dtype=prec, **kw)
+        qf = lensing.qest(shape, g, th, dtype=prec, prune=False, **kw)
+        wl, wk = qp.leg_cols, qp.kappa_cols
+        assert 0 < wl < wk < N // 2 + 1 and qf.leg_cols == 0 and qf.kappa_cols == 0
+        e = qp.eng
+        x = e.to_real(t1)
+        kT = e.rfft(x)
+        # width-limited forward transform: same leading columns, rest untouched
+        kTw = e.hc(); kTw[:] = 7.0
+        e.rfft(x, out=kTw, width=wl)
+        assert torch.equal(kTw[:, :wl], kT[:, :wl]) and bool((kTw[:, wl:] == 7.0).all())
+        full = qf.reconstruct_tt_hc(kT).clone()
+        dirty = e.hc(); dirty[:] = 3.0
+        pr = qp.reconstruct_tt_hc(kTw, out=dirty)          # garbage beyond wl in the input, garbage in `out`
+        scale = float(full.abs().max())
+        assert float((pr - full).abs().max()) / scale < tol
+        assert bool((pr[:, wk:] == 0).all()) and bool((full[:, wk:N // 2 + 1] == 0).all())
+        pr2 = qp.reconstruct_tt_hc(kTw, out=dirty)         # second use of the same output plane
+        assert torch.equal(pr2, pr)
+        # width-limited inverse transform of a band-limited plane
+        kf = kT.clone(); kf[:, wl:] = 0
+        r_full = e.irfft(kf)
+        kf[:, wl:] = 5.0
+        r_w = e.irfft(kf, width=wl)
+        assert float((r_w - r_full).abs().max()) / float(r_full.abs().max()) < (1e-13 if prec == "f64" else 1e-6)
+        # restricted binning: same sums
+        edges = torch.as_tensor(np.linspace(20, 3000, 15), device=e.device)
+        ids = e.modl_digitize(edges, half=True)
+        s_full, c_full = e.bin_power(full, full, 1.0, ids, 16, herm=True)
+        s_w, c_w = e.bin_power(pr, pr, 1.0, ids, 16, herm=True, active_cols=wk)
+        assert float(((s_w[1:-1] - s_full[1:-1]) / s_full[1:-1]).abs().max()) < 10 * tol
+        assert bool((c_w[1:-1] <= c_full[1:-1]).all())
