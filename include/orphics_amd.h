@@ -77,7 +77,7 @@ int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, dou
 /* One constituent pass of the transforms above, for per-kernel timing (bench.py roofline):
  * pass_id 0 = R2C row pass (real in -> hc out), 1 = column pass 1 (hc -> hc, out != in),
  * 2 = column pass 2 (in place on `out`; `in` ignored), 3 = C2R row pass (hc -> real). */
-int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream);
+int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, void* stream);
 
 /* Column half of the transforms above on an hc plane (all ny-point column DFTs of the nx/2+1
  * valid columns), out != in.  With oa_qe_rows it forms the fused estimator pipeline. */

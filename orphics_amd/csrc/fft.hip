@@ -133,14 +133,15 @@ static int c2c_impl(oa_plan* p, const void* in, void* out, int inverse, double s
 }
 
 template <typename T>
-static int pass_impl(oa_plan* p, int pass_id, const void* in, void* out, hipStream_t st) {
+static int pass_impl(oa_plan* p, int pass_id, const void* in, void* out, int width, hipStream_t st) {
     HipLauncher q{st};
     auto f = view<T>(p);
+    const int w = f.clampw(width);
     switch (pass_id) {
-        case 0: f.rows(q, ROW_R2C, in, p->nx / 2, out, p->kp, (T)1); break;
-        case 1: f.cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, p->nx / 2 + 1, false, (T)1, 1); break;
-        case 2: f.cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, p->nx / 2 + 1, false, (T)1, 2); break;
-        case 3: f.rows(q, ROW_C2R, in, p->kp, out, p->nx / 2, (T)1); break;
+        case 0: f.rows(q, ROW_R2C, in, p->nx / 2, out, p->kp, (T)1, w); break;
+        case 1: f.cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, w, false, (T)1, 1); break;
+        case 2: f.cols(q, (const cx<T>*)in, p->kp, (cx<T>*)out, p->kp, w, false, (T)1, 2); break;
+        case 3: f.rows(q, ROW_C2R, in, p->kp, out, p->nx / 2, (T)1, w); break;
         default: return fail("oa_fft_pass: pass_id must be 0..3");
     }
     return q.rc;
@@ -221,10 +222,10 @@ int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* 
                               : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream);
 }
 
-int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, void* stream) {
+int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, void* stream) {
     OA_REQUIRE(p && in && out, "oa_fft_pass: NULL argument");
-    return p->dtype == OA_F32 ? pass_impl<float>(p, pass_id, in, out, (hipStream_t)stream)
-                              : pass_impl<double>(p, pass_id, in, out, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? pass_impl<float>(p, pass_id, in, out, width, (hipStream_t)stream)
+                              : pass_impl<double>(p, pass_id, in, out, width, (hipStream_t)stream);
 }
 
 int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, void* stream) {

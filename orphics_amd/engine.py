@@ -258,9 +258,9 @@ class Engine(object):
         check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, int(width), _stream()))
         return out
 
-    def fft_pass(self, pass_id, src, dst):
+    def fft_pass(self, pass_id, src, dst, width=0):
         """Launch one constituent FFT pass (per-kernel timing in bench.py)."""
-        check(self.lib.oa_fft_pass(self.plan, int(pass_id), _ptr(src), _ptr(dst), _stream()))
+        check(self.lib.oa_fft_pass(self.plan, int(pass_id), _ptr(src), _ptr(dst), int(width), _stream()))
 
     # ---- layouts ----------------------------------------------------------------
     def hc_to_full(self, k):

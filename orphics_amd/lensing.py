@@ -135,6 +135,15 @@ class Estimator(object):
         w = int(np.nonzero(nz)[0].max()) + 1 if nz.any() else 1
         return 0 if w >= self.nxh + 1 else w
 
+    def _prep_out(self, out, wk, accumulate=False):
+        """Output plane whose columns >= wk (never written by the pruned kernels) are zero."""
+        if out is None:
+            return self.eng.hc()                               # zero-initialised
+        if wk and not accumulate and not self._is_clean(out):
+            out[:, wk:] = 0                                    # zeroed once per output plane
+            self._clean[id(out)] = weakref.ref(out)
+        return out
+
     def _is_clean(self, t):
         r = self._clean.get(id(t))
         if r is not None and r() is t:
@@ -248,11 +257,7 @@ class Estimator(object):
             # columns + divergence (2 passes + 1 fused pass): the filtered legs, the real-space planes
             # and the pre-divergence planes never exist in HBM
             wl, wk = self._W["TT"]
-            if out is None:
-                out = e.hc()                                   # zero-initialised
-            elif wk and not self._is_clean(out):
-                out[:, wk:] = 0                                # inactive columns: zeroed once per output plane
-                self._clean[id(out)] = weakref.ref(out)
+            out = self._prep_out(out, wk)
             cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"], width=wl)
             Gx, Gy, _ = w["G"]
             e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk)
@@ -445,7 +450,7 @@ class Estimator(object):
         Fnorm = -(L * (L + 1.) / 2.) * AL * self.mask_K
         # device filter planes per weight term and trig piece: (sign, FG, FH, swap_legs)
         c, s_ = np.cos(self.ang_h), np.sin(self.ang_h)
-        pieces = []
+        pieces, hostf = [], []
         for (cg, p, A, B, trig) in g:
             FGh, FHh = (P[A], P[B]) if p == 1 else (P[B], P[A])
             FGh, FHh = _safe_div(FGh, self.beam), _safe_div(FHh, self.beam)
@@ -459,7 +464,9 @@ class Estimator(object):
                 fg = FGh if tg is None else FGh * tg
                 fh = FHh if th is None else FHh * th
                 pieces.append((cg * sg, self._hcreal(self.eng, fg), self._hcreal(self.eng, fh), p == 2))
-        self._gen[XY] = dict(pieces=pieces, Fnorm=self._hcreal(self.eng, Fnorm), R=R)
+                hostf += [fg, fh]
+        self._gen[XY] = dict(pieces=pieces, Fnorm=self._hcreal(self.eng, Fnorm), R=R,
+                             wl=self._support_cols(*hostf), wk=self._support_cols(Fnorm))
         return self._gen[XY]
 
     def reconstruct_hc(self, XY, kX, kY, out=None, norm=None, accumulate=False):
@@ -474,11 +481,18 @@ class Estimator(object):
             self._acc = (e.hc(), e.hc())
         ax, ay = self._acc
         scale0 = 1.0 / float(e.npix) ** 2
+        # active columns: legs from this estimator's filters; kappa from its normalisation (an external
+        # ``norm`` plane -- MV weights -- is bounded by the kappa mask)
+        wl = G["wl"]
+        if norm is not None and getattr(self, "_wK", None) is None:
+            self._wK = self._support_cols(self.mask_K)
+        wk = G["wk"] if norm is None else self._wK
+        out = self._prep_out(out, wk, accumulate)
         for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
             kg, kh = (kY, kX) if swap else (kX, kY)
-            e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch))
-            e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0))
-        return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate)
+            e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch), width=wl)
+            e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0), win=wl, wout=wk)
+        return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk)
 
     # ---- minimum-variance combination (BASELINE config 3) -------------------------------------------
     def mv_weights(self, estimators=("TT", "TE", "EE", "EB", "TB")):

@@ -58,6 +58,7 @@ class GaussianN0MonteCarlo(object):
         self.mf = torch.zeros((e.ny, e.kp, 2), dtype=torch.float64, device=e.device) if mean_field else None
         self.mf_count = torch.zeros(1, dtype=torch.int64, device=e.device)
         self._kT, self._kk, self._p = e.hc(), e.hc(), e.hcreal()
+        _, self.counts = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True)
 
     def run_local(self, sims):
         """Process the given global sim indices on this rank's GPU."""
@@ -68,7 +69,10 @@ class GaussianN0MonteCarlo(object):
         for i in sims:
             e.grf_hc(self.base_seed, int(i), self.cs, out=self._kT)
             q.reconstruct_tt_hc(self._kT, out=self._kk)
-            sums, counts = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True)
+            # kappa_hat vanishes beyond q.kappa_cols: only those columns are visited; the mode counts are
+            # data-independent and were taken over the whole plane in __init__
+            sums, _ = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True, active_cols=q.kappa_cols)
+            counts = self.counts
             # bin means sums/counts of the interior bins are formed inside the accumulation kernel
             check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))
             if self.mean_field:
