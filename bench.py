@@ -67,36 +67,72 @@ def build_pipeline(N, res_arcmin, prec, torch, prune=True):
                 beam_h=beam_h, noise_h=noise_h, tmask_h=tmask_h, kmask_h=kmask_h, cl_h=cl_h)
 
 
-def bandlimited_leg(P, args, torch, tmaps, norm):
+def timed_steps(torch, step, nsteps, nwarm=10):
+    for i in range(nwarm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(nsteps):
+        step(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / nsteps
+
+
+def bandlimited_leg(P, args, torch, tmaps, ref_p1d):
     """Same job (R2C of the full-resolution map -> kappa_hat -> 19 bandpowers) with the reconstruction on the
-    smallest grid that holds the band-limited legs and their products exactly."""
+    smallest grid that holds the band-limited legs and their products exactly (lensing.BandlimitedEstimator)."""
     from orphics_amd import lensing
     N = args.n
     bl = lensing.BandlimitedEstimator((N, N), P["geom"], P["theory"], **P["qkw"])
-    eng, es = P["eng"], bl.q.eng
+    es = bl.q.eng
     ids = es.modl_digitize(torch.as_tensor(P["edges"], device=es.device), half=True)
     nrm = bl.gsmall.area / float(bl.n ** 2) ** 2
-    kT = eng.hc()
+    kk = es.hc()
+    _, counts = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True)
+    res = {}
 
     def step(i):
-        eng.rfft(tmaps[i & 1], out=kT)
-        kk = bl.reconstruct_tt_hc(kT)
-        return es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True)
-    for i in range(3):
-        s_small, c_small = step(i)
+        bl.reconstruct_tt_from_map(tmaps[i & 1], out=kk)
+        res["sums"], _ = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True, active_cols=bl.q.kappa_cols)
+    dt = timed_steps(torch, step, args.steps)
+    step(0)
+    p1d = res["sums"][1:-1] / counts[1:-1]
+    return {"reconstructions_per_s": 1.0 / dt, "internal_grid": bl.n,
+            "max_rel_bandpower_diff_vs_headline_path": float((p1d / ref_p1d - 1).abs().max().item()),
+            "note": "opt-in lensing.BandlimitedEstimator: input R2C at full resolution (active columns only), estimator "
+                    "on the coarse grid; exact for band-limited filters (coarse Nyquist > ell_max_X + ell_max_Y)"}
+
+
+def dense_leg(P, args, torch, tmaps, ref_p1d, norm):
+    """The same job with prune=False: every plane processed over all nx/2+1 columns (what a filter without a
+    band limit costs).  Reported beside the headline for transparency."""
+    from orphics_amd import lensing
+    q = lensing.qest((args.n, args.n), P["geom"], P["theory"], prune=False, **P["qkw"])
+    eng = q.eng
+    ns = max(1, args.streams)
+    qs = [q] + [q.fork() for _ in range(ns - 1)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    kTs, kks = [e.eng.hc() for e in qs], [e.eng.hc() for e in qs]
+    res = {}
+
+    def step(i):
+        j = i % ns
+        with torch.cuda.stream(streams[j]):
+            e = qs[j].eng
+            e.rfft(tmaps[i & 1], out=kTs[j])
+            qs[j].reconstruct_tt_hc(kTs[j], out=kks[j])
+            res[i & 1] = e.bin_power(kks[j], kks[j], norm, P["ids"], P["nids"], herm=True)
+    dt = timed_steps(torch, step, args.steps)
+    step(0)
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    # agreement with the full-resolution bandpowers of the same map
-    kk = P["q"].reconstruct_tt_hc(eng.rfft(tmaps[0], out=kT))
-    s_full, c_full = eng.bin_power(kk, kk, norm, P["ids"], P["nids"], herm=True)
-    s_small, c_small = step(0)
-    rel = float(((s_small[1:-1] / c_small[1:-1]) / (s_full[1:-1] / c_full[1:-1]) - 1).abs().max().item())
-    return {"reconstructions_per_s": 1.0 / dt, "internal_grid": bl.n, "max_rel_bandpower_diff_vs_full": rel,
-            "note": "opt-in; exact for band-limited filters (coarse Nyquist > ell_max_X + ell_max_Y)"}
+    sums, counts = res[0]
+    p1d = sums[1:-1] / counts[1:-1]
+    A = 4 * args.n * args.n if args.prec == "f32" else 8 * args.n * args.n
+    return {"reconstructions_per_s": 1.0 / dt, "streams_per_gpu": ns,
+            "max_rel_bandpower_diff_vs_headline_path": float((p1d / ref_p1d - 1).abs().max().item()),
+            "pipeline_achieved_GBs_on_survey_37.25A": 37.25 * A / dt / 1e9,
+            "pipeline_frac_of_hbm_peak": 37.25 * A / dt / 1e9 / HBM_PEAK_GBS,
+            "note": "prune=False: all nx/2+1 columns of every plane are transformed (filters without a band limit)"}
 
 
 def time_kernel(torch, fn, reps=20, warm=3):
@@ -161,9 +197,9 @@ def main():
                     help="process all nx/2+1 columns of every plane even where the band-limited filters vanish")
     ap.add_argument("--trace-steps", action="store_true", help="stderr: throughput per 20 timed steps (diagnostic)")
     ap.add_argument("--preroll", type=float, default=1.5, help="seconds of untimed load before the warm-up steps (clock ramp)")
-    ap.add_argument("--bandlimited", action="store_true",
-                    help="also time the opt-in coarse-grid estimator (lensing.BandlimitedEstimator) and report it under "
-                         "'extra'; never the headline value")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two side measurements reported under 'extra' (never the headline value): the dense "
+                         "pipeline (prune=False) and the opt-in coarse-grid lensing.BandlimitedEstimator")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams: independent realisations are issued round-robin "
                     "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
     args = ap.parse_args()
@@ -367,8 +403,15 @@ def main():
                        "parallelism": "independent realisations per GPU + 1 all-reduce of bandpower moments"},
             "roofline": roofline,
         }
-        if args.bandlimited:
-            out["extra"] = {"bandlimited": bandlimited_leg(P, args, torch, tmaps, norm)}
+        if world == 1 and not args.no_extras and not args.no_prune:
+            # bandpowers of map 0 through the headline path: the yardstick for the two side measurements
+            e0 = qs[0].eng
+            e0.rfft(tmaps[0], out=kTs[0], width=wl)
+            qs[0].reconstruct_tt_hc(kTs[0], out=kks[0])
+            s0, _ = e0.bin_power(kks[0], kks[0], norm, P["ids"], nids, herm=True, active_cols=wk)
+            ref_p1d = s0[1:-1] / counts[1:-1]
+            out["extra"] = {"dense": dense_leg(P, args, torch, tmaps, ref_p1d, norm),
+                            "bandlimited": bandlimited_leg(P, args, torch, tmaps, ref_p1d)}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, args.res)
         print(json.dumps(out))

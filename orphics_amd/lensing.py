@@ -601,6 +601,13 @@ class BandlimitedEstimator(object):
         hc_resample(self.big, kT_full, self.q.eng, self.scale, out=self._kc)
         return self.q.reconstruct_tt_hc(self._kc, out=out)
 
+    def reconstruct_tt_from_map(self, tmap, out=None):
+        """Real full-resolution map in: only the columns the leg filters keep are transformed, then cropped."""
+        if getattr(self, "_kbig", None) is None:
+            self._kbig = self.big.hc()
+        self.big.rfft(tmap, out=self._kbig, width=self.q.leg_cols)
+        return self.reconstruct_tt_hc(self._kbig, out=out)
+
     def kappa_full_hc(self, kappa_small):
         """Embed the coarse kappa_hat DFT into the full-resolution hc grid."""
         from .engine import hc_resample
