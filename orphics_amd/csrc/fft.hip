@@ -12,10 +12,13 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_k
 #ifndef OA_QE_WAVES_PER_EU
 #define OA_QE_WAVES_PER_EU 3
 #endif
-template <typename T> constexpr int qe_waves_per_eu() { return sizeof(T) == 8 ? 1 : OA_QE_WAVES_PER_EU; }
+// rows of >= 16384 points need 512-thread workgroups (2 waves/SIMD each): budget the registers for exactly that
+template <typename T, class SEQ> constexpr int qe_waves_per_eu() {
+    return sizeof(T) == 8 ? 1 : (row_maxnt<SEQ>() > 256 ? 2 : OA_QE_WAVES_PER_EU);
+}
 
 template <typename T, class SEQ>
-__global__ __launch_bounds__(row_maxnt<SEQ>(), qe_waves_per_eu<T>()) void row_qe_kernel(RowQeArgs<T> a) {
+__global__ __launch_bounds__(row_maxnt<SEQ>(), (qe_waves_per_eu<T, SEQ>())) void row_qe_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_qe_body<T, SEQ>(c, a);
 }
