@@ -1,0 +1,163 @@
+"""The FFT / fused-estimator pass bodies (orphics_amd/csrc/fft_kernels.hpp) run under the CPU thread
+emulator (tests/emul: std::thread + std::barrier, one std::thread per HIP thread) and are compared with
+NumPy.  This validates every index computation of the kernels -- including the active-column (pruned)
+variants -- without a GPU; the GPU tests then only have to confirm the same code on the device."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL = os.path.join(HERE, "emul")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(EMUL, "libemul_fft.so")
+    src = os.path.join(EMUL, "emul_fft.cpp")
+    hdr = os.path.join(HERE, "..", "orphics_amd", "csrc", "fft_kernels.hpp")
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.emu_kpitch.restype = ctypes.c_long
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _hc(lib, ny, nx, fill=0.0):
+    kp = lib.emu_kpitch(nx)
+    a = np.zeros((ny, kp), dtype=np.complex128)
+    a[:] = fill
+    return a
+
+
+def _band_limited(rng, ny, nx, w):
+    """Random Hermitian-consistent hc plane that vanishes for columns >= w (and is real at kx = 0 self-pairs)."""
+    x = rng.standard_normal((ny, nx))
+    k = np.fft.rfft2(x)
+    k[:, w:] = 0
+    return k
+
+
+@pytest.mark.parametrize("ny,nx", [(32, 32), (64, 128), (128, 64), (32, 512)])
+def test_r2c_c2r_match_numpy(emu, ny, nx):
+    rng = np.random.default_rng(ny * 1000 + nx)
+    x = rng.standard_normal((ny, nx))
+    out = _hc(emu, ny, nx)
+    assert emu.emu_r2c_f64(ny, nx, _p(x), _p(out), ctypes.c_double(1.0)) == 0
+    ref = np.fft.rfft2(x)
+    assert np.abs(out[:, :nx // 2 + 1] - ref).max() < 1e-11 * np.abs(ref).max()
+    back = np.zeros((ny, nx))
+    assert emu.emu_c2r_f64(ny, nx, _p(out), _p(back), ctypes.c_double(1.0 / (ny * nx))) == 0
+    assert np.abs(back - x).max() < 1e-12
+    # float32 build of the same bodies
+    x32 = x.astype(np.float32)
+    kp = emu.emu_kpitch(nx)
+    o32 = np.zeros((ny, kp), dtype=np.complex64)
+    assert emu.emu_r2c_f32(ny, nx, _p(x32), _p(o32), ctypes.c_double(1.0)) == 0
+    assert np.abs(o32[:, :nx // 2 + 1] - ref).max() < 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("ny,nx,w", [(64, 128, 9), (64, 128, 32), (32, 512, 70), (128, 64, 33)])
+def test_active_columns_r2c_c2r(emu, ny, nx, w):
+    """width-limited R2C writes exactly the leading columns (same values) and nothing else; width-limited C2R
+    of a band-limited plane ignores whatever sits beyond the band."""
+    rng = np.random.default_rng(7 + w)
+    x = rng.standard_normal((ny, nx))
+    full = _hc(emu, ny, nx)
+    emu.emu_r2c_f64(ny, nx, _p(x), _p(full), ctypes.c_double(1.0))
+    part = _hc(emu, ny, nx, fill=99.0)
+    assert emu.emu_r2c_w_f64(ny, nx, _p(x), _p(part), ctypes.c_double(1.0), w) == 0
+    wv = min(w, nx // 2 + 1)
+    assert np.array_equal(part[:, :wv], full[:, :wv])
+    assert np.all(part[:, wv:] == 99.0)
+    k = _hc(emu, ny, nx)
+    k[:, :nx // 2 + 1] = _band_limited(rng, ny, nx, wv)
+    ref = np.fft.irfft2(k[:, :nx // 2 + 1], s=(ny, nx))
+    k[:, wv:] = 1e30                                      # must never be read
+    back = np.zeros((ny, nx))
+    assert emu.emu_c2r_w_f64(ny, nx, _p(k), _p(back), ctypes.c_double(1.0 / (ny * nx)), w) == 0
+    assert np.abs(back - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def _col_ifft(k, ny):
+    return np.fft.ifft(k, axis=0) * ny
+
+
+@pytest.mark.parametrize("ny,nx,win,wout", [(32, 64, 0, 0), (32, 128, 20, 41), (64, 256, 33, 64), (32, 512, 100, 150)])
+def test_fused_row_stage(emu, ny, nx, win, wout):
+    """row_qe: P = R2C(C2R(G) * C2R(H)) row by row, with and without active-column limits."""
+    rng = np.random.default_rng(100 + nx + win)
+    W = nx // 2 + 1
+    wi = win if win else W
+    planes = []
+    for _ in range(3):      # inputs are column-transformed legs: Hermitian along x only matters per row
+        k = (rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W)))
+        k[:, 0] = k[:, 0].real
+        if nx // 2 < wi:
+            k[:, nx // 2] = k[:, nx // 2].real
+        k[:, wi:] = 0
+        planes.append(k)
+    gx, gy, h = planes
+    rows = lambda k: np.fft.irfft(k, n=nx, axis=1) * nx          # unnormalised C2R rows
+    hr = rows(h)
+    ref = [np.fft.rfft(rows(g) * hr, axis=1) for g in (gx, gy)]
+    ins = []
+    for k in planes:
+        a = _hc(emu, ny, nx, fill=(1e30 if win else 0.0))      # garbage beyond the band must not be read
+        a[:, :wi] = k[:, :wi]
+        ins.append(a)
+    px, py = _hc(emu, ny, nx, fill=5.0), _hc(emu, ny, nx, fill=5.0)
+    assert emu.emu_qe_rows_w_f64(ny, nx, _p(ins[0]), _p(ins[1]), _p(ins[2]), _p(px), _p(py), ctypes.c_double(1.0), win, wout) == 0
+    wo = wout if wout else W
+    for got, want in ((px, ref[0]), (py, ref[1])):
+        assert np.abs(got[:, :wo] - want[:, :wo]).max() < 1e-11 * np.abs(want).max()
+        if wout:
+            assert np.all(got[:, wo:W] == 5.0)                    # untouched
+
+
+@pytest.mark.parametrize("ny,nx,w", [(64, 64, 0), (64, 128, 21), (128, 64, 32), (256, 64, 7)])
+def test_fused_column_stages(emu, ny, nx, w):
+    """col_legs (+ pass 2) = inverse column transforms of (i lx FG kX, i ly FG kX, FH kY);
+    col_div (after 2 pass-1 launches) = Fn * (i lx FFTcol[A] + i ly FFTcol[B]); both with active widths."""
+    rng = np.random.default_rng(5 + ny + w)
+    W = nx // 2 + 1
+    wv = w if w else W
+    kp = emu.emu_kpitch(nx)
+    ly = 2 * np.pi * np.fft.fftfreq(ny) * 100
+    lx = 2 * np.pi * np.fft.fftfreq(nx) * 100
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[ny // 2] = 0
+    lxd[nx // 2] = 0
+    kX = _hc(emu, ny, nx); kY = _hc(emu, ny, nx)
+    kX[:, :W] = rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W))
+    kY[:, :W] = rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W))
+    FG = np.zeros((ny, kp)); FH = np.zeros((ny, kp)); Fn = np.zeros((ny, kp))
+    FG[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
+    FH[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
+    Fn[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
+    outs = [_hc(emu, ny, nx, fill=3.0) for _ in range(3)]
+    lxh = np.ascontiguousarray(lxd)                     # the kernel indexes lxd by column (first W entries used)
+    assert emu.emu_legs_cols_w_f64(ny, nx, _p(kX), _p(kY), _p(FG), _p(FH), _p(lxh), _p(lyd), _p(outs[0]), _p(outs[1]),
+                                   _p(outs[2]), w) == 0
+    lx2, ly2 = lxd[None, :W], lyd[:, None]
+    refs = [_col_ifft(1j * lx2 * FG[:, :W] * kX[:, :W], ny), _col_ifft(1j * ly2 * FG[:, :W] * kX[:, :W], ny),
+            _col_ifft(FH[:, :W] * kY[:, :W], ny)]
+    for got, want in zip(outs, refs):
+        assert np.abs(got[:, :wv] - want[:, :wv]).max() < 1e-11 * np.abs(want).max()
+        if w:
+            assert np.all(got[:, wv:W] == 3.0)
+    A = _hc(emu, ny, nx); B = _hc(emu, ny, nx)
+    A[:, :W] = rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W))
+    B[:, :W] = rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W))
+    out = _hc(emu, ny, nx, fill=3.0)
+    assert emu.emu_cols_div_w_f64(ny, nx, _p(A), _p(B), _p(Fn), _p(lxh), _p(lyd), _p(out), w) == 0
+    want = Fn[:, :W] * (1j * lx2 * np.fft.fft(A[:, :W], axis=0) + 1j * ly2 * np.fft.fft(B[:, :W], axis=0))
+    assert np.abs(out[:, :wv] - want[:, :wv]).max() < 1e-11 * np.abs(want).max()
+    if w:
+        assert np.all(out[:, wv:W] == 3.0)
