@@ -329,41 +329,25 @@ def main():
         kern = {
             "row_fft_kernel<R2C>": (lambda: eng.fft_pass(0, r1, s1, wl), (1 + fl) * A, A + fl * Ah, 1),
             "col_fft_kernel<pass1,legs-width>": (lambda: eng.fft_pass(1, s1, s2, wl), fl * A, 2 * fl * Ah, 1),
-            "col_fft_kernel<pass2,legs-width>": (lambda: eng.fft_pass(2, s1, s2, wl), fl * A, 2 * fl * Ah, 4),
-            "col_fft_kernel<pass1,kappa-width>": (lambda: eng.fft_pass(1, s1, s2, wk), fk * A, 2 * fk * Ah, 2),
-            "col_legs_kernel(+3x pass2)": (legs_only, None, None, 1),
+            "col_fft_kernel<pass2,legs-width>": (lambda: eng.fft_pass(2, s1, s2, wl), fl * A, 2 * fl * Ah, 1),
+            # col_legs (filter multiply: read kT, write 3 legs; first half of the 3 inverse column stages) + ONE
+            # 3-plane launch of the second half
+            "legs_cols = col_legs_kernel + col_fft_kernel<pass2 x3 planes>": (legs_only, (4 * fl + 6 * fl) * A,
+                                                                             fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah, 1),
             "row_qe_kernel": (lambda: eng.qe_rows(s1, s2, s3, s4, s5, win=wl, wout=wk), (10 + 3 * fl + 2 * fk) * A, (3 * fl + 2 * fk) * Ah, 1),
-            "col_div_kernel(+2x pass1)": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk), None, None, 1),
+            # ONE 2-plane launch of the first half of the 2 forward column stages + col_div (second half + divergence)
+            "cols_div = col_fft_kernel<pass1 x2 planes> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk),
+                                                                           (4 * fk + 3 * fk) * A, 4 * fk * Ah + fk * (2 * Ah + Ah / 2 + Ah), 1),
             "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], nids, herm=True, active_cols=wk), 2.75 * fk * A, 1.5 * fk * Ah, 1),
         }
-        per, t = {}, {}
+        per, share = {}, {}
         for name, (fn, alg, actual, count) in kern.items():
             dt = time_kernel(torch, fn)
-            t[name] = dt * 1e3
-            if alg is not None:
-                per[name] = {"avg_ms": dt * 1e3, "launches_per_recon": count, "algorithmic_GB": alg / 1e9,
-                             "hbm_min_GB": actual / 1e9, "achieved_GBs": alg / dt / 1e9, "achieved_actual_GBs": actual / dt / 1e9}
-        # the composite launches include plain column passes: subtract them to isolate the fused kernels
-        p1l, p2l, p1k = (t["col_fft_kernel<pass1,legs-width>"], t["col_fft_kernel<pass2,legs-width>"],
-                         t["col_fft_kernel<pass1,kappa-width>"])
-        t_legs = max(t["col_legs_kernel(+3x pass2)"] - 3 * p2l, 1e-6)
-        t_div = max(t["col_div_kernel(+2x pass1)"] - 2 * p1k, 1e-6)
-        # col_legs: filter multiply (read kT, write 3 legs) + first half of 3 inverse column stages; col_div: second
-        # half of 2 forward column stages + divergence (read 2, write 1)
-        a_legs, m_legs = (4 * fl + 3 * fl) * A, fl * (Ah + 2 * Ah / 2 + 3 * Ah)
-        a_div, m_div = (2 * fk + 3 * fk) * A, fk * (2 * Ah + Ah / 2 + Ah)
-        per["col_legs_kernel"] = {"avg_ms": t_legs, "launches_per_recon": 1, "algorithmic_GB": a_legs / 1e9, "hbm_min_GB": m_legs / 1e9,
-                                  "achieved_GBs": a_legs / t_legs / 1e6, "achieved_actual_GBs": m_legs / t_legs / 1e6}
-        per["col_div_kernel"] = {"avg_ms": t_div, "launches_per_recon": 1, "algorithmic_GB": a_div / 1e9, "hbm_min_GB": m_div / 1e9,
-                                 "achieved_GBs": a_div / t_div / 1e6, "achieved_actual_GBs": m_div / t_div / 1e6}
-        share = {"row_fft_kernel<R2C>": t["row_fft_kernel<R2C>"], "col_fft_kernel": p1l + 4 * p2l + 2 * p1k,
-                 "col_legs_kernel": t_legs, "row_qe_kernel": t["row_qe_kernel"], "col_div_kernel": t_div,
-                 "bin_kernel<power>": t["bin_kernel<power>"]}
+            share[name] = dt * 1e3 * count
+            per[name] = {"avg_ms": dt * 1e3, "launches_per_recon": count, "algorithmic_GB": alg / 1e9,
+                         "hbm_min_GB": actual / 1e9, "achieved_GBs": alg / dt / 1e9, "achieved_actual_GBs": actual / dt / 1e9}
         dom = max(share, key=share.get)
-        if dom == "col_fft_kernel":
-            d_alg, d_act, d_t = (5 * fl + 2 * fk) * A, (5 * fl + 2 * fk) * 2 * Ah, share[dom]   # 7 launches
-        else:
-            d_alg, d_act, d_t = per[dom]["algorithmic_GB"] * 1e9, per[dom]["hbm_min_GB"] * 1e9, share[dom]
+        d_alg, d_act, d_t = per[dom]["algorithmic_GB"] * 1e9, per[dom]["hbm_min_GB"] * 1e9, per[dom]["avg_ms"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath) and N == 8192 and args.prec == "f32" and not args.no_prune:

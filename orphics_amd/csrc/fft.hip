@@ -91,12 +91,12 @@ struct HipLauncher {
         if (!ok && !rc) rc = fail("fft: unsupported column length");
     }
     template <typename T>
-    void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
+    void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a, int nz = 1) {
         const bool ok = dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
             if constexpr (seq_logl<S>() <= 8) {
                 if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
-                go(col_fft_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+                go(col_fft_kernel<T, S>, dim3(gx, gy, nz), nt, smem, a);
             } else {
                 if (!rc) rc = fail("fft: unsupported column sub-length");
             }

@@ -29,7 +29,10 @@
 namespace oa {
 
 constexpr int EPT = 16;        // complex points per thread per stage
-constexpr int COL_LOGC = 5;    // log2 columns per column tile (compile-time: index math folds to masks/shifts)
+#ifndef OA_COL_LOGC
+#define OA_COL_LOGC 5
+#endif
+constexpr int COL_LOGC = OA_COL_LOGC;  // log2 columns per column tile (compile-time: index math folds to masks/shifts)
 constexpr int MAX_STAGES = 8;
 
 struct Stages {
@@ -332,9 +335,11 @@ struct RowStore {
 
 // C2R prologue: half-complex rows (global) -> packed Z'[k] = (X[k]+conj X[L-k]) + i W_N^{-k} (X[k]-conj X[L-k]),
 // stored SWAPPED in LDS (the inverse runs as a forward transform of the swapped data).  Caller syncs.
-template <typename T, class Ctx>
-OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
-                        const cx<T>* tw, int logTw, int win = 0x7fffffff) {   // columns >= win are zero and never read
+// GUARD: columns >= win are zero and never read (active-column mode); the unguarded body keeps every load
+// unconditional so the compiler batches them (dense mode is HBM-latency bound).
+template <typename T, bool GUARD, class Ctx>
+OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
+                             const cx<T>* tw, int logTw, int win) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
@@ -343,9 +348,15 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
         for (int rep = 0; rep < 2; ++rep) {
             const int kk = rep ? (L >> 1) : k;
             if (rep && k != 0) break;
-            cx<T> A = mk<T>((T)0, (T)0), B = A;
-            if (kk < win) A = row[kk];
-            if (L - kk < win) B = row[L - kk];
+            cx<T> A, B;
+            if (GUARD) {
+                A = mk<T>((T)0, (T)0); B = A;
+                if (kk < win) A = row[kk];
+                if (L - kk < win) B = row[L - kk];
+            } else {
+                A = row[kk];
+                B = row[L - kk];
+            }
             const cx<T> w = tw[kk << sh];  // W_N^k
             const cx<T> d1 = A - conj(B), d2 = B - conj(A);
             const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
@@ -355,12 +366,18 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
         }
     }
 }
+template <typename T, class Ctx>
+OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
+                        const cx<T>* tw, int logTw, int win = 0x7fffffff) {
+    if (win > (1 << logL)) c2r_prologue_impl<T, false>(ctx, s, in, pitch, r0, logL, logC, NT, RS, tw, logTw, win);
+    else c2r_prologue_impl<T, true>(ctx, s, in, pitch, r0, logL, logC, NT, RS, tw, logTw, win);
+}
 
 // R2C epilogue: packed transform Z in LDS -> X[k] = E + W_N^k O, X[L-k] = conj(E - W_N^k O), straight to global.
-template <typename T, class Ctx>
-OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
-                        const cx<T>* tw, int logTw, T scale, bool accumulate = false, int wout = 0x7fffffff) {
-    // only columns < wout are produced (the caller's consumers never look at the others)
+// GUARD: only columns < wout are produced (the caller's consumers never look at the others).
+template <typename T, bool GUARD, class Ctx>
+OA_HD void r2c_epilogue_impl(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
+                             const cx<T>* tw, int logTw, T scale, bool accumulate, int wout) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
@@ -369,8 +386,8 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
         for (int rep = 0; rep < 2; ++rep) {
             const int kk = rep ? (L >> 1) : k;
             if (rep && k != 0) break;
-            const bool w1 = kk < wout, w2 = (L - kk) < wout;
-            if (!w1 && !w2) continue;
+            const bool w1 = !GUARD || kk < wout, w2 = !GUARD || (L - kk) < wout;
+            if (GUARD && !w1 && !w2) continue;
             const cx<T> Zk = s[lds_addr<true>(kk, c, 0, RS)];
             const cx<T> Zm = s[lds_addr<true>((L - kk) & (L - 1), c, 0, RS)];
             const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
@@ -385,6 +402,12 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
             if (w2) row[L - kk] = o2;
         }
     }
+}
+template <typename T, class Ctx>
+OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
+                        const cx<T>* tw, int logTw, T scale, bool accumulate = false, int wout = 0x7fffffff) {
+    if (wout > (1 << logL)) r2c_epilogue_impl<T, false>(ctx, s, out, pitch, r0, logL, logC, NT, RS, tw, logTw, scale, accumulate, wout);
+    else r2c_epilogue_impl<T, true>(ctx, s, out, pitch, r0, logL, logC, NT, RS, tw, logTw, scale, accumulate, wout);
 }
 
 template <typename T, int MODE, class SEQ, class Ctx>
@@ -518,6 +541,10 @@ template <typename T>
 struct ColArgs {
     const cx<T>* in;
     cx<T>* out;
+    // batched launch (grid z = plane 0..2): element offsets of planes 1 and 2 from plane 0.  Offsets + arithmetic
+    // select on purpose: a ?: chain over pointer members is turned into an indexed read of the by-value
+    // argument struct, which drags the whole struct into scratch memory (2x slower passes)
+    long in_off1, in_off2, out_off1, out_off2;
     long in_pitch, out_pitch;  // complex elements
     int width;                 // valid columns
     int logL, logC, NT;
@@ -792,8 +819,11 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     if (a.twiddle)
         for (int i = tid; i < (1 << logL); i += CNT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
     ctx.sync();
-    const ColLoad<T> ld{a.in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
-    const ColStore<T> st{a.out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
+    const int z = ctx.bid_z();
+    const cx<T>* in = a.in + (long)(z & 1) * a.in_off1 + (long)(z >> 1) * a.in_off2;
+    cx<T>* out = a.out + (long)(z & 1) * a.out_off1 + (long)(z >> 1) * a.out_off2;
+    const ColLoad<T> ld{in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
+    const ColStore<T> st{out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
                          a.twiddle ? ti : nullptr, (unsigned)g, a.scale};
     fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
 }

@@ -10,6 +10,7 @@ struct GpuCtx {
     OA_D int tid() const { return threadIdx.x; }
     OA_D int bid_x() const { return blockIdx.x; }
     OA_D int bid_y() const { return blockIdx.y; }
+    OA_D int bid_z() const { return blockIdx.z; }
     OA_D void sync() const { __syncthreads(); }
     OA_D void* smem() const { return sm; }
 };

@@ -91,9 +91,11 @@ struct Fft2dPlan {
     // ---- full column transform of `width` columns (two passes) -------------
     // in -> out (out != in), result in natural order in `out`.
     // which: 0 = both passes, 1 = pass 1 only, 2 = pass 2 only (microbenchmarks)
+    // nb > 1: the same pass over up to 3 planes in ONE launch (grid z = plane; in place only, which = 1 or 2
+    // with in == out for pass 2 / distinct planes for pass 1) -- small active-column launches fill the chip better
     template <class Launcher>
     void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
-              T scale, int which = 0) const {
+              T scale, int which = 0, int nb = 1, const cx<T>* const* ins = nullptr, cx<T>* const* outs = nullptr) const {
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -103,20 +105,28 @@ struct Fft2dPlan {
         if (which != 2) {
             // pass 1: length N1 over y1 (stride N2), twiddle, write block-transposed
             a.in = in; a.in_pitch = in_pitch; a.out = out; a.out_pitch = out_pitch;
+            if (nb > 1) {
+                a.in_off1 = ins[1] - in; a.out_off1 = outs[1] - out;
+                if (nb > 2) { a.in_off2 = ins[2] - in; a.out_off2 = outs[2] - out; }
+            }
             a.logL = logN1; a.NT = (int)((N1 * C) / EPT); a.st = make_stages(logN1);
             a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
             a.twiddle = (logN2 > 0) ? 1 : 0;
             a.scale = (logN2 > 0) ? (T)1 : scale;
-            q.col(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), a);
+            q.col(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), a, nb);
         }
         if (logN2 == 0 || which == 1) return;
         // pass 2: length N2 over y2 (stride N1), in place, natural order out
         a.in = out; a.in_pitch = out_pitch; a.out = out; a.out_pitch = out_pitch;
+        if (nb > 1) {
+            a.in_off1 = a.out_off1 = outs[1] - out;
+            if (nb > 2) a.in_off2 = a.out_off2 = outs[2] - out;
+        }
         a.logL = logN2; a.NT = (int)((N2 * C) / EPT); a.st = make_stages(logN2);
         if (a.NT < 1) a.NT = 1;
         a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;
         a.twiddle = 0; a.scale = scale;
-        q.col(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), a);
+        q.col(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), a, nb);
     }
 
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
@@ -134,7 +144,8 @@ struct Fft2dPlan {
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
         cx<T>* outs[3] = {gx, gy, h};
-        for (int i = 0; i < 3; ++i) cols(q, outs[i], kp, outs[i], kp, width, true, (T)1, 2);
+        const cx<T>* ins[3] = {gx, gy, h};
+        cols(q, gx, kp, gx, kp, width, true, (T)1, 2, 3, ins, outs);      // pass 2 of the three planes, one launch
     }
 
     // (B) forward column transforms of two row-transformed planes + divergence * Fnorm
@@ -147,8 +158,9 @@ struct Fft2dPlan {
         const int C = 1 << COLC;
         const int width = clampw(wmax);
         const int tiles = (width + C - 1) / C;
-        cols(q, pa, kp, tmpA, kp, width, false, (T)1, 1);
-        cols(q, pb, kp, tmpB, kp, width, false, (T)1, 1);
+        const cx<T>* ins[2] = {pa, pb};
+        cx<T>* outs[2] = {tmpA, tmpB};
+        cols(q, pa, kp, tmpA, kp, width, false, (T)1, 1, 2, ins, outs);   // pass 1 of both planes, one launch
         ColDivArgs<T> a{};
         a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = kp; a.width = width;
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;

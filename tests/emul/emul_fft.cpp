@@ -12,27 +12,29 @@
 using namespace oa;
 
 struct EmuCtx {
-    int tid_, bx_, by_;
+    int tid_, bx_, by_, bz_;
     std::barrier<>* bar;
     char* sm;
     int tid() const { return tid_; }
     int bid_x() const { return bx_; }
     int bid_y() const { return by_; }
+    int bid_z() const { return bz_; }
     void sync() const { bar->arrive_and_wait(); }
     void* smem() const { return sm; }
 };
 
 struct EmuLauncher {
     template <class F>
-    void run(int gx, int gy, int nt, size_t smem, F body) {
+    void run(int gx, int gy, int nt, size_t smem, F body, int gz = 1) {
         std::vector<char> sm(smem + 64);
         std::barrier<> bar(nt);
         std::vector<std::thread> th;
         for (int t = 0; t < nt; ++t)
             th.emplace_back([&, t]() {
-                for (int by = 0; by < gy; ++by)
+                for (int bz = 0; bz < gz; ++bz)
+                  for (int by = 0; by < gy; ++by)
                     for (int bx = 0; bx < gx; ++bx) {
-                        EmuCtx c{t, bx, by, &bar, sm.data()};
+                        EmuCtx c{t, bx, by, bz, &bar, sm.data()};
                         body(c);
                         bar.arrive_and_wait();
                     }
@@ -68,10 +70,10 @@ struct EmuLauncher {
             run(gx, gy, nt, smem, [&](EmuCtx& c) { col_div_body<T, S>(c, a); });
         });
     }
-    template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a) {
+    template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a, int nz = 1) {
         dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
-            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fft_body<T, S>(c, a); });
+            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fft_body<T, S>(c, a); }, nz);
         });
     }
 };
