@@ -351,6 +351,11 @@ OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, lo
             cx<T> A, B;
             if (GUARD) {
                 A = mk<T>((T)0, (T)0); B = A;
+                if (kk >= win && L - kk >= win) {          // both partners beyond the band: Z' = 0, no arithmetic
+                    s[lds_addr<true>(kk, c, 0, RS)] = A;
+                    if (kk != 0 && 2 * kk != L) s[lds_addr<true>(L - kk, c, 0, RS)] = A;
+                    continue;
+                }
                 if (kk < win) A = row[kk];
                 if (L - kk < win) B = row[L - kk];
             } else {
