@@ -93,7 +93,7 @@ def bandlimited_leg(P, args, torch, tmaps, ref_p1d):
 
     def step(i):
         bl.reconstruct_tt_from_map(tmaps[i & 1], out=kk)
-        res["sums"], _ = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True, active_cols=bl.q.kappa_cols)
+        res["sums"], _ = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True, active_cols=bl.q.kappa_cols, active_rows=bl.q.kappa_rows)
     dt = timed_steps(torch, step, args.steps)
     step(0)
     p1d = res["sums"][1:-1] / counts[1:-1]
@@ -241,6 +241,7 @@ def main():
     wl, wk = q.leg_cols, q.kappa_cols
     # mode counts per bin do not depend on the data: taken once over the whole plane
     _, counts = eng.bin_power(kT, kT, norm, P["ids"], nids, herm=True)
+    torch.cuda.synchronize()                 # `counts` is read from every stream below
 
     def step(i):
         j = i % ns
@@ -249,7 +250,7 @@ def main():
             # columns beyond the filters' support are neither produced nor read (exact: the masks zero them)
             e.rfft(tmaps[i & 1], out=kTs[j], width=wl)
             qs[j].reconstruct_tt_hc(kTs[j], out=kks[j])
-            sums, _ = e.bin_power(kks[j], kks[j], norm, P["ids"], nids, herm=True, active_cols=wk)   # |kappa_hat|^2 binned in one kernel
+            sums, _ = e.bin_power(kks[j], kks[j], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)   # |kappa_hat|^2 binned in one kernel
             # bin means (bin2D.bin) + ensemble moments (Statistics.add_to_stats) in one small kernel
             check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), d, _ptr(mom_n[j]), _ptr(mom_S[j]), _ptr(mom_C[j]), _stream()))
 
@@ -338,7 +339,7 @@ def main():
             # ONE 2-plane launch of the first half of the 2 forward column stages + col_div (second half + divergence)
             "cols_div = col_fft_kernel<pass1 x2 planes> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk),
                                                                            (4 * fk + 3 * fk) * A, 4 * fk * Ah + fk * (2 * Ah + Ah / 2 + Ah), 1),
-            "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], nids, herm=True, active_cols=wk), 2.75 * fk * A, 1.5 * fk * Ah, 1),
+            "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows), 2.75 * fk * A, 1.5 * fk * Ah, 1),
         }
         per, share = {}, {}
         for name, (fn, alg, actual, count) in kern.items():
@@ -392,7 +393,7 @@ def main():
             e0 = qs[0].eng
             e0.rfft(tmaps[0], out=kTs[0], width=wl)
             qs[0].reconstruct_tt_hc(kTs[0], out=kks[0])
-            s0, _ = e0.bin_power(kks[0], kks[0], norm, P["ids"], nids, herm=True, active_cols=wk)
+            s0, _ = e0.bin_power(kks[0], kks[0], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)
             ref_p1d = s0[1:-1] / counts[1:-1]
             out["extra"] = {"dense": dense_leg(P, args, torch, tmaps, ref_p1d, norm),
                             "bandlimited": bandlimited_leg(P, args, torch, tmaps, ref_p1d)}

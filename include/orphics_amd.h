@@ -189,9 +189,10 @@ int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights,
  * plane is never written.  Same ids / multiplicity / determinism contract as oa_bin (mode 0).
  * active_cols > 0 (Hermitian mode only): only columns < active_cols of each row are visited (planes that
  * vanish beyond them): sums are unchanged, COUNTS then cover the visited columns only -- take the
- * data-independent counts from one full oa_bin_power / oa_bin call at plan time. */
+ * data-independent counts from one full oa_bin_power / oa_bin call at plan time.  active_rows > 0 (with
+ * active_cols): additionally only the rows of the band y < active_rows or y > ny - active_rows. */
 int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const int32_t* ids, const void* weights, long n,
-                 int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch, int active_cols,
+                 int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch, int active_cols, int active_rows,
                  void* stream);
 
 /* ---- Gaussian random fields (MapGen.get_map, maps.py:1576-1587) --------------

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
                                                         const int32_t* __restrict__ ids,
                                                         const T* __restrict__ w, const double* __restrict__ aux, long n,
                                                         int nids, int mode, int skip_nan, unsigned hp, int nxh, unsigned wq,
-                                                        double* __restrict__ part_sum, double* __restrict__ part_w,
+                                                        unsigned rb, double* __restrict__ part_sum, double* __restrict__ part_w,
                                                         unsigned long long* __restrict__ part_cnt) {
     extern __shared__ __attribute__((aligned(16))) char sm_raw[];
     double* s_sum = reinterpret_cast<double*>(sm_raw);                        // [WAVES][nids]
@@ -112,13 +112,20 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
     double* row_w = s_w + wv * nids;
     unsigned long long* row_cnt = s_cnt + wv * nids;
 
-    // wq > 0: visit only the first wq 4-element chunks of every row of pitch hp (active columns)
-    const long nchunks = wq ? (n / hp) * (long)wq : (n + 3) / 4;
+    // wq > 0: visit only the first wq 4-element chunks of every row of pitch hp (active columns); rb > 0: and
+    // only the rows of the band |ky index| < rb, i.e. y < rb or y > ny - rb  (2 rb - 1 rows)
+    const long nyf = n / hp;
+    const long nrows = (wq && rb && 2L * rb - 1 < nyf) ? 2L * rb - 1 : nyf;
+    const long nchunks = wq ? nrows * (long)wq : (n + 3) / 4;
     for (long base = (long)blockIdx.x * BIN_BLOCK; base < nchunks; base += (long)gridDim.x * BIN_BLOCK) {
         const long cv = base + tid;      // virtual chunk index over the visited region
         const bool cin = cv < nchunks;
         long c = cv;
-        if (wq) { const long r = cv / wq; c = r * (long)(hp >> 2) + (cv - r * wq); }
+        if (wq) {
+            const long r = cv / wq;
+            const long y = (nrows == nyf || r < (long)rb) ? r : nyf - nrows + r;
+            c = y * (long)(hp >> 2) + (cv - r * wq);
+        }
         const long i0 = c * 4;
         int id[4];
         double v[4], cw[4];
@@ -238,10 +245,11 @@ template <typename T>
 static int bin_impl(const void* data, const void* data2, double pnorm, bool power, const int32_t* ids, const void* weights,
                     const double* aux, long n, int nids, int mode,
                     int skip_nan, long hp, int nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
-                    hipStream_t st, int active_cols = 0) {
+                    hipStream_t st, int active_cols = 0, int active_rows = 0) {
     unsigned wq = 0;                                  // 4-element chunks visited per row (0 = whole rows)
     if (active_cols > 0 && nxh >= 0 && hp > 0 && (long)active_cols < hp && n % hp == 0) wq = (unsigned)((active_cols + 3) / 4);
-    const long nchunks = wq ? (n / hp) * (long)wq : (n + 3) / 4;
+    const unsigned rb = (wq && active_rows > 0 && 2L * active_rows - 1 < n / hp) ? (unsigned)active_rows : 0u;
+    const long nchunks = wq ? (rb ? 2L * rb - 1 : n / hp) * (long)wq : (n + 3) / 4;
     int G = (int)((nchunks + BIN_BLOCK - 1) / BIN_BLOCK);
     if (G < 1) G = 1;
     if (G > BIN_GMAX) G = BIN_GMAX;
@@ -257,7 +265,7 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
             OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)smem));                                                                  \
         hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, (const T*)data2, pnorm, ids,       \
-                           (const T*)weights, aux, n, nids, mode, skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, wq,    \
+                           (const T*)weights, aux, n, nids, mode, skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, wq, rb, \
                            part_sum, part_w, part_cnt);                                                              \
     }
     if (weighted && power) OA_BIN_LAUNCH(true, true)
@@ -324,17 +332,17 @@ int oa_bin(int dtype, const void* data, const int32_t* ids, const void* weights,
 
 int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const int32_t* ids, const void* weights, long n,
                  int nids, long herm_pitch, int herm_nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
-                 int active_cols, void* stream) {
+                 int active_cols, int active_rows, void* stream) {
     OA_REQUIRE(k1 && k2 && ids && sums && scratch && n >= 0, "oa_bin_power: bad argument");
     OA_REQUIRE(nids >= 1 && nids <= BIN_MAX_IDS, "oa_bin_power: nids (= nedges+1) must be in [1,1024]");
     OA_REQUIRE(weights ? (wsums != nullptr) : (counts != nullptr), "oa_bin_power: counts (unweighted) / wsums (weighted) required");
     if (herm_nxh >= 0) OA_REQUIRE(herm_pitch > 0 && herm_pitch % 4 == 0, "oa_bin_power: herm_pitch must be a positive multiple of 4");
     if (dtype == OA_F32)
         return bin_impl<float>(k1, k2, norm, true, ids, weights, nullptr, n, nids, 0, 0, herm_pitch, herm_nxh, sums, counts,
-                               wsums, scratch, (hipStream_t)stream, active_cols);
+                               wsums, scratch, (hipStream_t)stream, active_cols, active_rows);
     if (dtype == OA_F64)
         return bin_impl<double>(k1, k2, norm, true, ids, weights, nullptr, n, nids, 0, 0, herm_pitch, herm_nxh, sums, counts,
-                                wsums, scratch, (hipStream_t)stream, active_cols);
+                                wsums, scratch, (hipStream_t)stream, active_cols, active_rows);
     return fail("oa_bin_power: bad dtype");
 }
 

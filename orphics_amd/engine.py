@@ -86,9 +86,10 @@ def dev_bin(data, ids, nids, weights=None, aux=None, mode=0, skip_nan=False, her
     return sums, (counts if weights is None else wsums)
 
 
-def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1, active_cols=0):
+def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1, active_cols=0, active_rows=0):
     """Binned Re(conj k1 k2)*norm without materialising the 2-D power (oa_bin_power).
     ``active_cols`` > 0: visit only those leading columns of each row (planes that vanish beyond them);
+    ``active_rows`` > 0: and only the rows y < active_rows or y > ny - active_rows;
     the returned counts then cover the visited region only."""
     lib = _lib.load()
     n = k1.numel()
@@ -106,7 +107,7 @@ def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1, active_col
     sums = torch.empty(nids, dtype=torch.float64, device=k1.device)
     counts = torch.empty(nids, dtype=torch.int64, device=k1.device)
     check(lib.oa_bin_power(_CODE[prec], _ptr(k1), _ptr(k2), float(norm), _ptr(ids), None, n, int(nids), int(herm_pitch),
-                           int(herm_nxh), _ptr(sums), _ptr(counts), None, _ptr(scr), int(active_cols), _stream()))
+                           int(herm_nxh), _ptr(sums), _ptr(counts), None, _ptr(scr), int(active_cols), int(active_rows), _stream()))
     return sums, counts
 
 
@@ -395,9 +396,9 @@ class Engine(object):
         return dev_bin(data, ids, nids, weights=weights, aux=aux, mode=mode, skip_nan=skip_nan,
                        herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1)
 
-    def bin_power(self, k1, k2, norm, ids, nids, herm=True, active_cols=0):
+    def bin_power(self, k1, k2, norm, ids, nids, herm=True, active_cols=0, active_rows=0):
         return dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=self.kp if herm else 0, herm_nxh=self.nxh if herm else -1,
-                             active_cols=active_cols if herm else 0)
+                             active_cols=active_cols if herm else 0, active_rows=active_rows if herm else 0)
 
     # ---- random fields / accumulators ---------------------------------------------------
     def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):

@@ -84,7 +84,7 @@ class Estimator(object):
         self.grad_cut = grad_cut
         self.cl_grad = {"TT": np.where(ml >= 0, cfun_g("TT", np.abs(ml)), 0.0)}
         self.cl_len = {"TT": np.where(ml >= 0, theory.lCl("TT", np.abs(ml)), 0.0)}
-        self.AL, self.Nlkk, self._F, self._W = {}, {}, {}, {}
+        self.AL, self.Nlkk, self._F, self._W, self._R = {}, {}, {}, {}, {}
         self._work = None
         self._setup_tt()
         if pol:
@@ -124,6 +124,7 @@ class Estimator(object):
         self.R_TT = R
         self._F["TT"] = (self._hcreal(self.eng, Wg), self._hcreal(self.eng, Wh), self._hcreal(self.eng, Fnorm))
         self._W["TT"] = (self._support_cols(Wg, Wh), self._support_cols(Fnorm))
+        self._R["TT"] = (self._support_rows(Wg, Wh), self._support_rows(Fnorm))
 
     def _support_cols(self, *planes):
         """Number of leading hc columns outside which all the given half-plane filters vanish (0 = no pruning)."""
@@ -134,6 +135,26 @@ class Estimator(object):
             nz |= np.any(np.asarray(a) != 0, axis=0)
         w = int(np.nonzero(nz)[0].max()) + 1 if nz.any() else 1
         return 0 if w >= self.nxh + 1 else w
+
+    def _support_rows(self, *planes):
+        """Row band outside which all the given half-plane filters vanish: rows y < rb or y > Ny - rb may be
+        non-zero (rb = 1 + the largest |ky index|); 0 = no pruning."""
+        if not self.prune:
+            return 0
+        Ny = self.shape[-2]
+        nz = np.zeros(Ny, dtype=bool)
+        for a in planes:
+            nz |= np.any(np.asarray(a) != 0, axis=1)
+        if not nz.any():
+            return 1
+        y = np.nonzero(nz)[0]
+        rb = int(np.minimum(y, Ny - y).max()) + 1
+        return 0 if 2 * rb - 1 >= Ny else rb
+
+    @property
+    def kappa_rows(self):
+        """Row band of kappa_hat (``Engine.bin_power(..., active_rows=q.kappa_rows)``)."""
+        return self._R["TT"][1]
 
     def _prep_out(self, out, wk, accumulate=False):
         """Output plane whose columns >= wk (never written by the pruned kernels) are zero."""

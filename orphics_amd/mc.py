@@ -71,7 +71,7 @@ class GaussianN0MonteCarlo(object):
             q.reconstruct_tt_hc(self._kT, out=self._kk)
             # kappa_hat vanishes beyond q.kappa_cols: only those columns are visited; the mode counts are
             # data-independent and were taken over the whole plane in __init__
-            sums, _ = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True, active_cols=q.kappa_cols)
+            sums, _ = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True, active_cols=q.kappa_cols, active_rows=q.kappa_rows)
             counts = self.counts
             # bin means sums/counts of the interior bins are formed inside the accumulation kernel
             check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))

@@ -440,3 +440,8 @@ def test_active_column_pruning_is_exact():
         s_w, c_w = e.bin_power(pr, pr, 1.0, ids, 16, herm=True, active_cols=wk)
         assert float(((s_w[1:-1] - s_full[1:-1]) / s_full[1:-1]).abs().max()) < 10 * tol
         assert bool((c_w[1:-1] <= c_full[1:-1]).all())
+        rk = qp.kappa_rows
+        assert 0 < rk < N // 2 and bool((full[rk:N - rk + 1] == 0).all())        # kappa_hat vanishes outside the row band
+        s_b, c_b = e.bin_power(pr, pr, 1.0, ids, 16, herm=True, active_cols=wk, active_rows=rk)
+        assert float(((s_b[1:-1] - s_full[1:-1]) / s_full[1:-1]).abs().max()) < 10 * tol
+        assert bool((c_b[1:-1] <= c_w[1:-1]).all())

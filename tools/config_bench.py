@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE.json configs that are not bench.py's headline (run on the GPU box):
+   config 3: 8192^2 0.5' full TT/TE/EE/EB/TB minimum-variance reconstruction on one GPU
+   config 4: Monte-Carlo N0 + mean-field on 4096^2 maps (per-GPU rate of the sharded job)
+usage: python tools/config_bench.py [mv|mc|all] [--n N]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from orphics_amd import cosmology, lensing, maps, mc
+from orphics_amd.geometry import FlatGeometry
+
+
+def setup(N, res, pol, prune=True):
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = ((ml > 300) & (ml < 2000)).astype(np.int64)
+    kmask = ((ml > 20) & (ml < 3500)).astype(np.int64)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_P=tmask, noise2d_P=2 * noise, kmask_K=kmask,
+                     pol=pol, unlensed_equals_lensed=True, prune=prune)
+    return shape, g, th, ml, beam, noise, q
+
+
+def timeit(fn, n):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def mv(N=8192, res=0.5):
+    for prune in (True, False):
+        shape, g, th, ml, beam, noise, q = setup(N, res, True, prune)
+        e = q.eng
+        ks = [e.grf_hc(7, i) for i in range(3)]
+        out = e.hc()
+        q.reconstruct_mv_hc(*ks, out=out)                      # builds every estimator's filters / normalisation
+        dt = timeit(lambda: q.reconstruct_mv_hc(*ks, out=out), 10)
+        npieces = sum(len(q._gen[x]["pieces"]) for x in ("TT", "TE", "EE", "EB", "TB") if x in q._gen)
+        print("config 3: %d^2 MV (TT,TE,EE,EB,TB; %d separable leg pieces) prune=%s: %.2f ms per MV reconstruction = %.1f /s"
+              % (N, npieces, prune, dt * 1e3, 1 / dt), flush=True)
+        del q, ks, out
+        torch.cuda.empty_cache()
+
+
+def mcn0(N=4096, res=0.5, nsims=200):
+    shape, g, th, ml, beam, noise, q = setup(N, res, False)
+    nxh = N // 2
+    tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :nxh + 1]
+    edges = np.linspace(20, 3500, 20)
+    for mf in (False, True):
+        drv = mc.GaussianN0MonteCarlo(q, tot, edges, mean_field=mf)
+        drv.run_local(range(5))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        drv.run_local(range(5, 5 + nsims))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nsims
+        print("config 4: %d^2 MC N0%s: %.3f ms per simulated realisation = %.0f sims/s per GPU (1000 sims on 8 GPUs ~ %.2f s)"
+              % (N, " + mean-field stack" if mf else "", dt * 1e3, 1 / dt, 125 * dt), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("mv", "all"):
+        mv()
+    if what in ("mc", "all"):
+        mcn0()
