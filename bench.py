@@ -248,7 +248,7 @@ def main():
         with torch.cuda.stream(streams[j]):
             e = qs[j].eng
             # columns beyond the filters' support are neither produced nor read (exact: the masks zero them)
-            e.rfft(tmaps[i & 1], out=kTs[j], width=wl)
+            e.rfft(tmaps[i & 1], out=kTs[j], width=wl, rband=q.leg_rows)
             qs[j].reconstruct_tt_hc(kTs[j], out=kks[j])
             sums, _ = e.bin_power(kks[j], kks[j], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)   # |kappa_hat|^2 binned in one kernel
             # bin means (bin2D.bin) + ensemble moments (Statistics.add_to_stats) in one small kernel
@@ -325,7 +325,7 @@ def main():
         lib = eng.lib
 
         def legs_only():    # the fused legs + inverse column pass-1 kernel, then 3 x pass 2
-            check(lib.oa_qe_legs_cols(eng.plan, _ptr(kT), _ptr(kT), _ptr(FG), _ptr(FH), _ptr(s1), _ptr(s2), _ptr(s3), wl, _stream()))
+            check(lib.oa_qe_legs_cols(eng.plan, _ptr(kT), _ptr(kT), _ptr(FG), _ptr(FH), _ptr(s1), _ptr(s2), _ptr(s3), wl, q.leg_rows, _stream()))
 
         kern = {
             "row_fft_kernel<R2C>": (lambda: eng.fft_pass(0, r1, s1, wl), (1 + fl) * A, A + fl * Ah, 1),
@@ -337,7 +337,7 @@ def main():
                                                                              fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah, 1),
             "row_qe_kernel": (lambda: eng.qe_rows(s1, s2, s3, s4, s5, win=wl, wout=wk), (10 + 3 * fl + 2 * fk) * A, (3 * fl + 2 * fk) * Ah, 1),
             # ONE 2-plane launch of the first half of the 2 forward column stages + col_div (second half + divergence)
-            "cols_div = col_fft_kernel<pass1 x2 planes> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk),
+            "cols_div = col_fft_kernel<pass1 x2 planes> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk, rband=q.kappa_rows),
                                                                            (4 * fk + 3 * fk) * A, 4 * fk * Ah + fk * (2 * Ah + Ah / 2 + Ah), 1),
             "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows), 2.75 * fk * A, 1.5 * fk * Ah, 1),
         }
@@ -391,7 +391,7 @@ def main():
         if world == 1 and not args.no_extras and not args.no_prune:
             # bandpowers of map 0 through the headline path: the yardstick for the two side measurements
             e0 = qs[0].eng
-            e0.rfft(tmaps[0], out=kTs[0], width=wl)
+            e0.rfft(tmaps[0], out=kTs[0], width=wl, rband=q.leg_rows)
             qs[0].reconstruct_tt_hc(kTs[0], out=kks[0])
             s0, _ = e0.bin_power(kks[0], kks[0], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)
             ref_p1d = s0[1:-1] / counts[1:-1]

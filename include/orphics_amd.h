@@ -70,8 +70,12 @@ int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx);
  * column kx >= width.  A transform told so neither reads nor produces those columns -- same arithmetic on
  * the remaining ones, so results are unchanged; HBM traffic and column-pass work scale with width/(nx/2+1).
  * width <= 0 (or > nx/2+1) means all columns.  r2c: only columns < width of hc_out are written;
- * c2r / inverse cols: columns >= width of the input are taken as zero and never read. */
-int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, void* stream);
+ * c2r / inverse cols: columns >= width of the input are taken as zero and never read.
+ * ACTIVE ROWS (`rband`): the same masks also confine the planes to the row band |ky index| < rband, i.e. rows
+ * y < rband or y > ny - rband.  rband > 0 on oa_fft_r2c: only the band rows hold the transform (the others are left
+ * undefined); on oa_qe_cols_div: rows outside the band are not written;
+ * on oa_qe_legs_cols: input rows outside the band are not read (the filters vanish there).  0 = all rows. */
+int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, int rband, void* stream);
 int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream);
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream);
 /* One constituent pass of the transforms above, for per-kernel timing (bench.py roofline):
@@ -99,9 +103,9 @@ int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* 
  *  oa_qe_cols_div  : oa_fft_cols(forward) of the two oa_qe_rows outputs + oa_qe_div in one go:
  *                    out (+)= Fnorm * (i lx FFT[Px] + i ly FFT[Py]). */
 int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                    int width, void* stream);
+                    int width, int rband, void* stream);
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
-                   int width, void* stream);
+                   int width, int rband, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of

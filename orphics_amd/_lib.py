@@ -29,14 +29,14 @@ SIGNATURES = {
     "oa_plan_kpitch": (c_long, [c_void_p]),
     "oa_plan_scratch_bytes": (c_long, [c_void_p]),
     "oa_plan_set_laxes": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "oa_fft_r2c": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
+    "oa_fft_r2c": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_void_p]),
     "oa_fft_c2r": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
     "oa_fft_c2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_fft_pass": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "oa_fft_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p]),
     "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_int, c_int, c_int, c_void_p]),
-    "oa_qe_legs_cols": (c_int, [c_void_p] * 8 + [c_int, c_void_p]),
-    "oa_qe_cols_div": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "oa_qe_legs_cols": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
+    "oa_qe_cols_div": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
     "oa_hc_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

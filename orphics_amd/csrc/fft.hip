@@ -114,10 +114,10 @@ static Fft2dPlan<T> view(const oa_plan* p) {
 }
 
 template <typename T>
-static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, int width, hipStream_t st) {
+static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, int width, int rband, hipStream_t st) {
     if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->kp * sizeof(cx<T>))) return rc;
     HipLauncher q{st};
-    view<T>(p).r2c(q, (const T*)in, (cx<T>*)out, (cx<T>*)p->scratch, (T)scale, width);
+    view<T>(p).r2c(q, (const T*)in, (cx<T>*)out, (cx<T>*)p->scratch, (T)scale, width, rband);
     return q.rc;
 }
 template <typename T>
@@ -169,22 +169,22 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
 
 template <typename T>
 static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy,
-                          void* h, int width, hipStream_t st) {
+                          void* h, int width, int rband, hipStream_t st) {
     HipLauncher q{st};
     view<T>(p).legs_cols(q, (const cx<T>*)kX, (const cx<T>*)kY, (const T*)FG, (const T*)FH, (const T*)p->lxd,
-                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width);
+                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, rband);
     return q.rc;
 }
 template <typename T>
 static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
-                         int width, hipStream_t st) {
+                         int width, int rband, hipStream_t st) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
     view<T>(p).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
-                        (cx<T>*)out, tA, tB, accumulate, width);
+                        (cx<T>*)out, tA, tB, accumulate, width, rband);
     return q.rc;
 }
 
@@ -195,20 +195,20 @@ using namespace oa;
 extern "C" {
 
 int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                    int width, void* stream) {
+                    int width, int rband, void* stream) {
     OA_REQUIRE(p && kX && kY && FG && FH && gx && gy && h, "oa_qe_legs_cols: NULL argument");
     OA_REQUIRE(p->have_laxes, "oa_qe_legs_cols: call oa_plan_set_laxes first");
     OA_REQUIRE(gx != kX && gy != kX && h != kX && gx != kY && gy != kY && h != kY, "oa_qe_legs_cols: outputs alias inputs");
-    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, (hipStream_t)stream)
-                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream)
+                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream);
 }
 
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
-                   int width, void* stream) {
+                   int width, int rband, void* stream) {
     OA_REQUIRE(p && px_rows && py_rows && Fnorm && out, "oa_qe_cols_div: NULL argument");
     OA_REQUIRE(p->have_laxes, "oa_qe_cols_div: call oa_plan_set_laxes first");
-    return p->dtype == OA_F32 ? cols_div_impl<float>(p, px_rows, py_rows, Fnorm, out, accumulate, width, (hipStream_t)stream)
-                              : cols_div_impl<double>(p, px_rows, py_rows, Fnorm, out, accumulate, width, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? cols_div_impl<float>(p, px_rows, py_rows, Fnorm, out, accumulate, width, rband, (hipStream_t)stream)
+                              : cols_div_impl<double>(p, px_rows, py_rows, Fnorm, out, accumulate, width, rband, (hipStream_t)stream);
 }
 
 int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, int width, void* stream) {
@@ -231,11 +231,11 @@ int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, v
                               : pass_impl<double>(p, pass_id, in, out, width, (hipStream_t)stream);
 }
 
-int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, void* stream) {
+int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, int rband, void* stream) {
     OA_REQUIRE(p && real_in && hc_out, "oa_fft_r2c: NULL argument");
     OA_REQUIRE(real_in != hc_out, "oa_fft_r2c: in-place not supported");
-    return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, width, (hipStream_t)stream)
-                              : r2c_impl<double>(p, real_in, hc_out, scale, width, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, width, rband, (hipStream_t)stream)
+                              : r2c_impl<double>(p, real_in, hc_out, scale, width, rband, (hipStream_t)stream);
 }
 
 int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream) {

@@ -550,6 +550,7 @@ struct ColArgs {
     // select on purpose: a ?: chain over pointer members is turned into an indexed read of the by-value
     // argument struct, which drags the whole struct into scratch memory (2x slower passes)
     long in_off1, in_off2, out_off1, out_off2;
+    int rband, ny;             // rband > 0: output rows outside the band (rband <= y <= ny - rband) are not stored
     long in_pitch, out_pitch;  // complex elements
     int width;                 // valid columns
     int logL, logC, NT;
@@ -584,8 +585,10 @@ struct ColStore {
     const cx<T>* tw;  // LDS table of the inter-pass twiddles W_N^(g k), k < L, or nullptr
     unsigned g;
     T scale;
+    int rb, row0, rowstep, ny;   // rb > 0: rows row0 + k*rowstep inside [rb, ny - rb] are not stored
     template <typename U> OA_HD void put(int k, int c, cx<U> v) const {
         if (c >= ncols) return;
+        if (rb) { const int y = row0 + k * rowstep; if (y >= rb && y <= ny - rb) return; }
         if (tw) v = v * tw[k];
         if (inv) v = swp(v);
         base[(unsigned)k * kstride + (unsigned)c] = v * scale;
@@ -666,6 +669,7 @@ struct ColLegsArgs {
     int logTw;
     long in_gs, in_ns, out_gs, out_ks;
     int twiddle;
+    int rband, ny;   // rband > 0: the filters vanish on input rows rband <= y <= ny - rband, which are not read
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -702,14 +706,16 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             const unsigned i = (unsigned)n * nstr + (unsigned)c;
             cx<T> kx = mk<T>((T)0, (T)0), ky = kx;
             T fg = 0, fh = 0;
-            if (ok) { kx = kXb[i]; ky = kYb[i]; fg = FGb[i]; fh = FHb[i]; }
+            bool live = ok;
+            if (a.rband) { const int y = (int)(g * a.in_gs) + n * (int)a.in_ns; live = ok && !(y >= a.rband && y <= a.ny - a.rband); }
+            if (live) { kx = kXb[i]; ky = kYb[i]; fg = FGb[i]; fh = FHb[i]; }
             gv[u * R0 + t] = kx * fg;
             v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
     }
     {   // H = FH kY
         const ColStore<T> st{a.h + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
-                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1};
+                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
     }
@@ -722,7 +728,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             for (int t = 0; t < R0; ++t) v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * lx);
         }
         const ColStore<T> st{a.gx + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
-                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1};
+                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
     }
@@ -737,7 +743,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             }
         }
         const ColStore<T> st{a.gy + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
-                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1};
+                             a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
     }
 }
@@ -758,6 +764,7 @@ struct ColDivArgs {
     int logTw;
     long in_gs, in_ns, out_gs, out_ks;
     int accumulate;
+    int rband, ny;   // rband > 0: Fn vanishes on output rows rband <= y <= ny - rband, which are not written
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -799,6 +806,7 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
         for (int t = 0; t < RL; ++t) {
             const int k = base + (t << logNs);
             const unsigned y = (unsigned)(g * a.out_gs) + (unsigned)k * (unsigned)a.out_ks;
+            if (a.rband && (int)y >= a.rband && (int)y <= a.ny - a.rband) continue;
             const unsigned i = (unsigned)k * ostr + (unsigned)c;
             cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y]) * Fnb[i];
             if (a.accumulate) d = d + outb[i];
@@ -829,7 +837,7 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     cx<T>* out = a.out + (long)(z & 1) * a.out_off1 + (long)(z >> 1) * a.out_off2;
     const ColLoad<T> ld{in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
     const ColStore<T> st{out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
-                         a.twiddle ? ti : nullptr, (unsigned)g, a.scale};
+                         a.twiddle ? ti : nullptr, (unsigned)g, a.scale, a.rband, (int)(g * a.out_gs), (int)a.out_ks, a.ny};
     fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
 }
 

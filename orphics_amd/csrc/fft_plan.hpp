@@ -42,6 +42,8 @@ struct Fft2dPlan {
 
     // active-column count of an hc plane: <= 0 or too large means all nx/2+1 columns
     int clampw(int w) const { return (w <= 0 || w > nx / 2 + 1) ? nx / 2 + 1 : w; }
+    // row band: rows y < rb or y > ny - rb are active; 0 (or a band covering every row) = all rows
+    int clampr(int rb) const { return (rb <= 0 || 2L * rb - 1 >= ny) ? 0 : rb; }
 
     // ---- row passes -------------------------------------------------------
     template <class Launcher>
@@ -95,7 +97,8 @@ struct Fft2dPlan {
     // with in == out for pass 2 / distinct planes for pass 1) -- small active-column launches fill the chip better
     template <class Launcher>
     void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
-              T scale, int which = 0, int nb = 1, const cx<T>* const* ins = nullptr, cx<T>* const* outs = nullptr) const {
+              T scale, int which = 0, int nb = 1, const cx<T>* const* ins = nullptr, cx<T>* const* outs = nullptr,
+              int rband = 0) const {   // rband: the natural-order result (pass 2) is stored on the band rows only
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -125,14 +128,14 @@ struct Fft2dPlan {
         a.logL = logN2; a.NT = (int)((N2 * C) / EPT); a.st = make_stages(logN2);
         if (a.NT < 1) a.NT = 1;
         a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;
-        a.twiddle = 0; a.scale = scale;
+        a.twiddle = 0; a.scale = scale; a.rband = clampr(rband); a.ny = ny;
         q.col(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), a, nb);
     }
 
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
     template <class Launcher>
     void legs_cols(Launcher& q, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
-                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff) const {
+                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0) const {
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -142,6 +145,7 @@ struct Fft2dPlan {
         a.kX = kX; a.kY = kY; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
         a.pitch = kp; a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
+        a.rband = clampr(rband); a.ny = ny;
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
@@ -152,7 +156,7 @@ struct Fft2dPlan {
     //     tmpA, tmpB: two hc scratch planes
     template <class Launcher>
     void cols_div(Launcher& q, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
-                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff) const {
+                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0) const {
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -165,16 +169,17 @@ struct Fft2dPlan {
         a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = kp; a.width = width;
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
         a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
+        a.rband = clampr(rband); a.ny = ny;
         q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a);
     }
 
     // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane
     template <class Launcher>
     // only the first `wmax` columns of `out` are produced when wmax is given
-    void r2c(Launcher& q, const T* in, cx<T>* out, cx<T>* tmp, T scale, int wmax = 0x7fffffff) const {
+    void r2c(Launcher& q, const T* in, cx<T>* out, cx<T>* tmp, T scale, int wmax = 0x7fffffff, int rband = 0) const {
         const int w = clampw(wmax);
         rows(q, ROW_R2C, in, nx / 2, tmp, kp, (T)1, w);
-        cols(q, tmp, kp, out, kp, w, false, scale);
+        cols(q, tmp, kp, out, kp, w, false, scale, 0, 1, nullptr, nullptr, rband);
     }
     // half-complex -> real; input preserved; tmp: two hc planes (tmp, tmp2)
     template <class Launcher>

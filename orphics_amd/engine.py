@@ -198,13 +198,14 @@ class Engine(object):
         return t
 
     # ---- FFTs ------------------------------------------------------------------
-    def rfft(self, x, scale=1.0, out=None, width=0):
+    def rfft(self, x, scale=1.0, out=None, width=0, rband=0):
         """real (ny,nx) -> hc; unnormalised forward (maps.py:1636).  ``width`` > 0: only the first ``width``
         columns of ``out`` are produced (callers that filter with a band-limited mask; see ACTIVE COLUMNS in
-        include/orphics_amd.h) -- the rest of ``out`` is left untouched."""
+        include/orphics_amd.h) -- the rest of ``out`` is left untouched; ``rband`` > 0: only the rows
+        y < rband or y > ny - rband of those columns hold the transform, the other rows are undefined."""
         self._chk(x, "real")
         out = self.hc() if out is None else self._chk(out, "hc")
-        check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), int(width), _stream()))
+        check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), int(width), int(rband), _stream()))
         return out
 
     def irfft(self, k, scale=None, out=None, width=0):
@@ -241,22 +242,22 @@ class Engine(object):
                                   1 if accumulate else 0, int(win), int(wout), _stream()))
         return px, py
 
-    def qe_legs_cols(self, kX, kY, FG, FH, out, width=0):
+    def qe_legs_cols(self, kX, kY, FG, FH, out, width=0, rband=0):
         """Fused leg filters + inverse column transforms (3 planes out, ready for qe_rows); ``width`` > 0:
         the filters vanish for columns >= width, which are neither read nor produced."""
         self._chk(kX, "hc"); self._chk(kY, "hc"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
         gx, gy, h = out
         for t in out:
             self._chk(t, "hc")
-        check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), int(width), _stream()))
+        check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), int(width), int(rband), _stream()))
         return out
 
-    def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False, width=0):
+    def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False, width=0, rband=0):
         """Fused forward column transforms + divergence * normalisation; ``width`` > 0: only the first
         ``width`` columns of ``out`` are produced (Fnorm vanishes beyond them)."""
         self._chk(px, "hc"); self._chk(py, "hc"); self._chk(Fnorm, "hcreal")
         out = self.hc() if out is None else self._chk(out, "hc")
-        check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, int(width), _stream()))
+        check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, int(width), int(rband), _stream()))
         return out
 
     def fft_pass(self, pass_id, src, dst, width=0):

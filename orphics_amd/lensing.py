@@ -156,22 +156,31 @@ class Estimator(object):
         """Row band of kappa_hat (``Engine.bin_power(..., active_rows=q.kappa_rows)``)."""
         return self._R["TT"][1]
 
-    def _prep_out(self, out, wk, accumulate=False):
-        """Output plane whose columns >= wk (never written by the pruned kernels) are zero."""
+    def _prep_out(self, out, wk, rk=0, accumulate=False):
+        """Output plane whose inactive region (columns >= wk, rows outside the band rk: never written by the
+        pruned kernels) is zero."""
         if out is None:
             return self.eng.hc()                               # zero-initialised
-        if wk and not accumulate and not self._is_clean(out):
-            out[:, wk:] = 0                                    # zeroed once per output plane
-            self._clean[id(out)] = weakref.ref(out)
+        if (wk or rk) and not accumulate and not self._is_clean(out, (wk, rk)):
+            if wk:
+                out[:, wk:] = 0                                # zeroed once per output plane
+            if rk:
+                out[rk:out.shape[0] - rk + 1] = 0
+            self._clean[id(out)] = (weakref.ref(out), (wk, rk))
         return out
 
-    def _is_clean(self, t):
+    def _is_clean(self, t, region):
         r = self._clean.get(id(t))
-        if r is not None and r() is t:
+        if r is not None and r[0]() is t and r[1] == region:
             return True
         if len(self._clean) > 64:
-            self._clean = {k: v for k, v in self._clean.items() if v() is not None}
+            self._clean = {k: v for k, v in self._clean.items() if v[0]() is not None}
         return False
+
+    @property
+    def leg_rows(self):
+        """Row band of the input transform the TT estimator reads (``Engine.rfft(..., rband=q.leg_rows)``)."""
+        return self._R["TT"][0]
 
     @property
     def leg_cols(self):
@@ -278,11 +287,12 @@ class Estimator(object):
             # columns + divergence (2 passes + 1 fused pass): the filtered legs, the real-space planes
             # and the pre-divergence planes never exist in HBM
             wl, wk = self._W["TT"]
-            out = self._prep_out(out, wk)
-            cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"], width=wl)
+            rl, rk = self._R["TT"]
+            out = self._prep_out(out, wk, rk)
+            cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"], width=wl, rband=rl)
             Gx, Gy, _ = w["G"]
             e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk)
-            return e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk)
+            return e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk)
         Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
         gx, gy, h = self._real_buffers()
         e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
@@ -487,7 +497,8 @@ class Estimator(object):
                 pieces.append((cg * sg, self._hcreal(self.eng, fg), self._hcreal(self.eng, fh), p == 2))
                 hostf += [fg, fh]
         self._gen[XY] = dict(pieces=pieces, Fnorm=self._hcreal(self.eng, Fnorm), R=R,
-                             wl=self._support_cols(*hostf), wk=self._support_cols(Fnorm))
+                             wl=self._support_cols(*hostf), wk=self._support_cols(Fnorm),
+                             rl=self._support_rows(*hostf), rk=self._support_rows(Fnorm))
         return self._gen[XY]
 
     def reconstruct_hc(self, XY, kX, kY, out=None, norm=None, accumulate=False):
@@ -506,14 +517,15 @@ class Estimator(object):
         # ``norm`` plane -- MV weights -- is bounded by the kappa mask)
         wl = G["wl"]
         if norm is not None and getattr(self, "_wK", None) is None:
-            self._wK = self._support_cols(self.mask_K)
-        wk = G["wk"] if norm is None else self._wK
-        out = self._prep_out(out, wk, accumulate)
+            self._wK = (self._support_cols(self.mask_K), self._support_rows(self.mask_K))
+        wk, rk = (G["wk"], G["rk"]) if norm is None else self._wK
+        rl = G["rl"]
+        out = self._prep_out(out, wk, rk, accumulate)
         for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
             kg, kh = (kY, kX) if swap else (kX, kY)
-            e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch), width=wl)
+            e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch), width=wl, rband=rl)
             e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0), win=wl, wout=wk)
-        return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk)
+        return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk, rband=rk)
 
     # ---- minimum-variance combination (BASELINE config 3) -------------------------------------------
     def mv_weights(self, estimators=("TT", "TE", "EE", "EB", "TB")):
@@ -626,7 +638,7 @@ class BandlimitedEstimator(object):
         """Real full-resolution map in: only the columns the leg filters keep are transformed, then cropped."""
         if getattr(self, "_kbig", None) is None:
             self._kbig = self.big.hc()
-        self.big.rfft(tmap, out=self._kbig, width=self.q.leg_cols)
+        self.big.rfft(tmap, out=self._kbig, width=self.q.leg_cols, rband=self.q.leg_rows)
         return self.reconstruct_tt_hc(self._kbig, out=out)
 
     def kappa_full_hc(self, kappa_small):

@@ -91,11 +91,11 @@ struct Holder {
 };
 
 template <typename T>
-static int do_r2c(int ny, int nx, const T* in, cx<T>* out, double scale, int width = 0) {
+static int do_r2c(int ny, int nx, const T* in, cx<T>* out, double scale, int width = 0, int rband = 0) {
     Holder<T> h(ny, nx);
     std::vector<cx<T>> tmp((size_t)ny * h.p.kp);
     EmuLauncher q;
-    h.p.r2c(q, in, out, tmp.data(), (T)scale, width);
+    h.p.r2c(q, in, out, tmp.data(), (T)scale, width, rband);
     return 0;
 }
 template <typename T>
@@ -126,19 +126,19 @@ static int do_qe_rows(int ny, int nx, const cx<T>* gx, const cx<T>* gy, const cx
 
 template <typename T>
 static int do_legs_cols(int ny, int nx, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
-                        cx<T>* gx, cx<T>* gy, cx<T>* h, int width = 0) {
+                        cx<T>* gx, cx<T>* gy, cx<T>* h, int width = 0, int rband = 0) {
     Holder<T> hd(ny, nx);
     EmuLauncher q;
-    hd.p.legs_cols(q, kX, kY, FG, FH, lxd, lyd, gx, gy, h, width);
+    hd.p.legs_cols(q, kX, kY, FG, FH, lxd, lyd, gx, gy, h, width, rband);
     return 0;
 }
 template <typename T>
 static int do_cols_div(int ny, int nx, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
-                       int width = 0) {
+                       int width = 0, int rband = 0) {
     Holder<T> hd(ny, nx);
     std::vector<cx<T>> tA((size_t)ny * hd.p.kp), tB((size_t)ny * hd.p.kp);
     EmuLauncher q;
-    hd.p.cols_div(q, pa, pb, Fn, lxd, lyd, out, tA.data(), tB.data(), 0, width);
+    hd.p.cols_div(q, pa, pb, Fn, lxd, lyd, out, tA.data(), tB.data(), 0, width, rband);
     return 0;
 }
 
@@ -159,19 +159,19 @@ int emu_qe_rows_f64(int ny, int nx, const void* gx, const void* gy, const void* 
     return do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s);
 }
 // active-column variants (width / win / wout as in include/orphics_amd.h)
-int emu_r2c_w_f64(int ny, int nx, const double* in, void* out, double s, int width) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s, width); }
+int emu_r2c_w_f64(int ny, int nx, const double* in, void* out, double s, int width, int rband) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s, width, rband); }
 int emu_c2r_w_f64(int ny, int nx, const void* in, double* out, double s, int width) { return do_c2r<double>(ny, nx, (const cx<double>*)in, out, s, width); }
 int emu_qe_rows_w_f64(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout) {
     return do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s, win, wout);
 }
 int emu_legs_cols_w_f64(int ny, int nx, const void* kX, const void* kY, const double* FG, const double* FH, const double* lxd,
-                        const double* lyd, void* gx, void* gy, void* h, int width) {
+                        const double* lyd, void* gx, void* gy, void* h, int width, int rband) {
     return do_legs_cols<double>(ny, nx, (const cx<double>*)kX, (const cx<double>*)kY, FG, FH, lxd, lyd, (cx<double>*)gx,
-                                (cx<double>*)gy, (cx<double>*)h, width);
+                                (cx<double>*)gy, (cx<double>*)h, width, rband);
 }
 int emu_cols_div_w_f64(int ny, int nx, const void* pa, const void* pb, const double* Fn, const double* lxd, const double* lyd,
-                       void* out, int width) {
-    return do_cols_div<double>(ny, nx, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out, width);
+                       void* out, int width, int rband) {
+    return do_cols_div<double>(ny, nx, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out, width, rband);
 }
 long emu_kpitch(int nx) { return kpitch_for(nx); }
 int emu_r2c_f32(int ny, int nx, const float* in, void* out, double s) { return do_r2c<float>(ny, nx, in, (cx<float>*)out, s); }

@@ -72,10 +72,18 @@ def test_active_columns_r2c_c2r(emu, ny, nx, w):
     full = _hc(emu, ny, nx)
     emu.emu_r2c_f64(ny, nx, _p(x), _p(full), ctypes.c_double(1.0))
     part = _hc(emu, ny, nx, fill=99.0)
-    assert emu.emu_r2c_w_f64(ny, nx, _p(x), _p(part), ctypes.c_double(1.0), w) == 0
+    assert emu.emu_r2c_w_f64(ny, nx, _p(x), _p(part), ctypes.c_double(1.0), w, 0) == 0
     wv = min(w, nx // 2 + 1)
     assert np.array_equal(part[:, :wv], full[:, :wv])
     assert np.all(part[:, wv:] == 99.0)
+    # + row band: only rows y < rb or y > ny - rb of the leading columns are produced
+    rb = max(2, ny // 8)
+    band = np.r_[0:rb, ny - rb + 1:ny]
+    off = np.r_[rb:ny - rb + 1]
+    part2 = _hc(emu, ny, nx, fill=99.0)
+    assert emu.emu_r2c_w_f64(ny, nx, _p(x), _p(part2), ctypes.c_double(1.0), w, rb) == 0
+    assert np.array_equal(part2[band][:, :wv], full[band][:, :wv])
+    assert np.all(part2[:, wv:] == 99.0)                  # rows outside the band hold pass-1 intermediates: undefined
     k = _hc(emu, ny, nx)
     k[:, :nx // 2 + 1] = _band_limited(rng, ny, nx, wv)
     ref = np.fft.irfft2(k[:, :nx // 2 + 1], s=(ny, nx))
@@ -121,8 +129,8 @@ def test_fused_row_stage(emu, ny, nx, win, wout):
             assert np.all(got[:, wo:W] == 5.0)                    # untouched
 
 
-@pytest.mark.parametrize("ny,nx,w", [(64, 64, 0), (64, 128, 21), (128, 64, 32), (256, 64, 7)])
-def test_fused_column_stages(emu, ny, nx, w):
+@pytest.mark.parametrize("ny,nx,w,rb", [(64, 64, 0, 0), (64, 128, 21, 0), (128, 64, 32, 9), (256, 64, 7, 40), (64, 64, 0, 5)])
+def test_fused_column_stages(emu, ny, nx, w, rb):
     """col_legs (+ pass 2) = inverse column transforms of (i lx FG kX, i ly FG kX, FH kY);
     col_div (after 2 pass-1 launches) = Fn * (i lx FFTcol[A] + i ly FFTcol[B]); both with active widths."""
     rng = np.random.default_rng(5 + ny + w)
@@ -141,10 +149,14 @@ def test_fused_column_stages(emu, ny, nx, w):
     FG[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
     FH[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
     Fn[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
+    off = np.r_[rb:ny - rb + 1] if rb else np.zeros(0, dtype=int)
+    FG[off] = 0; FH[off] = 0; Fn[off] = 0                # filters vanish outside the row band ...
+    kXg, kYg = kX.copy(), kY.copy()
+    kXg[off] = 1e30; kYg[off] = 1e30                     # ... where the inputs must never be read
     outs = [_hc(emu, ny, nx, fill=3.0) for _ in range(3)]
     lxh = np.ascontiguousarray(lxd)                     # the kernel indexes lxd by column (first W entries used)
-    assert emu.emu_legs_cols_w_f64(ny, nx, _p(kX), _p(kY), _p(FG), _p(FH), _p(lxh), _p(lyd), _p(outs[0]), _p(outs[1]),
-                                   _p(outs[2]), w) == 0
+    assert emu.emu_legs_cols_w_f64(ny, nx, _p(kXg), _p(kYg), _p(FG), _p(FH), _p(lxh), _p(lyd), _p(outs[0]), _p(outs[1]),
+                                   _p(outs[2]), w, rb) == 0
     lx2, ly2 = lxd[None, :W], lyd[:, None]
     refs = [_col_ifft(1j * lx2 * FG[:, :W] * kX[:, :W], ny), _col_ifft(1j * ly2 * FG[:, :W] * kX[:, :W], ny),
             _col_ifft(FH[:, :W] * kY[:, :W], ny)]
@@ -156,8 +168,11 @@ def test_fused_column_stages(emu, ny, nx, w):
     A[:, :W] = rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W))
     B[:, :W] = rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W))
     out = _hc(emu, ny, nx, fill=3.0)
-    assert emu.emu_cols_div_w_f64(ny, nx, _p(A), _p(B), _p(Fn), _p(lxh), _p(lyd), _p(out), w) == 0
+    assert emu.emu_cols_div_w_f64(ny, nx, _p(A), _p(B), _p(Fn), _p(lxh), _p(lyd), _p(out), w, rb) == 0
     want = Fn[:, :W] * (1j * lx2 * np.fft.fft(A[:, :W], axis=0) + 1j * ly2 * np.fft.fft(B[:, :W], axis=0))
-    assert np.abs(out[:, :wv] - want[:, :wv]).max() < 1e-11 * np.abs(want).max()
+    on = np.setdiff1d(np.arange(ny), off)
+    assert np.abs(out[on][:, :wv] - want[on][:, :wv]).max() < 1e-11 * np.abs(want).max()
     if w:
         assert np.all(out[:, wv:W] == 3.0)
+    if rb:
+        assert np.all(out[off] == 3.0)                    # rows outside the band are not written

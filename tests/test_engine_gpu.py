@@ -235,7 +235,7 @@ def test_error_behaviour_is_loud():
     assert lib.oa_plan_create(100, 64, 0, ctypes.byref(h)) != 0 and b"powers of two" in lib.oa_last_error()
     assert lib.oa_plan_create(16, 64, 0, ctypes.byref(h)) != 0 and b">= 32" in lib.oa_last_error()
     assert lib.oa_plan_create(64, 64, 7, ctypes.byref(h)) != 0 and b"dtype" in lib.oa_last_error()
-    assert lib.oa_fft_r2c(e.plan, None, None, 1.0, 0, None) != 0 and b"NULL" in lib.oa_last_error()
+    assert lib.oa_fft_r2c(e.plan, None, None, 1.0, 0, 0, None) != 0 and b"NULL" in lib.oa_last_error()
     x = torch.zeros(64, 64, device="cuda")
     assert lib.oa_bin(0, ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), None, None, 10, 5000, 0, 0, 0, -1,
                       ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(x.data_ptr()), None) != 0

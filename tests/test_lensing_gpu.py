@@ -419,6 +419,13 @@ def test_active_column_pruning_is_exact():
         kTw = e.hc(); kTw[:] = 7.0
         e.rfft(x, out=kTw, width=wl)
         assert torch.equal(kTw[:, :wl], kT[:, :wl]) and bool((kTw[:, wl:] == 7.0).all())
+        rl = qp.leg_rows
+        assert 0 < rl < N // 2
+        kTw[:] = 7.0
+        e.rfft(x, out=kTw, width=wl, rband=rl)             # band rows of the leading columns only
+        band = np.r_[0:rl, N - rl + 1:N]
+        assert torch.equal(kTw[band][:, :wl], kT[band][:, :wl]) and bool((kTw[:, wl:] == 7.0).all())
+        kTw[rl:N - rl + 1] = 1e30                            # whatever sits outside the band must never be read
         full = qf.reconstruct_tt_hc(kT).clone()
         dirty = e.hc(); dirty[:] = 3.0
         pr = qp.reconstruct_tt_hc(kTw, out=dirty)          # garbage beyond wl in the input, garbage in `out`
