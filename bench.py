@@ -112,15 +112,14 @@ def dense_leg(P, args, torch, tmaps, ref_p1d, norm):
     ns = max(1, args.streams)
     qs = [q] + [q.fork() for _ in range(ns - 1)]
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
-    kTs, kks = [e.eng.hc() for e in qs], [e.eng.hc() for e in qs]
+    kks = [e.eng.hc() for e in qs]
     res = {}
 
     def step(i):
         j = i % ns
         with torch.cuda.stream(streams[j]):
             e = qs[j].eng
-            e.rfft(tmaps[i & 1], out=kTs[j])
-            qs[j].reconstruct_tt_hc(kTs[j], out=kks[j])
+            qs[j].reconstruct_tt_from_map(tmaps[i & 1], out=kks[j])
             res[i & 1] = e.bin_power(kks[j], kks[j], norm, P["ids"], P["nids"], herm=True)
     dt = timed_steps(torch, step, args.steps)
     step(0)
@@ -247,9 +246,9 @@ def main():
         j = i % ns
         with torch.cuda.stream(streams[j]):
             e = qs[j].eng
-            # columns beyond the filters' support are neither produced nor read (exact: the masks zero them)
-            e.rfft(tmaps[i & 1], out=kTs[j], width=wl, rband=q.leg_rows)
-            qs[j].reconstruct_tt_hc(kTs[j], out=kks[j])
+            # map -> kappa_hat: columns / rows beyond the filters' support are neither produced nor read (exact: the
+            # masks zero them); the map's transform is consumed inside the fused leg kernel
+            qs[j].reconstruct_tt_from_map(tmaps[i & 1], out=kks[j])
             sums, _ = e.bin_power(kks[j], kks[j], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)   # |kappa_hat|^2 binned in one kernel
             # bin means (bin2D.bin) + ensemble moments (Statistics.add_to_stats) in one small kernel
             check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), d, _ptr(mom_n[j]), _ptr(mom_S[j]), _ptr(mom_C[j]), _stream()))
@@ -324,17 +323,17 @@ def main():
         FG, FH, Fn = q._F["TT"]
         lib = eng.lib
 
-        def legs_only():    # the fused legs + inverse column pass-1 kernel, then 3 x pass 2
-            check(lib.oa_qe_legs_cols(eng.plan, _ptr(kT), _ptr(kT), _ptr(FG), _ptr(FH), _ptr(s1), _ptr(s2), _ptr(s3), wl, q.leg_rows, _stream()))
+        def map_legs():     # row R2C + forward column pass 1 + fused (forward pass 2, legs, inverse pass 1) + 3-plane pass 2
+            eng.qe_map_legs_cols(tmaps[0], FG, FH, out=(s1, s2, s3), width=wl, rband=q.leg_rows)
 
         kern = {
             "row_fft_kernel<R2C>": (lambda: eng.fft_pass(0, r1, s1, wl), (1 + fl) * A, A + fl * Ah, 1),
             "col_fft_kernel<pass1,legs-width>": (lambda: eng.fft_pass(1, s1, s2, wl), fl * A, 2 * fl * Ah, 1),
-            "col_fft_kernel<pass2,legs-width>": (lambda: eng.fft_pass(2, s1, s2, wl), fl * A, 2 * fl * Ah, 1),
-            # col_legs (filter multiply: read kT, write 3 legs; first half of the 3 inverse column stages) + ONE
-            # 3-plane launch of the second half
-            "legs_cols = col_legs_kernel + col_fft_kernel<pass2 x3 planes>": (legs_only, (4 * fl + 6 * fl) * A,
-                                                                             fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah, 1),
+            # whole C-ABI call oa_qe_map_legs_cols = the two entries above + col_fwdlegs_kernel (second half of the
+            # forward column stage, filter multiply, first half of the 3 inverse column stages) + ONE 3-plane launch
+            # of their second half
+            "map_legs_cols (whole call)": (map_legs, (1 + fl) * A + 2 * fl * A + (4 * fl + 6 * fl) * A,
+                                           A + fl * Ah + 2 * fl * Ah + fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah, 1),
             "row_qe_kernel": (lambda: eng.qe_rows(s1, s2, s3, s4, s5, win=wl, wout=wk), (10 + 3 * fl + 2 * fk) * A, (3 * fl + 2 * fk) * Ah, 1),
             # ONE 2-plane launch of the first half of the 2 forward column stages + col_div (second half + divergence)
             "cols_div = col_fft_kernel<pass1 x2 planes> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk, rband=q.kappa_rows),
@@ -347,6 +346,15 @@ def main():
             share[name] = dt * 1e3 * count
             per[name] = {"avg_ms": dt * 1e3, "launches_per_recon": count, "algorithmic_GB": alg / 1e9,
                          "hbm_min_GB": actual / 1e9, "achieved_GBs": alg / dt / 1e9, "achieved_actual_GBs": actual / dt / 1e9}
+        whole = "map_legs_cols (whole call)"
+        t_fl = max(per[whole]["avg_ms"] - per["row_fft_kernel<R2C>"]["avg_ms"] - per["col_fft_kernel<pass1,legs-width>"]["avg_ms"], 1e-6)
+        name_fl = "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<pass2 x3 planes>"
+        a_fl, m_fl = (fl + 4 * fl + 6 * fl) * A, fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah
+        per[name_fl] = {"avg_ms": t_fl, "launches_per_recon": 1, "algorithmic_GB": a_fl / 1e9, "hbm_min_GB": m_fl / 1e9,
+                        "achieved_GBs": a_fl / t_fl / 1e6, "achieved_actual_GBs": m_fl / t_fl / 1e6,
+                        "derived": "whole call minus its row and pass-1 launches"}
+        share[name_fl] = t_fl
+        del share[whole]
         dom = max(share, key=share.get)
         d_alg, d_act, d_t = per[dom]["algorithmic_GB"] * 1e9, per[dom]["hbm_min_GB"] * 1e9, per[dom]["avg_ms"]
         traffic = None
@@ -391,8 +399,7 @@ def main():
         if world == 1 and not args.no_extras and not args.no_prune:
             # bandpowers of map 0 through the headline path: the yardstick for the two side measurements
             e0 = qs[0].eng
-            e0.rfft(tmaps[0], out=kTs[0], width=wl, rband=q.leg_rows)
-            qs[0].reconstruct_tt_hc(kTs[0], out=kks[0])
+            qs[0].reconstruct_tt_from_map(tmaps[0], out=kks[0])
             s0, _ = e0.bin_power(kks[0], kks[0], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)
             ref_p1d = s0[1:-1] / counts[1:-1]
             out["extra"] = {"dense": dense_leg(P, args, torch, tmaps, ref_p1d, norm),

@@ -104,6 +104,12 @@ int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* 
  *                    out (+)= Fnorm * (i lx FFT[Px] + i ly FFT[Py]). */
 int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                     int width, int rband, void* stream);
+/* oa_qe_map_legs_cols: oa_fft_r2c + oa_qe_legs_cols for the common case that BOTH legs come from one real map
+ * (kappa_from_map("TT", T), lensing.py:973): the forward column pass 2, the leg filters and the inverse column
+ * pass 1 run in one kernel -- the map's transform kT never exists in HBM.  Same outputs as
+ * oa_qe_legs_cols(plan, kT, kT, ...). */
+int oa_qe_map_legs_cols(oa_plan* p, const void* real_map, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                        int width, int rband, void* stream);
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
                    int width, int rband, void* stream);
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "oa_fft_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p]),
     "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_int, c_int, c_int, c_void_p]),
     "oa_qe_legs_cols": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
+    "oa_qe_map_legs_cols": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
     "oa_qe_cols_div": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
     "oa_hc_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -80,6 +80,11 @@ struct HipLauncher {
         rc = launch_col_legs<T>(st, gx, gy, nt, smem, logL, a);   // separate translation unit (fft_legs.hip)
     }
     template <typename T>
+    void col_fwdlegs(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a) {
+        if (rc) return;
+        rc = launch_col_fwdlegs<T>(st, gx, gy, nt, smem, logL, a);
+    }
+    template <typename T>
     void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
         const bool ok = dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
@@ -175,6 +180,30 @@ static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void
                          (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, rband);
     return q.rc;
 }
+// real map -> the three column-transformed leg planes (both legs from this one map)
+template <typename T>
+static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                              int width, int rband, hipStream_t st) {
+    const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
+    if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
+    HipLauncher q{st};
+    auto f = view<T>(p);
+    cx<T>* tA = (cx<T>*)p->scratch;
+    cx<T>* tB = tA + (size_t)p->ny * p->kp;
+    const int w = f.clampw(width);
+    f.rows(q, ROW_R2C, map, p->nx / 2, tA, p->kp, (T)1, w);
+    if (Fft2dPlan<T>::has_fwdlegs(p->logNy)) {
+        f.cols(q, tA, p->kp, tB, p->kp, w, false, (T)1, 1);                       // forward pass 1 only
+        f.legs_cols_from_pass1(q, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
+                               (cx<T>*)gy, (cx<T>*)h, width, rband);
+    } else {
+        f.cols(q, tA, p->kp, tB, p->kp, w, false, (T)1, 0, 1, nullptr, nullptr, rband);
+        f.legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
+                    (cx<T>*)h, width, rband);
+    }
+    return q.rc;
+}
+
 template <typename T>
 static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
                          int width, int rband, hipStream_t st) {
@@ -201,6 +230,15 @@ int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, 
     OA_REQUIRE(gx != kX && gy != kX && h != kX && gx != kY && gy != kY && h != kY, "oa_qe_legs_cols: outputs alias inputs");
     return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream)
                               : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream);
+}
+
+int oa_qe_map_legs_cols(oa_plan* p, const void* real_map, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                        int width, int rband, void* stream) {
+    OA_REQUIRE(p && real_map && FG && FH && gx && gy && h, "oa_qe_map_legs_cols: NULL argument");
+    OA_REQUIRE(p->have_laxes, "oa_qe_map_legs_cols: call oa_plan_set_laxes first");
+    OA_REQUIRE(gx != gy && gx != h && gy != h, "oa_qe_map_legs_cols: outputs alias each other");
+    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, real_map, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream)
+                              : map_legs_cols_impl<double>(p, real_map, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream);
 }
 
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,

@@ -749,6 +749,113 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
 }
 
 // ===========================================================================
+// (A') the same with the FORWARD column pass 2 of the input map in front: when both legs come from one real map,
+//      kT itself never exists in HBM.  The forward column transform is split Ny = N1f * L (pass 1: N1f points,
+//      pass 2: L points, L = 2^floor(log2(Ny)/2)); its pass-2 tile of group g holds exactly the rows g + N1f*n that
+//      an inverse transform split the other way round (pass 1: L points at stride N1f, pass 2: N1f points) needs
+//      for ITS pass 1.  The inverse pipelines run the REVERSED radix sequence, so the forward result (last radix
+//      RL, bins j + t*L/RL in register t) is already the operand layout of their first stage (same trick as the
+//      fused row stage).  in = output of the forward column pass 1 (block-transposed, twiddled).
+// ===========================================================================
+template <class SEQ> struct RevSeq {
+    using type = Seq<SEQ::rget(0), (SEQ::n > 1 ? SEQ::rget(1) : 1), (SEQ::n > 2 ? SEQ::rget(2) : 1), (SEQ::n > 3 ? SEQ::rget(3) : 1)>;
+};
+
+template <typename T>
+struct ColFwdLegsArgs {
+    const cx<T>* in;            // forward pass-1 output of the map's row transform
+    const T* FG; const T* FH;
+    const T* lxd; const T* lyd;
+    cx<T>* gx; cx<T>* gy; cx<T>* h;
+    long pitch;
+    int width;
+    const cx<T>* tw;            // W_Ny^k
+    int logTw;
+    long n1f;                   // row stride of the tile: rows g + n1f * n, n < L
+    int rband, ny;
+};
+
+template <typename T, class SEQF, class Ctx>
+OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
+    using SEQI = typename RevSeq<SEQF>::type;
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    constexpr int logL = seq_total_log<SEQF>();
+    constexpr int RL = SEQF::get(SEQF::n - 1), LRL = Log2x<RL>::v, NB = EPT / RL;
+    constexpr int logNs = logL - LRL;
+    constexpr int logC = COL_LOGC;
+    constexpr int NT = ((1 << (logL + COL_LOGC)) / EPT) > 0 ? ((1 << (logL + COL_LOGC)) / EPT) : 1;
+    static_assert(SEQI::get(0) == RL, "inverse pipelines must start with the forward pipeline's last radix");
+    const int tid = ctx.tid();
+    const int c0 = ctx.bid_x() << logC;
+    const long g = ctx.bid_y();
+    int ncols = a.width - c0;
+    if (ncols > (1 << logC)) ncols = 1 << logC;
+    cx<T> gv[EPT], v[EPT];
+    cx<T>* twl = s + (1 << (logL + logC));
+    cx<T>* ti = twl + tw_lds_size(logL);
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    for (int i = tid; i < (1 << logL); i += NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];   // inverse inter-pass W_Ny^(g k)
+    ctx.sync();
+    const long org = g * a.pitch + c0;
+    const unsigned rstr = (unsigned)(a.n1f * a.pitch);
+    // forward pass 2 of this tile, result left in registers: gv[u*RL+t] = kT[row g + n1f*(j_u + t*Ns)][c]
+    const ColLoad<T> ld{a.in + org, rstr, ncols, false};
+    col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, logC, twl, logL, ld);
+    ctx.sync();
+    const T* FGb = a.FG + org; const T* FHb = a.FH + org;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b & ((1 << logC) - 1), j = b >> logC;
+        const bool ok = c < ncols;
+#pragma unroll
+        for (int t = 0; t < RL; ++t) {
+            const int k = j + (t << logNs);
+            const unsigned i = (unsigned)k * rstr + (unsigned)c;
+            T fg = 0, fh = 0;
+            bool live = ok;
+            if (a.rband) { const int y = (int)g + k * (int)a.n1f; live = ok && !(y >= a.rband && y <= a.ny - a.rband); }
+            if (live) { fg = FGb[i]; fh = FHb[i]; }
+            const cx<T> kx = gv[u * RL + t];
+            gv[u * RL + t] = kx * fg;
+            v[u * RL + t] = swp(kx * fh);
+        }
+    }
+    // inverse pass 1 (length L, input stride n1f): outputs block-transposed at rows g*L + k, twiddled by W_Ny^(g k)
+    const long oorg = g * ((long)1 << logL) * a.pitch + c0;
+    {   // H = FH kT
+        const ColStore<T> st{a.h + oorg, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
+        col_pipeline_from_regs<T, SEQI>(ctx, s, v, tid, NT, logC, twl, logL, st);
+        ctx.sync();
+    }
+    {   // Gx = i lx FG kT
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = (tid + u * NT) & ((1 << logC) - 1);
+            const T lx = (c < ncols) ? a.lxd[c0 + c] : (T)0;
+#pragma unroll
+            for (int t = 0; t < RL; ++t) v[u * RL + t] = swp(mul_pi(gv[u * RL + t]) * lx);
+        }
+        const ColStore<T> st{a.gx + oorg, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
+        col_pipeline_from_regs<T, SEQI>(ctx, s, v, tid, NT, logC, twl, logL, st);
+        ctx.sync();
+    }
+    {   // Gy = i ly FG kT
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int j = (tid + u * NT) >> logC;
+#pragma unroll
+            for (int t = 0; t < RL; ++t) {
+                const unsigned y = (unsigned)g + (unsigned)(j + (t << logNs)) * (unsigned)a.n1f;
+                v[u * RL + t] = swp(mul_pi(gv[u * RL + t]) * a.lyd[y]);
+            }
+        }
+        const ColStore<T> st{a.gy + oorg, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
+        col_pipeline_from_regs<T, SEQI>(ctx, s, v, tid, NT, logC, twl, logL, st);
+    }
+}
+
+// ===========================================================================
 // (B) divergence * normalisation fused into the forward column pass 2:
 //     out = Fn * (i lx FFTcol[A] + i ly FFTcol[B])   (+ out if accumulate)
 // ===========================================================================

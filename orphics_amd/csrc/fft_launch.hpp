@@ -59,5 +59,7 @@ inline void launch_go(int& rc, hipStream_t st, K kern, dim3 grid, int nt, size_t
 // independent global loads schedule better around compiler-visible arithmetic)
 template <typename T>
 int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a);
+template <typename T>
+int launch_col_fwdlegs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a);
 
 }  // namespace oa

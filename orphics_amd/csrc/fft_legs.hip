@@ -27,6 +27,30 @@ int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int log
     return rc;
 }
 
+template <typename T, class SEQ>
+__global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_fwdlegs_kernel(ColFwdLegsArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_fwdlegs_body<T, SEQ>(c, a);
+}
+
+template <typename T>
+int launch_col_fwdlegs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a) {
+    int rc = 0;
+    const bool ok = dispatch_seq(logL, [&](auto seq) {
+        using S = decltype(seq);
+        if constexpr (seq_logl<S>() >= 5 && seq_logl<S>() <= 7) {
+            if (nt > col_maxnt<S>()) { rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
+            launch_go(rc, st, col_fwdlegs_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+        } else {
+            rc = fail("fft: unsupported column sub-length");
+        }
+    });
+    if (!ok && !rc) rc = fail("fft: unsupported column length");
+    return rc;
+}
+
+template int launch_col_fwdlegs<float>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsArgs<float>&);
+template int launch_col_fwdlegs<double>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsArgs<double>&);
 template int launch_col_legs<float>(hipStream_t, int, int, int, size_t, int, const ColLegsArgs<float>&);
 template int launch_col_legs<double>(hipStream_t, int, int, int, size_t, int, const ColLegsArgs<double>&);
 

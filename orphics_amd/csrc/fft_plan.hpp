@@ -98,8 +98,9 @@ struct Fft2dPlan {
     template <class Launcher>
     void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
               T scale, int which = 0, int nb = 1, const cx<T>* const* ins = nullptr, cx<T>* const* outs = nullptr,
-              int rband = 0) const {   // rband: the natural-order result (pass 2) is stored on the band rows only
-        const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
+              int rband = 0, bool swap = false) const {   // rband: the natural-order result (pass 2) is stored on the band rows only
+        // swap: split Ny the other way round (pass 1 the SHORTER length) -- the inverse after legs_cols_from_pass1
+        const int logN1 = swap ? logNy / 2 : (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
         const int tiles = (width + C - 1) / C;
@@ -150,6 +151,29 @@ struct Fft2dPlan {
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
         cols(q, gx, kp, gx, kp, width, true, (T)1, 2, 3, ins, outs);      // pass 2 of the three planes, one launch
+    }
+
+    // (A') legs straight from the forward column pass 1 of the map's row transform (both legs from ONE map):
+    //      forward pass 2 + filters + inverse pass 1 in one kernel, then the 3-plane inverse pass 2.
+    //      Returns false when this geometry has no fused kernel (caller falls back to cols + legs_cols).
+    static bool has_fwdlegs(int logNy) { return logNy / 2 >= 5 && logNy / 2 <= 7; }
+    template <class Launcher>
+    bool legs_cols_from_pass1(Launcher& q, const cx<T>* p1, const T* FG, const T* FH, const T* lxd, const T* lyd,
+                              cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0) const {
+        if (!has_fwdlegs(logNy)) return false;
+        const int logL = logNy / 2, logN1f = logNy - logL;
+        const long L = 1L << logL, N1f = 1L << logN1f;
+        const int C = 1 << COLC;
+        const int width = clampw(wmax);
+        const int tiles = (width + C - 1) / C;
+        ColFwdLegsArgs<T> a{};
+        a.in = p1; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
+        a.pitch = kp; a.width = width; a.tw = tw_y; a.logTw = logNy; a.n1f = N1f; a.rband = clampr(rband); a.ny = ny;
+        q.col_fwdlegs(tiles, (int)N1f, (int)((L * C) / EPT), ((size_t)L * C + tw_lds_size(logL) + L) * sizeof(cx<T>), logL, a);
+        cx<T>* outs[3] = {gx, gy, h};
+        const cx<T>* ins[3] = {gx, gy, h};
+        cols(q, gx, kp, gx, kp, width, true, (T)1, 2, 3, ins, outs, 0, true);   // inverse pass 2, split swapped
+        return true;
     }
 
     // (B) forward column transforms of two row-transformed planes + divergence * Fnorm

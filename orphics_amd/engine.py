@@ -252,6 +252,17 @@ class Engine(object):
         check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), int(width), int(rband), _stream()))
         return out
 
+    def qe_map_legs_cols(self, tmap, FG, FH, out, width=0, rband=0):
+        """Real map -> the three column-transformed leg planes (both legs from this map): row R2C, forward column
+        pass 1, then ONE kernel for forward pass 2 + leg filters + inverse pass 1, then the inverse pass 2."""
+        self._chk(tmap, "real"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
+        gx, gy, h = out
+        for t in out:
+            self._chk(t, "hc")
+        check(self.lib.oa_qe_map_legs_cols(self.plan, _ptr(tmap), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h),
+                                           int(width), int(rband), _stream()))
+        return out
+
     def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False, width=0, rband=0):
         """Fused forward column transforms + divergence * normalisation; ``width`` > 0: only the first
         ``width`` columns of ``out`` are produced (Fnorm vanishes beyond them)."""

@@ -302,6 +302,21 @@ class Estimator(object):
         e.rfft(gx, out=Px); e.rfft(gy, out=Py)
         return e.qe_div(Px, Py, Fn, out=out)
 
+    def reconstruct_tt_from_map(self, tmap, out=None):
+        """TT reconstruction straight from a real device map (both legs from it): the map's transform is consumed
+        inside the fused leg kernel and never written (``Engine.qe_map_legs_cols``).  Same result as
+        ``reconstruct_tt_hc(eng.rfft(tmap))``."""
+        e = self.eng
+        FG, FH, Fn = self._F["TT"]
+        w = self._buffers()
+        wl, wk = self._W["TT"]
+        rl, rk = self._R["TT"]
+        out = self._prep_out(out, wk, rk)
+        cx, cy, ch = e.qe_map_legs_cols(tmap, FG, FH, out=w["C"], width=wl, rband=rl)
+        Gx, Gy, _ = w["G"]
+        e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk)
+        return e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk)
+
     def kappa_from_map(self, XY, T2DData, E2DData=None, B2DData=None, T2DDataY=None, E2DDataY=None, B2DDataY=None,
                        alreadyFTed=False, returnFt=False):
         """qest.kappa_from_map (lensing.py:973-976; notebook cell 4).  The X

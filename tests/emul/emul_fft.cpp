@@ -64,6 +64,13 @@ struct EmuLauncher {
             run(gx, gy, nt, smem, [&](EmuCtx& c) { col_legs_body<T, S>(c, a); });
         });
     }
+    template <typename T> void col_fwdlegs(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a) {
+        dispatch_seq(logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_total_log<S>() >= 5 && seq_total_log<S>() <= 7)
+                run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fwdlegs_body<T, S>(c, a); });
+        });
+    }
     template <typename T> void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
@@ -142,7 +149,25 @@ static int do_cols_div(int ny, int nx, const cx<T>* pa, const cx<T>* pb, const T
     return 0;
 }
 
+// real map -> leg planes through the fused forward-pass-2 + legs kernel (geometry must support it)
+template <typename T>
+static int do_map_legs_cols(int ny, int nx, const T* map, const T* FG, const T* FH, const T* lxd, const T* lyd, cx<T>* gx,
+                            cx<T>* gy, cx<T>* h, int width, int rband) {
+    Holder<T> hd(ny, nx);
+    if (!Fft2dPlan<T>::has_fwdlegs(hd.p.logNy)) return 1;
+    std::vector<cx<T>> tA((size_t)ny * hd.p.kp), tB((size_t)ny * hd.p.kp);
+    EmuLauncher q;
+    const int w = hd.p.clampw(width);
+    hd.p.rows(q, ROW_R2C, map, nx / 2, tA.data(), hd.p.kp, (T)1, w);
+    hd.p.cols(q, tA.data(), hd.p.kp, tB.data(), hd.p.kp, w, false, (T)1, 1);
+    return hd.p.legs_cols_from_pass1(q, tB.data(), FG, FH, lxd, lyd, gx, gy, h, width, rband) ? 0 : 1;
+}
+
 extern "C" {
+int emu_map_legs_cols_f64(int ny, int nx, const double* map, const double* FG, const double* FH, const double* lxd,
+                          const double* lyd, void* gx, void* gy, void* h, int width, int rband) {
+    return do_map_legs_cols<double>(ny, nx, map, FG, FH, lxd, lyd, (cx<double>*)gx, (cx<double>*)gy, (cx<double>*)h, width, rband);
+}
 int emu_legs_cols_f64(int ny, int nx, const void* kX, const void* kY, const double* FG, const double* FH, const double* lxd,
                       const double* lyd, void* gx, void* gy, void* h) {
     return do_legs_cols<double>(ny, nx, (const cx<double>*)kX, (const cx<double>*)kY, FG, FH, lxd, lyd, (cx<double>*)gx,

@@ -176,3 +176,35 @@ def test_fused_column_stages(emu, ny, nx, w, rb):
         assert np.all(out[:, wv:W] == 3.0)
     if rb:
         assert np.all(out[off] == 3.0)                    # rows outside the band are not written
+
+
+@pytest.mark.parametrize("ny,nx,w,rb", [(1024, 64, 0, 0), (2048, 64, 20, 100), (8192, 64, 33, 300)])
+def test_fused_forward_pass2_legs(emu, ny, nx, w, rb):
+    """col_fwdlegs: real map -> (row R2C, forward column pass 1) -> ONE kernel doing forward pass 2 + leg filters +
+    inverse pass 1 with the column length split the other way round -> inverse pass 2.  Must equal the inverse column
+    transforms of (i lx FG kT, i ly FG kT, FH kT) with kT = rfft2(map); 2048 / 8192 exercise the asymmetric split."""
+    rng = np.random.default_rng(ny + w)
+    W = nx // 2 + 1
+    wv = w if w else W
+    kp = emu.emu_kpitch(nx)
+    x = rng.standard_normal((ny, nx))
+    kT = np.fft.rfft2(x)
+    lyd = 2 * np.pi * np.fft.fftfreq(ny) * 100
+    lxd = 2 * np.pi * np.fft.fftfreq(nx) * 100
+    lyd[ny // 2] = 0
+    lxd[nx // 2] = 0
+    FG = np.zeros((ny, kp)); FH = np.zeros((ny, kp))
+    FG[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
+    FH[:, :wv] = rng.uniform(0.5, 1.5, (ny, wv))
+    if rb:
+        off = np.r_[rb:ny - rb + 1]
+        FG[off] = 0; FH[off] = 0
+    outs = [_hc(emu, ny, nx, fill=3.0) for _ in range(3)]
+    assert emu.emu_map_legs_cols_f64(ny, nx, _p(x), _p(FG), _p(FH), _p(lxd), _p(lyd), _p(outs[0]), _p(outs[1]), _p(outs[2]),
+                                     w, rb) == 0
+    lx2, ly2 = lxd[None, :W], lyd[:, None]
+    refs = [_col_ifft(1j * lx2 * FG[:, :W] * kT, ny), _col_ifft(1j * ly2 * FG[:, :W] * kT, ny), _col_ifft(FH[:, :W] * kT, ny)]
+    for got, want in zip(outs, refs):
+        assert np.abs(got[:, :wv] - want[:, :wv]).max() < 1e-10 * np.abs(want).max()
+        if w:
+            assert np.all(got[:, wv:W] == 3.0)

@@ -452,3 +452,21 @@ def test_active_column_pruning_is_exact():
         s_b, c_b = e.bin_power(pr, pr, 1.0, ids, 16, herm=True, active_cols=wk, active_rows=rk)
         assert float(((s_b[1:-1] - s_full[1:-1]) / s_full[1:-1]).abs().max()) < 10 * tol
         assert bool((c_b[1:-1] <= c_w[1:-1]).all())
+
+
+@pytest.mark.parametrize("N,res", [(1024, 1.0), (2048, 1.0)])
+def test_reconstruct_from_map_fused_forward_legs(N, res):
+    """reconstruct_tt_from_map (forward column pass 2 + leg filters + inverse pass 1 in one kernel; kT never
+    written) == reconstruct_tt_hc(rfft(map)), pruned and dense; 2048 exercises the asymmetric column split."""
+    from orphics_amd import lensing
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, res, seed=9)
+    kw = dict(noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True)
+    for prec, tol in (("f64", 1e-12), ("f32", 3e-6)):
+        for prune in (True, False):
+            q = lensing.qest(shape, g, th, dtype=prec, prune=prune, **kw)
+            e = q.eng
+            x = e.to_real(t1)
+            ref = q.reconstruct_tt_hc(e.rfft(x)).clone()
+            got = q.reconstruct_tt_from_map(x)
+            w = N // 2 + 1
+            assert float((got - ref)[:, :w].abs().max()) / float(ref.abs().max()) < tol
