@@ -325,10 +325,19 @@ class Estimator(object):
         X, Y = XY[0], XY[1]
         if fields[X][0] is None or (fields[Y][0] is None and fields[Y][1] is None):
             raise ValueError("estimator %s needs the %s and %s data" % (XY, X, Y))
-        kX, kind = self._as_hc(fields[X][0], alreadyFTed)
         ysrc = fields[Y][1] if fields[Y][1] is not None else fields[Y][0]
-        kY = kX if (ysrc is fields[X][0]) else self._as_hc(ysrc, alreadyFTed)[0]
-        if XY == "TT":
+        xsrc = fields[X][0]
+        if XY == "TT" and ysrc is xsrc and not alreadyFTed and not isinstance(xsrc, HalfPlane):
+            # both legs from one real map: its transform is consumed inside the fused leg kernel
+            kind = "np" if isinstance(xsrc, np.ndarray) else "torch"
+            kft = self.reconstruct_tt_from_map(self.eng.to_real(xsrc))
+            kX = kY = None
+        else:
+            kX, kind = self._as_hc(xsrc, alreadyFTed)
+            kY = kX if (ysrc is xsrc) else self._as_hc(ysrc, alreadyFTed)[0]
+        if kX is None:
+            pass
+        elif XY == "TT":
             kft = self.reconstruct_tt_hc(kX, kY)
         else:
             kft = self.reconstruct_hc(XY, kX, kY)
