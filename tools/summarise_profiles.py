@@ -38,7 +38,8 @@ def counter_medians(d, counter):
     return {k: (statistics.median(v), len(v)) for k, v in vals.items()}
 
 
-SHORT = (("row_qe_kernel", "row_qe_kernel"), ("col_legs_kernel", "col_legs_kernel"), ("col_div_kernel", "col_div_kernel"),
+SHORT = (("row_qe_kernel", "row_qe_kernel"), ("col_legs_kernel", "col_legs_kernel"), ("col_fwdlegs_kernel", "col_fwdlegs_kernel"),
+         ("col_div_kernel", "col_div_kernel"),
          ("bin_kernel", "bin_kernel<power>"), ("row_fft_kernel<float, 0", "row_fft_kernel<R2C>"),
          ("col_fft_kernel", "col_fft_kernel"))
 
@@ -71,7 +72,7 @@ def main():
         if hits:
             traffic[short] = max(hits) if short != "col_fft_kernel" else sum(hits) / len(hits)
     json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
-    for k in ("row_qe_kernel", "col_legs_kernel", "col_div_kernel", "bin_kernel<power>", "row_fft_kernel<R2C>", "col_fft_kernel"):
+    for k in ("row_qe_kernel", "col_legs_kernel", "col_fwdlegs_kernel", "col_div_kernel", "bin_kernel<power>", "row_fft_kernel<R2C>", "col_fft_kernel"):
         print(k, traffic.get(k))
 
 
