@@ -66,7 +66,8 @@ int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx);
  * oa_fft_c2c : full -> full, forward (inverse=0) or inverse (inverse=1),
  *              out != in (MapGen non-Hermitian draws maps.py:1578-1587, pol legs). */
 /* ACTIVE COLUMNS (`width`, `win`, `wout` arguments below): band-limited filters (the k-space masks of
- * lensing.Estimator, lensing.py:533-560) leave every hc plane on the estimator path exactly zero beyond some
+ * lensing.Estimator built with maps.mask_kspace, maps.py:1936-1948: the tellmax / kellmax of
+ * tutorials/tt_verification.ipynb) leave every hc plane on the estimator path exactly zero beyond some
  * column kx >= width.  A transform told so neither reads nor produces those columns -- same arithmetic on
  * the remaining ones, so results are unchanged; HBM traffic and column-pass work scale with width/(nx/2+1).
  * width <= 0 (or > nx/2+1) means all columns.  r2c: only columns < width of hc_out are written;
@@ -126,7 +127,7 @@ int oa_fullreal_to_hc(oa_plan* p, const void* fullreal_in, void* hcreal_out, voi
 /* Fourier-space regridding of an hc plane between two grids of the SAME patch (same delta-ell):
  * out(l) = scale * in(l) for the modes both grids hold, 0 elsewhere; the smaller grid's Nyquist row /
  * column is zeroed.  Crop = exact down-sampling of a band-limited field (enmap.downgrade_fft-like,
- * lensing.py:106), embed = exact up-sampling. */
+ * lensing.py:103), embed = exact up-sampling. */
 int oa_hc_resample(int dtype, const void* in, int ny_in, int nx_in, long kp_in, void* out, int ny_out, int nx_out,
                    long kp_out, double scale, void* stream);
 
@@ -219,7 +220,7 @@ int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, vo
 /* ---- one-pass moment accumulation (Statistics.add, stats.py:1068-1090) ---------
  * n += 1 ; S += x ; C += x x^T  for a device vector x of length d (float64). */
 int oa_moments_add(const double* x, int d, int64_t* n, double* S, double* C, void* stream);
-/* Same with x_a = sums[a] / counts[a] (the bin means of stats.bin2D.bin, stats.py:1327-1343) formed in the
+/* Same with x_a = sums[a] / counts[a] (the bin means of stats.bin2D.bin, stats.py:790-811) formed in the
  * kernel: feeds the interior slots of oa_bin / oa_bin_power output directly (pass sums+1, counts+1, d=nbins). */
 int oa_moments_add_binned(const double* sums, const int64_t* counts, int d, int64_t* n, double* S, double* C, void* stream);
 /* stack accumulation (Statistics.add_stack, stats.py:1124-1150): acc(f64) += x (dtype) */
