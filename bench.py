@@ -111,7 +111,7 @@ def dense_leg(P, args, torch, tmaps, ref_p1d, norm):
     eng = q.eng
     ns = max(1, args.streams)
     qs = [q] + [q.fork() for _ in range(ns - 1)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    streams = [torch.cuda.Stream() for _ in range(ns)]
     kks = [e.eng.hc() for e in qs]
     res = {}
 
@@ -227,7 +227,8 @@ def main():
     tmaps = [eng.irfft(eng.grf_hc(1234 + rank, i, P["cs"]), scale=1.0 / np.sqrt(eng.npix)) for i in range(2)]
     ns = max(1, args.streams)
     qs = [q] + [q.fork() for _ in range(ns - 1)]              # shared filters, private plan + work buffers
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(ns - 1)]
+    # every realisation stream is a side stream (measured ~3 % better than pairing the default stream with one)
+    streams = [torch.cuda.Stream() for _ in range(ns)]
     kTs, kks = [e.eng.hc() for e in qs], [e.eng.hc() for e in qs]
     kT, kk = kTs[0], kks[0]
     p2d = eng.hcreal()
