@@ -3,9 +3,10 @@
 per second on N^2 0.5' maps (BASELINE.json metric; default N = 8192).
 
 One "step" = one reconstruction from a real-space map resident in HBM:
-  R2C FFT(T) -> [leg filters + inverse column pass] -> 3 column passes -> [fused row stage:
-  3 C2R, 2 products, 2 R2C in LDS] -> 2 column passes -> [column pass + divergence * A_L]
-  -> [|kappa_hat|^2 + radial bandpowers] -> moment accumulation   ([...] = one fused kernel).
+  row R2C -> forward column pass 1 -> [forward column pass 2 + leg filters + inverse column pass 1] -> inverse
+  column pass 2 (3 planes, one launch) -> [fused row stage: 3 C2R, 2 products, 2 R2C in LDS] -> forward column
+  pass 1 (2 planes, one launch) -> [forward column pass 2 + divergence * A_L] -> [|kappa_hat|^2 + radial
+  bandpowers] -> [bin means + moment accumulation]                                ([...] = one fused kernel).
 Multi-GPU: independent realisations per rank (weak scaling, no data-path
 collective) + ONE RCCL all-reduce of the bandpower moments at the end.
 
@@ -23,6 +24,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes on this driver)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
