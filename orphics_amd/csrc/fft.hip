@@ -20,7 +20,11 @@ template <typename T, class SEQ> constexpr int qe_waves_per_eu() {
 template <typename T, class SEQ>
 __global__ __launch_bounds__(row_maxnt<SEQ>(), (qe_waves_per_eu<T, SEQ>())) void row_qe_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
+#ifdef OA_QE_INPLACE   // in-place DIF/DIT variant: 18 instead of 30 barriers per row, same speed on gfx950 (measured)
+    row_qe_body_inplace<T, SEQ>(c, a);
+#else
     row_qe_body<T, SEQ>(c, a);
+#endif
 }
 
 

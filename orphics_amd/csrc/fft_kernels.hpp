@@ -537,6 +537,101 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// In-place variant of the fused row stage.  The Stockham stages above read one index set and write another, so
+// every LDS->LDS stage costs two barriers (all reads before any write, all writes before the next reads).  Here the
+// inverse transforms are decimation-in-frequency IN PLACE (natural order in, digit-reversed order out) and the
+// forward transforms decimation-in-time IN PLACE (digit-reversed in, natural out): a thread rewrites exactly the
+// points it read, so a stage needs ONE barrier, and the real-space product -- elementwise, hence indifferent to the
+// common permutation of both factors -- sits between the last DIF stage and the first DIT stage, which own the same
+// 16 contiguous points per thread: h, the product and both of those stages stay in registers without any barrier.
+// 18 barriers per row instead of 30.
+//   stage of block size B = 2^logB, radix R, sub-stride S = B/R: sets { q*B + j + t*S : t < R },  j < S
+//   DIF: y = DFT_R(x) ; y_t *= W_B^(j t)        DIT: x_t *= W_B^(j t) ; y = DFT_R(x)
+// ---------------------------------------------------------------------------
+template <typename T, int R, bool DIT, bool TO_LDS, bool FROM_LDS>
+OA_HD void ip_stage(cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC, int RS, int logB, const cx<T>* tw) {
+    constexpr int LR = Log2c<R>::v;
+    constexpr int NB = EPT / R;
+    const int logS = logB - LR, logSets = logL - LR;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b >> logSets, sg = b & ((1 << logSets) - 1);
+        const int j = sg & ((1 << logS) - 1), q = sg >> logS;
+        const int base = (q << logB) + j;
+        cx<T>* w = v + u * R;
+        if (FROM_LDS) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) w[t] = s[lds_addr<true>(base + (t << logS), c, logC, RS)];
+        }
+        if (DIT && logS > 0) apply_twiddles<T, R>(w, tw, j, logL - logB, tw_lds_h(logL));
+        Dft<T, R>::run(w);
+        if (!DIT && logS > 0) apply_twiddles<T, R>(w, tw, j, logL - logB, tw_lds_h(logL));
+        if (TO_LDS) {
+#pragma unroll
+            for (int t = 0; t < R; ++t) s[lds_addr<true>(base + (t << logS), c, logC, RS)] = w[t];
+        }
+    }
+}
+
+// log2 of the block size of DIF stage i (radix order SEQ::get(0), get(1), ...): L / (r0 ... r_{i-1})
+template <class SEQ> constexpr int dif_logb(int i) { return seq_total_log<SEQ>() - fwd_logns<SEQ>(i); }
+
+// natural-order spectrum in LDS (caller synced) -> digit-reversed transform; the LAST stage stays in registers v
+template <typename T, class SEQ, class Ctx>
+OA_HD void dif_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC, int RS, const cx<T>* tw) {
+    constexpr int n = SEQ::n;
+    cx<T> w[EPT];
+    if constexpr (n >= 2) { ip_stage<T, SEQ::get(0), false, true, true>(s, w, tid, NT, logL, logC, RS, dif_logb<SEQ>(0), tw); ctx.sync(); }
+    if constexpr (n >= 3) { ip_stage<T, SEQ::get(1), false, true, true>(s, w, tid, NT, logL, logC, RS, dif_logb<SEQ>(1), tw); ctx.sync(); }
+    if constexpr (n >= 4) { ip_stage<T, SEQ::get(2), false, true, true>(s, w, tid, NT, logL, logC, RS, dif_logb<SEQ>(2), tw); ctx.sync(); }
+    ip_stage<T, SEQ::get(n - 1), false, false, true>(s, v, tid, NT, logL, logC, RS, dif_logb<SEQ>(n - 1), tw);
+}
+// registers v (digit-reversed data, the layout dif_to_regs leaves) -> natural-order transform in LDS (synced)
+template <typename T, class SEQ, class Ctx>
+OA_HD void dit_from_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC, int RS, const cx<T>* tw) {
+    constexpr int n = SEQ::n;
+    cx<T> w[EPT];
+    ip_stage<T, SEQ::get(n - 1), true, true, false>(s, v, tid, NT, logL, logC, RS, dif_logb<SEQ>(n - 1), tw);
+    ctx.sync();
+    if constexpr (n >= 4) { ip_stage<T, SEQ::get(2), true, true, true>(s, w, tid, NT, logL, logC, RS, dif_logb<SEQ>(2), tw); ctx.sync(); }
+    if constexpr (n >= 3) { ip_stage<T, SEQ::get(1), true, true, true>(s, w, tid, NT, logL, logC, RS, dif_logb<SEQ>(1), tw); ctx.sync(); }
+    if constexpr (n >= 2) { ip_stage<T, SEQ::get(0), true, true, true>(s, w, tid, NT, logL, logC, RS, dif_logb<SEQ>(0), tw); ctx.sync(); }
+}
+
+template <typename T, class SEQ, class Ctx>
+OA_HD void row_qe_body_inplace(Ctx& ctx, const RowQeArgs<T>& a) {
+    cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
+    const int tid = ctx.tid(), NT = a.NT;
+    constexpr int logL = seq_total_log<SEQ>();
+    const int logC = a.logC, C = 1 << logC, RS = a.rowStride;
+    const long r0 = (long)ctx.bid_x() * C;
+    cx<T> hreg[EPT], v[EPT];
+    cx<T>* twl = work + C * RS;
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+
+    c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
+    ctx.sync();
+    dif_to_regs<T, SEQ>(ctx, work, hreg, tid, NT, logL, logC, RS, twl);
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) hreg[t] = mk<T>(hreg[t].y * a.scale, hreg[t].x * a.scale);  // unswap -> (h[2n], h[2n+1])
+    ctx.sync();
+    for (int leg = 0; leg < 2; ++leg) {
+        const cx<T>* src = leg ? a.gy : a.gx;
+        cx<T>* dst = leg ? a.py : a.px;
+        c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
+        ctx.sync();
+        dif_to_regs<T, SEQ>(ctx, work, v, tid, NT, logL, logC, RS, twl);
+        // swapped C2R result (im, re) = (x[2n+1], x[2n]) at the same permuted positions as h: product, repacked for R2C
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].x, v[t].x * hreg[t].y);
+        dit_from_regs<T, SEQ>(ctx, work, v, tid, NT, logL, logC, RS, twl);   // this thread rewrites the points it just read
+        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
+        ctx.sync();
+    }
+}
+
 // ===========================================================================
 // Column pass: [L][C] tiles of strided rows.  grid = (column tiles, groups).
 //   input  row of point n in group g : g*in_gs  + n*in_ns

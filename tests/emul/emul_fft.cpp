@@ -23,6 +23,8 @@ struct EmuCtx {
     void* smem() const { return sm; }
 };
 
+static bool stockham_qe = false;   // which fused-row-stage body the emulator runs (both are tested)
+
 struct EmuLauncher {
     template <class F>
     void run(int gx, int gy, int nt, size_t smem, F body, int gz = 1) {
@@ -55,7 +57,7 @@ struct EmuLauncher {
     template <typename T> void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
-            run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_body<T, S>(c, a); });
+            run(grid, 1, nt, smem, [&](EmuCtx& c) { if (stockham_qe) row_qe_body<T, S>(c, a); else row_qe_body_inplace<T, S>(c, a); });
         });
     }
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
@@ -198,6 +200,7 @@ int emu_cols_div_w_f64(int ny, int nx, const void* pa, const void* pb, const dou
                        void* out, int width, int rband) {
     return do_cols_div<double>(ny, nx, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out, width, rband);
 }
+void emu_set_stockham_qe(int on) { stockham_qe = on != 0; }
 long emu_kpitch(int nx) { return kpitch_for(nx); }
 int emu_r2c_f32(int ny, int nx, const float* in, void* out, double s) { return do_r2c<float>(ny, nx, in, (cx<float>*)out, s); }
 int emu_r2c_f64(int ny, int nx, const double* in, void* out, double s) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s); }

@@ -97,9 +97,13 @@ def _col_ifft(k, ny):
     return np.fft.ifft(k, axis=0) * ny
 
 
-@pytest.mark.parametrize("ny,nx,win,wout", [(32, 64, 0, 0), (32, 128, 20, 41), (64, 256, 33, 64), (32, 512, 100, 150)])
-def test_fused_row_stage(emu, ny, nx, win, wout):
-    """row_qe: P = R2C(C2R(G) * C2R(H)) row by row, with and without active-column limits."""
+@pytest.mark.parametrize("stockham", [0, 1])
+@pytest.mark.parametrize("ny,nx,win,wout", [(32, 64, 0, 0), (32, 128, 20, 41), (64, 256, 33, 64), (32, 512, 100, 150),
+                                            (32, 2048, 200, 330), (32, 8192, 380, 664)])
+def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
+    """row_qe: P = R2C(C2R(G) * C2R(H)) row by row, with and without active-column limits; both kernel bodies
+    (Stockham = the product kernel, in-place DIF/DIT = the -DOA_QE_INPLACE variant with 18 instead of 30 barriers)."""
+    emu.emu_set_stockham_qe(stockham)
     rng = np.random.default_rng(100 + nx + win)
     W = nx // 2 + 1
     wi = win if win else W
