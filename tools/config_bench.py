@@ -41,7 +41,7 @@ def timeit(fn, n):
 
 
 def mv(N=8192, res=0.5):
-    for prune in (True, False):
+    for prune in ((True,) if "--no-dense" in sys.argv else (True, False)):
         shape, g, th, ml, beam, noise, q = setup(N, res, True, prune)
         e = q.eng
         ks = [e.grf_hc(7, i) for i in range(3)]
