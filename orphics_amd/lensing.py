@@ -671,8 +671,30 @@ class BandlimitedEstimator(object):
         return hc_resample(self.q.eng, kappa_small, self.big, 1.0 / self.scale)
 
 
-def qest(shape, wcs, theory, **kwargs):
-    """``lensing.qest(...)`` constructor name used by the reference notebooks."""
+    def kappa_from_map(self, XY, T2DData, alreadyFTed=False, returnFt=False, **unused):
+        """``qest.kappa_from_map("TT", map)`` (lensing.py:973) with full-resolution containers in and out, the
+        reconstruction itself on the coarse grid: NumPy map in -> NumPy kappa map (or full-plane FT) out, device
+        tensor in -> device tensor out."""
+        if XY != "TT":
+            raise NotImplementedError("BandlimitedEstimator: TT only (use Estimator for polarisation)")
+        torch = _torch()
+        e = self.big
+        as_np = isinstance(T2DData, np.ndarray)
+        if alreadyFTed:
+            small = self.reconstruct_tt_hc(e.full_to_hc(e.to_complex(T2DData)))
+        else:
+            small = self.reconstruct_tt_from_map(e.to_real(T2DData))
+        kfull = self.kappa_full_hc(small)
+        out = e.hc_to_full(kfull) if returnFt else e.irfft(kfull)
+        return out.cpu().numpy() if as_np else out
+
+
+def qest(shape, wcs, theory, internal_grid=None, **kwargs):
+    """``lensing.qest(...)`` constructor name used by the reference notebooks.  ``internal_grid="auto"`` (or a
+    power-of-two side) returns the :class:`BandlimitedEstimator` (TT, band-limited masks required)."""
+    if internal_grid is not None:
+        return BandlimitedEstimator(shape, wcs, theory, n_small=None if internal_grid == "auto" else int(internal_grid),
+                                    **kwargs)
     return Estimator(shape, wcs, theory, **kwargs)
 
 

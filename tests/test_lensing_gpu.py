@@ -470,3 +470,21 @@ def test_reconstruct_from_map_fused_forward_legs(N, res):
             got = q.reconstruct_tt_from_map(x)
             w = N // 2 + 1
             assert float((got - ref)[:, :w].abs().max()) / float(ref.abs().max()) < tol
+
+
+def test_bandlimited_kappa_from_map_matches_estimator():
+    """qest(..., internal_grid="auto").kappa_from_map == the full-resolution estimator's output (NumPy in/out)."""
+    from orphics_amd import lensing
+    N, res = 1024, 1.0
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, res, seed=12)
+    kw = dict(noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True, dtype="f64")
+    q = lensing.qest(shape, g, th, **kw)
+    qb = lensing.qest(shape, g, th, internal_grid="auto", **kw)
+    assert isinstance(qb, lensing.BandlimitedEstimator) and qb.n < N
+    a = q.kappa_from_map("TT", t1)
+    b = qb.kappa_from_map("TT", t1)
+    assert isinstance(b, np.ndarray) and b.shape == a.shape
+    assert np.abs(a - b).max() < 1e-9 * np.abs(a).max()
+    fa = q.kappa_from_map("TT", t1, returnFt=True)
+    fb = qb.kappa_from_map("TT", t1, returnFt=True)
+    assert np.abs(fa - fb).max() < 1e-9 * np.abs(fa).max()
