@@ -59,8 +59,22 @@ struct oa_plan {
     double* ly64;    // double[ny]
     double* lx64;    // double[nx]
     bool have_laxes;
+    // sides that are not powers of two: chirp-z (Bluestein) state, see czt.hip.  pow2 == false then.
+    bool pow2;
+    oa_plan* inner;            // (My, Mx) power-of-two plan
+    int My, Mx;
+    void* chirp_y; void* chirp_x;            // cx<T>[ny], cx<T>[nx]
+    void* cz_bhat; void* cz_a; void* cz_f;   // cx<T>[My*Mx]: chirp-kernel transform, two work planes
+    void* cz_full;                           // cx<T>[ny*nx]
 };
 
 namespace oa {
 int plan_ensure_scratch(oa_plan* p, size_t bytes);
+int czt_setup(oa_plan* p);
+void czt_release(oa_plan* p);
+int czt_c2c(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st);
+int czt_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, hipStream_t st);
+int czt_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStream_t st);
 }
+#define OA_NEED_POW2(p, what) \
+    OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

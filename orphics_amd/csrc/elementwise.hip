@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void hc_to_full_kernel(const cx<T>* __restrict
     cx<T> v;
     if (x <= nxh) v = hc[(long)y * kp + x];
     else {
-        const int ym = (ny - y) & (ny - 1);
+        const int ym = y ? ny - y : 0;
         v = conj(hc[(long)ym * kp + (nx - x)]);
     }
     full[(long)y * nx + x] = v;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void hcreal_to_full_kernel(const T* __restrict
     const int nxh = nx / 2;
     T v;
     if (x <= nxh) v = hc[(long)y * kp + x];
-    else v = hc[(long)((ny - y) & (ny - 1)) * kp + (nx - x)];
+    else v = hc[(long)(y ? ny - y : 0) * kp + (nx - x)];
     full[(long)y * nx + x] = v;
 }
 

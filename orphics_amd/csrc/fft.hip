@@ -230,6 +230,7 @@ extern "C" {
 int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                     int width, int rband, void* stream) {
     OA_REQUIRE(p && kX && kY && FG && FH && gx && gy && h, "oa_qe_legs_cols: NULL argument");
+    OA_NEED_POW2(p, "oa_qe_legs_cols");
     OA_REQUIRE(p->have_laxes, "oa_qe_legs_cols: call oa_plan_set_laxes first");
     OA_REQUIRE(gx != kX && gy != kX && h != kX && gx != kY && gy != kY && h != kY, "oa_qe_legs_cols: outputs alias inputs");
     return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream)
@@ -239,6 +240,7 @@ int oa_qe_legs_cols(oa_plan* p, const void* kX, const void* kY, const void* FG, 
 int oa_qe_map_legs_cols(oa_plan* p, const void* real_map, const void* FG, const void* FH, void* gx, void* gy, void* h,
                         int width, int rband, void* stream) {
     OA_REQUIRE(p && real_map && FG && FH && gx && gy && h, "oa_qe_map_legs_cols: NULL argument");
+    OA_NEED_POW2(p, "oa_qe_map_legs_cols");
     OA_REQUIRE(p->have_laxes, "oa_qe_map_legs_cols: call oa_plan_set_laxes first");
     OA_REQUIRE(gx != gy && gx != h && gy != h, "oa_qe_map_legs_cols: outputs alias each other");
     return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, real_map, FG, FH, gx, gy, h, width, rband, (hipStream_t)stream)
@@ -248,6 +250,7 @@ int oa_qe_map_legs_cols(oa_plan* p, const void* real_map, const void* FG, const 
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
                    int width, int rband, void* stream) {
     OA_REQUIRE(p && px_rows && py_rows && Fnorm && out, "oa_qe_cols_div: NULL argument");
+    OA_NEED_POW2(p, "oa_qe_cols_div");
     OA_REQUIRE(p->have_laxes, "oa_qe_cols_div: call oa_plan_set_laxes first");
     return p->dtype == OA_F32 ? cols_div_impl<float>(p, px_rows, py_rows, Fnorm, out, accumulate, width, rband, (hipStream_t)stream)
                               : cols_div_impl<double>(p, px_rows, py_rows, Fnorm, out, accumulate, width, rband, (hipStream_t)stream);
@@ -255,6 +258,7 @@ int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const v
 
 int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double scale, int width, void* stream) {
     OA_REQUIRE(p && hc_in && hc_out, "oa_fft_cols: NULL argument");
+    OA_NEED_POW2(p, "oa_fft_cols");
     OA_REQUIRE(hc_in != hc_out, "oa_fft_cols: in-place not supported");
     return p->dtype == OA_F32 ? cols_impl<float>(p, hc_in, hc_out, inverse, scale, width, (hipStream_t)stream)
                               : cols_impl<double>(p, hc_in, hc_out, inverse, scale, width, (hipStream_t)stream);
@@ -263,12 +267,14 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
                int accumulate, int win, int wout, void* stream) {
     OA_REQUIRE(p && gx && gy && h && px && py, "oa_qe_rows: NULL argument");
+    OA_NEED_POW2(p, "oa_qe_rows");
     return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream)
                               : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream);
 }
 
 int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, void* stream) {
     OA_REQUIRE(p && in && out, "oa_fft_pass: NULL argument");
+    OA_NEED_POW2(p, "oa_fft_pass");
     return p->dtype == OA_F32 ? pass_impl<float>(p, pass_id, in, out, width, (hipStream_t)stream)
                               : pass_impl<double>(p, pass_id, in, out, width, (hipStream_t)stream);
 }
@@ -276,6 +282,7 @@ int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, v
 int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, int rband, void* stream) {
     OA_REQUIRE(p && real_in && hc_out, "oa_fft_r2c: NULL argument");
     OA_REQUIRE(real_in != hc_out, "oa_fft_r2c: in-place not supported");
+    if (!p->pow2) return czt_r2c(p, real_in, hc_out, scale, (hipStream_t)stream);   // width / rband hints do not apply
     return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, width, rband, (hipStream_t)stream)
                               : r2c_impl<double>(p, real_in, hc_out, scale, width, rband, (hipStream_t)stream);
 }
@@ -283,6 +290,7 @@ int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int 
 int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream) {
     OA_REQUIRE(p && hc_in && real_out, "oa_fft_c2r: NULL argument");
     OA_REQUIRE(hc_in != real_out, "oa_fft_c2r: in-place not supported");
+    if (!p->pow2) return czt_c2r(p, hc_in, real_out, scale, (hipStream_t)stream);
     return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, width, (hipStream_t)stream)
                               : c2r_impl<double>(p, hc_in, real_out, scale, width, (hipStream_t)stream);
 }
@@ -290,6 +298,7 @@ int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int 
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream) {
     OA_REQUIRE(p && full_in && full_out, "oa_fft_c2c: NULL argument");
     OA_REQUIRE(full_in != full_out, "oa_fft_c2c: in-place not supported");
+    if (!p->pow2) return czt_c2c(p, full_in, full_out, inverse, scale, (hipStream_t)stream);
     return p->dtype == OA_F32 ? c2c_impl<float>(p, full_in, full_out, inverse, scale, (hipStream_t)stream)
                               : c2c_impl<double>(p, full_in, full_out, inverse, scale, (hipStream_t)stream);
 }

@@ -51,10 +51,14 @@ int oa_device_count(void) {
 int oa_plan_create(int ny, int nx, int dtype, oa_plan** out) {
     OA_REQUIRE(out != nullptr, "oa_plan_create: out is NULL");
     *out = nullptr;
-    OA_REQUIRE(is_pow2(ny) && is_pow2(nx), "oa_plan_create: ny and nx must be powers of two");
+    const bool pow2 = is_pow2(ny) && is_pow2(nx);
     OA_REQUIRE(ny >= 32 && nx >= 32, "oa_plan_create: ny and nx must be >= 32");
     OA_REQUIRE(ny <= 32768 && nx <= 32768, "oa_plan_create: ny and nx must be <= 32768");
     OA_REQUIRE(dtype == OA_F32 || dtype == OA_F64, "oa_plan_create: dtype must be OA_F32 or OA_F64");
+    if (!pow2) {
+        OA_REQUIRE(ny % 2 == 0 && nx % 2 == 0, "oa_plan_create: sides that are not powers of two must be even");
+        OA_REQUIRE(ny <= 8192 && nx <= 8192, "oa_plan_create: sides that are not powers of two must be <= 8192 (chirp-z work planes)");
+    }
     if (dtype == OA_F64) OA_REQUIRE(nx <= 16384, "oa_plan_create: float64 plans support nx <= 16384 (LDS row budget)");
     int ndev = 0;
     OA_HIP(hipGetDeviceCount(&ndev));
@@ -62,9 +66,9 @@ int oa_plan_create(int ny, int nx, int dtype, oa_plan** out) {
     oa_plan* p = new oa_plan();
     memset(p, 0, sizeof(*p));
     p->ny = ny; p->nx = nx; p->logNy = ilog2(ny); p->logNx = ilog2(nx);
-    p->dtype = dtype; p->kp = kpitch_for(nx);
+    p->dtype = dtype; p->kp = kpitch_for(nx); p->pow2 = pow2;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail("hipGetDevice failed"); }
-    int rc = (dtype == OA_F32) ? upload_tables<float>(p) : upload_tables<double>(p);
+    int rc = pow2 ? ((dtype == OA_F32) ? upload_tables<float>(p) : upload_tables<double>(p)) : czt_setup(p);
     if (rc) { oa_plan_destroy(p); return rc; }
     *out = p;
     return 0;
@@ -73,6 +77,7 @@ int oa_plan_create(int ny, int nx, int dtype, oa_plan** out) {
 int oa_plan_destroy(oa_plan* p) {
     if (!p) return 0;
     (void)hipDeviceSynchronize();
+    czt_release(p);
     if (p->tw_x) (void)hipFree(p->tw_x);
     if (p->tw_y) (void)hipFree(p->tw_y);
     if (p->scratch) (void)hipFree(p->scratch);

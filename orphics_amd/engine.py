@@ -150,6 +150,8 @@ class Engine(object):
         self.kp = int(self.lib.oa_plan_kpitch(h))
         self.nxh = self.nx // 2
         self.npix = self.ny * self.nx
+        # power-of-two sides: LDS FFT kernels + fused estimator kernels; other even sides: chirp-z FFTs only
+        self.pow2 = (self.ny & (self.ny - 1)) == 0 and (self.nx & (self.nx - 1)) == 0
         self._laxes = None
         self._bin_scratch = None
 

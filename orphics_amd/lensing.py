@@ -282,7 +282,7 @@ class Estimator(object):
         kY = kX if kY is None else kY
         FG, FH, Fn = self._F["TT"]
         w = self._buffers()
-        if fused:
+        if fused and e.pow2:
             # legs+inverse columns (1 fused pass + 3 in-place passes) -> fused row stage -> forward
             # columns + divergence (2 passes + 1 fused pass): the filtered legs, the real-space planes
             # and the pre-divergence planes never exist in HBM
@@ -307,6 +307,8 @@ class Estimator(object):
         inside the fused leg kernel and never written (``Engine.qe_map_legs_cols``).  Same result as
         ``reconstruct_tt_hc(eng.rfft(tmap))``."""
         e = self.eng
+        if not e.pow2:                       # chirp-z sizes: modular chain of public calls
+            return self.reconstruct_tt_hc(e.rfft(tmap), out=out)
         FG, FH, Fn = self._F["TT"]
         w = self._buffers()
         wl, wk = self._W["TT"]
@@ -529,6 +531,8 @@ class Estimator(object):
         """General estimator on hc tensors: kX = DFT of field XY[0], kY = DFT of field XY[1].
         ``norm`` overrides the divergence/normalisation plane (MV weights), ``accumulate`` adds into ``out``."""
         e = self.eng
+        if not e.pow2:
+            raise NotImplementedError("polarisation / general estimators need power-of-two map sides (TT works on any even side)")
         G = self._setup_general(XY)
         w = self._buffers()
         Gx, Gy, H = w["G"]

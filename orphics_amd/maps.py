@@ -34,8 +34,9 @@ def _is_tensor(x):
 def _engine(shape, prec):
     from .engine import Engine
     Ny, Nx = shape[-2:]
-    if Ny < 32 or Nx < 32 or (Ny & (Ny - 1)) or (Nx & (Nx - 1)):
-        raise NotImplementedError("orphics_amd FFTs need power-of-two map sides >= 32, got %dx%d" % (Ny, Nx))
+    if Ny < 32 or Nx < 32 or Ny % 2 or Nx % 2:
+        raise NotImplementedError("orphics_amd FFTs need even map sides >= 32 (powers of two for the fast fused "
+                                  "kernels, any other even side through the chirp-z path), got %dx%d" % (Ny, Nx))
     return Engine.get(Ny, Nx, prec)
 
 

@@ -226,13 +226,14 @@ def test_error_behaviour_is_loud():
     with pytest.raises(TypeError):
         e.rfft(np.zeros((64, 64), np.float32))                           # host memory is not a device plane
     with pytest.raises(NotImplementedError):
-        maps.FourierCalc((100, 100), FlatGeometry.from_res((100, 100), 2.0)).fft(np.zeros((100, 100)))
+        maps.FourierCalc((101, 100), FlatGeometry.from_res((101, 100), 2.0)).fft(np.zeros((101, 100)))   # odd side
     with pytest.raises(ValueError):
         stats.bin2D(np.ones((8, 8)), np.array([3., 2., 1.]))
     with pytest.raises(TypeError):
         stats.bin2D(np.ones((8, 8)), np.array([1., 2., 3.])).bin(np.ones((8, 8)) * 1j)
     h = ctypes.c_void_p()
-    assert lib.oa_plan_create(100, 64, 0, ctypes.byref(h)) != 0 and b"powers of two" in lib.oa_last_error()
+    assert lib.oa_plan_create(101, 64, 0, ctypes.byref(h)) != 0 and b"must be even" in lib.oa_last_error()
+    assert lib.oa_plan_create(10000, 64, 0, ctypes.byref(h)) != 0 and b"<= 8192" in lib.oa_last_error()
     assert lib.oa_plan_create(16, 64, 0, ctypes.byref(h)) != 0 and b">= 32" in lib.oa_last_error()
     assert lib.oa_plan_create(64, 64, 7, ctypes.byref(h)) != 0 and b"dtype" in lib.oa_last_error()
     assert lib.oa_fft_r2c(e.plan, None, None, 1.0, 0, 0, None) != 0 and b"NULL" in lib.oa_last_error()
@@ -244,3 +245,31 @@ def test_error_behaviour_is_loud():
     e2 = __import__("orphics_amd.engine", fromlist=["Engine"]).Engine(64, 64, "f32")
     with pytest.raises(_lib.OrphicsAmdError):
         e2.qe_legs(e2.hc(), e2.hc(), e2.hcreal(), e2.hcreal())
+
+
+@pytest.mark.parametrize("ny,nx", [(96, 160), (600, 750), (250, 36)])
+def test_non_power_of_two_sides_chirp_z(ny, nx):
+    """Even sides that are not powers of two (reference notebooks: 600, 750, 2400) go through the chirp-z path:
+    rfft / irfft / cfft equal NumPy; the fused estimator entry points refuse loudly."""
+    from orphics_amd.engine import Engine
+    from orphics_amd._lib import OrphicsAmdError
+    rng = np.random.default_rng(ny + nx)
+    x = rng.standard_normal((ny, nx))
+    z = rng.standard_normal((ny, nx)) + 1j * rng.standard_normal((ny, nx))
+    for prec, tol in (("f64", 1e-11), ("f32", 2e-5)):
+        e = Engine(ny, nx, prec)
+        assert not e.pow2
+        xt = torch.as_tensor(x, dtype=e.rdt, device=e.device)
+        k = e.rfft(xt)
+        ref = np.fft.rfft2(x)
+        assert np.abs(k.cpu().numpy()[:, :nx // 2 + 1] - ref).max() < tol * np.abs(ref).max()
+        back = e.irfft(k)
+        assert np.abs(back.cpu().numpy() - x).max() < tol * 10
+        zt = torch.as_tensor(z, dtype=e.cdt, device=e.device)
+        f = e.cfft(zt)
+        reff = np.fft.fft2(z)
+        assert np.abs(f.cpu().numpy() - reff).max() < tol * np.abs(reff).max()
+        b = e.cfft(f, inverse=True, scale=1.0 / (ny * nx))
+        assert np.abs(b.cpu().numpy() - z).max() < tol * 10
+        with pytest.raises(OrphicsAmdError, match="power-of-two"):
+            e.fft_cols(k)

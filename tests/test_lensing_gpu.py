@@ -488,3 +488,35 @@ def test_bandlimited_kappa_from_map_matches_estimator():
     fa = q.kappa_from_map("TT", t1, returnFt=True)
     fb = qb.kappa_from_map("TT", t1, returnFt=True)
     assert np.abs(fa - fb).max() < 1e-9 * np.abs(fa).max()
+
+
+def test_tt_estimator_on_non_power_of_two_map():
+    """A 480 x 600 patch (chirp-z FFTs, modular estimator chain): kappa bandpowers == NumPy oracle."""
+    from orphics_amd import cosmology, lensing, maps, stats
+    from orphics_amd.geometry import FlatGeometry
+    from oracle import maps_oracle as mo
+    from oracle import qe_oracle as qo
+    from oracle import stats_oracle as so
+    shape = (480, 600)
+    g = FlatGeometry.from_res(shape, 2.0)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    cltt = th.lCl("TT", ml)
+    rng = np.random.default_rng(3)
+    tmap = np.fft.ifft2(np.fft.fft2(rng.standard_normal(shape)) * np.sqrt((cltt * beam ** 2 + noise) / g.pixarea)).real
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True, dtype="f64")
+    rec = q.kappa_from_map("TT", tmap)
+    ref = qo.QEOracleTT(shape, g.step_y, g.step_x, cltt, cltt, noise, beam, tmask, kmask_K=kmask).kappa_from_map("TT", tmap)
+    assert np.abs(rec - ref).max() < 1e-8 * np.abs(ref).max()
+    edges = np.linspace(20, 3500, 20)
+    p2d, _, _ = maps.FourierCalc(shape, g).power2d(rec)
+    _, p1d = stats.bin2D(ml, edges).bin(p2d)
+    _, p1r = so.bin2D(ml, edges).bin(mo.FourierCalc(shape, g.step_y, g.step_x).power2d(ref)[0])
+    assert np.max(np.abs(p1d / p1r - 1)) < 1e-9
+    with pytest.raises(NotImplementedError):
+        lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_P=tmask, kmask_K=kmask, pol=True,
+                     dtype="f64").reconstruct_hc("EE", q.eng.hc(), q.eng.hc())
