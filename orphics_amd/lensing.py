@@ -39,6 +39,9 @@ def _safe_div(num, den):
     return out
 
 
+_CLEAN = {}    # id(plane) -> (weakref, (kappa_cols, kappa_rows)): output planes known to be zero outside that region
+
+
 class Estimator(object):
     """Flat-sky QE.  Keywords follow the reference's ``lensing.qest`` call
     (tt_verification.ipynb cell 3):
@@ -59,7 +62,6 @@ class Estimator(object):
         # prune: let the fused kernels skip the hc columns on which the (band-limited) filters vanish --
         # same arithmetic on the remaining columns, identical results (include/orphics_amd.h, ACTIVE COLUMNS)
         self.prune = bool(prune)
-        self._clean = {}                    # id -> weakref of output planes whose inactive columns are known zero
         self.shape = tuple(shape)
         self.wcs = wcs
         self.geom = as_geometry(shape, wcs)
@@ -166,15 +168,19 @@ class Estimator(object):
                 out[:, wk:] = 0                                # zeroed once per output plane
             if rk:
                 out[rk:out.shape[0] - rk + 1] = 0
-            self._clean[id(out)] = (weakref.ref(out), (wk, rk))
+            _CLEAN[id(out)] = (weakref.ref(out), (wk, rk))
         return out
 
-    def _is_clean(self, t, region):
-        r = self._clean.get(id(t))
+    @staticmethod
+    def _is_clean(t, region):
+        # process-wide registry (shared by every estimator and fork): an output plane is "clean" for a region if the
+        # LAST pruned writer that prepared it left everything outside that same region zero
+        r = _CLEAN.get(id(t))
         if r is not None and r[0]() is t and r[1] == region:
             return True
-        if len(self._clean) > 64:
-            self._clean = {k: v for k, v in self._clean.items() if v[0]() is not None}
+        if len(_CLEAN) > 256:
+            for k in [k for k, v in _CLEAN.items() if v[0]() is None]:
+                del _CLEAN[k]
         return False
 
     @property
@@ -237,7 +243,6 @@ class Estimator(object):
         other._work = None
         other._rwork = None
         other._acc = None
-        other._clean = {}
         return other
 
     # ---- data plumbing -----------------------------------------------------------------
