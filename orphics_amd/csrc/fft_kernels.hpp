@@ -33,12 +33,6 @@ constexpr int EPT = 16;        // complex points per thread per stage
 #define OA_COL_LOGC 5
 #endif
 constexpr int COL_LOGC = OA_COL_LOGC;  // log2 columns per column tile (compile-time: index math folds to masks/shifts)
-constexpr int MAX_STAGES = 8;
-
-struct Stages {
-    int n;
-    int radix[MAX_STAGES];
-};
 
 enum RowMode { ROW_R2C = 0, ROW_C2R = 1, ROW_C2C_F = 2, ROW_C2C_I = 3 };
 
@@ -304,7 +298,6 @@ struct RowArgs {
     int logC;                  // rows per workgroup
     int NT;                    // threads per workgroup = L*C/EPT
     int rowStride;             // LDS complex elements per row
-    Stages st;
     const cx<T>* tw;           // master table W_M^k, k < M, M = 2^logTw >= 2L (real modes) or L
     int logTw;
     T scale;
@@ -649,7 +642,6 @@ struct ColArgs {
     long in_pitch, out_pitch;  // complex elements
     int width;                 // valid columns
     int logL, logC, NT;
-    Stages st;
     const cx<T>* tw;           // master table of length 2^logTw (= Ny)
     int logTw;
     long in_gs, in_ns, out_gs, out_ks;

@@ -7,14 +7,6 @@
 
 namespace oa {
 
-inline Stages make_stages(int logL) {
-    Stages s{};
-    int rem = logL;
-    while (rem >= 4) { s.radix[s.n++] = 16; rem -= 4; }
-    if (rem) s.radix[s.n++] = 1 << rem;
-    return s;
-}
-
 template <typename T>
 inline std::vector<cx<T>> make_twiddles(int M) {
     std::vector<cx<T>> t((size_t)M);
@@ -60,7 +52,6 @@ struct Fft2dPlan {
         a.NT = (L * C) / EPT;
         if (a.NT < 1) a.NT = 1;
         a.rowStride = L + (L >> 4) + 2;
-        a.st = make_stages(a.logL);
         a.tw = tw_x;
         a.logTw = logNx;
         a.scale = scale;
@@ -113,7 +104,7 @@ struct Fft2dPlan {
                 a.in_off1 = ins[1] - in; a.out_off1 = outs[1] - out;
                 if (nb > 2) { a.in_off2 = ins[2] - in; a.out_off2 = outs[2] - out; }
             }
-            a.logL = logN1; a.NT = (int)((N1 * C) / EPT); a.st = make_stages(logN1);
+            a.logL = logN1; a.NT = (int)((N1 * C) / EPT);
             a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
             a.twiddle = (logN2 > 0) ? 1 : 0;
             a.scale = (logN2 > 0) ? (T)1 : scale;
@@ -126,7 +117,7 @@ struct Fft2dPlan {
             a.in_off1 = a.out_off1 = outs[1] - out;
             if (nb > 2) a.in_off2 = a.out_off2 = outs[2] - out;
         }
-        a.logL = logN2; a.NT = (int)((N2 * C) / EPT); a.st = make_stages(logN2);
+        a.logL = logN2; a.NT = (int)((N2 * C) / EPT);
         if (a.NT < 1) a.NT = 1;
         a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;
         a.twiddle = 0; a.scale = scale; a.rband = clampr(rband); a.ny = ny;
