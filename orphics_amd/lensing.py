@@ -537,7 +537,7 @@ class Estimator(object):
         ``norm`` overrides the divergence/normalisation plane (MV weights), ``accumulate`` adds into ``out``."""
         e = self.eng
         if not e.pow2:
-            raise NotImplementedError("polarisation / general estimators need power-of-two map sides (TT works on any even side)")
+            return self._reconstruct_hc_modular(XY, kX, kY, out, norm, accumulate)
         G = self._setup_general(XY)
         w = self._buffers()
         Gx, Gy, H = w["G"]
@@ -559,6 +559,33 @@ class Estimator(object):
             e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch), width=wl, rband=rl)
             e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0), win=wl, wout=wk)
         return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk, rband=rk)
+
+    def _reconstruct_hc_modular(self, XY, kX, kY, out=None, norm=None, accumulate=False):
+        """The same estimator through the modular public calls only (map sides that are not powers of two, where
+        the fused kernels do not exist): per separable piece legs -> 3 C2R -> 2 real-space products, summed over
+        the pieces in real space (the forward transform is linear), then 2 R2C and the divergence."""
+        e = self.eng
+        G = self._setup_general(XY)
+        w = self._buffers()
+        gx, gy, h = self._real_buffers()
+        if getattr(self, "_racc", None) is None:
+            self._racc = (e.real(), e.real())
+        ax, ay = self._racc
+        for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
+            kg, kh = (kY, kX) if swap else (kX, kY)
+            Gx, Gy, H = e.qe_legs(kg, kh, FG, FH, out=w["G"])
+            e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
+            e.mul_real(gx, h, out=gx)
+            e.mul_real(gy, h, out=gy)
+            if i == 0:
+                e.axpby(gx, gx, float(sign), 0.0, out=ax)
+                e.axpby(gy, gy, float(sign), 0.0, out=ay)
+            else:
+                e.axpby(gx, ax, float(sign), 1.0, out=ax)
+                e.axpby(gy, ay, float(sign), 1.0, out=ay)
+        Px, Py = w["P"]
+        e.rfft(ax, out=Px); e.rfft(ay, out=Py)
+        return e.qe_div(Px, Py, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate)
 
     # ---- minimum-variance combination (BASELINE config 3) -------------------------------------------
     def mv_weights(self, estimators=("TT", "TE", "EE", "EB", "TB")):
