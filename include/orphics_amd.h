@@ -50,7 +50,8 @@ int oa_device_count(void);
  * estimator kernel.  Other EVEN sides (<= 8192; the reference notebooks use 600, 750, 2400) are served exactly by a
  * chirp-z (Bluestein) evaluation on an inner power-of-two plan: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and all
  * per-mode / binning / RNG kernels work, `width` / `rband` hints are ignored, and the fused oa_qe_rows /
- * oa_qe_*_cols / oa_fft_cols / oa_fft_pass calls return an error (use the modular oa_qe_legs .. oa_qe_div chain). */
+ * oa_qe_*_cols / oa_fft_cols / oa_fft_pass calls return an error (use the modular oa_qe_legs .. oa_qe_div chain,
+ * as orphics_amd/lensing.py:_reconstruct_hc_modular does). */
 int oa_plan_create(int ny, int nx, int dtype, oa_plan** out);
 int oa_plan_destroy(oa_plan* p);
 long oa_plan_kpitch(const oa_plan* p);
