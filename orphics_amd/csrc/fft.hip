@@ -17,13 +17,13 @@ template <typename T, class SEQ> constexpr int qe_waves_per_eu() {
     return sizeof(T) == 8 ? 1 : (row_maxnt<SEQ>() > 256 ? 2 : OA_QE_WAVES_PER_EU);
 }
 
-template <typename T, class SEQ>
+template <typename T, class SEQ, int NZ>
 __global__ __launch_bounds__(row_maxnt<SEQ>(), (qe_waves_per_eu<T, SEQ>())) void row_qe_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
 #ifdef OA_QE_INPLACE   // in-place DIF/DIT variant: 18 instead of 30 barriers per row, same speed on gfx950 (measured)
     row_qe_body_inplace<T, SEQ>(c, a);
 #else
-    row_qe_body<T, SEQ>(c, a);
+    row_qe_body<T, SEQ, NZ>(c, a);
 #endif
 }
 
@@ -71,7 +71,13 @@ struct HipLauncher {
             using S = decltype(seq);
             if constexpr (seq_logl<S>() >= 4) {
                 if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
-                go(row_qe_kernel<T, S>, dim3(grid), nt, smem, a);
+                // active columns: the first inverse stage gathers its few live taps straight from global memory
+                if constexpr (S::n >= 2 && S::rget(0) == 16 && sizeof(T) == 4) {
+                    const int nz = qe_first_stage_nz(a.logL, 16, a.win);
+                    if (nz == 1) { go(row_qe_kernel<T, S, 1>, dim3(grid), nt, smem, a); return; }
+                    if (nz == 2) { go(row_qe_kernel<T, S, 2>, dim3(grid), nt, smem, a); return; }
+                }
+                go(row_qe_kernel<T, S, 0>, dim3(grid), nt, smem, a);
             } else {
                 if (!rc) rc = fail("fft: unsupported row length");
             }

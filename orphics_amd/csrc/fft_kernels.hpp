@@ -484,11 +484,66 @@ OA_HD void forward_tail(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC,
     if constexpr (SEQ::n >= 4) lds_stage<T, SEQ, 3, false>(ctx, s, tid, NT, logL, logC, RS, tw, logTw);
 }
 
+// ---- active-column first stage of the inverse row transforms ------------------------------------------------
+// With win active columns only the taps t < NZ and t >= R-NZ of the first (radix R, stride S = L/R) inverse stage
+// can carry data (n = j + t*S < win, or its mirror partner L-n < win).  Those few operands are untangled straight
+// from the half-complex rows,  Z'[n] = (X[n] + conj X[L-n]) + i conj(W_N^n) (X[n] - conj X[L-n]),  the others are
+// literal (negative) zeros that the compiler folds out of the butterfly: no prologue pass through LDS, no LDS reads
+// in this stage, one barrier less per transform.  NZ = 0 selects the general prologue path.
+template <typename T>
+OA_HD cx<T> c2r_tap(const cx<T>* row, int n, int L, int win, const cx<T>* tw, int sh) {
+    const int m = L - n;
+    cx<T> A = mk<T>((T)0, (T)0), B = A;
+    if (n >= win && m >= win) return A;
+    if (n < win) A = row[n];
+    if (m < win) B = row[m];
+    const cx<T> d = A - conj(B);
+    return swp((A + conj(B)) + mul_pi(conj(tw[n << sh]) * d));
+}
+// smallest supported NZ in {1, 2} that covers `win` for a first stage of radix 16 on L points, or 0 (general path).
+// Only radix-16 first stages (rows of 8192 points and up in the reversed sequence <16,16,16>) keep the variant inside
+// the register budget; measured slower (spills) for the radix-8 first stage of 4096-point rows and for NZ = 4.
+OA_HD int qe_first_stage_nz(int logL, int R, int win) {
+    if (R != 16 || win <= 0 || win > (1 << logL)) return 0;
+    const int S = (1 << logL) / R;
+    const int need = (win + S - 1) / S;
+    return need <= 1 ? 1 : (need <= 2 ? 2 : 0);
+}
+
+template <typename T, class SEQ, int NZ, class Ctx>
+OA_HD void inverse_to_regs_pruned(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logL, int logC, int RS, const cx<T>* tw,
+                                  const cx<T>* in, long pitch, long r0, const cx<T>* gtw, int logTw, int win) {
+    constexpr int n = SEQ::n;
+    constexpr int R = SEQ::rget(0), LR = Log2c<R>::v, NB = EPT / R;
+    static_assert(n >= 2, "pruned first stage needs at least two stages");
+    const int logLR = logL - LR, L = 1 << logL, sh = logTw - (logL + 1);
+    {
+        cx<T> w[EPT];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int b = tid + u * NT;
+            const int j = b & ((1 << logLR) - 1), c = b >> logLR;
+            const cx<T>* row = in + (r0 + c) * pitch;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                if (t < NZ || t >= R - NZ) w[u * R + t] = c2r_tap<T>(row, j + (t << logLR), L, win, gtw, sh);
+                else w[u * R + t] = mk<T>((T)-0.0, (T)-0.0);
+            }
+            Dft<T, R>::run(w + u * R);
+        }
+        stage_out<T, R, true, false>(s, w, tid, NT, logL, logC, RS, 0, NoStore{});
+    }
+    ctx.sync();
+    if constexpr (n >= 3) lds_stage<T, SEQ, 1, true>(ctx, s, tid, NT, logL, logC, RS, tw, logL);
+    if constexpr (n >= 4) lds_stage<T, SEQ, 2, true>(ctx, s, tid, NT, logL, logC, RS, tw, logL);
+    stage_in<T, SEQ::get(0), true, false>(s, v, tid, NT, logL, logC, RS, rev_logns<SEQ>(n - 1), tw, logL, NoLoad{});
+}
+
 // The inverse transforms run the REVERSED radix sequence, so their last stage has radix R0 and leaves
 // point n = j + t*(L/R0) in register t of thread j -- exactly the operand layout of the forward
 // transform's first (twiddle-free) stage.  h therefore stays in 16 registers per thread, the
 // real-space product is a register multiply, and the only LDS is one padded work row set.
-template <typename T, class SEQ, class Ctx>
+template <typename T, class SEQ, int NZ = 0, class Ctx>
 OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
@@ -501,20 +556,29 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* twl = work + C * RS;                   // two-level stage-twiddle table (LDS)
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
 
-    c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
-    ctx.sync();
-    inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
-    stage_in<T, R0, true, false>(work, hreg, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
+    if constexpr (NZ > 0 && SEQ::n >= 2) {
+        ctx.sync();   // twiddle table complete before the first LDS-reading stage
+        inverse_to_regs_pruned<T, SEQ, NZ>(ctx, work, hreg, tid, NT, logL, logC, RS, twl, a.h, a.pitch, r0, a.tw, a.logTw, a.win);
+    } else {
+        c2r_prologue<T>(ctx, work, a.h, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
+        ctx.sync();
+        inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
+        stage_in<T, R0, true, false>(work, hreg, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
+    }
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = mk<T>(hreg[t].y * a.scale, hreg[t].x * a.scale);  // unswap -> (h[2n], h[2n+1])
     ctx.sync();
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? a.gy : a.gx;
         cx<T>* dst = leg ? a.py : a.px;
-        c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
-        ctx.sync();
-        inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
-        stage_in<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
+        if constexpr (NZ > 0 && SEQ::n >= 2) {
+            inverse_to_regs_pruned<T, SEQ, NZ>(ctx, work, v, tid, NT, logL, logC, RS, twl, src, a.pitch, r0, a.tw, a.logTw, a.win);
+        } else {
+            c2r_prologue<T>(ctx, work, src, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, a.win);
+            ctx.sync();
+            inverse_head<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
+            stage_in<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, lastns, twl, logL, NoLoad{});
+        }
         // v holds the swapped C2R result: (im, re) = (x[2n+1], x[2n]); product with h, repacked for R2C
 #pragma unroll
         for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].x, v[t].x * hreg[t].y);

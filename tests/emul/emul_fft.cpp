@@ -57,7 +57,14 @@ struct EmuLauncher {
     template <typename T> void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
-            run(grid, 1, nt, smem, [&](EmuCtx& c) { if (stockham_qe) row_qe_body<T, S>(c, a); else row_qe_body_inplace<T, S>(c, a); });
+            int nz = 0;
+            if constexpr (S::n >= 2) nz = qe_first_stage_nz(a.logL, S::rget(0), a.win);
+            run(grid, 1, nt, smem, [&](EmuCtx& c) {
+                if (!stockham_qe) row_qe_body_inplace<T, S>(c, a);
+                else if (nz == 1) row_qe_body<T, S, 1>(c, a);
+                else if (nz == 2) row_qe_body<T, S, 2>(c, a);
+                else row_qe_body<T, S, 0>(c, a);
+            });
         });
     }
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
