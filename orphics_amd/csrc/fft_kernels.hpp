@@ -1045,9 +1045,25 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     ctx.sync();
     const ColLoad<T> la{a.A + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     const ColLoad<T> lb{a.B + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
-    col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL, la);
-    ctx.sync();
-    col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL, lb);
+    if constexpr (n == 2) {
+        // both tiles' global loads are issued back to back (twice the bytes in flight per workgroup) before either
+        // plane goes through LDS
+        constexpr int R0 = SEQ::get(0);
+        constexpr int l0 = Log2x<R0>::v;
+        stage_in<T, R0, false, true>(s, va, tid, NT, logL, logC, 0, 0, twl, logL, la);
+        stage_in<T, R0, false, true>(s, vb, tid, NT, logL, logC, 0, 0, twl, logL, lb);
+        stage_out<T, R0, false, false>(s, va, tid, NT, logL, logC, 0, 0, NoStore{});
+        ctx.sync();
+        stage_in<T, RL, false, false>(s, va, tid, NT, logL, logC, 0, l0, twl, logL, NoLoad{});
+        ctx.sync();
+        stage_out<T, R0, false, false>(s, vb, tid, NT, logL, logC, 0, 0, NoStore{});
+        ctx.sync();
+        stage_in<T, RL, false, false>(s, vb, tid, NT, logL, logC, 0, l0, twl, logL, NoLoad{});
+    } else {
+        col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL, la);
+        ctx.sync();
+        col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL, lb);
+    }
     const long oorg = g * a.out_gs * a.pitch + c0;
     const T* Fnb = a.Fn + oorg;
     cx<T>* outb = a.out + oorg;
