@@ -364,6 +364,14 @@ def main():
                         "derived": "whole call minus its row and pass-1 launches"}
         share[name_fl] = t_fl
         del share[whole]
+        # the fused row stage is arithmetic, not bandwidth, bound: 5 packed N/2-point complex transforms per row
+        # (5 L log2 L flop each) against the f32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s counts every lane
+        # as an FMA; an FFT is ~2/3 additions, so ~50 % of it is the practical ceiling of butterfly code)
+        Lrow = N // 2
+        qe_flop = N * 5 * 5.0 * Lrow * np.log2(Lrow)
+        per["row_qe_kernel"]["fft_GFLOP_per_launch"] = qe_flop / 1e9
+        per["row_qe_kernel"]["achieved_TFLOPs"] = qe_flop / (per["row_qe_kernel"]["avg_ms"] * 1e-3) / 1e12
+        per["row_qe_kernel"]["frac_of_f32_vector_peak_157.3"] = per["row_qe_kernel"]["achieved_TFLOPs"] / 157.3
         dom = max(share, key=share.get)
         d_alg, d_act, d_t = per[dom]["algorithmic_GB"] * 1e9, per[dom]["hbm_min_GB"] * 1e9, per[dom]["avg_ms"]
         traffic = None
