@@ -67,7 +67,9 @@ struct HipLauncher {
     }
     template <typename T>
     void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
-        const bool ok = dispatch_seq(a.logL, [&](auto seq) {
+        // rows of 16384 / 32768 points: put the short radix FIRST so that the reversed (inverse) sequence starts with
+        // a radix-16 stage and the active-column first stage applies (the plain greedy order would start it with 2 / 4)
+        const bool ok = dispatch_seq_qe(a.logL, [&](auto seq) {
             using S = decltype(seq);
             if constexpr (seq_logl<S>() >= 4) {
                 if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }

@@ -286,6 +286,16 @@ inline bool dispatch_seq(int logL, F&& f) {
     }
 }
 
+// radix sequences of the fused row stage: as dispatch_seq, except that 4-stage lengths lead with the short radix
+template <class F>
+inline bool dispatch_seq_qe(int logL, F&& f) {
+    switch (logL) {
+        case 13: f(Seq<2, 16, 16, 16>{}); return true;
+        case 14: f(Seq<4, 16, 16, 16>{}); return true;
+        default: return dispatch_seq(logL, f);
+    }
+}
+
 // ===========================================================================
 // Row pass: contiguous sequences.  One workgroup transforms C rows.
 // ===========================================================================

@@ -55,7 +55,7 @@ struct EmuLauncher {
         });
     }
     template <typename T> void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
-        dispatch_seq(a.logL, [&](auto seq) {
+        dispatch_seq_qe(a.logL, [&](auto seq) {
             using S = decltype(seq);
             int nz = 0;
             if constexpr (S::n >= 2) nz = qe_first_stage_nz(a.logL, S::rget(0), a.win);

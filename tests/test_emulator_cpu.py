@@ -100,7 +100,7 @@ def _col_ifft(k, ny):
 @pytest.mark.parametrize("stockham", [0, 1])
 @pytest.mark.parametrize("ny,nx,win,wout", [(32, 64, 0, 0), (32, 128, 20, 41), (64, 256, 33, 64), (32, 512, 100, 150),
                                             (32, 2048, 200, 330), (32, 8192, 380, 664), (32, 8192, 200, 330),
-                                            (64, 512, 30, 60)])
+                                            (64, 512, 30, 60), (32, 16384, 380, 664), (32, 16384, 0, 0)])
 def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
     """row_qe: P = R2C(C2R(G) * C2R(H)) row by row, with and without active-column limits; both kernel bodies
     (Stockham = the product kernel, in-place DIF/DIT = the -DOA_QE_INPLACE variant with 18 instead of 30 barriers).
