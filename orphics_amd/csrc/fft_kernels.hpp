@@ -287,6 +287,8 @@ inline bool dispatch_seq(int logL, F&& f) {
 }
 
 // radix sequences of the fused row stage: as dispatch_seq, except that 4-stage lengths lead with the short radix
+// (3-stage lengths with a short radix -- 1024..4096-point rows -- were measured faster in the greedy order: their
+// active-column variants spill)
 template <class F>
 inline bool dispatch_seq_qe(int logL, F&& f) {
     switch (logL) {
