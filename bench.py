@@ -10,15 +10,27 @@ One "step" = one reconstruction from a real-space map resident in HBM:
 Multi-GPU: independent realisations per rank (weak scaling, no data-path
 collective) + ONE RCCL all-reduce of the bandpower moments at the end.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-Prints one JSON line (rank 0) with `roofline` (dominant kernel, live HIP-event
-timing on the launch stream) and `cpu_baseline` (NumPy oracle on host cores).
+With N > 1 and no torchrun environment the script starts N ranks itself (a child
+``python -m torch.distributed.run`` started BEFORE this process touches the GPU);
+under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE and checks them against --gpus.
+
+Prints one JSON line (rank 0):
+  value / ms_per_step : whole-job reconstructions/s over the K timed steps (max over ranks)
+  roofline            : the dominant kernel against the roof that binds it -- "valu" (f32 vector peak, on the
+                        arithmetic it executes) for the fused row stage, "hbm" (on the bytes it moves) otherwise;
+                        `frac` <= 1 by construction.  `hbm` holds the memory side: the dense pipeline against
+                        SURVEY 8d's 37.25 A bytes and every bandwidth-bound kernel on its own bytes.
+  extra               : side legs of the same job (never the headline): dense (prune=False), bandlimited,
+                        f64 (the reference's arithmetic type), wideband (T filter ell < 6000)
+  cpu_baseline        : NumPy/SciPy oracle on the host cores (workers = 1 and = nproc, median of 5 after warm-up)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,10 +41,71 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
+VALU_PEAK_TFLOPS = 157.3   # f32 vector peak (MI355X_MICROARCH.md chip table)
+PROFILE_TAG = "r02"        # profiles/traffic_<tag>.json, profiles/flops_<tag>.json
 
 
-def build_pipeline(N, res_arcmin, prec, torch, prune=True):
+# --------------------------------------------------------------------------------------------------------------
+# launch plumbing
+# --------------------------------------------------------------------------------------------------------------
+def resolve_world(gpus, env):
+    """(world, rank, local_rank, spawn): ``spawn`` = this process must start the ranks itself.
+    Raises SystemExit when the torchrun environment contradicts --gpus."""
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: python -m "
+                             "torch.distributed.run --nproc-per-node %d bench.py --gpus %d ...)" % (gpus, world, gpus, gpus))
+        return world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), False
+    if gpus > 1:
+        return gpus, 0, 0, True
+    return 1, 0, 0, False
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(gpus, argv):
+    """Start ``gpus`` ranks as CHILD processes, one per GPU, with the torchrun environment (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  This parent has made no GPU call and never execs; it returns non-zero
+    if any rank fails (the others are then terminated)."""
+    import torch   # device_count() does not initialise the GPU
+    backend = os.environ.get("OA_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (gpus, ndev))
+    port = str(_free_port())
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:          # one rank died: the rest would hang in the next collective
+                    other.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------------------
+# pipeline construction
+# --------------------------------------------------------------------------------------------------------------
+def build_pipeline(N, res_arcmin, prec, torch, prune=True, tlmax=2000.0, klmax=3500.0, row_grid="auto"):
     from orphics_amd import cosmology, lensing, maps
     from orphics_amd.geometry import FlatGeometry
     shape = (N, N)
@@ -41,8 +114,8 @@ def build_pipeline(N, res_arcmin, prec, torch, prune=True):
     nxh = N // 2
     ly, lx = geom.laxes()
     ml_h = np.sqrt(ly[:, None] ** 2 + lx[None, :nxh + 1] ** 2)
-    # half-plane inputs are expanded only where the public constructor wants full planes;
-    # here everything is even-symmetric, so build full planes by mirroring cheaply
+
+    # the public constructor takes full planes; everything here is even-symmetric: mirror the half planes
     def full(a_h):
         out = np.empty(shape, dtype=a_h.dtype)
         out[:, :nxh + 1] = a_h
@@ -51,11 +124,11 @@ def build_pipeline(N, res_arcmin, prec, torch, prune=True):
         return out
     beam_h = maps.gauss_beam(ml_h, 1.5)
     noise_h = np.full(ml_h.shape, cosmology.white_noise_power(1.0))
-    tmask_h = ((ml_h > 300) & (ml_h < 2000)).astype(np.int64)
-    kmask_h = ((ml_h > 20) & (ml_h < 3500)).astype(np.int64)
+    tmask_h = ((ml_h > 300) & (ml_h < tlmax)).astype(np.int64)
+    kmask_h = ((ml_h > 20) & (ml_h < klmax)).astype(np.int64)
     qkw = dict(noise2d=full(noise_h), beam2d=full(beam_h), kmask=full(tmask_h), kmask_K=full(kmask_h),
                unlensed_equals_lensed=True, dtype=prec)
-    q = lensing.qest(shape, geom, theory, prune=prune, **qkw)
+    q = lensing.qest(shape, geom, theory, prune=prune, row_grid=row_grid, **qkw)
     eng = q.eng
     # synthetic observed maps: GRF with C_l^TT B^2 + N
     cl_h = theory.lCl("TT", ml_h)
@@ -66,77 +139,123 @@ def build_pipeline(N, res_arcmin, prec, torch, prune=True):
     ed = torch.as_tensor(edges, device=eng.device)
     ids = eng.modl_digitize(ed, half=True)
     return dict(q=q, qkw=qkw, eng=eng, geom=geom, cs=cs_d, ids=ids, nids=len(edges) + 1, edges=edges, theory=theory,
-                beam_h=beam_h, noise_h=noise_h, tmask_h=tmask_h, kmask_h=kmask_h, cl_h=cl_h)
+                tlmax=tlmax, prec=prec)
 
 
-def timed_steps(torch, step, nsteps, nwarm=10):
-    for i in range(nwarm):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(nsteps):
-        step(i)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / nsteps
+def make_maps(P, torch, seed, n=2):
+    eng = P["eng"]
+    return [eng.irfft(eng.grf_hc(seed, i, P["cs"]), scale=1.0 / np.sqrt(eng.npix)) for i in range(n)]
+
+
+class Runner(object):
+    """`ns` estimator handles on `ns` HIP streams (shared filters, private plan + work buffers), device-side
+    bandpower moments per stream: step(i) = map -> kappa_hat -> 19 bandpowers -> (n, S, C) accumulation."""
+
+    def __init__(self, P, torch, tmaps, ns):
+        from orphics_amd.engine import _ptr, _stream
+        from orphics_amd._lib import check
+        self.P, self.torch, self.tmaps, self.ns = P, torch, tmaps, max(1, ns)
+        q, eng = P["q"], P["eng"]
+        self.q, self.eng = q, eng
+        self.d = P["nids"] - 2
+        N = eng.ny
+        self.norm = P["geom"].area / float(N * N) ** 2
+        self.qs = [q] + [q.fork() for _ in range(self.ns - 1)]
+        self.streams = [torch.cuda.Stream() for _ in range(self.ns)]
+        self.kks = [e.new_output() for e in self.qs]
+        d = self.d
+        self.mom_n = [torch.zeros(1, dtype=torch.int64, device=eng.device) for _ in range(self.ns)]
+        self.mom_S = [torch.zeros(d, dtype=torch.float64, device=eng.device) for _ in range(self.ns)]
+        self.mom_C = [torch.zeros(d, d, dtype=torch.float64, device=eng.device) for _ in range(self.ns)]
+        # mode counts per bin do not depend on the data: taken once over the whole plane
+        z = eng.hc()
+        _, self.counts = eng.bin_power(z, z, self.norm, P["ids"], P["nids"], herm=True)
+        torch.cuda.synchronize()
+        self._ptr, self._stream, self._check = _ptr, _stream, check
+        self.last = {}
+
+    def step(self, i):
+        j = i % self.ns
+        q, P = self.q, self.P
+        with self.torch.cuda.stream(self.streams[j]):
+            e = self.qs[j].eng
+            self.qs[j].reconstruct_tt_from_map(self.tmaps[i & 1], out=self.kks[j])
+            sums, _ = e.bin_power(self.kks[j], self.kks[j], self.norm, P["ids"], P["nids"], herm=True,
+                                  active_cols=q.kappa_cols, active_rows=q.kappa_rows)
+            self._check(e.lib.oa_moments_add_binned(self._ptr(sums[1:]), self._ptr(self.counts[1:]), self.d, self._ptr(self.mom_n[j]),
+                                                    self._ptr(self.mom_S[j]), self._ptr(self.mom_C[j]), self._stream()))
+            self.last[i & 1] = sums
+
+    def zero(self):
+        for j in range(self.ns):
+            self.mom_n[j].zero_(); self.mom_S[j].zero_(); self.mom_C[j].zero_()
+
+    def bandpowers(self, which=0):
+        """bandpowers of map `which` through this runner's path"""
+        self.step(which)
+        self.torch.cuda.synchronize()
+        return self.last[which][1:-1] / self.counts[1:-1]
+
+    def rate(self, nsteps, nwarm=10):
+        for i in range(nwarm):
+            self.step(i)
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            self.step(i)
+        self.torch.cuda.synchronize()
+        return nsteps / (time.perf_counter() - t0)
+
+
+def side_leg(torch, args, name, ref_p1d, seed, **kw):
+    """One side measurement: its own estimator + runner on the same synthetic job; bandpowers compared with `ref_p1d`
+    (same maps: the GRF draw depends only on (seed, index))."""
+    P = build_pipeline(args.n, args.res, kw.pop("prec", args.prec), torch, **kw)
+    tm = make_maps(P, torch, seed)
+    R = Runner(P, torch, tm, args.streams)
+    rate = R.rate(args.steps)
+    p1d = R.bandpowers(0)
+    out = {"reconstructions_per_s": rate, "streams_per_gpu": R.ns}
+    if ref_p1d is not None:
+        out["max_rel_bandpower_diff"] = float((p1d.double() / ref_p1d.double() - 1).abs().max().item())
+    return out, p1d, P, R
 
 
 def bandlimited_leg(P, args, torch, tmaps, ref_p1d):
-    """Same job (R2C of the full-resolution map -> kappa_hat -> 19 bandpowers) with the reconstruction on the
-    smallest grid that holds the band-limited legs and their products exactly (lensing.BandlimitedEstimator)."""
+    """Same job with the reconstruction on the smallest grid that holds the band-limited legs and their products
+    exactly (opt-in lensing.BandlimitedEstimator)."""
     from orphics_amd import lensing
     N = args.n
     bl = lensing.BandlimitedEstimator((N, N), P["geom"], P["theory"], **P["qkw"])
     es = bl.q.eng
     ids = es.modl_digitize(torch.as_tensor(P["edges"], device=es.device), half=True)
     nrm = bl.gsmall.area / float(bl.n ** 2) ** 2
-    kk = es.hc()
-    _, counts = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True)
+    kk = bl.q.new_output()
+    _, counts = es.bin_power(es.hc(), es.hc(), nrm, ids, P["nids"], herm=True)
     res = {}
 
     def step(i):
         bl.reconstruct_tt_from_map(tmaps[i & 1], out=kk)
         res["sums"], _ = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True, active_cols=bl.q.kappa_cols, active_rows=bl.q.kappa_rows)
-    dt = timed_steps(torch, step, args.steps)
+    for i in range(10):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
     step(0)
+    torch.cuda.synchronize()
     p1d = res["sums"][1:-1] / counts[1:-1]
     return {"reconstructions_per_s": 1.0 / dt, "internal_grid": bl.n,
-            "max_rel_bandpower_diff_vs_headline_path": float((p1d / ref_p1d - 1).abs().max().item()),
+            "max_rel_bandpower_diff": float((p1d / ref_p1d - 1).abs().max().item()),
             "note": "opt-in lensing.BandlimitedEstimator: input R2C at full resolution (active columns only), estimator "
                     "on the coarse grid; exact for band-limited filters (coarse Nyquist > ell_max_X + ell_max_Y)"}
 
 
-def dense_leg(P, args, torch, tmaps, ref_p1d, norm):
-    """The same job with prune=False: every plane processed over all nx/2+1 columns (what a filter without a
-    band limit costs).  Reported beside the headline for transparency."""
-    from orphics_amd import lensing
-    q = lensing.qest((args.n, args.n), P["geom"], P["theory"], prune=False, **P["qkw"])
-    eng = q.eng
-    ns = max(1, args.streams)
-    qs = [q] + [q.fork() for _ in range(ns - 1)]
-    streams = [torch.cuda.Stream() for _ in range(ns)]
-    kks = [e.eng.hc() for e in qs]
-    res = {}
-
-    def step(i):
-        j = i % ns
-        with torch.cuda.stream(streams[j]):
-            e = qs[j].eng
-            qs[j].reconstruct_tt_from_map(tmaps[i & 1], out=kks[j])
-            res[i & 1] = e.bin_power(kks[j], kks[j], norm, P["ids"], P["nids"], herm=True)
-    dt = timed_steps(torch, step, args.steps)
-    step(0)
-    torch.cuda.synchronize()
-    sums, counts = res[0]
-    p1d = sums[1:-1] / counts[1:-1]
-    A = 4 * args.n * args.n if args.prec == "f32" else 8 * args.n * args.n
-    return {"reconstructions_per_s": 1.0 / dt, "streams_per_gpu": ns,
-            "max_rel_bandpower_diff_vs_headline_path": float((p1d / ref_p1d - 1).abs().max().item()),
-            "pipeline_achieved_GBs_on_survey_37.25A": 37.25 * A / dt / 1e9,
-            "pipeline_frac_of_hbm_peak": 37.25 * A / dt / 1e9 / HBM_PEAK_GBS,
-            "note": "prune=False: all nx/2+1 columns of every plane are transformed (filters without a band limit)"}
-
-
 def time_kernel(torch, fn, reps=20, warm=3):
+    """Mean duration (s) of `fn`'s launches on the CURRENT stream (HIP events recorded on that stream)."""
     for _ in range(warm):
         fn()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -147,44 +266,163 @@ def time_kernel(torch, fn, reps=20, warm=3):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3  # seconds per launch
+    return e0.elapsed_time(e1) / reps * 1e-3
 
 
-def cpu_baseline(N_gpu, res_arcmin, budget_n=None):
-    """NumPy/SciPy oracle (float64, full-plane C2C like the reference) on a bounded sample."""
+# --------------------------------------------------------------------------------------------------------------
+# executed arithmetic of the fused row stage (tools/count_flops: the kernel body run on the host over a counting
+# scalar type -- adds/multiplies with non-constant operands, packed-asm complex products as 6, a+-ib as 2)
+# --------------------------------------------------------------------------------------------------------------
+def row_qe_flops(N, win, wout, mrow=0):
+    """(flops per launch, row grid, provenance).  Falls back to the nominal 5 L log2 L radix-2 count x 5 transforms."""
+    W = N // 2 + 1
+    win = W if not win else win
+    wout = W if not wout else wout
+    exe = os.path.join(ROOT, "tools", "_bin", "count_flops")
+    if os.path.exists(exe):
+        try:
+            out = subprocess.run([exe, str(N), str(win), str(wout), str(mrow)], capture_output=True, text=True, timeout=300)
+            d = json.loads(out.stdout.strip().splitlines()[-1])
+            return float(d["flops_per_row"]) * N, int(d["mrow"]), "tools/count_flops (executed arithmetic of the kernel body, per row x rows)"
+        except Exception:
+            pass
+    M = N
+    if mrow < 0:
+        M = 64
+        while M < 2 * win + wout and M < N:
+            M *= 2
+    elif mrow > 0:
+        M = mrow
+    L = M // 2
+    return N * 5 * 5.0 * L * np.log2(L), M, "nominal 5 L log2 L per packed transform x 5 (count_flops not built: upper bound)"
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(path):
+        try:
+            return json.load(open(path))
+        except Exception:
+            return None
+    return None
+
+
+def per_kernel_table(torch, P, R, args):
+    """Live per-kernel timings (HIP events on the launch stream) with the bytes each kernel must move once
+    (inputs + outputs on its active columns / rows) and, for the row stage, the arithmetic it executes."""
+    q, eng = P["q"], P["eng"]
+    N = eng.ny
+    es = 4 if P["prec"] == "f32" else 8
+    A = es * N * N
+    W = N // 2 + 1
+    Ah = 2 * es * N * W
+    wl, wk = q.leg_cols, q.kappa_cols
+    rl, rk = q.leg_rows, q.kappa_rows
+    fl, fk = (wl or W) / float(W), (wk or W) / float(W)
+    gl = (2 * rl - 1) / float(N) if rl else 1.0       # active row fractions
+    gk = (2 * rk - 1) / float(N) if rk else 1.0
+    s1, s2, s3, s4, s5 = eng.hc(), eng.hc(), eng.hc(), eng.hc(), eng.hc()
+    r1 = R.tmaps[0]
+    kk = q.new_output()
+    FG, FH, Fn = q._F["TT"]
+    norm = R.norm
+
+    def map_legs():
+        eng.qe_map_legs_cols(r1, FG, FH, out=(s1, s2, s3), width=wl, rband=rl)
+
+    # name -> (launcher, bytes it must move once)
+    kern = {
+        "row_fft_kernel<R2C>": (lambda: eng.fft_pass(0, r1, s1, wl), A + fl * Ah),
+        "col_fft_kernel<fwd pass1, leg width>": (lambda: eng.fft_pass(1, s1, s2, wl), 2 * fl * Ah),
+        "map_legs_cols (whole call)": (map_legs, None),
+        "row_qe_kernel": (lambda: eng.qe_rows(s1, s2, s3, s4, s5, win=wl, wout=wk, mrow=q.mrow), (3 * fl + 2 * fk) * Ah),
+        # one 2-plane pass-1 launch (read 2, write 2) + col_div (read 2 + Fn/2, write the band rows of 1)
+        "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk, rband=rk),
+                                                                 4 * fk * Ah + fk * (2 * Ah + gk * Ah / 2 + gk * Ah)),
+        "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], P["nids"], herm=True, active_cols=wk, active_rows=rk),
+                              1.5 * fk * gk * Ah),
+    }
+    per = {}
+    for name, (fn, moved) in kern.items():
+        dt = time_kernel(torch, fn)
+        per[name] = {"avg_ms": dt * 1e3}
+        if moved is not None:
+            per[name].update({"hbm_min_GB": moved / 1e9, "hbm_GBs": moved / dt / 1e9, "hbm_frac": moved / dt / 1e9 / HBM_PEAK_GBS})
+    whole = per.pop("map_legs_cols (whole call)")
+    t_fl = max(whole["avg_ms"] - per["row_fft_kernel<R2C>"]["avg_ms"] - per["col_fft_kernel<fwd pass1, leg width>"]["avg_ms"], 1e-6)
+    # col_fwdlegs (read pass-1 plane on the band rows' tiles + 2 real filter planes, write 3) + 3-plane inverse pass 2 (r+w 3)
+    m_fl = fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah
+    per["fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>"] = {
+        "avg_ms": t_fl, "hbm_min_GB": m_fl / 1e9, "hbm_GBs": m_fl / t_fl / 1e6, "hbm_frac": m_fl / t_fl / 1e6 / HBM_PEAK_GBS,
+        "derived": "whole oa_qe_map_legs_cols call minus its row and pass-1 launches"}
+    flops, mrow, how = row_qe_flops(N, wl, wk, q.mrow)
+    rq = per["row_qe_kernel"]
+    rq.update({"executed_GFLOP": flops / 1e9, "flop_count": how, "row_grid": mrow, "TFLOPs": flops / (rq["avg_ms"] * 1e-3) / 1e12,
+               "valu_frac": flops / (rq["avg_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+               "arithmetic_intensity_flop_per_B": flops / (rq["hbm_min_GB"] * 1e9)})
+    return per, dict(A=A, Ah=Ah, fl=fl, fk=fk, W=W, wl=wl, wk=wk, rl=rl, rk=rk, mrow=mrow)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# CPU baseline (SURVEY 8d: scipy.fft workers = 1 and = nproc, one warm-up + median of 5, CPU model stated)
+# --------------------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N_gpu, res_arcmin, reps=5):
+    """NumPy/SciPy oracle (float64, full-plane C2C like the reference) on a bounded sample, scaled N^2 log N."""
     from oracle import maps_oracle as mo
     from oracle import qe_oracle as qo
     from oracle import stats_oracle as so
     cores = os.cpu_count() or 1
-    if budget_n is None:
-        budget_n = 8192 if cores >= 64 else 4096     # keep the sample to ~10-30 s of CPU work
-    Ns = min(N_gpu, budget_n)
-    mo.set_workers(cores)
     res = res_arcmin * np.pi / 180. / 60.
-    shape = (Ns, Ns)
-    rng = np.random.default_rng(0)
-    ml = mo.modlmap(shape, res, -res)
-    mask = ((ml > 300) & (ml < 2000)).astype(np.float64)
-    Wg = mask / (1.0 + ml)
-    Wh = mask / (1.0 + ml)
-    Fn = ((ml > 20) & (ml < 3500)) * 1e-3
-    q = qo.QEOracleTT.for_timing(shape, res, -res, Wg, Wh, Fn)
-    fc = mo.FourierCalc(shape, res, -res)
-    binner = so.bin2D(ml, np.linspace(20, 3500, 20))
-    tmap = rng.standard_normal(shape)
-    t0 = time.perf_counter()
-    kT = fc.fft(tmap)
-    kk = q.kappa_ft(kT)
-    p2d = fc.f2power(kk, kk)
-    binner.bin(p2d)
-    dt = time.perf_counter() - t0
-    # scale N^2 log2(N^2) to the GPU workload size
-    scale = (N_gpu / Ns) ** 2 * (np.log2(float(N_gpu)) / np.log2(float(Ns)))
-    return {"value": 1.0 / (dt * scale), "unit": "reconstructions/s", "cores": cores, "kind": "port",
-            "sample": "one %dx%d float64 full-plane reconstruction (%.1f s), scaled x%.2f (N^2 log N) to %dx%d"
-                      % (Ns, Ns, dt, scale, N_gpu, N_gpu)}
+
+    def one(Ns, workers):
+        mo.set_workers(workers)
+        shape = (Ns, Ns)
+        rng = np.random.default_rng(0)
+        ml = mo.modlmap(shape, res, -res)
+        mask = ((ml > 300) & (ml < 2000)).astype(np.float64)
+        Wg = mask / (1.0 + ml)
+        Wh = mask / (1.0 + ml)
+        Fn = ((ml > 20) & (ml < 3500)) * 1e-3
+        q = qo.QEOracleTT.for_timing(shape, res, -res, Wg, Wh, Fn)
+        fc = mo.FourierCalc(shape, res, -res)
+        binner = so.bin2D(ml, np.linspace(20, 3500, 20))
+        tmap = rng.standard_normal(shape)
+        ts = []
+        for r in range(reps + 1):                       # first pass = warm-up (pocketfft plans, page faults)
+            t0 = time.perf_counter()
+            kT = fc.fft(tmap)
+            kk = q.kappa_ft(kT)
+            p2d = fc.f2power(kk, kk)
+            binner.bin(p2d)
+            ts.append(time.perf_counter() - t0)
+        ts = ts[1:]
+        scale = (N_gpu / Ns) ** 2 * (np.log2(float(N_gpu)) / np.log2(float(Ns)))
+        return {"sample_side": Ns, "median_s": float(np.median(ts)), "min_s": float(np.min(ts)), "runs": reps,
+                "scale_to_workload": scale, "reconstructions_per_s": 1.0 / (float(np.median(ts)) * scale)}
+    n_all = min(N_gpu, 4096 if cores >= 32 else 2048)
+    n_one = min(N_gpu, 2048 if cores >= 32 else 1024)
+    all_c = one(n_all, cores)
+    one_c = one(n_one, 1)
+    import scipy
+    return {"value": all_c["reconstructions_per_s"], "unit": "reconstructions/s", "cores": cores, "kind": "port",
+            "sample": "oracle (float64 full-plane C2C) TT reconstruction + binned auto-power: %dx%d on %d scipy.fft workers, "
+                      "%dx%d on 1 worker; one warm-up then median of %d runs; scaled by N^2 log N to %dx%d"
+                      % (n_all, n_all, cores, n_one, n_one, reps, N_gpu, N_gpu),
+            "workers_all": all_c, "workers_1": one_c, "value_workers_1": one_c["reconstructions_per_s"],
+            "cpu_model": cpu_model(), "numpy": np.__version__, "scipy": scipy.__version__}
 
 
+# --------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,24 +431,28 @@ def main():
     ap.add_argument("--n", type=int, default=8192, help="map side (default 8192, the metric's size)")
     ap.add_argument("--res", type=float, default=0.5)
     ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--tlmax", type=float, default=2000.0, help="upper ell of the T filter (SURVEY 8d: 2000; high-res variant 6000)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-prune", action="store_true",
                     help="process all nx/2+1 columns of every plane even where the band-limited filters vanish")
     ap.add_argument("--trace-steps", action="store_true", help="stderr: throughput per 20 timed steps (diagnostic)")
     ap.add_argument("--preroll", type=float, default=1.5, help="seconds of untimed load before the warm-up steps (clock ramp)")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="skip the two side measurements reported under 'extra' (never the headline value): the dense "
-                         "pipeline (prune=False) and the opt-in coarse-grid lensing.BandlimitedEstimator")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side legs reported under 'extra' (never the headline value)")
+    ap.add_argument("--extras", default="fullres_rows,dense,bandlimited,f64,wideband", help="comma list of side legs to run")
+    ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
+                    help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
+                         "(exact for band-limited filters; library default), full = the map's nx points")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams: independent realisations are issued round-robin "
                     "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
     args = ap.parse_args()
 
+    world, rank, local_rank, spawn = resolve_world(args.gpus, os.environ)
+    if spawn:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     backend = os.environ.get("OA_BENCH_BACKEND", "nccl")      # "gloo": rehearse the N>1 path on a box with fewer GPUs
@@ -223,74 +465,44 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
 
     N = args.n
-    P = build_pipeline(N, args.res, args.prec, torch, prune=not args.no_prune)
+    P = build_pipeline(N, args.res, args.prec, torch, prune=not args.no_prune, tlmax=args.tlmax, row_grid=args.row_grid)
     q, eng = P["q"], P["eng"]
-    nids = P["nids"]
-    d = nids - 2
-    norm = P["geom"].area / float(N * N) ** 2
-
-    # two resident input maps (distinct realisations per rank)
-    tmaps = [eng.irfft(eng.grf_hc(1234 + rank, i, P["cs"]), scale=1.0 / np.sqrt(eng.npix)) for i in range(2)]
-    ns = max(1, args.streams)
-    qs = [q] + [q.fork() for _ in range(ns - 1)]              # shared filters, private plan + work buffers
-    # every realisation stream is a side stream (measured ~3 % better than pairing the default stream with one)
-    streams = [torch.cuda.Stream() for _ in range(ns)]
-    kTs, kks = [e.eng.hc() for e in qs], [e.eng.hc() for e in qs]
-    kT, kk = kTs[0], kks[0]
-    p2d = eng.hcreal()
-    mom_n = [torch.zeros(1, dtype=torch.int64, device=eng.device) for _ in range(ns)]
-    mom_S = [torch.zeros(d, dtype=torch.float64, device=eng.device) for _ in range(ns)]
-    mom_C = [torch.zeros(d, d, dtype=torch.float64, device=eng.device) for _ in range(ns)]
-    from orphics_amd.engine import _ptr, _stream
-    from orphics_amd._lib import check
-
-    wl, wk = q.leg_cols, q.kappa_cols
-    # mode counts per bin do not depend on the data: taken once over the whole plane
-    _, counts = eng.bin_power(kT, kT, norm, P["ids"], nids, herm=True)
-    torch.cuda.synchronize()                 # `counts` is read from every stream below
-
-    def step(i):
-        j = i % ns
-        with torch.cuda.stream(streams[j]):
-            e = qs[j].eng
-            # map -> kappa_hat: columns / rows beyond the filters' support are neither produced nor read (exact: the
-            # masks zero them); the map's transform is consumed inside the fused leg kernel
-            qs[j].reconstruct_tt_from_map(tmaps[i & 1], out=kks[j])
-            sums, _ = e.bin_power(kks[j], kks[j], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)   # |kappa_hat|^2 binned in one kernel
-            # bin means (bin2D.bin) + ensemble moments (Statistics.add_to_stats) in one small kernel
-            check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), d, _ptr(mom_n[j]), _ptr(mom_S[j]), _ptr(mom_C[j]), _stream()))
+    seed = 1234 + rank                                    # distinct realisations per rank
+    tmaps = make_maps(P, torch, seed)
+    R = Runner(P, torch, tmaps, args.streams)
+    ns = R.ns
 
     # pre-roll: a fresh box idles at ~550 MHz sclk and needs a few hundred ms of load to reach its sustained
     # clocks; W warm-up steps alone (~10 ms) would leave the ramp inside the timed region.  Untimed, uncounted.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preroll:
         for i in range(8):
-            step(i)
+            R.step(i)
         torch.cuda.synchronize()
     for i in range(args.warmup):
-        step(i)
+        R.step(i)
     torch.cuda.synchronize()
     # rehearse the end-of-job reduction once (first use of a torch op / of the RCCL communicator loads code
     # objects and opens connections: tens of ms that belong to start-up, not to the K timed steps)
-    wn, wS, wC = sum(mom_n), sum(mom_S), sum(mom_C)
+    wn, wS, wC = sum(R.mom_n), sum(R.mom_S), sum(R.mom_C)
     if world > 1:
         dist.all_reduce(wn); dist.all_reduce(wS); dist.all_reduce(wC)
     torch.cuda.synchronize()
     del wn, wS, wC
-    for j in range(ns):                      # the timed region counts only its own realisations
-        mom_n[j].zero_(); mom_S[j].zero_(); mom_C[j].zero_()
+    R.zero()                                 # the timed region counts only its own realisations
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs = []
     for i in range(args.steps):
-        step(i)
+        R.step(i)
         if args.trace_steps:
             ev = torch.cuda.Event(enable_timing=True)
-            ev.record(streams[i % ns])
+            ev.record(R.streams[i % ns])
             evs.append(ev)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic: must stay < elapsed)
     torch.cuda.synchronize()
@@ -299,7 +511,7 @@ def main():
         sys.stderr.write("event span first->last step end: %.2f ms; wall to issue %.2f ms\n" % (ts[-1], t_issue * 1e3))
         for a in range(0, len(ts) - 20, 20):
             sys.stderr.write("steps %4d-%4d: %.1f recon/s\n" % (a, a + 20, 20.0 / max(ts[a + 20] - ts[a], 1e-9) * 1e3))
-    mom_n, mom_S, mom_C = sum(mom_n), sum(mom_S), sum(mom_C)     # per-stream accumulators
+    mom_n, mom_S, mom_C = sum(R.mom_n), sum(R.mom_S), sum(R.mom_C)     # per-stream accumulators
     if world > 1:
         # the ensemble reduce of Statistics.allreduce (stats.py:1209-1230): n, sum, cross
         dist.all_reduce(mom_n)
@@ -317,110 +529,118 @@ def main():
     assert total == args.steps * max(world, 1), "moment counter %d != steps x ranks" % total
 
     if rank == 0:
-        es = 4 if args.prec == "f32" else 8
-        A = es * N * N                        # one real plane
-        W = N // 2 + 1                        # hc columns
-        Ah = 2 * es * N * W                   # one half-complex plane (valid columns)
-        fl = (wl or W) / float(W)             # active fraction of the leg planes / of the input transform
-        fk = (wk or W) / float(W)             # active fraction of the product / kappa planes
-        # ---- live per-kernel timing (HIP events on the launch stream) ----
-        # per launch: (launcher, SURVEY-8d algorithmic bytes of the stages it covers -- 2-D FFT = row stage 2A +
-        # column stage 2A, my two column passes carry A each; plane terms scale with the active-column fraction
-        # of the plane they move --, bytes the kernel itself must move once (inputs + outputs), launches/recon)
-        s1, s2, s3, s4, s5 = eng.hc(), eng.hc(), eng.hc(), eng.hc(), eng.hc()
-        r1 = eng.real()
-        FG, FH, Fn = q._F["TT"]
-        lib = eng.lib
-
-        def map_legs():     # row R2C + forward column pass 1 + fused (forward pass 2, legs, inverse pass 1) + 3-plane pass 2
-            eng.qe_map_legs_cols(tmaps[0], FG, FH, out=(s1, s2, s3), width=wl, rband=q.leg_rows)
-
-        kern = {
-            "row_fft_kernel<R2C>": (lambda: eng.fft_pass(0, r1, s1, wl), (1 + fl) * A, A + fl * Ah, 1),
-            "col_fft_kernel<pass1,legs-width>": (lambda: eng.fft_pass(1, s1, s2, wl), fl * A, 2 * fl * Ah, 1),
-            # whole C-ABI call oa_qe_map_legs_cols = the two entries above + col_fwdlegs_kernel (second half of the
-            # forward column stage, filter multiply, first half of the 3 inverse column stages) + ONE 3-plane launch
-            # of their second half
-            "map_legs_cols (whole call)": (map_legs, (1 + fl) * A + 2 * fl * A + (4 * fl + 6 * fl) * A,
-                                           A + fl * Ah + 2 * fl * Ah + fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah, 1),
-            "row_qe_kernel": (lambda: eng.qe_rows(s1, s2, s3, s4, s5, win=wl, wout=wk), (10 + 3 * fl + 2 * fk) * A, (3 * fl + 2 * fk) * Ah, 1),
-            # ONE 2-plane launch of the first half of the 2 forward column stages + col_div (second half + divergence)
-            "cols_div = col_fft_kernel<pass1 x2 planes> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk, rband=q.kappa_rows),
-                                                                           (4 * fk + 3 * fk) * A, 4 * fk * Ah + fk * (2 * Ah + Ah / 2 + Ah), 1),
-            "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows), 2.75 * fk * A, 1.5 * fk * Ah, 1),
-        }
-        per, share = {}, {}
-        for name, (fn, alg, actual, count) in kern.items():
-            dt = time_kernel(torch, fn)
-            share[name] = dt * 1e3 * count
-            per[name] = {"avg_ms": dt * 1e3, "launches_per_recon": count, "algorithmic_GB": alg / 1e9,
-                         "hbm_min_GB": actual / 1e9, "achieved_GBs": alg / dt / 1e9, "achieved_actual_GBs": actual / dt / 1e9}
-        whole = "map_legs_cols (whole call)"
-        t_fl = max(per[whole]["avg_ms"] - per["row_fft_kernel<R2C>"]["avg_ms"] - per["col_fft_kernel<pass1,legs-width>"]["avg_ms"], 1e-6)
-        name_fl = "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<pass2 x3 planes>"
-        a_fl, m_fl = (fl + 4 * fl + 6 * fl) * A, fl * (Ah + 2 * Ah / 2 + 3 * Ah) + 6 * fl * Ah
-        per[name_fl] = {"avg_ms": t_fl, "launches_per_recon": 1, "algorithmic_GB": a_fl / 1e9, "hbm_min_GB": m_fl / 1e9,
-                        "achieved_GBs": a_fl / t_fl / 1e6, "achieved_actual_GBs": m_fl / t_fl / 1e6,
-                        "derived": "whole call minus its row and pass-1 launches"}
-        share[name_fl] = t_fl
-        del share[whole]
-        # the fused row stage is arithmetic, not bandwidth, bound: 5 packed N/2-point complex transforms per row
-        # (5 L log2 L flop each) against the f32 vector peak (MI355X_MICROARCH.md: 157.3 TFLOP/s counts every lane
-        # as an FMA; an FFT is ~2/3 additions, so ~50 % of it is the practical ceiling of butterfly code)
-        Lrow = N // 2
-        qe_flop = N * 5 * 5.0 * Lrow * np.log2(Lrow)
-        per["row_qe_kernel"]["fft_GFLOP_per_launch"] = qe_flop / 1e9
-        per["row_qe_kernel"]["achieved_TFLOPs"] = qe_flop / (per["row_qe_kernel"]["avg_ms"] * 1e-3) / 1e12
-        per["row_qe_kernel"]["frac_of_f32_vector_peak_157.3"] = per["row_qe_kernel"]["achieved_TFLOPs"] / 157.3
+        per, G = per_kernel_table(torch, P, R, args)
+        A, W = G["A"], G["W"]
+        share = {k: v["avg_ms"] for k, v in per.items()}
         dom = max(share, key=share.get)
-        d_alg, d_act, d_t = per[dom]["algorithmic_GB"] * 1e9, per[dom]["hbm_min_GB"] * 1e9, per[dom]["avg_ms"]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath) and N == 8192 and args.prec == "f32" and not args.no_prune:
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
-        # canonical stage model of SURVEY 8d restricted to the active columns of each plane it moves:
-        # FFT(T) (1+3fl) + filter multiply 4fl + 3 inverse FFTs 3(3fl+1) + products 5 + 2 forward FFTs 2(1+3fk)
-        # + divergence 3fk + power/bin 1.25fk  (fl = fk = 1 gives the survey's 37.25 A)
-        alg_recon = (11 + 16 * fl + 10.25 * fk) * A
         rate = total / elapsed / max(world, 1)
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": d_alg / d_t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": d_alg / d_t / 1e6 / HBM_PEAK_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": d_alg, "hbm_min_bytes_per_launch": d_act,
-                    "achieved_on_hbm_min_bytes": d_act / d_t / 1e6, "frac_on_hbm_min_bytes": d_act / d_t / 1e6 / HBM_PEAK_GBS,
-                    "note": "achieved = SURVEY 8d algorithmic bytes of the stages the (fused) kernel covers, restricted to the "
-                            "active columns, / live HIP-event duration; a fused kernel keeps most of those bytes in LDS/registers, "
-                            "so achieved can exceed the HBM peak -- *_hbm_min_* = bytes the kernel itself must move",
-                    "active_columns": {"legs": wl or W, "kappa": wk or W, "of": W},
-                    "share_of_recon_ms": share, "per_kernel": per,
-                    "pipeline": {"algorithmic_bytes_per_recon": alg_recon, "achieved_GBs": alg_recon * rate / 1e9,
-                                 "frac": alg_recon * rate / 1e9 / HBM_PEAK_GBS,
-                                 "survey_unpruned_bytes_per_recon": 37.25 * A,
-                                 "survey_unpruned_equivalent_GBs": 37.25 * A * rate / 1e9}}
+        traffic_tab = None
+        if N == 8192 and args.prec == "f32" and args.tlmax == 2000.0:      # PMC traffic exists for the profiled configurations
+            suf = "_dense" if args.no_prune else ("_fullrows" if args.row_grid == "full" else "")
+            traffic_tab = load_profile_json("traffic_%s%s.json" % (PROFILE_TAG, suf))
+        short = dom.split(" ")[0]
+        traffic = (traffic_tab or {}).get(short)
+        d = per[dom]
+        ridge = VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if "TFLOPs" in d and d["arithmetic_intensity_flop_per_B"] > ridge:
+            roofline = {"bound": "valu", "kernel": dom, "achieved": d["TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": d["valu_frac"], "traffic": traffic, "flops_per_launch": d["executed_GFLOP"] * 1e9,
+                        "flop_count": d["flop_count"], "arithmetic_intensity_flop_per_B": d["arithmetic_intensity_flop_per_B"],
+                        "ridge_flop_per_B": ridge, "hbm_bytes_per_launch": d["hbm_min_GB"] * 1e9, "hbm_frac_on_those_bytes": d["hbm_frac"],
+                        "note": "the fused row stage (3 C2R + 2 products + 2 R2C per row in LDS/registers) moves %.2f GB per launch and executes "
+                                "%.1f GFLOP: arithmetic intensity above the ridge -> priced against the f32 vector peak on the arithmetic "
+                                "it executes (pruned taps not counted)" % (d["hbm_min_GB"], d["executed_GFLOP"])}
+        else:
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": d["hbm_frac"], "traffic": traffic, "bytes_per_launch": d["hbm_min_GB"] * 1e9,
+                        "note": "achieved = bytes the kernel must move once (inputs + outputs on its active columns/rows) / live HIP-event duration"}
+        assert roofline["frac"] <= 1.0, "roofline fraction %g > 1: byte/flop model is wrong" % roofline["frac"]
+        roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
+        roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
+                                "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}
+        roofline["active_rows"] = {"legs": (2 * G["rl"] - 1) if G["rl"] else N, "kappa": (2 * G["rk"] - 1) if G["rk"] else N, "of": N}
+        roofline["share_of_recon_ms"] = share
+        roofline["per_kernel"] = per
+        roofline["pmc_traffic_bytes_per_launch"] = {k: v for k, v in (traffic_tab or {}).items() if not k.startswith("_")} or None
+        if traffic_tab:
+            for k, v in per.items():           # real (PMC) bytes / live duration for every kernel of the step
+                b = traffic_tab.get(k.split(" ")[0])
+                if b:
+                    v["pmc_GB"] = b / 1e9
+                    v["pmc_GBs"] = b / (v["avg_ms"] * 1e-3) / 1e9
+                    v["pmc_hbm_frac"] = v["pmc_GBs"] / HBM_PEAK_GBS
         out = {
             "metric": "QE kappa reconstructions/sec on %d^2 maps" % N,
-            "value": total / elapsed, "unit": "reconstructions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": total / elapsed, "unit": "reconstructions/s", "n_gpus": world, "world_size": (dist.get_world_size() if world > 1 else 1),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
             "config": {"workload": "TT quadratic estimator (lensing.Estimator) on %dx%d %.2f-arcmin flat-sky GRF maps, "
-                                   "incl. R2C of the input map and 19-bin kappa auto-bandpowers; T filter ell in (300,2000), "
-                                   "1.5' beam, 1 uK' noise" % (N, N, args.res),
-                       "map_side": N, "res_arcmin": args.res, "estimator": "TT", "nbins": d,
+                                   "incl. R2C of the input map and 19-bin kappa auto-bandpowers; T filter ell in (300,%d), "
+                                   "kappa mask (20,3500), 1.5' beam, 1 uK' noise" % (N, N, args.res, int(args.tlmax)),
+                       "map_side": N, "res_arcmin": args.res, "estimator": "TT", "nbins": R.d,
                        "streams_per_gpu": ns,
                        "parallelism": "independent realisations per GPU + 1 all-reduce of bandpower moments"},
             "roofline": roofline,
         }
+        hbm = {"peak_GBs": HBM_PEAK_GBS,
+               "kernels_on_own_bytes": {k: {"GBs": v["hbm_GBs"], "frac": v["hbm_frac"]} for k, v in per.items() if "hbm_GBs" in v and k != "row_qe_kernel"},
+               "survey_8d_bytes_per_recon_dense": 37.25 * A}
         if world == 1 and not args.no_extras and not args.no_prune:
-            # bandpowers of map 0 through the headline path: the yardstick for the two side measurements
-            e0 = qs[0].eng
-            qs[0].reconstruct_tt_from_map(tmaps[0], out=kks[0])
-            s0, _ = e0.bin_power(kks[0], kks[0], norm, P["ids"], nids, herm=True, active_cols=wk, active_rows=q.kappa_rows)
-            ref_p1d = s0[1:-1] / counts[1:-1]
-            out["extra"] = {"dense": dense_leg(P, args, torch, tmaps, ref_p1d, norm),
-                            "bandlimited": bandlimited_leg(P, args, torch, tmaps, ref_p1d)}
+            want = [w for w in args.extras.split(",") if w]
+            ref_p1d = R.bandpowers(0)
+            extra = {}
+            G = dict(G)
+            if "fullres_rows" in want and G["mrow"] < N:
+                leg, _, Pf, Rf = side_leg(torch, args, "fullres_rows", ref_p1d, seed, tlmax=args.tlmax, row_grid="full")
+                perf, _ = per_kernel_table(torch, Pf, Rf, args)
+                rqf = perf["row_qe_kernel"]
+                leg["row_qe_kernel"] = {k: rqf[k] for k in ("avg_ms", "executed_GFLOP", "TFLOPs", "valu_frac", "row_grid")}
+                leg["share_of_recon_ms"] = {k: v["avg_ms"] for k, v in perf.items()}
+                leg["note"] = "row_grid='full': the fused row stage on all nx points of every row (the round-1 configuration)"
+                extra["fullres_rows"] = leg
+                del Pf, Rf, perf
+                torch.cuda.empty_cache()
+            if "dense" in want:
+                leg, _, _, _ = side_leg(torch, args, "dense", ref_p1d, seed, prune=False, tlmax=args.tlmax)
+                rd = leg["reconstructions_per_s"]
+                leg["note"] = "prune=False: all nx/2+1 columns of every plane are transformed (filters without a band limit)"
+                leg["pipeline_GBs_on_survey_37.25A"] = 37.25 * A * rd / 1e9
+                leg["pipeline_frac_of_hbm_peak_on_survey_37.25A"] = 37.25 * A * rd / 1e9 / HBM_PEAK_GBS
+                dense_pmc = (load_profile_json("traffic_%s_dense.json" % PROFILE_TAG) or {}).get("bytes_per_recon") if N == 8192 and args.prec == "f32" else None
+                if dense_pmc:
+                    leg["pmc_bytes_per_recon"] = dense_pmc
+                    leg["pipeline_GBs_on_pmc_bytes"] = dense_pmc * rd / 1e9
+                    leg["pipeline_frac_of_hbm_peak_on_pmc_bytes"] = dense_pmc * rd / 1e9 / HBM_PEAK_GBS
+                extra["dense"] = leg
+                hbm["dense_pipeline"] = {k: leg[k] for k in leg if k.startswith("pipeline_") or k == "pmc_bytes_per_recon"}
+                torch.cuda.empty_cache()
+            if "bandlimited" in want:
+                extra["bandlimited"] = bandlimited_leg(P, args, torch, tmaps, ref_p1d)
+                torch.cuda.empty_cache()
+            if "f64" in want and args.prec == "f32":
+                leg, _, _, _ = side_leg(torch, args, "f64", ref_p1d, seed, prec="f64", tlmax=args.tlmax)
+                leg["note"] = "the same job through the float64 / complex128 kernels (the reference's arithmetic type, maps.py:1613); " \
+                              "max_rel_bandpower_diff = f32 headline vs this leg on the same map"
+                extra["f64"] = leg
+                torch.cuda.empty_cache()
+            if "wideband" in want and args.tlmax < 6000.0:
+                leg, p_w, Pw, Rw = side_leg(torch, args, "wideband", None, seed, tlmax=6000.0)
+                leg["active_columns"] = {"legs": Pw["q"].leg_cols or W, "kappa": Pw["q"].kappa_cols or W, "of": W}
+                leg["note"] = "SURVEY 8d high-res variant: T filter ell in (300,6000) on the same 0.5' maps"
+                perw, _ = per_kernel_table(torch, Pw, Rw, args)
+                leg["share_of_recon_ms"] = {k: v["avg_ms"] for k, v in perw.items()}
+                leg["row_qe_valu_frac"] = perw["row_qe_kernel"]["valu_frac"]
+                del Rw, Pw, perw
+                torch.cuda.empty_cache()
+                if "f64" in want and args.prec == "f32":
+                    leg64, _, _, _ = side_leg(torch, args, "wideband64", p_w, seed, prec="f64", tlmax=6000.0)
+                    leg["max_rel_bandpower_diff_vs_f64"] = leg64["max_rel_bandpower_diff"]
+                    leg["f64_reconstructions_per_s"] = leg64["reconstructions_per_s"]
+                extra["wideband"] = leg
+                torch.cuda.empty_cache()
+            out["extra"] = extra
+        out["hbm"] = hbm
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, args.res)
         print(json.dumps(out))

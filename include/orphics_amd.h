@@ -98,9 +98,14 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
  * planes awaiting oa_fft_cols(..., inverse=0).  Replaces 3 x oa_fft_c2r rows + 2 x oa_mul_real +
  * 2 x oa_fft_r2c rows: the real-space planes never touch HBM.  accumulate != 0 adds the result to
  * the existing px, py (estimators whose weight is a sum of separable terms: cos/sin spin-2 pieces;
- * `scale` carries the sign). */
+ * `scale` carries the sign).
+ * ROW GRID (`mrow`): legs that vanish beyond column `win` have real-space products band-limited to 2 (win - 1), so
+ * the row transforms may run on any grid of mrow >= 2 win + wout points (power of two <= nx): no aliased product
+ * frequency reaches the kept columns k < wout, which therefore equal the full-length result (the grid-size factor
+ * is folded into the scale; rounding differs at the 1e-7 level in f32).  The real-space planes live in LDS only.
+ * mrow = 0: full length nx;  mrow < 0: the smallest alias-free power of two;  otherwise checked against the bound. */
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-               int accumulate, int win, int wout, void* stream);
+               int accumulate, int win, int wout, int mrow, void* stream);
 
 /* Fused estimator column stages (the fast path of lensing.Estimator.reconstruct_*):
  *  oa_qe_legs_cols : oa_qe_legs + oa_fft_cols(inverse) of the three leg planes in one go -- kX, kY and the

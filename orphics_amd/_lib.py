@@ -34,7 +34,7 @@ SIGNATURES = {
     "oa_fft_c2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_fft_pass": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "oa_fft_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p]),
-    "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_int, c_int, c_int, c_void_p]),
+    "oa_qe_rows": (c_int, [c_void_p] * 6 + [c_double, c_int, c_int, c_int, c_int, c_void_p]),
     "oa_qe_legs_cols": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "oa_qe_map_legs_cols": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
     "oa_qe_cols_div": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),

@@ -176,11 +176,16 @@ static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double 
 }
 template <typename T>
 static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-                        int accumulate, int win, int wout, hipStream_t st) {
+                        int accumulate, int win, int wout, int mrow, hipStream_t st) {
     HipLauncher q{st};
     auto f = view<T>(p);
-    f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate,
-              f.clampw(win), f.clampw(wout));
+    const int wi = f.clampw(win), wo = f.clampw(wout);
+    if (mrow < 0) mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo);      // auto: smallest alias-free grid
+    if (mrow > 0 && mrow < p->nx) {
+        if (!is_pow2(mrow) || mrow < 64) return fail("oa_qe_rows: mrow must be a power of two >= 64");
+        if (2L * wi + wo > mrow) return fail("oa_qe_rows: mrow < 2*win + wout would alias the leg products into the kept columns");
+    }
+    f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate, wi, wo, mrow);
     return q.rc;
 }
 
@@ -273,11 +278,11 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
 }
 
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-               int accumulate, int win, int wout, void* stream) {
+               int accumulate, int win, int wout, int mrow, void* stream) {
     OA_REQUIRE(p && gx && gy && h && px && py, "oa_qe_rows: NULL argument");
     OA_NEED_POW2(p, "oa_qe_rows");
-    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream)
-                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, (hipStream_t)stream);
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, (hipStream_t)stream)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, (hipStream_t)stream);
 }
 
 int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, void* stream) {

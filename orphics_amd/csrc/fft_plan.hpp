@@ -2,6 +2,7 @@
 // Shared by the HIP launcher (fft.hip) and the CPU emulator (tests/emul).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include "fft_kernels.hpp"
 
@@ -62,13 +63,31 @@ struct Fft2dPlan {
     }
 
     // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
+    // mrow: length of the real row transforms (power of two, <= nx; 0 = nx).  Legs that vanish beyond column `win`
+    // have products band-limited to 2 (win - 1), so the row stage evaluated on ANY grid of mrow >= 2 win + wout
+    // points yields the same product columns k < wout (no aliasing reaches them) times mrow / nx -- folded into the
+    // scale here.  The real-space planes exist only in LDS, so the sampling grid is not observable.
+    static int row_grid_min(int nx, int win, int wout) {
+        long need = 2L * win + wout;
+        int m = 64;
+        while (m < need && m < nx) m <<= 1;
+        return m >= nx ? nx : m;
+    }
+    // rows per workgroup of the fused row stage (tuning hook: OA_QE_ROWS_PER_WG in the environment)
+    static int qe_rows_per_wg(int L) {
+        static const int forced = [] { const char* e = getenv("OA_QE_ROWS_PER_WG"); return e ? atoi(e) : 0; }();
+        if (forced > 0) return forced;
+        return 4096 / L;
+    }
     template <class Launcher>
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
-                 int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff) const {
+                 int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0) const {
         RowQeArgs<T> a{};
-        a.logL = logNx - 1;
+        const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
+        if (logM < logNx) scale = scale * (T)((double)nx / (double)(1 << logM));
+        a.logL = logM - 1;
         const int L = 1 << a.logL;
-        int C = 4096 / L;
+        int C = qe_rows_per_wg(L);
         if (C < 1) C = 1;
         if (C > ny) C = ny;
         a.logC = ilog2(C);

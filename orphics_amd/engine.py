@@ -18,6 +18,11 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _dirty(t):
+    mark_dirty(t)
+    return t
+
+
 _RDT = {"f32": torch.float32, "f64": torch.float64}
 _CDT = {"f32": torch.complex64, "f64": torch.complex128}
 _CODE = {"f32": OA_F32, "f64": OA_F64}
@@ -34,6 +39,51 @@ def precision_of(x, default="f64"):
 
 
 _BIN_SCRATCH = {}
+
+# ---- estimator-owned output planes ------------------------------------------------------------------------
+# The pruned estimator kernels write only the active region of kappa_hat (leading columns x row band); the rest of
+# the plane must already be zero.  Re-zeroing ~A bytes per reconstruction would cost more than the divergence
+# kernel itself, so planes handed out by ``lensing.Estimator.new_output()`` are tracked here: (weakref, region the
+# complement of which is known to be zero, torch version counter at that time).  ANY write through an Engine wrapper
+# (``out=`` arguments below call :func:`mark_dirty`) or through an in-place torch op (bumps ``_version``) drops the
+# guarantee and the next reconstruction zero-fills again.  Planes that did not come from ``new_output()`` are never
+# trusted: their complement is zeroed on every call.
+_OWNED = {}
+
+
+def register_owned(t):
+    import weakref
+    if len(_OWNED) > 256:
+        for k in [k for k, v in _OWNED.items() if v[0]() is None]:
+            del _OWNED[k]
+    _OWNED[t.data_ptr()] = [weakref.ref(t), None, t._version]
+    return t
+
+
+def mark_dirty(t):
+    """Forget what is known about the contents of plane ``t`` (called by every wrapper that writes into ``out=``)."""
+    if t is None:
+        return
+    r = _OWNED.get(t.data_ptr())
+    if r is not None:
+        r[1] = None
+
+
+def owned_clean_region(t):
+    """Region whose complement is known zero for an estimator-owned plane, else None."""
+    r = _OWNED.get(t.data_ptr())
+    if r is None or r[0]() is not t or r[2] != t._version:
+        return None
+    return r[1]
+
+
+def set_clean_region(t, region):
+    r = _OWNED.get(t.data_ptr())
+    if r is not None and r[0]() is t:
+        r[1] = region
+        r[2] = t._version
+        return True
+    return False
 
 
 def cuda_device():
@@ -116,7 +166,7 @@ def hc_resample(src_eng, k, dst_eng, scale=1.0, out=None):
     src_eng._chk(k, "hc")
     if src_eng.prec != dst_eng.prec:
         raise ValueError("hc_resample: precision mismatch")
-    out = dst_eng.hc() if out is None else dst_eng._chk(out, "hc")
+    out = dst_eng.hc() if out is None else _dirty(dst_eng._chk(out, "hc"))
     check(src_eng.lib.oa_hc_resample(src_eng.code, _ptr(k), src_eng.ny, src_eng.nx, src_eng.kp, _ptr(out), dst_eng.ny,
                                      dst_eng.nx, dst_eng.kp, float(scale), _stream()))
     return out
@@ -206,7 +256,7 @@ class Engine(object):
         include/orphics_amd.h) -- the rest of ``out`` is left untouched; ``rband`` > 0: only the rows
         y < rband or y > ny - rband of those columns hold the transform, the other rows are undefined."""
         self._chk(x, "real")
-        out = self.hc() if out is None else self._chk(out, "hc")
+        out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), int(width), int(rband), _stream()))
         return out
 
@@ -214,7 +264,7 @@ class Engine(object):
         """hc -> real; default scale 1/Npix (pixell fft.ifft normalize=True, maps.py:1633).
         ``width`` > 0 asserts that columns >= width of ``k`` are zero (they are not read)."""
         self._chk(k, "hc")
-        out = self.real() if out is None else self._chk(out, "real")
+        out = self.real() if out is None else _dirty(self._chk(out, "real"))
         if scale is None:
             scale = 1.0 / self.npix
         check(self.lib.oa_fft_c2r(self.plan, _ptr(k), _ptr(out), float(scale), int(width), _stream()))
@@ -222,26 +272,28 @@ class Engine(object):
 
     def cfft(self, z, inverse=False, scale=1.0, out=None):
         self._chk(z, "full")
-        out = self.full() if out is None else self._chk(out, "full")
+        out = self.full() if out is None else _dirty(self._chk(out, "full"))
         check(self.lib.oa_fft_c2c(self.plan, _ptr(z), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
         return out
 
     def fft_cols(self, k, inverse=False, scale=1.0, out=None, width=0):
         """Column transforms only (hc -> hc, out != in); ``width`` > 0: first ``width`` columns only."""
         self._chk(k, "hc")
-        out = self.hc() if out is None else self._chk(out, "hc")
+        out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_fft_cols(self.plan, _ptr(k), _ptr(out), 1 if inverse else 0, float(scale), int(width), _stream()))
         return out
 
-    def qe_rows(self, gx, gy, h, px, py, scale=None, accumulate=False, win=0, wout=0):
+    def qe_rows(self, gx, gy, h, px, py, scale=None, accumulate=False, win=0, wout=0, mrow=0):
         """Fused row stage: P = R2C(C2R(G) * C2R(H)) for G in (gx, gy).  ``win``: leg columns >= win are zero
-        (not read); ``wout``: only product columns < wout are written."""
+        (not read); ``wout``: only product columns < wout are written; ``mrow``: row-transform grid (0 = nx,
+        -1 = smallest alias-free power of two >= 2 win + wout; include/orphics_amd.h, ROW GRID)."""
         for t in (gx, gy, h, px, py):
             self._chk(t, "hc")
+        _dirty(px); _dirty(py)
         if scale is None:
             scale = 1.0 / float(self.npix) ** 2
         check(self.lib.oa_qe_rows(self.plan, _ptr(gx), _ptr(gy), _ptr(h), _ptr(px), _ptr(py), float(scale),
-                                  1 if accumulate else 0, int(win), int(wout), _stream()))
+                                  1 if accumulate else 0, int(win), int(wout), int(mrow), _stream()))
         return px, py
 
     def qe_legs_cols(self, kX, kY, FG, FH, out, width=0, rband=0):
@@ -250,7 +302,7 @@ class Engine(object):
         self._chk(kX, "hc"); self._chk(kY, "hc"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
         gx, gy, h = out
         for t in out:
-            self._chk(t, "hc")
+            _dirty(self._chk(t, "hc"))
         check(self.lib.oa_qe_legs_cols(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h), int(width), int(rband), _stream()))
         return out
 
@@ -260,7 +312,7 @@ class Engine(object):
         self._chk(tmap, "real"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
         gx, gy, h = out
         for t in out:
-            self._chk(t, "hc")
+            _dirty(self._chk(t, "hc"))
         check(self.lib.oa_qe_map_legs_cols(self.plan, _ptr(tmap), _ptr(FG), _ptr(FH), _ptr(gx), _ptr(gy), _ptr(h),
                                            int(width), int(rband), _stream()))
         return out
@@ -269,7 +321,7 @@ class Engine(object):
         """Fused forward column transforms + divergence * normalisation; ``width`` > 0: only the first
         ``width`` columns of ``out`` are produced (Fnorm vanishes beyond them)."""
         self._chk(px, "hc"); self._chk(py, "hc"); self._chk(Fnorm, "hcreal")
-        out = self.hc() if out is None else self._chk(out, "hc")
+        out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, int(width), int(rband), _stream()))
         return out
 
@@ -314,7 +366,7 @@ class Engine(object):
         n = self._same(k1, k2)
         if k1.dtype != self.cdt or k2.dtype != self.cdt:
             raise ValueError("f2power: complex dtype mismatch")
-        out = torch.empty(k1.shape, dtype=self.rdt, device=self.device) if out is None else out
+        out = torch.empty(k1.shape, dtype=self.rdt, device=self.device) if out is None else _dirty(out)
         check(self.lib.oa_f2power(self.code, _ptr(k1), _ptr(k2), _ptr(out), float(norm), n, _stream()))
         return out
 
@@ -322,7 +374,7 @@ class Engine(object):
         n = self._same(k, f)
         if k.dtype != self.cdt or f.dtype != self.rdt:
             raise ValueError("cmul_real: dtype mismatch")
-        out = torch.empty_like(k) if out is None else out
+        out = torch.empty_like(k) if out is None else _dirty(out)
         check(self.lib.oa_cmul_real(self.code, _ptr(k), _ptr(f), _ptr(out), n, _stream()))
         return out
 
@@ -330,7 +382,7 @@ class Engine(object):
         n = self._same(a, b)
         if a.dtype != self.rdt or b.dtype != self.rdt:
             raise ValueError("mul_real: dtype mismatch")
-        out = torch.empty_like(a) if out is None else out
+        out = torch.empty_like(a) if out is None else _dirty(out)
         check(self.lib.oa_mul_real(self.code, _ptr(a), _ptr(b), _ptr(out), n, _stream()))
         return out
 
@@ -338,7 +390,7 @@ class Engine(object):
         n = self._same(a, b)
         if a.dtype != self.rdt or b.dtype != self.rdt:
             raise ValueError("axpby: dtype mismatch")
-        out = torch.empty_like(a) if out is None else out
+        out = torch.empty_like(a) if out is None else _dirty(out)
         check(self.lib.oa_axpby_real(self.code, _ptr(a), _ptr(b), _ptr(out), float(alpha), float(beta), n, _stream()))
         return out
 
@@ -364,13 +416,14 @@ class Engine(object):
         if out is None:
             out = (self.hc(), self.hc(), self.hc())
         Gx, Gy, H = out
+        _dirty(Gx); _dirty(Gy); _dirty(H)
         check(self.lib.oa_qe_legs(self.plan, _ptr(kX), _ptr(kY), _ptr(FG), _ptr(FH), _ptr(Gx), _ptr(Gy), _ptr(H),
                                   int(phase_g), int(phase_h), 1 if h_times_i else 0, _stream()))
         return Gx, Gy, H
 
     def qe_div(self, Px, Py, Fnorm, out=None, accumulate=False):
         self._chk(Px, "hc"); self._chk(Py, "hc"); self._chk(Fnorm, "hcreal")
-        out = self.hc() if out is None else self._chk(out, "hc")
+        out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_qe_div(self.plan, _ptr(Px), _ptr(Py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, _stream()))
         return out
 
@@ -383,7 +436,7 @@ class Engine(object):
         return shift, delta
 
     def lens_gather(self, src, sx, sy, dx, dy, px, py, coef, out, accumulate):
-        self._chk(src, "real"); self._chk(out, "real"); self._chk(dx, "real"); self._chk(dy, "real")
+        self._chk(src, "real"); _dirty(self._chk(out, "real")); self._chk(dx, "real"); self._chk(dy, "real")
         if sx.dtype != torch.int32 or sy.dtype != torch.int32 or sx.numel() != src.numel() or sy.numel() != src.numel():
             raise ValueError("lens_gather: shifts must be int32 planes")
         check(self.lib.oa_lens_gather(self.plan, _ptr(src), _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy), int(px), int(py),
@@ -418,7 +471,7 @@ class Engine(object):
     def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):
         if covsqrt_hc is not None:
             self._chk(covsqrt_hc, "hcreal")
-        out = self.hc() if out is None else self._chk(out, "hc")
+        out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_grf_hc(self.plan, int(seed), int(stream_id), _ptr(covsqrt_hc), _ptr(out), _stream()))
         return out
 

@@ -11,8 +11,6 @@ Per reconstruction (TT): 1 fused leg-filter kernel, 3 C2R FFTs, 2 real
 products, 2 R2C FFTs, 1 divergence/normalisation kernel -- all HIP, all on the
 half-plane layout.
 """
-import weakref
-
 import numpy as np
 
 from . import maps
@@ -39,9 +37,6 @@ def _safe_div(num, den):
     return out
 
 
-_CLEAN = {}    # id(plane) -> (weakref, (kappa_cols, kappa_rows)): output planes known to be zero outside that region
-
-
 class Estimator(object):
     """Flat-sky QE.  Keywords follow the reference's ``lensing.qest`` call
     (tt_verification.ipynb cell 3):
@@ -58,10 +53,15 @@ class Estimator(object):
 
     def __init__(self, shape, wcs, theory, noise2d=None, beam2d=None, kmask=None, noise2d_P=None, kmask_P=None,
                  kmask_K=None, pol=False, grad_cut=None, unlensed_equals_lensed=False, bigell=9000, dtype="f32",
-                 theory_norm=None, prune=True):
+                 theory_norm=None, prune=True, iau=False, row_grid="auto"):
         # prune: let the fused kernels skip the hc columns on which the (band-limited) filters vanish --
         # same arithmetic on the remaining columns, identical results (include/orphics_amd.h, ACTIVE COLUMNS)
         self.prune = bool(prune)
+        # row_grid: grid of the fused row stage's real-space products.  "auto" (with prune): the smallest power of two
+        # >= 2 leg_cols + kappa_cols -- exact for band-limited filters (include/orphics_amd.h, ROW GRID); None / "full":
+        # always the map's own nx points.
+        self.mrow = -1 if (self.prune and row_grid == "auto") else (0 if row_grid in (None, "full", "auto") else int(row_grid))
+        self.iau = bool(iau)          # polarisation angle convention of the E/B inputs (FourierCalc(iau=...), maps.py:1600)
         self.shape = tuple(shape)
         self.wcs = wcs
         self.geom = as_geometry(shape, wcs)
@@ -95,7 +95,7 @@ class Estimator(object):
                 self.cl_len[sp] = np.where(ml >= 0, theory.lCl(sp, np.abs(ml)), 0.0)
             self.noise["P"] = _half(noise2d_P, self.nxh) if noise2d_P is not None else 2.0 * self.noise["T"]
             self.mask["P"] = _half(kmask_P, self.nxh).astype(np.float64) if kmask_P is not None else self.mask["T"]
-            sgn = 1 if getattr(self, "iau", False) else -1
+            sgn = 1 if self.iau else -1
             lyg, lxg = np.meshgrid(self.ly, self.lxh, indexing="ij")
             self.ang_h = sgn * 2 * np.arctan2(-lxg, lyg)       # pixell queb_rotmat angle (maps.py:1607)
             self._gen = {}
@@ -158,30 +158,34 @@ class Estimator(object):
         """Row band of kappa_hat (``Engine.bin_power(..., active_rows=q.kappa_rows)``)."""
         return self._R["TT"][1]
 
+    def new_output(self):
+        """A zero-initialised kappa_hat plane OWNED by the estimator family: pass it as ``out=`` to the
+        ``reconstruct_*`` calls of a Monte-Carlo loop.  The pruned kernels write only the active region of kappa_hat;
+        for an owned plane the zero-fill of the rest is done once and remembered (``engine._OWNED``), and forgotten
+        again as soon as anything else writes into the plane through an Engine wrapper or an in-place torch op.
+        Any other tensor passed as ``out=`` is zero-filled outside the active region on EVERY call."""
+        from .engine import register_owned
+        return register_owned(self.eng.hc())
+
     def _prep_out(self, out, wk, rk=0, accumulate=False):
         """Output plane whose inactive region (columns >= wk, rows outside the band rk: never written by the
         pruned kernels) is zero."""
+        from .engine import owned_clean_region
         if out is None:
             return self.eng.hc()                               # zero-initialised
-        if (wk or rk) and not accumulate and not self._is_clean(out, (wk, rk)):
+        if (wk or rk) and not accumulate and owned_clean_region(out) != (wk, rk):
             if wk:
-                out[:, wk:] = 0                                # zeroed once per output plane
+                out[:, wk:] = 0
             if rk:
                 out[rk:out.shape[0] - rk + 1] = 0
-            _CLEAN[id(out)] = (weakref.ref(out), (wk, rk))
         return out
 
-    @staticmethod
-    def _is_clean(t, region):
-        # process-wide registry (shared by every estimator and fork): an output plane is "clean" for a region if the
-        # LAST pruned writer that prepared it left everything outside that same region zero
-        r = _CLEAN.get(id(t))
-        if r is not None and r[0]() is t and r[1] == region:
-            return True
-        if len(_CLEAN) > 256:
-            for k in [k for k, v in _CLEAN.items() if v[0]() is None]:
-                del _CLEAN[k]
-        return False
+    def _done_out(self, out, wk, rk=0):
+        """After the pruned divergence kernel wrote ``out``: an owned plane is zero outside (wk, rk) again."""
+        from .engine import set_clean_region
+        if wk or rk:
+            set_clean_region(out, (wk, rk))
+        return out
 
     @property
     def leg_rows(self):
@@ -281,8 +285,8 @@ class Estimator(object):
         fused=False: the modular sequence of public C-ABI calls (3 C2R, 2 products, 2 R2C).
 
         With ``prune`` (default) only the first ``leg_cols`` columns of kX / kY are read and only the first
-        ``kappa_cols`` columns of the result are computed; the remaining columns of ``out`` are zero (an ``out``
-        plane is zero-filled there the first time it is seen and must not be scribbled on afterwards)."""
+        ``kappa_cols`` columns of the result are computed; the remaining columns of ``out`` are zero-filled (on
+        every call, unless ``out`` came from :meth:`new_output`)."""
         e = self.eng
         kY = kX if kY is None else kY
         FG, FH, Fn = self._F["TT"]
@@ -296,8 +300,8 @@ class Estimator(object):
             out = self._prep_out(out, wk, rk)
             cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"], width=wl, rband=rl)
             Gx, Gy, _ = w["G"]
-            e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk)
-            return e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk)
+            e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk, mrow=self.mrow)
+            return self._done_out(e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk), wk, rk)
         Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
         gx, gy, h = self._real_buffers()
         e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
@@ -321,8 +325,8 @@ class Estimator(object):
         out = self._prep_out(out, wk, rk)
         cx, cy, ch = e.qe_map_legs_cols(tmap, FG, FH, out=w["C"], width=wl, rband=rl)
         Gx, Gy, _ = w["G"]
-        e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk)
-        return e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk)
+        e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk, mrow=self.mrow)
+        return self._done_out(e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk), wk, rk)
 
     def kappa_from_map(self, XY, T2DData, E2DData=None, B2DData=None, T2DDataY=None, E2DDataY=None, B2DDataY=None,
                        alreadyFTed=False, returnFt=False):
@@ -557,8 +561,9 @@ class Estimator(object):
         for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
             kg, kh = (kY, kX) if swap else (kX, kY)
             e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch), width=wl, rband=rl)
-            e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0), win=wl, wout=wk)
-        return e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk, rband=rk)
+            e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0), win=wl, wout=wk, mrow=self.mrow)
+        e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk, rband=rk)
+        return self._done_out(out, wk, rk)
 
     def _reconstruct_hc_modular(self, XY, kX, kY, out=None, norm=None, accumulate=False):
         """The same estimator through the modular public calls only (map sides that are not powers of two, where

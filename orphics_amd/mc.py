@@ -52,51 +52,37 @@ class GaussianN0MonteCarlo(object):
         self.nids = self.edges.size + 1
         self.d = self.nids - 2
         self.norm = geom.area / float(e.npix) ** 2
-        self.n = torch.zeros(1, dtype=torch.int64, device=e.device)
-        self.S = torch.zeros(self.d, dtype=torch.float64, device=e.device)
-        self.C = torch.zeros(self.d, self.d, dtype=torch.float64, device=e.device)
-        self.mf = torch.zeros((e.ny, e.kp, 2), dtype=torch.float64, device=e.device) if mean_field else None
-        self.mf_count = torch.zeros(1, dtype=torch.int64, device=e.device)
-        self._kT, self._kk, self._p = e.hc(), e.hc(), e.hcreal()
-        _, self.counts = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True)
+        # device-resident ensemble accumulators: (n, sum, cross) of the bandpower vectors and the mean-field stack
+        self.acc = Statistics(comm=self.comm if hasattr(self.comm, "dist") else None, device=e.device)
+        self._kT, self._kk = e.hc(), qest.new_output()
+        _, self.counts = e.bin_power(self._kT, self._kT, self.norm, self.ids, self.nids, herm=True)
 
     def run_local(self, sims):
         """Process the given global sim indices on this rank's GPU."""
         torch = _torch()
-        from ._lib import check
-        from .engine import _ptr, _stream
         e, q = self.eng, self.q
         for i in sims:
             e.grf_hc(self.base_seed, int(i), self.cs, out=self._kT)
             q.reconstruct_tt_hc(self._kT, out=self._kk)
-            # kappa_hat vanishes beyond q.kappa_cols: only those columns are visited; the mode counts are
-            # data-independent and were taken over the whole plane in __init__
+            # kappa_hat vanishes beyond q.kappa_cols / outside q.kappa_rows: only that region is visited; the mode
+            # counts are data-independent and were taken over the whole plane in __init__
             sums, _ = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True, active_cols=q.kappa_cols, active_rows=q.kappa_rows)
-            counts = self.counts
             # bin means sums/counts of the interior bins are formed inside the accumulation kernel
-            check(e.lib.oa_moments_add_binned(_ptr(sums[1:]), _ptr(counts[1:]), self.d, _ptr(self.n), _ptr(self.S), _ptr(self.C), _stream()))
+            self.acc.add_binned("n0", sums[1:-1], self.counts[1:-1])
             if self.mean_field:
-                ri = torch.view_as_real(self._kk)  # (ny, kp, 2)
-                check(e.lib.oa_stack_add(e.code, _ptr(ri), _ptr(self.mf), ri.numel(), _stream()))
-                self.mf_count += 1
+                self.acc.add_stack("mf", torch.view_as_real(self._kk))      # (ny, kp, 2) interleaved re, im
         return self
 
     def run(self, nsims):
-        """Shard ``nsims`` with mpi.mpi_distribute (mpi.py:78-91), run, reduce once;
-        returns a reduced :class:`Statistics` (label 'n0' = kappa auto bandpowers,
-        stack 'mf' = interleaved (re,im) sum of kappa_hat DFTs if mean_field)."""
+        """Shard ``nsims`` with mpi.mpi_distribute (mpi.py:78-91), run, reduce once; returns the reduced
+        :class:`Statistics` (label 'n0' = kappa auto bandpowers, stack 'mf' = interleaved (re, im) sum of the
+        kappa_hat DFTs if mean_field; ``stack_sum('mf', on_device=True)`` keeps it on the GPU)."""
         comm = self.comm
         size, rank = comm.Get_size(), comm.Get_rank()
         _, tasks = _mpi.mpi_distribute(nsims, size, allow_empty=True)
         self.run_local(tasks[rank])
-        tens = [self.n, self.S, self.C] + ([self.mf, self.mf_count] if self.mean_field else [])
-        allreduce_tensors(tens, comm)
-        st = Statistics(comm=None)
-        st.add_moments("n0", int(self.n.item()), self.S.cpu().numpy(), self.C.cpu().numpy())
-        if self.mean_field:
-            st.add_stack_sum("mf", self.mf.cpu().numpy(), int(self.mf_count.item()))
-        st.allreduce()
-        return st
+        self.acc.allreduce()
+        return self.acc
 
     @property
     def centers(self):

@@ -208,323 +208,447 @@ def get_stats(binned_vectors):
 
 
 class Stats(object):
-    """Legacy container (stats.py:577-735): vectors gathered to ``root`` and
-    reduced with :func:`get_stats`; stacks summed to ``root``."""
+    """Legacy per-realisation container (contract of stats.py:577-735): every rank keeps the vectors it was
+    given, ``get_stats`` gathers them on ``root`` and summarises them with :func:`get_stats`; ``get_stacks``
+    returns ensemble means of running array sums.  Here the gather / sum go through
+    :class:`orphics_amd.mpi.TorchComm` (gloo or RCCL) instead of tagged Send/Recv pairs."""
+
+    RESERVED = "stats"
 
     def __init__(self, comm=None, root=0, loopover=None, tag_start=333):
-        self.comm = comm if comm is not None else _mpi.fakeMpiComm()
-        self.rank = self.comm.Get_rank()
-        self.numcores = self.comm.Get_size()
-        self.columns = {}
-        self.vectors = {}
-        self.little_stack = {}
-        self.little_stack_count = {}
-        self.tag_start = tag_start
+        self.comm = _mpi.fakeMpiComm() if comm is None else comm
+        self.rank, self.numcores = self.comm.Get_rank(), self.comm.Get_size()
         self.root = root
-        self.loopover = list(range(root + 1, self.numcores)) if loopover is None else loopover
+        self.tag_start = tag_start                       # kept for signature compatibility (no tagged messages here)
+        self.loopover = [r for r in range(self.numcores) if r != root] if loopover is None else loopover
+        self.vectors, self.columns = {}, {}
+        self.little_stack, self.little_stack_count = {}, {}
+        self.stats, self.stacks, self.stack_count = {}, {}, {}
+
+    @classmethod
+    def _admit(cls, label, data, what):
+        if label == cls.RESERVED:
+            raise AssertionError("the label %r is reserved" % cls.RESERVED)
+        data = np.asarray(data)
+        if np.iscomplexobj(data):
+            raise TypeError("%s of complex arrays is not supported: pass real and imaginary parts under two labels" % what)
+        return data
 
     def add_to_stats(self, label, vector, exclude=False):
-        """stats.py:614-631."""
-        assert label != 'stats', "Sorry, 'stats' is a forbidden label."
-        vector = np.asarray(vector)
-        if np.iscomplexobj(vector):
-            print("ERROR: stats on complex arrays not supported. Do the real and imaginary parts separately.")
-            raise TypeError
+        """Record one realisation of a 1-D quantity (stats.py:614-631).  ``exclude`` only declares the label
+        (so that every rank knows its width) without contributing a sample."""
+        vector = self._admit(label, vector, "statistics")
         if label not in self.vectors:
-            self.vectors[label] = []
-            self.columns[label] = vector.shape
+            self.vectors[label], self.columns[label] = [], vector.shape
         if not exclude:
             self.vectors[label].append(vector)
 
     def add_to_stack(self, label, arr, exclude=False):
-        """stats.py:634-650."""
-        assert label != 'stats', "Sorry, 'stats' is a forbidden label."
-        if np.iscomplexobj(arr):
-            print("ERROR: stacking of complex arrays not supported. Stack the real and imaginary parts separately.")
-            raise TypeError
+        """Add an array to a running sum (stats.py:634-650)."""
+        arr = self._admit(label, arr, "stacking")
         if label not in self.little_stack:
-            self.little_stack[label] = arr * 0.
+            self.little_stack[label] = np.zeros(arr.shape, dtype=np.float64)
             self.little_stack_count[label] = 0
         if not exclude:
-            self.little_stack[label] += arr
+            self.little_stack[label] = self.little_stack[label] + arr
             self.little_stack_count[label] += 1
 
     def get_stacks(self, verbose=True):
-        """stats.py:653-691 (sum to root then divide by the total count)."""
-        self.stacks = {}
-        self.stack_count = {}
-        for label in self.little_stack.keys():
-            local = np.array(self.little_stack[label]).astype(np.float64)
-            cnt = np.array([self.little_stack_count[label]], dtype=np.int64)
+        """Ensemble mean of every stack on ``root`` (stats.py:653-691): sum of sums / sum of counts."""
+        for label, part in self.little_stack.items():
+            total = np.array(part, dtype=np.float64)
+            count = np.array([self.little_stack_count[label]], dtype=np.int64)
             if self.numcores > 1:
-                local = self.comm.allreduce_array(local)
-                cnt = self.comm.allreduce_array(cnt)
+                total, count = self.comm.allreduce_array(total), self.comm.allreduce_array(count)
             if self.rank == self.root:
-                self.stack_count[label] = int(cnt[0])
-                self.stacks[label] = local / self.stack_count[label]
+                self.stack_count[label] = int(count[0])
+                self.stacks[label] = total / self.stack_count[label]
 
     def get_stats(self, verbose=True, skip_stats=False):
-        """stats.py:693-735."""
-        self.stats = {}
-        for label in list(self.vectors.keys()):
-            mine = np.array(self.vectors[label], dtype=np.float64).reshape((-1,) + tuple(self.columns[label]))
+        """Collect all realisations on ``root`` and summarise (stats.py:693-735)."""
+        for label in list(self.vectors):
+            width = tuple(self.columns[label])
+            local = np.asarray(self.vectors[label], dtype=np.float64).reshape((-1,) + width)
             if self.numcores > 1:
-                parts = self.comm.gather_arrays(mine, root=self.root)
+                pieces = self.comm.gather_arrays(local, root=self.root)
                 if self.rank != self.root:
                     continue
-                parts = [p for p in parts if p.shape[0] > 0]
-                self.vectors[label] = np.concatenate(parts, axis=0) if parts else mine
-            else:
-                self.vectors[label] = mine
+                pieces = [p for p in pieces if len(p)]
+                local = np.concatenate(pieces, axis=0) if pieces else local
+            self.vectors[label] = local
             if not skip_stats:
-                self.stats[label] = get_stats(self.vectors[label])
+                self.stats[label] = get_stats(local)
 
     def dump(self, path):
-        """stats.py:737-743."""
-        for d, name in zip([self.vectors, self.stacks], ['vectors', 'stack']):
-            for key in d.keys():
-                np.save(f"{path}/mstats_dump_{name}_{key}.npy", d[key])
-        for key in self.stats.keys():
-            for skey in self.stats[key].keys():
-                np.savetxt(f"{path}/mstats_dump_stats_{key}_{skey}.txt", np.atleast_1d(self.stats[key][skey]))
+        """One file per item (format of stats.py:737-743, read back by :func:`load_stats`)."""
+        for kind, table in (("vectors", self.vectors), ("stack", self.stacks)):
+            for label, arr in table.items():
+                np.save(f"{path}/mstats_dump_{kind}_{label}.npy", arr)
+        for label, summary in self.stats.items():
+            for name, val in summary.items():
+                np.savetxt(f"{path}/mstats_dump_stats_{label}_{name}.txt", np.atleast_1d(val))
+
+
+def load_stats(path):
+    """Read a directory written by :meth:`Stats.dump` (stats.py:745-772): an object with ``vectors``,
+    ``stacks`` (label -> array) and ``stats`` (label -> {mean, cov, ...}; one-element summaries come back as scalars)."""
+    import glob
+    import os
+    import types
+    out = types.SimpleNamespace(vectors={}, stacks={}, stats={})
+    for kind, table in (("vectors", out.vectors), ("stack", out.stacks)):
+        prefix = "mstats_dump_%s_" % kind
+        for f in glob.glob(os.path.join(path, prefix + "*.npy")):
+            table[os.path.basename(f)[len(prefix):-len(".npy")]] = np.load(f)
+    prefix = "mstats_dump_stats_"
+    summary_names = ("mean", "cov", "covmean", "errmean", "err", "corr")       # longest match first for *_errmean vs *_err
+    for f in glob.glob(os.path.join(path, prefix + "*.txt")):
+        stem = os.path.basename(f)[len(prefix):-len(".txt")]
+        name = next((n for n in summary_names if stem.endswith("_" + n)), None)
+        if name is None:
+            label, _, name = stem.rpartition("_")
+        else:
+            label = stem[:-(len(name) + 1)]
+        arr = np.loadtxt(f)
+        out.stats.setdefault(label, {})[name] = arr.ravel()[0] if arr.size == 1 else arr
+    return out
+
+
+# ---- one-pass ensemble moments -----------------------------------------------------------------------------------
+class _Moments(object):
+    """count, sum x, sum x x^T of d-vectors.  ``xp`` is numpy (host) or torch (device tensors, float64)."""
+    __slots__ = ("dim", "count", "first", "second", "cell")
+
+    def __init__(self, dim, first, second):
+        self.dim, self.count, self.first, self.second = int(dim), 0, first, second
+        self.cell = None        # device mode: the int64 counter the accumulation kernels increment
+
+
+class _Stack(object):
+    __slots__ = ("shape", "count", "total")
+
+    def __init__(self, shape, total):
+        self.shape, self.count, self.total = tuple(int(v) for v in shape), 0, total
 
 
 class Statistics(object):
-    """stats.py:918-1530: one-pass (n, sum, cross) moments and stack sums with
-    a SUM all-reduce.  ``comm`` is None (single process), an mpi4py
-    communicator, or :class:`orphics_amd.mpi.TorchComm` (RCCL / gloo)."""
+    """One-pass ensemble statistics with a single SUM reduction at the end (the contract of stats.py:918-1530).
 
-    def __init__(self, comm=None, dtype=np.float64):
+    Two kinds of labels: *stats* labels collect d-vectors x_i as (n, sum x, sum x x^T) -- enough for mean, variance
+    and covariance without keeping the samples; *stack* labels keep (k, sum A) of equally shaped arrays.
+    ``allreduce()`` sums everything over the ranks of ``comm`` (``None`` = single process, a
+    :class:`orphics_amd.mpi.TorchComm` = gloo / RCCL, or an mpi4py communicator); only then are ``mean / cov / var /
+    count / stack_sum / stack_count`` available.
+
+    MI355X specifics: with ``device=`` the accumulators are float64 tensors on that GPU, fed by the HIP kernels
+    ``oa_moments_add`` / ``oa_moments_add_binned`` / ``oa_stack_add`` from device-resident samples (a Monte-Carlo
+    loop never copies a bandpower vector to the host), and the reduction is ONE packed all-reduce of all labels
+    (plus one for the integer counts) instead of three per label.  Without ``device`` everything is host NumPy.
+    """
+
+    def __init__(self, comm=None, dtype=np.float64, device=None):
         self.comm = comm
         self.dtype = np.dtype(dtype)
-        self._n = defaultdict(int)
-        self._sum = {}
-        self._cross = {}
-        self._dim_stats = {}
-        self._k = defaultdict(int)
-        self._stack_sum = {}
-        self._shape_stack = {}
-        self._N, self._SUM, self._CROSS = {}, {}, {}
-        self._K, self._STACK_SUM = {}, {}
-        self._reduced = False
+        self.device = device
+        self._vec, self._pile = {}, {}          # label -> _Moments / _Stack (this rank's share)
+        self._world = None                      # after allreduce(): (vec, pile) dicts of reduced HOST copies
 
+    # -- storage back ends ------------------------------------------------------------------------------------
     @property
     def mpi_enabled(self):
         return self.comm is not None
 
-    def _ensure_stats_label(self, label, d):
-        if label in self._shape_stack:
-            raise ValueError(f"Label {label!r} already used in stack mode.")
-        if label not in self._dim_stats:
-            self._dim_stats[label] = int(d)
-            self._sum[label] = np.zeros(d, dtype=self.dtype)
-            self._cross[label] = np.zeros((d, d), dtype=self.dtype)
-        elif self._dim_stats[label] != d:
-            raise ValueError(f"Stats dim mismatch for {label!r}: {self._dim_stats[label]} vs {d}")
+    def _zeros(self, shape):
+        if self.device is None:
+            return np.zeros(shape, dtype=self.dtype)
+        import torch
+        return torch.zeros(shape, dtype=torch.float64, device=self.device)
 
-    def _ensure_stack_label(self, label, shape):
-        if label in self._dim_stats:
-            raise ValueError(f"Label {label!r} already used in stats mode.")
-        if label not in self._shape_stack:
-            self._shape_stack[label] = tuple(int(s) for s in shape)
-            self._stack_sum[label] = np.zeros(shape, dtype=self.dtype)
-        elif self._shape_stack[label] != tuple(shape):
-            raise ValueError(f"Stack shape mismatch for {label!r}: {self._shape_stack[label]} vs {tuple(shape)}")
+    @staticmethod
+    def _is_device_tensor(x):
+        return type(x).__module__.startswith("torch") and getattr(x, "is_cuda", False)
 
+    def _slot_vec(self, label, dim):
+        if label in self._pile:
+            raise ValueError("label %r already collects stacked arrays; it cannot also collect vectors" % (label,))
+        m = self._vec.get(label)
+        if m is None:
+            m = self._vec[label] = _Moments(dim, self._zeros((dim,)), self._zeros((dim, dim)))
+        elif m.dim != dim:
+            raise ValueError("label %r collects vectors of length %d, got length %d" % (label, m.dim, dim))
+        return m
+
+    def _slot_pile(self, label, shape):
+        if label in self._vec:
+            raise ValueError("label %r already collects vectors; it cannot also collect stacked arrays" % (label,))
+        shape = tuple(int(v) for v in shape)
+        p = self._pile.get(label)
+        if p is None:
+            p = self._pile[label] = _Stack(shape, self._zeros(shape))
+        elif p.shape != shape:
+            raise ValueError("label %r stacks arrays of shape %s, got %s" % (label, p.shape, shape))
+        return p
+
+    def _to_store(self, a):
+        """sample / array in any container -> the accumulator's container (float64 on the accumulator's device)"""
+        if self.device is None:
+            if self._is_device_tensor(a) or type(a).__module__.startswith("torch"):
+                a = a.detach().cpu().numpy()
+            return np.asarray(a, dtype=self.dtype)
+        import torch
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64))
+        return t.to(device=self.device, dtype=torch.float64)
+
+    # -- accumulation -----------------------------------------------------------------------------------------
     def add(self, label, x):
-        """stats.py:1068-1090."""
-        x = np.asarray(x, dtype=self.dtype).ravel()
-        d = x.shape[0]
-        self._ensure_stats_label(label, d)
-        self._n[label] += 1
-        self._sum[label] += x
-        self._cross[label] += np.outer(x, x)
+        """One sample of a stats label (stats.py:1068-1090): n += 1, S += x, C += x x^T."""
+        if self.device is not None and self._is_device_tensor(x) and x.dtype.is_floating_point and x.element_size() == 8:
+            x = x.reshape(-1).contiguous()
+            m = self._slot_vec(label, x.numel())
+            self._device_add(m, x)
+            return
+        v = self._to_store(x).reshape(-1)
+        m = self._slot_vec(label, v.shape[0])
+        m.count += 1
+        m.first += v
+        m.second += (v[:, None] * v[None, :])
+
+    def _counter_cell(self, m):
+        if m.cell is None:
+            import torch
+            m.cell = torch.zeros(1, dtype=torch.int64, device=self.device)
+        return m.cell
+
+    def _device_add(self, m, x):
+        from ._lib import check, load
+        from .engine import _ptr, _stream
+        check(load().oa_moments_add(_ptr(x), m.dim, _ptr(self._counter_cell(m)), _ptr(m.first), _ptr(m.second), _stream()))
+        m.count += 1
+
+    def add_binned(self, label, sums, counts):
+        """Device shortcut for the Monte-Carlo loop: the sample is the vector of bin means sums/counts (the output
+        of ``Engine.bin_power`` / ``oa_bin``; stats.bin2D.bin semantics), formed inside the accumulation kernel."""
+        if self.device is None or not self._is_device_tensor(sums):
+            c = np.asarray(counts.cpu() if hasattr(counts, "cpu") else counts, dtype=np.float64)
+            t = np.asarray(sums.cpu() if hasattr(sums, "cpu") else sums, dtype=np.float64)
+            return self.add(label, t / c)
+        from ._lib import check, load
+        from .engine import _ptr, _stream
+        m = self._slot_vec(label, sums.numel())
+        check(load().oa_moments_add_binned(_ptr(sums), _ptr(counts), m.dim, _ptr(self._counter_cell(m)), _ptr(m.first), _ptr(m.second), _stream()))
+        m.count += 1
 
     def extend(self, label, X):
-        """stats.py:1092-1120."""
-        X = np.asarray(list(X) if not hasattr(X, "shape") else X, dtype=self.dtype)
-        if X.ndim == 1:
-            self.add(label, X)
-            return
-        if X.ndim != 2:
-            raise ValueError("X must be (m, d) or (d,).")
-        m, d = X.shape
-        self._ensure_stats_label(label, d)
-        self._n[label] += m
-        self._sum[label] += X.sum(axis=0)
-        self._cross[label] += X.T @ X
+        """Many samples at once (stats.py:1092-1120): rows of an (m, d) array, or one (d,) sample."""
+        X2 = self._to_store(X if hasattr(X, "shape") else list(X))
+        if X2.ndim == 1:
+            return self.add(label, X2)
+        if X2.ndim != 2:
+            raise ValueError("extend() takes an (m, d) block of samples or a single (d,) sample, got %d dimensions" % X2.ndim)
+        m = self._slot_vec(label, X2.shape[1])
+        m.count += int(X2.shape[0])
+        m.first += X2.sum(0)
+        m.second += X2.T @ X2
 
     def add_moments(self, label, n, S, C):
-        """Merge externally accumulated moments (device-side MC accumulators)."""
-        S = np.asarray(S, dtype=self.dtype)
-        self._ensure_stats_label(label, S.shape[0])
-        self._n[label] += int(n)
-        self._sum[label] += S
-        self._cross[label] += np.asarray(C, dtype=self.dtype)
+        """Merge moments accumulated elsewhere (another accumulator, a device-side Monte-Carlo loop)."""
+        S = self._to_store(S).reshape(-1)
+        m = self._slot_vec(label, S.shape[0])
+        m.count += int(n)
+        m.first += S
+        m.second += self._to_store(C)
 
     def add_stack(self, label, arr):
-        """stats.py:1124-1150."""
-        A = np.asarray(arr, dtype=self.dtype)
-        shape = () if A.ndim == 0 else A.shape
-        self._ensure_stack_label(label, shape)
-        self._k[label] += 1
-        self._stack_sum[label] += A
+        """One array of a stack label (stats.py:1124-1150): k += 1, total += arr."""
+        if self.device is not None and self._is_device_tensor(arr) and arr.dtype.is_floating_point:
+            from ._lib import OA_F32, OA_F64, check, load
+            from .engine import _ptr, _stream
+            a = arr.contiguous()
+            p = self._slot_pile(label, tuple(a.shape))
+            code = OA_F32 if a.element_size() == 4 else OA_F64
+            check(load().oa_stack_add(code, _ptr(a), _ptr(p.total), a.numel(), _stream()))
+            p.count += 1
+            return
+        a = self._to_store(arr)
+        p = self._slot_pile(label, tuple(a.shape))
+        p.count += 1
+        p.total += a
 
     def add_stack_sum(self, label, total, count):
-        """Merge an externally accumulated stack (sum of ``count`` arrays)."""
-        A = np.asarray(total, dtype=self.dtype)
-        self._ensure_stack_label(label, A.shape)
-        self._k[label] += int(count)
-        self._stack_sum[label] += A
+        """Merge a stack accumulated elsewhere (sum of ``count`` arrays)."""
+        a = self._to_store(total)
+        p = self._slot_pile(label, tuple(a.shape))
+        p.count += int(count)
+        p.total += a
 
-    def _union_dims(self):
-        """stats.py:1153-1182."""
-        local = {"stats": [(lab, d) for lab, d in self._dim_stats.items()],
-                 "stack": [(lab, shp) for lab, shp in self._shape_stack.items()]}
-        if not self.mpi_enabled:
-            return dict(self._dim_stats), dict(self._shape_stack)
-        all_lists = self.comm.allgather(local)
-        stats_union, stack_union = {}, {}
-        for entry in all_lists:
-            for lab, d in entry["stats"]:
-                if lab in stats_union and stats_union[lab] != d:
-                    raise ValueError(f"Stats dim mismatch for {lab!r} across ranks.")
-                if lab in stack_union:
-                    raise ValueError(f"Label {lab!r} used in stats and stack across ranks.")
-                stats_union[lab] = d
-            for lab, shp in entry["stack"]:
-                shp = tuple(shp)
-                if lab in stack_union and stack_union[lab] != shp:
-                    raise ValueError(f"Stack shape mismatch for {lab!r} across ranks.")
-                if lab in stats_union:
-                    raise ValueError(f"Label {lab!r} used in stats and stack across ranks.")
-                stack_union[lab] = shp
-        return stats_union, stack_union
+    # -- reduction ----------------------------------------------------------------------------------------------
+    def _schema(self):
+        return {"vec": {lab: m.dim for lab, m in self._vec.items()}, "pile": {lab: p.shape for lab, p in self._pile.items()}}
 
-    def _allreduce(self, arr):
-        if not self.mpi_enabled:
-            return arr
-        if hasattr(self.comm, "allreduce_array"):
-            return self.comm.allreduce_array(arr)
-        from mpi4py import MPI  # pragma: no cover - mpi4py path
-        buf = np.array(arr, copy=True)
-        self.comm.Allreduce(MPI.IN_PLACE, buf, op=MPI.SUM)
-        return buf
+    def _agree_on_schema(self):
+        """Union of the labels of all ranks (a label may be missing on some: it contributes zeros there,
+        stats.py:1153-1182); contradictory uses are an error on EVERY rank."""
+        mine = self._schema()
+        everyone = self.comm.allgather(mine) if (self.mpi_enabled and self.comm.Get_size() > 1) else [mine]
+        vec, pile = {}, {}
+        for sch in everyone:
+            for lab, dim in sch["vec"].items():
+                if vec.setdefault(lab, dim) != dim:
+                    raise ValueError("label %r has vector length %d on one rank and %d on another" % (lab, vec[lab], dim))
+            for lab, shape in sch["pile"].items():
+                if pile.setdefault(lab, tuple(shape)) != tuple(shape):
+                    raise ValueError("label %r stacks shape %s on one rank and %s on another" % (lab, pile[lab], tuple(shape)))
+        both = set(vec) & set(pile)
+        if both:
+            raise ValueError("label(s) %s collect vectors on one rank and stacked arrays on another" % sorted(both))
+        return vec, pile
+
+    def _sum_over_ranks(self, buf):
+        """SUM all-reduce of one flat buffer (NumPy array or torch tensor); identity without a communicator."""
+        if not self.mpi_enabled or self.comm.Get_size() == 1:
+            return buf
+        if hasattr(self.comm, "dist"):                          # TorchComm: tensors stay where they are (RCCL on GPU)
+            import torch
+            if isinstance(buf, torch.Tensor):
+                if buf.is_cuda or self.comm.backend != "nccl":
+                    self.comm.dist.all_reduce(buf, op=self.comm.dist.ReduceOp.SUM, group=self.comm.group)
+                    return buf
+                return self.comm.allreduce_array(buf.numpy())
+            return self.comm.allreduce_array(buf)
+        from mpi4py import MPI                                   # pragma: no cover - mpi4py communicators
+        out = np.array(buf, copy=True)
+        self.comm.Allreduce(MPI.IN_PLACE, out, op=MPI.SUM)
+        return out
+
+    PACK_LIMIT = 1 << 16      # device tensors with more elements than this are reduced in place, not packed
 
     def allreduce(self):
-        """stats.py:1184-1232."""
-        stats_union, stack_union = self._union_dims()
-        for lab, d in stats_union.items():
-            if lab not in self._dim_stats:
-                self._ensure_stats_label(lab, d)
-        for lab, shp in stack_union.items():
-            if lab not in self._shape_stack:
-                self._ensure_stack_label(lab, shp)
-        for lab in stats_union:
-            n_loc = np.array([self._n.get(lab, 0)], dtype=np.int64)
-            self._N[lab] = int(np.asarray(self._allreduce(n_loc)).ravel()[0])
-            self._SUM[lab] = self._allreduce(self._sum[lab])
-            self._CROSS[lab] = self._allreduce(self._cross[lab])
-        for lab in stack_union:
-            k_loc = np.array([self._k.get(lab, 0)], dtype=np.int64)
-            self._K[lab] = int(np.asarray(self._allreduce(k_loc)).ravel()[0])
-            self._STACK_SUM[lab] = self._allreduce(self._stack_sum[lab])
-        self._reduced = True
+        """Sum counts, first and second moments and stacks over all ranks (stats.py:1184-1232) -- here as ONE
+        all-reduce of the integer counts and ONE of a packed float64 buffer holding every small item of every label;
+        large device-resident stacks (mean-field planes) are reduced in place, one collective each, and stay on
+        the GPU until asked for."""
+        vec, pile = self._agree_on_schema()
+        for lab, dim in vec.items():
+            self._slot_vec(lab, dim)
+        for lab, shape in pile.items():
+            self._slot_pile(lab, shape)
+        order_v, order_p = sorted(vec), sorted(pile)
+        counts = np.array([self._vec[l].count for l in order_v] + [self._pile[l].count for l in order_p] + [0], dtype=np.int64)
+        counts = np.asarray(self._sum_over_ranks(counts))
+        items = []                                   # (kind, label, field, array)
+        for l in order_v:
+            items += [("vec", l, "first", self._vec[l].first), ("vec", l, "second", self._vec[l].second)]
+        for l in order_p:
+            items.append(("pile", l, "total", self._pile[l].total))
+        on_device = self.device is not None
+        small = [it for it in items if not (on_device and it[3].numel() > self.PACK_LIMIT)]
+        reduced = {}
+        if small:
+            if on_device:
+                import torch
+                flat = self._sum_over_ranks(torch.cat([it[3].reshape(-1) for it in small])).detach().cpu().numpy()
+            else:
+                flat = np.asarray(self._sum_over_ranks(np.concatenate([np.asarray(it[3]).reshape(-1) for it in small])))
+            at = 0
+            for kind, l, field, arr in small:
+                n = int(np.prod(tuple(arr.shape), dtype=np.int64)) if len(arr.shape) else 1
+                reduced[(kind, l, field)] = flat[at:at + n].reshape(tuple(arr.shape)).copy()
+                at += n
+        for kind, l, field, arr in items:
+            if (kind, l, field) not in reduced:
+                reduced[(kind, l, field)] = self._sum_over_ranks(arr.clone())
+        gv, gp = {}, {}
+        for i, l in enumerate(order_v):
+            g = _Moments(vec[l], reduced[("vec", l, "first")], reduced[("vec", l, "second")])
+            g.count = int(counts[i])
+            gv[l] = g
+        for i, l in enumerate(order_p):
+            g = _Stack(pile[l], reduced[("pile", l, "total")])
+            g.count = int(counts[len(order_v) + i])
+            gp[l] = g
+        self._world = (gv, gp)
+
+    # -- reduced results ----------------------------------------------------------------------------------------
+    def _reduced(self, kind, label):
+        if self._world is None:
+            raise RuntimeError("global results exist only after allreduce()")
+        table = self._world[0 if kind == "vec" else 1]
+        if label not in table:
+            raise KeyError("%r is not a %s label" % (label, "stats" if kind == "vec" else "stack"))
+        return table[label]
 
     def labels_stats(self):
-        return list(self._SUM.keys()) if self._reduced else list(self._dim_stats.keys())
+        return list(self._world[0]) if self._world is not None else list(self._vec)
 
     def labels_stack(self):
-        return list(self._STACK_SUM.keys()) if self._reduced else list(self._shape_stack.keys())
-
-    def _check_reduced(self):
-        if not self._reduced:
-            raise RuntimeError("Call .allreduce() before requesting global stats/stack.")
+        return list(self._world[1]) if self._world is not None else list(self._pile)
 
     def count(self, label):
-        self._check_reduced()
-        if label not in self._N:
-            raise KeyError(f"{label!r} is not a stats-mode label.")
-        return self._N[label]
+        return self._reduced("vec", label).count
 
     def stack_count(self, label):
-        self._check_reduced()
-        if label not in self._K:
-            raise KeyError(f"{label!r} is not a stack-mode label.")
-        return self._K[label]
+        return self._reduced("pile", label).count
+
+    def stack_sum(self, label, on_device=False):
+        """Reduced sum of a stack label (NumPy; ``on_device=True`` returns the GPU tensor of a device-resident stack)."""
+        t = self._reduced("pile", label).total
+        if hasattr(t, "detach"):
+            return t if on_device else t.detach().cpu().numpy()
+        return t
 
     def mean(self, label):
-        self._check_reduced()
-        if label not in self._SUM:
-            raise KeyError(f"{label!r} is not a stats-mode label.")
-        n = self._N[label]
-        return self._SUM[label] / n if n > 0 else np.full(self._SUM[label].shape, np.nan, dtype=self.dtype)
+        """sum / n; NaN when no rank contributed a sample."""
+        g = self._reduced("vec", label)
+        return g.first / g.count if g.count else np.full(g.dim, np.nan, dtype=self.dtype)
 
     def cov(self, label, ddof=1):
-        self._check_reduced()
-        if label not in self._CROSS:
-            raise KeyError(f"{label!r} is not a stats-mode label.")
-        n = self._N[label]
-        if n <= ddof:
-            d = self._SUM[label].shape[0]
-            return np.full((d, d), np.nan, dtype=self.dtype)
-        S, C = self._SUM[label], self._CROSS[label]
-        return (C - np.outer(S, S) / n) / (n - ddof)
+        """(sum x x^T - sum x sum x^T / n) / (n - ddof); NaN when n <= ddof."""
+        g = self._reduced("vec", label)
+        if g.count <= ddof:
+            return np.full((g.dim, g.dim), np.nan, dtype=self.dtype)
+        return (g.second - np.outer(g.first, g.first) / g.count) / (g.count - ddof)
 
     def var(self, label, ddof=1):
-        self._check_reduced()
-        if label not in self._CROSS:
-            raise KeyError(f"{label!r} is not a stats-mode label.")
-        n = self._N[label]
-        if n <= ddof:
-            return np.full(self._SUM[label].shape[0], np.nan, dtype=self.dtype)
-        S, C = self._SUM[label], self._CROSS[label]
-        return (np.diag(C) - (S * S) / n) / (n - ddof)
+        g = self._reduced("vec", label)
+        if g.count <= ddof:
+            return np.full(g.dim, np.nan, dtype=self.dtype)
+        return (np.diagonal(g.second) - g.first ** 2 / g.count) / (g.count - ddof)
 
-    def stack_sum(self, label):
-        self._check_reduced()
-        if label not in self._STACK_SUM:
-            raise KeyError(f"{label!r} is not a stack-mode label.")
-        return self._STACK_SUM[label]
-
+    # -- on-disk format (interoperable with the reference's post-processing, stats.py:1455-1530) ------------------
     def save_reduced(self, path, compressed=False, root_rank=0):
-        """stats.py:1455-1480 .npz schema; additionally stores ``stack/<label>/K``
-        (the reference forgets the stack count, stats.py:1507-1527)."""
-        self._check_reduced()
-        if self.mpi_enabled and not (self.comm.Get_rank() == root_rank):
+        """``.npz`` with keys ``stats/<label>/{N,SUM,CROSS}`` and ``stack/<label>/{SUM,K}`` (K: the stack count,
+        which the reference's writer omits and its reader therefore cannot restore)."""
+        if self._world is None:
+            raise RuntimeError("global results exist only after allreduce()")
+        if self.mpi_enabled and self.comm.Get_rank() != root_rank:
             return
-        arrays = {}
-        for lab in self._SUM.keys():
-            arrays[f"stats/{lab}/N"] = np.array(self._N[lab], dtype=np.int64)
-            arrays[f"stats/{lab}/SUM"] = self._SUM[lab]
-            arrays[f"stats/{lab}/CROSS"] = self._CROSS[lab]
-        for lab in self._STACK_SUM.keys():
-            arrays[f"stack/{lab}/SUM"] = self._STACK_SUM[lab]
-            arrays[f"stack/{lab}/K"] = np.array(self._K[lab], dtype=np.int64)
-        saver = np.savez_compressed if compressed else np.savez
-        saver(Path(path), **arrays)
+        blob = {}
+        for lab, g in self._world[0].items():
+            blob["stats/%s/N" % lab] = np.array(g.count, dtype=np.int64)
+            blob["stats/%s/SUM" % lab] = g.first
+            blob["stats/%s/CROSS" % lab] = g.second
+        for lab, g in self._world[1].items():
+            blob["stack/%s/SUM" % lab] = self.stack_sum(lab)
+            blob["stack/%s/K" % lab] = np.array(g.count, dtype=np.int64)
+        (np.savez_compressed if compressed else np.savez)(Path(path), **blob)
 
     @classmethod
     def load_reduced(cls, path, comm=None, dtype=np.float64):
-        """stats.py:1483-1530."""
         data = np.load(Path(path), allow_pickle=False)
-        acc = cls(comm=comm, dtype=dtype)
+        fields = defaultdict(dict)
         for key in data.files:
-            parts = key.split("/")
-            lab = parts[1]
-            if parts[0] == "stats":
-                if parts[2] == "N":
-                    acc._N[lab] = int(data[key])
-                elif parts[2] == "SUM":
-                    acc._SUM[lab] = np.array(data[key])
-                    acc._dim_stats[lab] = acc._SUM[lab].shape[0]
-                elif parts[2] == "CROSS":
-                    acc._CROSS[lab] = np.array(data[key])
-            elif parts[0] == "stack":
-                if parts[2] == "SUM":
-                    acc._STACK_SUM[lab] = np.array(data[key])
-                    acc._shape_stack[lab] = acc._STACK_SUM[lab].shape
-                elif parts[2] == "K":
-                    acc._K[lab] = int(data[key])
-        acc._reduced = True
-        return acc
+            kind, lab, item = key.split("/", 2)
+            fields[(kind, lab)][item] = np.array(data[key])
+        self = cls(comm=comm, dtype=dtype)
+        gv, gp = {}, {}
+        for (kind, lab), f in fields.items():
+            if kind == "stats":
+                g = _Moments(f["SUM"].shape[0], f["SUM"], f["CROSS"])
+                g.count = int(f["N"])
+                gv[lab] = g
+            elif kind == "stack":
+                g = _Stack(f["SUM"].shape, f["SUM"])
+                g.count = int(f["K"]) if "K" in f else 0
+                gp[lab] = g
+        self._world = (gv, gp)
+        return self

@@ -133,11 +133,12 @@ static int do_c2c(int ny, int nx, const cx<T>* in, cx<T>* out, int inverse, doub
 
 template <typename T>
 static int do_qe_rows(int ny, int nx, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, double s,
-                      int win = 0, int wout = 0) {
+                      int win = 0, int wout = 0, int mrow = 0) {
     Holder<T> hd(ny, nx);
     EmuLauncher q;
-    hd.p.rows_qe(q, gx, gy, h, px, py, (T)s, 0, hd.p.clampw(win), hd.p.clampw(wout));
-    return 0;
+    if (mrow < 0) mrow = Fft2dPlan<T>::row_grid_min(nx, hd.p.clampw(win), hd.p.clampw(wout));
+    hd.p.rows_qe(q, gx, gy, h, px, py, (T)s, 0, hd.p.clampw(win), hd.p.clampw(wout), mrow);
+    return mrow;
 }
 
 template <typename T>
@@ -187,16 +188,26 @@ int emu_cols_div_f64(int ny, int nx, const void* pa, const void* pb, const doubl
     return do_cols_div<double>(ny, nx, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out);
 }
 int emu_qe_rows_f32(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s) {
-    return do_qe_rows<float>(ny, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s);
+    do_qe_rows<float>(ny, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s);
+    return 0;
 }
 int emu_qe_rows_f64(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s) {
-    return do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s);
+    do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s);
+    return 0;
 }
 // active-column variants (width / win / wout as in include/orphics_amd.h)
 int emu_r2c_w_f64(int ny, int nx, const double* in, void* out, double s, int width, int rband) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s, width, rband); }
 int emu_c2r_w_f64(int ny, int nx, const void* in, double* out, double s, int width) { return do_c2r<double>(ny, nx, (const cx<double>*)in, out, s, width); }
 int emu_qe_rows_w_f64(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout) {
-    return do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s, win, wout);
+    do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s, win, wout);
+    return 0;
+}
+// row-grid variant (mrow as in oa_qe_rows; < 0 = auto); returns the grid used
+int emu_qe_rows_wm_f64(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout, int mrow) {
+    return do_qe_rows<double>(ny, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s, win, wout, mrow);
+}
+int emu_qe_rows_wm_f32(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout, int mrow) {
+    return do_qe_rows<float>(ny, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s, win, wout, mrow);
 }
 int emu_legs_cols_w_f64(int ny, int nx, const void* kX, const void* kY, const double* FG, const double* FH, const double* lxd,
                         const double* lyd, void* gx, void* gy, void* h, int width, int rband) {

@@ -135,6 +135,40 @@ def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
             assert np.all(got[:, wo:W] == 5.0)                    # untouched
 
 
+@pytest.mark.parametrize("ny,nx,win,wout,mrow,expect", [(32, 8192, 380, 664, -1, 2048), (32, 8192, 1139, 664, -1, 4096),
+                                                         (32, 2048, 100, 150, -1, 512), (32, 1024, 60, 100, 512, 512),
+                                                         (32, 512, 100, 150, -1, 512), (32, 4096, 190, 332, -1, 1024),
+                                                         (16, 16384, 380, 664, -1, 2048)])
+def test_fused_row_stage_on_alias_free_row_grid(emu, ny, nx, win, wout, mrow, expect):
+    """ROW GRID (include/orphics_amd.h): band-limited legs (columns >= win vanish) -> the row stage on a grid of
+    mrow >= 2 win + wout points returns the same product columns k < wout as the full-length transform
+    (through the actual kernel body, here at a shorter compile-time row length)."""
+    emu.emu_set_stockham_qe(1)
+    rng = np.random.default_rng(7 + nx + win)
+    W = nx // 2 + 1
+    planes = []
+    for _ in range(3):
+        k = (rng.standard_normal((ny, W)) + 1j * rng.standard_normal((ny, W)))
+        k[:, 0] = k[:, 0].real
+        k[:, win:] = 0
+        planes.append(k)
+    gx, gy, h = planes
+    rows = lambda k: np.fft.irfft(k, n=nx, axis=1) * nx
+    hr = rows(h)
+    ref = [np.fft.rfft(rows(g) * hr, axis=1) for g in (gx, gy)]
+    ins = []
+    for k in planes:
+        a = _hc(emu, ny, nx, fill=1e30)                         # garbage beyond the band must not be read
+        a[:, :win] = k[:, :win]
+        ins.append(a)
+    px, py = _hc(emu, ny, nx, fill=5.0), _hc(emu, ny, nx, fill=5.0)
+    used = emu.emu_qe_rows_wm_f64(ny, nx, _p(ins[0]), _p(ins[1]), _p(ins[2]), _p(px), _p(py), ctypes.c_double(1.0), win, wout, mrow)
+    assert used == expect
+    for got, want in ((px, ref[0]), (py, ref[1])):
+        assert np.abs(got[:, :wout] - want[:, :wout]).max() < 1e-11 * np.abs(want).max()
+        assert np.all(got[:, wout:W] == 5.0)
+
+
 @pytest.mark.parametrize("ny,nx,w,rb", [(64, 64, 0, 0), (64, 128, 21, 0), (128, 64, 32, 9), (256, 64, 7, 40), (64, 64, 0, 5)])
 def test_fused_column_stages(emu, ny, nx, w, rb):
     """col_legs (+ pass 2) = inverse column transforms of (i lx FG kX, i ly FG kX, FH kY);
