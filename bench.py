@@ -167,34 +167,31 @@ class Runner(object):
         self.mom_n = [torch.zeros(1, dtype=torch.int64, device=eng.device) for _ in range(self.ns)]
         self.mom_S = [torch.zeros(d, dtype=torch.float64, device=eng.device) for _ in range(self.ns)]
         self.mom_C = [torch.zeros(d, d, dtype=torch.float64, device=eng.device) for _ in range(self.ns)]
-        # mode counts per bin do not depend on the data: taken once over the whole plane
-        z = eng.hc()
-        _, self.counts = eng.bin_power(z, z, self.norm, P["ids"], P["nids"], herm=True)
+        # radial bins bound to every handle's plan: one C-ABI call per step (oa_qe_tt_moments)
+        for e in self.qs:
+            e.bind_bins(P["ids"], P["nids"], self.norm)
+        self.counts = q.bin_counts()            # data-independent mode counts per bin (whole plane)
         torch.cuda.synchronize()
         self._ptr, self._stream, self._check = _ptr, _stream, check
-        self.last = {}
 
     def step(self, i):
+        """map -> kappa_hat -> 19 bandpowers -> moments: ONE C-ABI call (oa_qe_tt_moments) on this step's stream"""
         j = i % self.ns
-        q, P = self.q, self.P
         with self.torch.cuda.stream(self.streams[j]):
-            e = self.qs[j].eng
-            self.qs[j].reconstruct_tt_from_map(self.tmaps[i & 1], out=self.kks[j])
-            sums, _ = e.bin_power(self.kks[j], self.kks[j], self.norm, P["ids"], P["nids"], herm=True,
-                                  active_cols=q.kappa_cols, active_rows=q.kappa_rows)
-            self._check(e.lib.oa_moments_add_binned(self._ptr(sums[1:]), self._ptr(self.counts[1:]), self.d, self._ptr(self.mom_n[j]),
-                                                    self._ptr(self.mom_S[j]), self._ptr(self.mom_C[j]), self._stream()))
-            self.last[i & 1] = sums
+            self.qs[j].tt_moments(self.tmaps[i & 1], self.mom_n[j], self.mom_S[j], self.mom_C[j])
+
+    def bandpowers(self, which=0):
+        """bandpowers of map `which` through this runner's path (public fine-grained calls, same kernels)"""
+        q, P, e = self.q, self.P, self.eng
+        kk = self.kks[0]
+        q.reconstruct_tt_from_map(self.tmaps[which], out=kk)
+        sums, _ = e.bin_power(kk, kk, self.norm, P["ids"], P["nids"], herm=True, active_cols=q.kappa_cols, active_rows=q.kappa_rows)
+        self.torch.cuda.synchronize()
+        return sums[1:-1] / self.counts[1:-1]
 
     def zero(self):
         for j in range(self.ns):
             self.mom_n[j].zero_(); self.mom_S[j].zero_(); self.mom_C[j].zero_()
-
-    def bandpowers(self, which=0):
-        """bandpowers of map `which` through this runner's path"""
-        self.step(which)
-        self.torch.cuda.synchronize()
-        return self.last[which][1:-1] / self.counts[1:-1]
 
     def rate(self, nsteps, nwarm=10):
         for i in range(nwarm):

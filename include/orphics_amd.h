@@ -27,6 +27,7 @@
 #ifndef ORPHICS_AMD_H
 #define ORPHICS_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -123,6 +124,64 @@ int oa_qe_map_legs_cols(oa_plan* p, const void* real_map, const void* FG, const 
                         int width, int rband, void* stream);
 int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const void* Fnorm, void* out, int accumulate,
                    int width, int rband, void* stream);
+
+/* ---- one-call entries (SURVEY.md section 8b export list) ---------------------------------------------------
+ * A plan that has been told its TT filters and its radial bins runs whole reconstructions per call; work planes are
+ * owned by the plan (allocated once by oa_plan_set_filters, never inside a stream-ordered call afterwards).
+ *  oa_plan_set_filters : FG, FH, Fnorm = the estimator's real hc-layout planes (gradient-leg weight C^g/(B C^tot),
+ *                        inverse-variance weight 1/(B C^tot), -L(L+1)/2 A_L mask_K; device memory owned by the
+ *                        caller, which keeps it alive), their active columns / rows (0 = all) and the row grid
+ *                        (mrow as in oa_qe_rows).  Replaces the filter set-up of lensing.qest(...).
+ *  oa_plan_set_bins    : radial-bin ids of the hc grid (oa_modl_digitize(..., pitch = kpitch, width = nx/2+1)) and
+ *                        the power normalisation area / Npix^2; takes the data-independent mode counts once.
+ *                        Replaces stats.bin2D.__init__ (stats.py:783-788).
+ *  oa_qe_tt            : qest.kappa_from_map("TT", ...) (lensing.py:973-976) in ONE call: pass a real map (both
+ *                        legs from it) XOR Fourier-space leg(s) kX [, kY]; kappa_hat's DFT goes to out_kappa_hc or,
+ *                        if NULL, to the plan-owned plane oa_plan_kappa(plan).  The pruned kernels write only
+ *                        kappa's active region (kappa_cols x row band); zero_outside != 0 zero-fills the rest of a
+ *                        caller-supplied plane first (pass 0 only if it is known to be zero there already, e.g. the
+ *                        previous call with the same filters wrote it).
+ *  oa_qe_pol           : the general separable estimator (TE, EE, EB, TB; lensing.Estimator.reconstruct_hc): the
+ *                        npieces (sign, FG, FH, swap-legs) terms are summed in the row stage, one divergence.
+ *                        host_* arrays live on the host; the planes they point to on the device.
+ *  oa_filter_map       : maps.filter_map (maps.py:1922-1923): real_out = Re IFFT(FFT(real_in) * filter).
+ *  oa_qe_tt_moments    : map -> kappa_hat -> binned auto-power -> n += 1, S += b, C += b b^T (Statistics.add of the
+ *                        bandpower vector, stats.py:1068-1090): one Monte-Carlo step per call.
+ *  oa_mc_run           : the Gaussian N0 / mean-field Monte-Carlo shard [sim_lo, sim_hi) of
+ *                        tutorials/tt_verification.ipynb cell 4: Philox GRF (key = (base_seed, sim)) with per-mode
+ *                        amplitude covsqrt_hc -> TT estimator -> bandpower moments (+ mean-field stack of kappa_hat,
+ *                        interleaved re/im doubles, if meanfield_acc != NULL).  No host synchronisation. */
+int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
+                        int leg_rows, int kappa_rows, int mrow);
+int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);
+void* oa_plan_kappa(oa_plan* p);
+const int64_t* oa_plan_bin_counts(oa_plan* p);
+int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
+             void* stream);
+int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* const* host_FG, const void* const* host_FH,
+              const int* host_swap, const void* kX, const void* kY, const void* Fnorm, void* out, int accumulate,
+              int leg_cols, int kappa_cols, int leg_rows, int kappa_rows, int mrow, int zero_outside, void* stream);
+int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream);
+int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, double* C, void* stream);
+int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S,
+              double* C, double* meanfield_acc, void* stream);
+
+/* ---- device memory helpers for hosts without a GPU array library (the reference passes NumPy arrays) --------- */
+int oa_malloc(void** out, size_t bytes);
+int oa_free(void* dptr);
+int oa_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream); /* 1 h2d, 2 d2h, 3 d2d */
+int oa_memset(void* dptr, int value, size_t bytes, void* stream);
+int oa_stream_synchronize(void* stream);
+
+/* ---- ensemble reduce over GPUs (Statistics.allreduce, stats.py:1209-1230) without torch.distributed ----------
+ * RCCL communicator over the ranks of one job (librccl.so is dlopen'ed on first use).  One rank calls
+ * oa_comm_unique_id and distributes the 128 bytes (MPI_Bcast in an mpi4py host), every rank then calls
+ * oa_comm_init with its rank; oa_allreduce sums a device buffer in place over the ranks, stream-ordered.
+ * dtype_code: 0 = float64, 1 = int64, 2 = float32. */
+int oa_comm_unique_id(void* id128);
+int oa_comm_init(int nranks, int rank, const void* id128, void** comm_out);
+int oa_comm_destroy(void* comm);
+int oa_allreduce(void* comm, void* device_buf, long count, int dtype_code, void* stream);
 
 /* ---- layout helpers ------------------------------------------------------ */
 /* hc -> full by Hermitian symmetry X(-l) = conj X(l) (what the reference's C2C of

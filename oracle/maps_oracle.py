@@ -263,6 +263,45 @@ def multi_pow(cov, exp):
     return np.moveaxis(res, 0, -1).reshape(cov.shape)
 
 
+def spec2flat(shape, step_y, step_x, cov, exp=1.0, smooth_width=0.0, area=None):
+    """enmap.spec2flat as MapGen uses it (maps.py:1573) -- PARITY UNPINNED (pixell absent): 1-D spectra sampled at
+    integer ell -> optional Gaussian smoothing in ell with weight ell -> x Npix/area -> per-ell matrix power ->
+    linear interpolation onto |ell|, 0 beyond the table.  Written independently of the product (explicit loops
+    over ell for the smoothing and the matrix power) so the two can be compared."""
+    cov = np.array(cov, dtype=np.float64)
+    if cov.ndim == 1:
+        cov = cov[None, None]
+    nc, nl = cov.shape[0], cov.shape[-1]
+    Ny, Nx = shape[-2:]
+    area = planar_area(shape, step_y, step_x) if area is None else area
+    if smooth_width > 0:
+        ell = np.arange(nl, dtype=np.float64)
+        wgt = np.maximum(ell, 0.5)
+        sm = np.empty_like(cov)
+        half = int(min(nl - 1, np.ceil(5 * smooth_width)))
+        for l in range(nl):
+            lo, hi = max(0, l - half), min(nl, l + half + 1)
+            k = np.exp(-0.5 * ((ell[lo:hi] - l) / smooth_width) ** 2)
+            # np.convolve(mode="same") zero-pads: the weight normalisation sees the same truncated window
+            sm[..., l] = (cov[..., lo:hi] * (wgt[lo:hi] * k)).sum(-1) / (wgt[lo:hi] * k).sum()
+        cov = sm
+    cov = cov * (Ny * Nx / area)
+    if exp != 1.0:
+        out = np.empty_like(cov)
+        for l in range(nl):
+            w, v = np.linalg.eigh(cov[:, :, l])
+            out[:, :, l] = (v * np.where(w > 0, w, 0.0) ** exp) @ v.T
+        cov = out
+    cov[~np.isfinite(cov)] = 0
+    ml = modlmap(shape, step_y, step_x)
+    ell = np.arange(nl, dtype=np.float64)
+    res = np.zeros((nc, nc) + ml.shape)
+    for i in range(nc):
+        for j in range(nc):
+            res[i, j] = np.interp(ml, ell, cov[i, j], right=0.0)
+    return res
+
+
 class MapGen(object):
     def __init__(self, shape, step_y, step_x, cov=None, covsqrt=None, pixel_units=False, area=None):
         """maps.py:1559-1573 (cov.ndim==4 branch only; the 3-D branch is

@@ -38,6 +38,25 @@ SIGNATURES = {
     "oa_qe_legs_cols": (c_int, [c_void_p] * 8 + [c_int, c_int, c_void_p]),
     "oa_qe_map_legs_cols": (c_int, [c_void_p] * 7 + [c_int, c_int, c_void_p]),
     "oa_qe_cols_div": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_void_p]),
+    "oa_plan_set_filters": (c_int, [c_void_p] * 4 + [c_int] * 5),
+    "oa_plan_set_bins": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p]),
+    "oa_plan_kappa": (c_void_p, [c_void_p]),
+    "oa_plan_bin_counts": (c_void_p, [c_void_p]),
+    "oa_qe_tt": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
+    "oa_qe_pol": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oa_filter_map": (c_int, [c_void_p] * 5),
+    "oa_qe_tt_moments": (c_int, [c_void_p] * 6),
+    "oa_mc_run": (c_int, [c_void_p, c_u64, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_malloc": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_size_t]),
+    "oa_free": (c_int, [c_void_p]),
+    "oa_memcpy": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]),
+    "oa_memset": (c_int, [c_void_p, c_int, ctypes.c_size_t, c_void_p]),
+    "oa_stream_synchronize": (c_int, [c_void_p]),
+    "oa_comm_unique_id": (c_int, [c_void_p]),
+    "oa_comm_init": (c_int, [c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "oa_comm_destroy": (c_int, [c_void_p]),
+    "oa_allreduce": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "oa_hc_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -107,58 +107,63 @@ def knox_cov(cl_tot, nmodes):
 
 
 class LensForecast(object):
-    """Gaussian bandpower covariance (cosmology.py:948-1094): only the pieces on the hot path's
-    output side -- loadKK / loadGenericCls, _bin_cls, KnoxCov, sigmaClSquared, sn."""
+    """Gaussian ("Knox") bandpower covariance for lensing / generic spectra -- the output-side contract of
+    cosmology.py:948-1094 that the hot path's N_L curves feed: register signal spectra (and optional noise curves)
+    under two-letter names like 'kk', then ask for the covariance of band-averaged C^XY with C^WZ.
+
+    Band average: ell-weighted mean over the integers ell_lo..ell_hi of C_ell (+ N_ell for auto-spectra);
+    cov(C^XY_b, C^WZ_b) = (C^XW_b C^YZ_b + C^XZ_b C^YW_b) / ((2 ell_mid + 1) (ell_hi - ell_lo) fsky)."""
 
     def __init__(self, theory=None):
         self.theory = TheorySpectra() if theory is None else theory
         self.Nls = {}
 
+    @staticmethod
+    def _noise_curve(ells, nls):
+        ells, nls = np.asarray(ells, dtype=float), np.asarray(nls, dtype=float)
+        return lambda x: np.interp(np.asarray(x, dtype=float), ells, nls, left=np.inf, right=np.inf)   # unknown noise = no information
+
     def loadKK(self, ellsCls, Cls, ellsNls, Nls, lpad=30000):
-        """cosmology.py:976-985: kk signal + reconstruction noise (inf outside the noise table)."""
-        ellsNls, Nls = np.asarray(ellsNls, float), np.asarray(Nls, float)
-        self.Nls['kk'] = lambda x: np.interp(np.asarray(x, float), ellsNls, Nls, left=np.inf, right=np.inf)
+        """kappa-kappa signal + reconstruction noise (cosmology.py:976-985)."""
+        self.Nls['kk'] = self._noise_curve(ellsNls, Nls)
         self.theory.loadGenericCls(ellsCls, Cls, 'kk', lpad=lpad)
 
     def loadGenericCls(self, specType, ellsCls, Cls, ellsNls=None, Nls=None):
-        """cosmology.py:1034-1036."""
+        """Any other spectrum, e.g. 'kg', 'gg' (cosmology.py:1034-1036); noise only makes sense for autos."""
         if Nls is not None:
-            e, n = np.asarray(ellsNls, float), np.asarray(Nls, float)
-            self.Nls[specType] = lambda x: np.interp(np.asarray(x, float), e, n, left=np.inf, right=np.inf)
+            self.Nls[specType] = self._noise_curve(ellsNls, Nls)
         self.theory.loadGenericCls(ellsCls, Cls, specType)
 
-    def _bin_cls(self, spec, ell_left, ell_right, noise=True, ntot=False):
-        """cosmology.py:1038-1052: ell-weighted mean of C_l (+N_l for autos) over [left, right]."""
-        a, b = spec
-        ells = np.arange(ell_left, ell_right + 1, 1)
-        cls = self.theory.gCl(spec, ells)
-        Noise = 0.
-        if noise:
-            Noise = self.Nls[spec](ells) if a == b else 0.
-        tot = Noise if (ntot and a == b and noise) else cls + Noise
-        return np.sum(ells * tot) / np.sum(ells)
+    def _band_average(self, spec, lo, hi, with_noise=True, noise_only=False):
+        ells = np.arange(lo, hi + 1, 1)
+        auto = spec[0] == spec[1]
+        noise = self.Nls[spec](ells) if (with_noise and auto) else 0.
+        total = noise if (noise_only and with_noise and auto) else self.theory.gCl(spec, ells) + noise
+        return float(np.sum(ells * total) / np.sum(ells))
+
+    _bin_cls = _band_average        # name used by reference-era callers
 
     def KnoxCov(self, specTypeXY, specTypeWZ, ellBinEdges, fsky, ntot=False):
-        """cosmology.py:1054-1082: cov(C^XY, C^WZ) = (C^XW C^YZ + C^XZ C^YW)/((2l+1) dl fsky)."""
+        """(variance per band, (S/N)^2 per band of XY, of WZ)  (cosmology.py:1054-1082)."""
         X, Y = specTypeXY
         W, Z = specTypeWZ
-        covs, sigs1, sigs2 = [], [], []
-        for ell_left, ell_right in zip(ellBinEdges[:-1], ellBinEdges[1:]):
-            ClSum = self._bin_cls(X + W, ell_left, ell_right, ntot=ntot) * self._bin_cls(Y + Z, ell_left, ell_right, ntot=ntot) \
-                + self._bin_cls(X + Z, ell_left, ell_right, ntot=ntot) * self._bin_cls(Y + W, ell_left, ell_right, ntot=ntot)
-            ellMid = (ell_right + ell_left) / 2.
-            ellWidth = ell_right - ell_left
-            var = ClSum / (2. * ellMid + 1.) / ellWidth / fsky
-            covs.append(var)
+        edges = np.asarray(ellBinEdges)
+        var, snr2_xy, snr2_wz = [], [], []
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            b = lambda sp: self._band_average(sp, lo, hi, noise_only=ntot)   # noqa: E731
+            pairs = b(X + W) * b(Y + Z) + b(X + Z) * b(Y + W)
+            v = pairs / (2. * (0.5 * (lo + hi)) + 1.) / (hi - lo) / fsky
+            var.append(v)
             with np.errstate(divide="ignore"):
-                sigs1.append(self._bin_cls(specTypeXY, ell_left, ell_right, noise=False) ** 2. * np.nan_to_num(1. / var))
-                sigs2.append(self._bin_cls(specTypeWZ, ell_left, ell_right, noise=False) ** 2. * np.nan_to_num(1. / var))
-        return np.array(covs), np.array(sigs1), np.array(sigs2)
+                inv = np.nan_to_num(1. / v)
+            snr2_xy.append(self._band_average(specTypeXY, lo, hi, with_noise=False) ** 2. * inv)
+            snr2_wz.append(self._band_average(specTypeWZ, lo, hi, with_noise=False) ** 2. * inv)
+        return np.array(var), np.array(snr2_xy), np.array(snr2_wz)
 
     def sigmaClSquared(self, specType, ellBinEdges, fsky, ntot=False):
         return self.KnoxCov(specType, specType, ellBinEdges, fsky, ntot=ntot)[0]
 
     def sn(self, ellBinEdges, fsky, specType, ntot=False):
-        """cosmology.py:1087-1094."""
-        var, sigs1, _ = self.KnoxCov(specType, specType, ellBinEdges, fsky, ntot=ntot)
-        return np.sqrt(sigs1.sum()), np.sqrt(var)
+        """Total signal-to-noise and per-band sigma(C_b) (cosmology.py:1087-1094)."""
+        var, snr2, _ = self.KnoxCov(specType, specType, ellBinEdges, fsky, ntot=ntot)
+        return np.sqrt(snr2.sum()), np.sqrt(var)

@@ -66,6 +66,7 @@ struct oa_plan {
     void* chirp_y; void* chirp_x;            // cx<T>[ny], cx<T>[nx]
     void* cz_bhat; void* cz_a; void* cz_f;   // cx<T>[My*Mx]: chirp-kernel transform, two work planes
     void* cz_full;                           // cx<T>[ny*nx]
+    void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
 };
 
 namespace oa {
@@ -75,6 +76,7 @@ void czt_release(oa_plan* p);
 int czt_c2c(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st);
 int czt_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, hipStream_t st);
 int czt_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStream_t st);
+void pipeline_release(oa_plan* p);
 }
 #define OA_NEED_POW2(p, what) \
     OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

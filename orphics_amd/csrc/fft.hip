@@ -28,6 +28,23 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), (qe_waves_per_eu<T, SEQ>())) void
 }
 
 
+template <class SEQ> constexpr int pair_nt() { return (1 << seq_logl<SEQ>()) / EPT; }
+// register budget of the two-rows-per-transform row stage: grids up to 2048 points keep h, the leg and the
+// butterfly temporaries in registers only at 2 waves/SIMD (at 3 they spill 17-45 VGPRs: 117 us vs 87 us at 8192^2,
+// profiles/r02e_rowqe_variants.txt); the 4096-point grid fits 3 waves/SIMD without spilling
+#ifdef OA_PAIR_WAVES_PER_EU
+template <typename T, class SEQ> constexpr int pair_waves_per_eu() { return sizeof(T) == 8 ? 1 : OA_PAIR_WAVES_PER_EU; }
+#else
+template <typename T, class SEQ> constexpr int pair_waves_per_eu() {
+    return sizeof(T) == 8 ? 1 : (seq_logl<SEQ>() == 12 ? 3 : 2);
+}
+#endif
+template <typename T, class SEQ, int NZ>
+__global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ>())) void row_qe_pair_kernel(RowQeArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_qe_pair_body<T, SEQ, NZ>(c, a);
+}
+
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_div_kernel(ColDivArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -68,23 +85,38 @@ struct HipLauncher {
     template <typename T>
     void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         // rows of 16384 / 32768 points: put the short radix FIRST so that the reversed (inverse) sequence starts with
-        // a radix-16 stage and the active-column first stage applies (the plain greedy order would start it with 2 / 4)
+        // a radix-16 stage (the plain greedy order would start it with 2 / 4)
         const bool ok = dispatch_seq_qe(a.logL, [&](auto seq) {
             using S = decltype(seq);
             if constexpr (seq_logl<S>() >= 4) {
                 if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
-                // active columns: the first inverse stage gathers its few live taps straight from global memory
-                if constexpr (S::n >= 2 && S::rget(0) == 16 && sizeof(T) == 4) {
-                    const int nz = qe_first_stage_nz(a.logL, 16, a.win);
-                    if (nz == 1) { go(row_qe_kernel<T, S, 1>, dim3(grid), nt, smem, a); return; }
-                    if (nz == 2) { go(row_qe_kernel<T, S, 2>, dim3(grid), nt, smem, a); return; }
+                // the first inverse stage gathers its live taps straight from the half-complex rows (untangle on
+                // load): NZ live taps per side, a power of two up to R/2 = every tap; NZ = 0: prologue pass through LDS
+                if constexpr (S::n >= 2 && sizeof(T) == 4) {
+                    dispatch_nz<S>(qe_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
+                        go(row_qe_kernel<T, S, decltype(nzc)::value>, dim3(grid), nt, smem, a);
+                    });
+                } else {
+                    go(row_qe_kernel<T, S, 0>, dim3(grid), nt, smem, a);
                 }
-                go(row_qe_kernel<T, S, 0>, dim3(grid), nt, smem, a);
             } else {
                 if (!rc) rc = fail("fft: unsupported row length");
             }
         });
         if (!ok && !rc) rc = fail("fft: unsupported row length");
+    }
+    template <typename T>
+    void row_qe_pair(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
+        const bool ok = dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_logl<S>() >= 10 && seq_logl<S>() <= 13) {
+                if (nt != pair_nt<S>()) { if (!rc) rc = fail("fft: pair row stage launched with the wrong workgroup size"); return; }
+                dispatch_pair_nz<S>(pair_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
+                    go(row_qe_pair_kernel<T, S, decltype(nzc)::value>, dim3(grid), nt, smem, a);
+                });
+            } else if (!rc) rc = fail("fft: unsupported row grid for the pair row stage");
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported row grid");
     }
     template <typename T>
     void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
@@ -180,8 +212,11 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
     HipLauncher q{st};
     auto f = view<T>(p);
     const int wi = f.clampw(win), wo = f.clampw(wout);
-    if (mrow < 0) mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo);      // auto: smallest alias-free grid
-    if (mrow > 0 && mrow < p->nx) {
+    if (mrow < 0) {                                                         // auto: smallest alias-free grid
+        mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo);
+        if (2L * wi + wo > mrow) mrow = 0;                                  // no band limit to exploit: full-length path
+    } else if (mrow > 0) {
+        if (mrow > p->nx) mrow = p->nx;
         if (!is_pow2(mrow) || mrow < 64) return fail("oa_qe_rows: mrow must be a power of two >= 64");
         if (2L * wi + wo > mrow) return fail("oa_qe_rows: mrow < 2*win + wout would alias the leg products into the kept columns");
     }

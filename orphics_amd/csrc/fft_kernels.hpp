@@ -24,6 +24,7 @@
 //  * real transforms use the packed N/2-point trick with an in-LDS
 //    (un)tangle step, so a real row costs half the LDS and flops.
 #pragma once
+#include <type_traits>
 #include "cx.hpp"
 
 namespace oa {
@@ -388,29 +389,35 @@ OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0
 template <typename T, bool GUARD, class Ctx>
 OA_HD void r2c_epilogue_impl(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r0, int logL, int logC, int NT, int RS,
                              const cx<T>* tw, int logTw, T scale, bool accumulate, int wout) {
-    const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
+    const int tid = ctx.tid(), L = 1 << logL;
     const int sh = logTw - (logL + 1);
-    for (int i = tid; i < (C << (logL - 1)); i += NT) {
-        const int c = i >> (logL - 1), k = i & ((L >> 1) - 1);
-        cx<T>* row = out + r0 * pitch + (unsigned)c * (unsigned)pitch;
-        for (int rep = 0; rep < 2; ++rep) {
-            const int kk = rep ? (L >> 1) : k;
-            if (rep && k != 0) break;
-            const bool w1 = !GUARD || kk < wout, w2 = !GUARD || (L - kk) < wout;
-            if (GUARD && !w1 && !w2) continue;
-            const cx<T> Zk = s[lds_addr<true>(kk, c, 0, RS)];
-            const cx<T> Zm = s[lds_addr<true>((L - kk) & (L - 1), c, 0, RS)];
-            const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
-            const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
-            const cx<T> wO = tw[kk << sh] * O;
-            cx<T> o1 = (E + wO) * scale, o2 = conj(E - wO) * scale;
-            if (accumulate) {
-                if (w1) o1 = o1 + row[kk];
-                if (2 * kk != L) { if (w2) o2 = o2 + row[L - kk]; } else o2 = o1;
-            }
-            if (w1) row[kk] = o1;
-            if (w2) row[L - kk] = o2;
+    // L/16 threads per row (NT = L C / 16): this thread's row c and first column k0 are fixed and it owns the 8
+    // column pairs (k, L - k), k = k0 + m L/16 -- a compile-time trip count once logL is, 32-bit offsets from two
+    // per-thread bases, so the loop body is loads + butterfly + stores
+    const int tpr = (NT >> logC) > 0 ? (NT >> logC) : 1;
+    const int c = tid / tpr, k0 = tid - c * tpr;
+    cx<T>* row = out + (r0 + c) * pitch;
+    const cx<T>* sr = s + c * RS;
+    auto pair = [&](int kk) {
+        const bool w1 = !GUARD || kk < wout, w2 = !GUARD || (L - kk) < wout;
+        if (GUARD && !w1 && !w2) return;
+        const int km = (L - kk) & (L - 1);
+        const cx<T> Zk = sr[kk + (kk >> 4)];
+        const cx<T> Zm = sr[km + (km >> 4)];
+        const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
+        const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
+        const cx<T> wO = tw[kk << sh] * O;
+        cx<T> o1 = (E + wO) * scale, o2 = conj(E - wO) * scale;
+        if (accumulate) {
+            if (w1) o1 = o1 + row[kk];
+            if (2 * kk != L) { if (w2) o2 = o2 + row[L - kk]; } else o2 = o1;
         }
+        if (w1) row[kk] = o1;
+        if (w2) row[L - kk] = o2;
+    };
+    if (c < (1 << logC)) {
+        for (int kk = k0; kk < (L >> 1); kk += tpr) pair(kk);
+        if (k0 == 0) pair(L >> 1);
     }
 }
 template <typename T, class Ctx>
@@ -512,14 +519,25 @@ OA_HD cx<T> c2r_tap(const cx<T>* row, int n, int L, int win, const cx<T>* tw, in
     const cx<T> d = A - conj(B);
     return swp((A + conj(B)) + mul_pi(conj(tw[n << sh]) * d));
 }
-// smallest supported NZ in {1, 2} that covers `win` for a first stage of radix 16 on L points, or 0 (general path).
-// Only radix-16 first stages (rows of 8192 points and up in the reversed sequence <16,16,16>) keep the variant inside
-// the register budget; measured slower (spills) for the radix-8 first stage of 4096-point rows and for NZ = 4.
+// Number of live taps per side (1 or 2) of a radix-16 first inverse stage on L points with `win` active columns,
+// or 0 = general prologue path.
 OA_HD int qe_first_stage_nz(int logL, int R, int win) {
+    // only radix-16 first stages with <= 2 live taps per side pay (rows of 8192 points and up at the reference's
+    // band limits): with more live taps the guarded per-tap loads serialise and the variants spill -- measured
+    // 1.2-2x slower than the prologue pass on 2048..4096-point rows (profiles/r02c_rowqe_variants.txt)
     if (R != 16 || win <= 0 || win > (1 << logL)) return 0;
     const int S = (1 << logL) / R;
     const int need = (win + S - 1) / S;
     return need <= 1 ? 1 : (need <= 2 ? 2 : 0);
+}
+// host-side: call f(std::integral_constant<int, NZ>) for the instantiated variant (NZ in {0, 1, 2})
+template <class SEQ, class F>
+inline void dispatch_nz(int nz, F&& f) {
+    if constexpr (SEQ::n >= 2 && SEQ::rget(0) == 16) {
+        if (nz == 1) { f(std::integral_constant<int, 1>{}); return; }
+        if (nz == 2) { f(std::integral_constant<int, 2>{}); return; }
+    }
+    f(std::integral_constant<int, 0>{});
 }
 
 template <typename T, class SEQ, int NZ, class Ctx>
@@ -602,6 +620,128 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
         ctx.sync();
         forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
         r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
+        ctx.sync();
+    }
+}
+
+// ===========================================================================
+// Fused QE row stage on an alias-free row grid, TWO ROWS PER TRANSFORM.
+// Band-limited legs (columns >= win vanish, 2 win + wout <= M) let the row stage run on M < nx points (ROW GRID,
+// include/orphics_amd.h).  On that grid two real rows are carried by ONE complex transform of length M instead of
+// two packed M/2-point transforms with their (un)tangle passes:
+//   Z[k] = X0[k] + i X1[k] (k < win),  Z[M-k] = conj X0[k] + i conj X1[k],  0 elsewhere
+//   IDFT_M(Z) = x0 + i x1;  the product with h0 + i h1 is taken per component: p = x0 h0 + i x1 h1;
+//   P = DFT_M(p):  P0[k] = (P[k] + conj P[M-k]) / 2,  P1[k] = (P[k] - conj P[M-k]) / (2i),  k < wout.
+// The packing costs one add per live tap of the first inverse stage (taken straight from the two half-complex rows,
+// dead taps are literal zeros), the unpacking one LDS pass over the wout kept columns -- no twiddles, no tangle.
+// One workgroup of M/16 threads per row pair; h0 + i h1 stays in 16 registers per thread as in row_qe_body.
+// ===========================================================================
+template <typename T, class SEQ, int NZ, class Ctx>
+OA_HD void pair_inverse_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int RS, const cx<T>* tw,
+                                const cx<T>* row0, const cx<T>* row1, int win) {
+    constexpr int n = SEQ::n;
+    constexpr int logM = seq_total_log<SEQ>();
+    constexpr int R = SEQ::rget(0), LR = Log2c<R>::v, NB = EPT / R;
+    static_assert(n >= 2, "pair kernel needs at least two stages");
+    constexpr int logS = logM - LR, M = 1 << logM;
+    {
+        cx<T> w[EPT];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int j = (tid + u * NT) & ((1 << logS) - 1);
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const int nn = j + (t << logS);
+                if (t < NZ) {                       // low side: Z[n] = X0[n] + i X1[n], n < win
+                    const bool ok = nn < win;
+                    const int idx = ok ? nn : 0;    // unconditional loads from a valid address, masked afterwards
+                    const cx<T> a0 = row0[idx], a1 = row1[idx];
+                    const cx<T> z = add_pi(a0, a1);
+                    w[u * R + t] = ok ? swp(z) : mk<T>((T)0, (T)0);
+                } else if (t >= R - NZ) {            // high side: Z[n] = conj X0[M-n] + i conj X1[M-n], M - n < win
+                    const int m = M - nn;
+                    const bool ok = m < win;
+                    const int idx = ok ? m : 0;
+                    const cx<T> a0 = row0[idx], a1 = row1[idx];
+                    const cx<T> z = mk<T>(a0.x + a1.y, a1.x - a0.y);
+                    w[u * R + t] = ok ? swp(z) : mk<T>((T)0, (T)0);
+                } else {
+                    w[u * R + t] = mk<T>((T)-0.0, (T)-0.0);
+                }
+            }
+            Dft<T, R>::run(w + u * R);
+        }
+        stage_out<T, R, true, false>(s, w, tid, NT, logM, 0, RS, 0, NoStore{});
+    }
+    ctx.sync();
+    if constexpr (n >= 3) lds_stage<T, SEQ, 1, true>(ctx, s, tid, NT, logM, 0, RS, tw, logM);
+    if constexpr (n >= 4) lds_stage<T, SEQ, 2, true>(ctx, s, tid, NT, logM, 0, RS, tw, logM);
+    stage_in<T, SEQ::get(0), true, false>(s, v, tid, NT, logM, 0, RS, rev_logns<SEQ>(n - 1), tw, logM, NoLoad{});
+}
+
+// live taps per side of the pair kernel's first inverse stage: ceil(win / (M/R)) rounded up to a power of two (<= R/2)
+OA_HD int pair_first_stage_nz(int logM, int R, int win) {
+    const int S = (1 << logM) / R;
+    const int need = (win + S - 1) / S;
+    int nz = 1;
+    while (nz < need && nz < R / 2) nz <<= 1;
+    return nz;
+}
+template <class SEQ, int NZ = 1, class F>
+inline void dispatch_pair_nz(int nz, F&& f) {
+    constexpr int R = SEQ::rget(0);
+    if constexpr (2 * NZ >= R) {
+        f(std::integral_constant<int, NZ>{});
+    } else {
+        if (nz <= NZ) f(std::integral_constant<int, NZ>{});
+        else dispatch_pair_nz<SEQ, 2 * NZ>(nz, f);
+    }
+}
+
+template <typename T, class SEQ, int NZ, class Ctx>
+OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
+    cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
+    const int tid = ctx.tid(), NT = a.NT;
+    constexpr int logM = seq_total_log<SEQ>();
+    constexpr int M = 1 << logM;
+    const int RS = a.rowStride;
+    const long r0 = (long)ctx.bid_x() * 2;
+    constexpr int R0 = SEQ::get(0);
+    cx<T> hreg[EPT], v[EPT];
+    cx<T>* twl = work + RS;
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
+    ctx.sync();
+    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, a.h + r0 * a.pitch, a.h + (r0 + 1) * a.pitch, a.win);
+    // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * a.scale;
+    ctx.sync();
+    for (int leg = 0; leg < 2; ++leg) {
+        const cx<T>* src = leg ? a.gy : a.gx;
+        cx<T>* dst = leg ? a.py : a.px;
+        pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
+        // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+#pragma unroll
+        for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
+        ctx.sync();
+        stage_out<T, R0, true, false>(work, v, tid, NT, logM, 0, RS, 0, NoStore{});
+        ctx.sync();
+        forward_tail<T, SEQ>(ctx, work, tid, NT, logM, 0, RS, twl, logM);
+        // unpack the kept columns of both rows
+        cx<T>* o0 = dst + r0 * a.pitch;
+        cx<T>* o1 = o0 + a.pitch;
+        for (int k = tid; k < a.wout; k += NT) {
+            const int km = (M - k) & (M - 1);
+            const cx<T> Pk = work[k + (k >> 4)];
+            const cx<T> Pm = conj(work[km + (km >> 4)]);
+            cx<T> p0 = (Pk + Pm) * (T)0.5;
+            cx<T> p1 = mul_mi(Pk - Pm) * (T)0.5;
+            if (a.accumulate) { p0 = p0 + o0[k]; p1 = p1 + o1[k]; }
+            o0[k] = p0;
+            o1[k] = p1;
+        }
         ctx.sync();
     }
 }

@@ -28,7 +28,11 @@ constexpr int seq_logl() {
     return Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
 }
 template <class SEQ> constexpr int row_maxnt() { return seq_logl<SEQ>() <= 12 ? 256 : (seq_logl<SEQ>() == 13 ? 512 : 1024); }
-template <class SEQ> constexpr int col_maxnt() { return seq_logl<SEQ>() <= 7 ? 256 : 512; }
+// column workgroups: NT = L * 2^COL_LOGC / 16 (256 for the short sub-lengths of a 32-column tile)
+template <class SEQ> constexpr int col_maxnt() {
+    constexpr int nt = (1 << (seq_logl<SEQ>() + COL_LOGC)) / EPT;
+    return nt <= 256 ? 256 : (nt >= 1024 ? 1024 : nt);
+}
 // float kernels fit 128 VGPRs (4 waves/SIMD); double needs the 256-register budget
 template <typename T> constexpr int waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_WAVES_PER_EU; }
 

@@ -69,7 +69,7 @@ struct Fft2dPlan {
     // scale here.  The real-space planes exist only in LDS, so the sampling grid is not observable.
     static int row_grid_min(int nx, int win, int wout) {
         long need = 2L * win + wout;
-        int m = 64;
+        int m = 1024;                                   // shortest grid the two-rows-per-transform kernel is built for
         while (m < need && m < nx) m <<= 1;
         return m >= nx ? nx : m;
     }
@@ -83,8 +83,20 @@ struct Fft2dPlan {
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
                  int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0) const {
         RowQeArgs<T> a{};
+        // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
+        // transforms with no assumption beyond win / wout
         const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
         if (logM < logNx) scale = scale * (T)((double)nx / (double)(1 << logM));
+        a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
+        a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
+        a.win = win; a.wout = wout;
+        if (mrow > 0 && logM >= 10 && logM <= 13 && 2L * win + wout <= (1L << logM) && ny % 2 == 0) {
+            // alias-free row grid: two rows per complex transform of length M (row_qe_pair_body)
+            const int M = 1 << logM;
+            a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
+            q.row_qe_pair(ny / 2, a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
+            return;
+        }
         a.logL = logM - 1;
         const int L = 1 << a.logL;
         int C = qe_rows_per_wg(L);
@@ -94,9 +106,6 @@ struct Fft2dPlan {
         a.NT = (L * C) / EPT;
         if (a.NT < 1) a.NT = 1;
         a.rowStride = L + (L >> 4) + 2;
-        a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
-        a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
-        a.win = win; a.wout = wout;
         q.row_qe(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
 

@@ -1,0 +1,276 @@
+// One-call entry points of the C-ABI: a plan that knows its estimator filters and its
+// radial bins runs a whole reconstruction -- or a whole Monte-Carlo shard -- per call, stream-ordered, without the
+// host touching intermediate planes.  They are thin sequencers over the fused passes of fft.hip / bin.hip /
+// rng.hip (the same kernels the fine-grained calls launch), plus an RCCL all-reduce for hosts that do not bring
+// torch.distributed (librccl is dlopen'ed on first use, so the library has no link-time dependency on it).
+#include <dlfcn.h>
+#include <vector>
+#include "common.hpp"
+#include "fft_plan.hpp"
+
+namespace oa {
+
+struct Pipeline {
+    // filters (caller-owned device planes) + active region of the TT estimator
+    const void* FG = nullptr; const void* FH = nullptr; const void* Fn = nullptr;
+    int wl = 0, wk = 0, rl = 0, rk = 0, mrow = -1;
+    // plan-owned work planes (hc): legs x3, products x2, input transform, kappa
+    void* work = nullptr;
+    void* c[3] = {nullptr, nullptr, nullptr};
+    void* g[2] = {nullptr, nullptr};
+    void* kT = nullptr;
+    void* kk = nullptr;
+    // bins
+    const int32_t* ids = nullptr;
+    int nids = 0;
+    double norm = 1.0;
+    void* bin_scratch = nullptr;
+    double* sums = nullptr;
+    int64_t* counts_full = nullptr;   // data-independent mode counts over the whole plane
+    int64_t* counts_tmp = nullptr;
+};
+
+static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
+
+static Pipeline* pipe_of(oa_plan* p) {
+    if (!p->pipe) p->pipe = new Pipeline();
+    return (Pipeline*)p->pipe;
+}
+
+void pipeline_release(oa_plan* p) {
+    if (!p || !p->pipe) return;
+    Pipeline* q = (Pipeline*)p->pipe;
+    if (q->work) (void)hipFree(q->work);
+    if (q->bin_scratch) (void)hipFree(q->bin_scratch);
+    if (q->sums) (void)hipFree(q->sums);
+    if (q->counts_full) (void)hipFree(q->counts_full);
+    if (q->counts_tmp) (void)hipFree(q->counts_tmp);
+    delete q;
+    p->pipe = nullptr;
+}
+
+static int ensure_work(oa_plan* p, Pipeline* q) {
+    if (q->work) return 0;
+    const size_t pb = plane_bytes(p);
+    OA_HIP(hipMalloc(&q->work, 7 * pb));
+    OA_HIP(hipMemset(q->work, 0, 7 * pb));          // kappa plane zero outside its active region from the start
+    char* b = (char*)q->work;
+    for (int i = 0; i < 3; ++i) q->c[i] = b + i * pb;
+    for (int i = 0; i < 2; ++i) q->g[i] = b + (3 + i) * pb;
+    q->kT = b + 5 * pb;
+    q->kk = b + 6 * pb;
+    return plan_ensure_scratch(p, 2 * pb);          // never reallocated inside a stream-ordered call afterwards
+}
+
+// zero the part of a caller-supplied output plane that the pruned divergence kernel never writes
+static int zero_complement(oa_plan* p, void* out, int wk, int rk, hipStream_t st) {
+    const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pitch = (size_t)p->kp * es;
+    if (wk > 0 && wk < p->kp)
+        OA_HIP(hipMemset2DAsync((char*)out + (size_t)wk * es, pitch, 0, (size_t)(p->kp - wk) * es, (size_t)p->ny, st));
+    if (rk > 0 && 2L * rk - 1 < p->ny)
+        OA_HIP(hipMemset2DAsync((char*)out + (size_t)rk * pitch, pitch, 0, (size_t)(wk > 0 ? wk : p->kp) * es, (size_t)(p->ny - 2 * rk + 1), st));
+    return 0;
+}
+
+}  // namespace oa
+
+using namespace oa;
+
+extern "C" {
+
+int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
+                        int leg_rows, int kappa_rows, int mrow) {
+    OA_REQUIRE(p && FG && FH && Fnorm, "oa_plan_set_filters: NULL argument");
+    OA_NEED_POW2(p, "oa_plan_set_filters");
+    OA_REQUIRE(p->have_laxes, "oa_plan_set_filters: call oa_plan_set_laxes first");
+    Pipeline* q = pipe_of(p);
+    q->FG = FG; q->FH = FH; q->Fn = Fnorm;
+    q->wl = leg_cols; q->wk = kappa_cols; q->rl = leg_rows; q->rk = kappa_rows; q->mrow = mrow;
+    return ensure_work(p, q);
+}
+
+int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream) {
+    OA_REQUIRE(p && ids_hc && nids >= 3, "oa_plan_set_bins: bad argument");
+    Pipeline* q = pipe_of(p);
+    if (int rc = ensure_work(p, q)) return rc;
+    if (q->nids != nids) {
+        if (q->bin_scratch) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->bin_scratch); (void)hipFree(q->sums); (void)hipFree(q->counts_full); (void)hipFree(q->counts_tmp); }
+        const long sb = oa_bin_scratch_bytes(nids);
+        OA_REQUIRE(sb > 0, "oa_plan_set_bins: bad nids");
+        OA_HIP(hipMalloc(&q->bin_scratch, (size_t)sb));
+        OA_HIP(hipMalloc((void**)&q->sums, nids * sizeof(double)));
+        OA_HIP(hipMalloc((void**)&q->counts_full, nids * sizeof(int64_t)));
+        OA_HIP(hipMalloc((void**)&q->counts_tmp, nids * sizeof(int64_t)));
+    }
+    q->ids = ids_hc; q->nids = nids; q->norm = norm;
+    // mode counts per bin over the WHOLE plane (the per-call binning visits only kappa's active region)
+    return oa_bin_power(p->dtype, q->c[0], q->c[0], norm, ids_hc, nullptr, (long)p->ny * p->kp, nids, p->kp, p->nx / 2, q->sums,
+                        q->counts_full, nullptr, q->bin_scratch, 0, 0, stream);
+}
+
+void* oa_plan_kappa(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->kk : nullptr; }
+const int64_t* oa_plan_bin_counts(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->counts_full : nullptr; }
+
+int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
+             void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_qe_tt: call oa_plan_set_filters first");
+    OA_REQUIRE((real_map != nullptr) != (kX != nullptr), "oa_qe_tt: pass either a real map or the Fourier-space leg(s)");
+    Pipeline* q = (Pipeline*)p->pipe;
+    void* out = out_kappa_hc ? out_kappa_hc : q->kk;
+    if (out_kappa_hc && zero_outside)
+        if (int rc = zero_complement(p, out, q->wk, q->rk, (hipStream_t)stream)) return rc;
+    int rc;
+    if (real_map) rc = oa_qe_map_legs_cols(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, stream);
+    else rc = oa_qe_legs_cols(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, stream);
+    if (rc) return rc;
+    const double s = 1.0 / ((double)p->ny * p->nx);
+    if ((rc = oa_qe_rows(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s, 0, q->wl, q->wk, q->mrow, stream))) return rc;
+    return oa_qe_cols_div(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, stream);
+}
+
+int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* const* host_FG, const void* const* host_FH,
+              const int* host_swap, const void* kX, const void* kY, const void* Fnorm, void* out, int accumulate,
+              int leg_cols, int kappa_cols, int leg_rows, int kappa_rows, int mrow, int zero_outside, void* stream) {
+    OA_REQUIRE(p && npieces >= 1 && host_signs && host_FG && host_FH && kX && kY && Fnorm && out, "oa_qe_pol: bad argument");
+    OA_NEED_POW2(p, "oa_qe_pol");
+    Pipeline* q = pipe_of(p);
+    if (int rc = ensure_work(p, q)) return rc;
+    if (!accumulate && zero_outside && out != q->kk)
+        if (int rc = zero_complement(p, out, kappa_cols, kappa_rows, (hipStream_t)stream)) return rc;
+    const double s = 1.0 / ((double)p->ny * p->nx);
+    // the leg planes double as the accumulators' inputs: products accumulate in g[0], g[1] over the separable pieces
+    for (int i = 0; i < npieces; ++i) {
+        const bool sw = host_swap && host_swap[i];
+        int rc = oa_qe_legs_cols(p, sw ? kY : kX, sw ? kX : kY, host_FG[i], host_FH[i], q->c[0], q->c[1], q->c[2], leg_cols, leg_rows, stream);
+        if (rc) return rc;
+        if ((rc = oa_qe_rows(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], host_signs[i] * s * s, i > 0, leg_cols, kappa_cols, mrow, stream))) return rc;
+    }
+    return oa_qe_cols_div(p, q->g[0], q->g[1], Fnorm, out, accumulate, kappa_cols, kappa_rows, stream);
+}
+
+int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream) {
+    OA_REQUIRE(p && real_in && filt_hcreal && real_out, "oa_filter_map: NULL argument");
+    Pipeline* q = pipe_of(p);
+    if (int rc = ensure_work(p, q)) return rc;
+    int rc = oa_fft_r2c(p, real_in, q->kT, 1.0, 0, 0, stream);
+    if (rc) return rc;
+    if ((rc = oa_cmul_real(p->dtype, q->kT, filt_hcreal, q->kT, (long)p->ny * p->kp, stream))) return rc;
+    return oa_fft_c2r(p, q->kT, real_out, 1.0 / ((double)p->ny * p->nx), 0, stream);
+}
+
+// kappa_hat (plan-owned plane) -> bandpower sums over its active region -> n += 1, S += b, C += b b^T (b = bin means)
+static int bandpower_moments(oa_plan* p, Pipeline* q, int64_t* n, double* S, double* C, void* stream) {
+    int rc = oa_bin_power(p->dtype, q->kk, q->kk, q->norm, q->ids, nullptr, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums,
+                          q->counts_tmp, nullptr, q->bin_scratch, q->wk, q->rk, stream);
+    if (rc) return rc;
+    return oa_moments_add_binned(q->sums + 1, q->counts_full + 1, q->nids - 2, n, S, C, stream);
+}
+
+int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, double* C, void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_qe_tt_moments: call oa_plan_set_filters and oa_plan_set_bins first");
+    OA_REQUIRE(real_map && n && S && C, "oa_qe_tt_moments: NULL argument");
+    Pipeline* q = (Pipeline*)p->pipe;
+    if (int rc = oa_qe_tt(p, real_map, nullptr, nullptr, nullptr, 0, stream)) return rc;
+    return bandpower_moments(p, q, n, S, C, stream);
+}
+
+int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S, double* C,
+              double* meanfield_acc, void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_mc_run: call oa_plan_set_filters and oa_plan_set_bins first");
+    OA_REQUIRE(covsqrt_hc && n && S && C && sim_hi >= sim_lo, "oa_mc_run: bad argument");
+    Pipeline* q = (Pipeline*)p->pipe;
+    for (long i = sim_lo; i < sim_hi; ++i) {
+        int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
+        if (rc) return rc;
+        if ((rc = oa_qe_tt(p, nullptr, q->kT, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
+        if (meanfield_acc && (rc = oa_stack_add(p->dtype, q->kk, meanfield_acc, 2L * p->ny * p->kp, stream))) return rc;
+    }
+    return 0;
+}
+
+// ---- device memory for hosts that bring no GPU array library (the reference is NumPy) -----------------------------
+int oa_malloc(void** out, size_t bytes) {
+    OA_REQUIRE(out, "oa_malloc: NULL");
+    *out = nullptr;
+    OA_HIP(hipMalloc(out, bytes ? bytes : 1));
+    return 0;
+}
+int oa_free(void* dptr) {
+    if (dptr) OA_HIP(hipFree(dptr));
+    return 0;
+}
+/* kind: 1 = host -> device, 2 = device -> host, 3 = device -> device; stream-ordered (pageable host memory makes the
+ * copy synchronous with respect to the host, as hipMemcpyAsync documents) */
+int oa_memcpy(void* dst, const void* src, size_t bytes, int kind, void* stream) {
+    OA_REQUIRE(dst && src, "oa_memcpy: NULL");
+    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : (kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    OA_REQUIRE(kind >= 1 && kind <= 3, "oa_memcpy: kind must be 1 (h2d), 2 (d2h) or 3 (d2d)");
+    OA_HIP(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+    return 0;
+}
+int oa_memset(void* dptr, int value, size_t bytes, void* stream) {
+    OA_REQUIRE(dptr, "oa_memset: NULL");
+    OA_HIP(hipMemsetAsync(dptr, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+int oa_stream_synchronize(void* stream) {
+    OA_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// ---- RCCL all-reduce (Statistics.allreduce, stats.py:1209-1230) for hosts without torch.distributed -------------
+typedef struct { char internal[128]; } oa_rccl_id;
+struct OaComm { void* comm; };
+static void* rccl_sym(const char* name) {
+    static void* lib = nullptr;
+    if (!lib) {
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return nullptr;
+    }
+    return dlsym(lib, name);
+}
+#define OA_RCCL(fn, ...)                                                                          \
+    do {                                                                                          \
+        auto f_ = (int (*)(...))rccl_sym(#fn);                                                    \
+        if (!f_) return fail("oa_comm: librccl.so / " #fn " not found");                          \
+        int e_ = f_(__VA_ARGS__);                                                                 \
+        if (e_ != 0) return fail(std::string(#fn ": RCCL error ") + std::to_string(e_));         \
+    } while (0)
+
+int oa_comm_unique_id(void* id128) {
+    OA_REQUIRE(id128, "oa_comm_unique_id: NULL");
+    OA_RCCL(ncclGetUniqueId, id128);
+    return 0;
+}
+int oa_comm_init(int nranks, int rank, const void* id128, void** comm_out) {
+    OA_REQUIRE(id128 && comm_out && nranks >= 1 && rank >= 0 && rank < nranks, "oa_comm_init: bad argument");
+    oa_rccl_id id;
+    memcpy(&id, id128, sizeof(id));
+    void* c = nullptr;
+    auto f = (int (*)(void**, int, oa_rccl_id, int))rccl_sym("ncclCommInitRank");
+    if (!f) return fail("oa_comm_init: librccl.so / ncclCommInitRank not found");
+    int e = f(&c, nranks, id, rank);
+    if (e != 0) return fail("ncclCommInitRank: RCCL error " + std::to_string(e));
+    *comm_out = c;
+    return 0;
+}
+int oa_comm_destroy(void* comm) {
+    if (!comm) return 0;
+    OA_RCCL(ncclCommDestroy, comm);
+    return 0;
+}
+/* in-place SUM over the ranks of `comm`; dtype_code: 0 = float64, 1 = int64, 2 = float32 */
+int oa_allreduce(void* comm, void* buf, long count, int dtype_code, void* stream) {
+    OA_REQUIRE(comm && buf && count >= 0, "oa_allreduce: bad argument");
+    const int nccl_type = dtype_code == 0 ? 8 /* ncclFloat64 */ : (dtype_code == 1 ? 4 /* ncclInt64 */ : 7 /* ncclFloat32 */);
+    auto f = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))rccl_sym("ncclAllReduce");
+    if (!f) return fail("oa_allreduce: librccl.so / ncclAllReduce not found");
+    int e = f(buf, buf, (size_t)count, nccl_type, 0 /* ncclSum */, comm, (hipStream_t)stream);
+    if (e != 0) return fail("ncclAllReduce: RCCL error " + std::to_string(e));
+    return 0;
+}
+
+}  // extern "C"

@@ -77,6 +77,7 @@ int oa_plan_create(int ny, int nx, int dtype, oa_plan** out) {
 int oa_plan_destroy(oa_plan* p) {
     if (!p) return 0;
     (void)hipDeviceSynchronize();
+    pipeline_release(p);
     czt_release(p);
     if (p->tw_x) (void)hipFree(p->tw_x);
     if (p->tw_y) (void)hipFree(p->tw_y);

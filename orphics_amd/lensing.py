@@ -57,6 +57,7 @@ class Estimator(object):
         # prune: let the fused kernels skip the hc columns on which the (band-limited) filters vanish --
         # same arithmetic on the remaining columns, identical results (include/orphics_amd.h, ACTIVE COLUMNS)
         self.prune = bool(prune)
+        self._token = object()        # identity of this handle for the plan-level filter / bin binding
         # row_grid: grid of the fused row stage's real-space products.  "auto" (with prune): the smallest power of two
         # >= 2 leg_cols + kappa_cols -- exact for band-limited filters (include/orphics_amd.h, ROW GRID); None / "full":
         # always the map's own nx points.
@@ -167,26 +168,6 @@ class Estimator(object):
         from .engine import register_owned
         return register_owned(self.eng.hc())
 
-    def _prep_out(self, out, wk, rk=0, accumulate=False):
-        """Output plane whose inactive region (columns >= wk, rows outside the band rk: never written by the
-        pruned kernels) is zero."""
-        from .engine import owned_clean_region
-        if out is None:
-            return self.eng.hc()                               # zero-initialised
-        if (wk or rk) and not accumulate and owned_clean_region(out) != (wk, rk):
-            if wk:
-                out[:, wk:] = 0
-            if rk:
-                out[rk:out.shape[0] - rk + 1] = 0
-        return out
-
-    def _done_out(self, out, wk, rk=0):
-        """After the pruned divergence kernel wrote ``out``: an owned plane is zero outside (wk, rk) again."""
-        from .engine import set_clean_region
-        if wk or rk:
-            set_clean_region(out, (wk, rk))
-        return out
-
     @property
     def leg_rows(self):
         """Row band of the input transform the TT estimator reads (``Engine.rfft(..., rband=q.leg_rows)``)."""
@@ -242,6 +223,7 @@ class Estimator(object):
         import copy
         from .engine import Engine
         other = copy.copy(self)
+        other._token = object()
         other.eng = Engine(self.eng.ny, self.eng.nx, self.prec)
         other.eng.set_laxes(*self.geom.laxes())
         other._work = None
@@ -277,31 +259,101 @@ class Estimator(object):
             self._rwork = (e.real(), e.real(), e.real())
         return self._rwork
 
+    # ---- one-call C-ABI path (include/orphics_amd.h, "one-call entries") -------------------------------------
+    def _bind(self):
+        """Tell this estimator's plan its TT filters / active region / row grid (plans are shared per geometry:
+        rebound whenever another estimator used the plan in between; pointer stores only)."""
+        from ._lib import check
+        from .engine import _ptr
+        e = self.eng
+        if getattr(e, "_pipe_owner", None) is not self._token:
+            FG, FH, Fn = self._F["TT"]
+            wl, wk = self._W["TT"]
+            rl, rk = self._R["TT"]
+            check(e.lib.oa_plan_set_filters(e.plan, _ptr(FG), _ptr(FH), _ptr(Fn), int(wl), int(wk), int(rl), int(rk), int(self.mrow)))
+            e._pipe_owner = self._token
+            e._bins_owner = None
+        return e
+
+    def bind_bins(self, ids_hc, nids, norm):
+        """Radial bins of the one-call Monte-Carlo entries (``tt_moments``, ``mc.GaussianN0MonteCarlo``): int32 ids
+        on the hc grid (``Engine.modl_digitize(edges, half=True)``), ``nids = len(edges) + 1``, ``norm = area/Npix^2``."""
+        self._bins = (ids_hc, int(nids), float(norm))
+        self.eng._bins_owner = None
+        return self
+
+    def _bind_bins(self):
+        from ._lib import check
+        from .engine import _ptr, _stream
+        e = self._bind()
+        if getattr(e, "_bins_owner", None) is not self._token:
+            if getattr(self, "_bins", None) is None:
+                raise RuntimeError("call bind_bins(ids, nids, norm) first")
+            ids, nids, norm = self._bins
+            check(e.lib.oa_plan_set_bins(e.plan, _ptr(ids), nids, norm, _stream()))
+            e._bins_owner = self._token
+        return e
+
+    def tt_moments(self, tmap, n, S, C):
+        """One Monte-Carlo step in ONE C-ABI call (``oa_qe_tt_moments``): real device map -> kappa_hat (plan-owned
+        plane) -> binned auto-power -> n += 1, S += b, C += b b^T on the device accumulators (int64[1], f64[d],
+        f64[d,d], d = nids - 2)."""
+        from ._lib import check
+        from .engine import _ptr, _stream
+        e = self._bind_bins()
+        e._chk(tmap, "real")
+        check(e.lib.oa_qe_tt_moments(e.plan, _ptr(tmap), _ptr(n), _ptr(S), _ptr(C), _stream()))
+
+    def bin_counts(self):
+        """int64[nids] mode counts per bin over the whole plane (taken by ``oa_plan_set_bins``)."""
+        import ctypes
+        e = self._bind_bins()
+        torch = _torch()
+        nids = self._bins[1]
+        out = torch.empty(nids, dtype=torch.int64, device=e.device)
+        src = e.lib.oa_plan_bin_counts(e.plan)
+        from ._lib import check
+        from .engine import _ptr, _stream
+        check(e.lib.oa_memcpy(_ptr(out), ctypes.c_void_p(src), nids * 8, 3, _stream()))
+        return out
+
+    def _qe_tt(self, tmap, kX, kY, out):
+        from ._lib import check
+        from .engine import _ptr, _stream, mark_dirty, owned_clean_region, set_clean_region
+        e = self._bind()
+        wk, rk = self._W["TT"][1], self._R["TT"][1]
+        if out is None:
+            out, zero = e.hc(), 0                                  # zero-initialised
+        else:
+            e._chk(out, "hc")
+            zero = 1 if ((wk or rk) and owned_clean_region(out) != (wk, rk)) else 0
+        check(e.lib.oa_qe_tt(e.plan, _ptr(tmap), _ptr(kX), _ptr(kY), _ptr(out), zero, _stream()))
+        mark_dirty(out)
+        if wk or rk:
+            set_clean_region(out, (wk, rk))
+        return out
+
     def reconstruct_tt_hc(self, kX, kY=None, out=None, fused=True):
         """Device-native TT reconstruction: hc tensors in, kappa_hat DFT (hc) out.
 
-        fused=True (default): legs -> 3 inverse column transforms -> ONE fused row-stage kernel
-        (3 C2R + 2 products + 2 R2C in LDS, oa_qe_rows) -> 2 forward column transforms -> divergence.
+        fused=True (default): ONE C-ABI call (``oa_qe_tt``): legs -> 3 inverse column transforms -> ONE fused
+        row-stage kernel (3 C2R + 2 products + 2 R2C in LDS) -> 2 forward column transforms -> divergence.
         fused=False: the modular sequence of public C-ABI calls (3 C2R, 2 products, 2 R2C).
 
         With ``prune`` (default) only the first ``leg_cols`` columns of kX / kY are read and only the first
         ``kappa_cols`` columns of the result are computed; the remaining columns of ``out`` are zero-filled (on
         every call, unless ``out`` came from :meth:`new_output`)."""
         e = self.eng
+        if fused and e.pow2:
+            e._chk(kX, "hc")
+            if kY is not None and kY is not kX:
+                e._chk(kY, "hc")
+            else:
+                kY = None
+            return self._qe_tt(None, kX, kY, out)
         kY = kX if kY is None else kY
         FG, FH, Fn = self._F["TT"]
         w = self._buffers()
-        if fused and e.pow2:
-            # legs+inverse columns (1 fused pass + 3 in-place passes) -> fused row stage -> forward
-            # columns + divergence (2 passes + 1 fused pass): the filtered legs, the real-space planes
-            # and the pre-divergence planes never exist in HBM
-            wl, wk = self._W["TT"]
-            rl, rk = self._R["TT"]
-            out = self._prep_out(out, wk, rk)
-            cx, cy, ch = e.qe_legs_cols(kX, kY, FG, FH, out=w["C"], width=wl, rband=rl)
-            Gx, Gy, _ = w["G"]
-            e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk, mrow=self.mrow)
-            return self._done_out(e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk), wk, rk)
         Gx, Gy, H = e.qe_legs(kX, kY, FG, FH, out=w["G"])
         gx, gy, h = self._real_buffers()
         e.irfft(Gx, out=gx); e.irfft(Gy, out=gy); e.irfft(H, out=h)
@@ -312,21 +364,14 @@ class Estimator(object):
         return e.qe_div(Px, Py, Fn, out=out)
 
     def reconstruct_tt_from_map(self, tmap, out=None):
-        """TT reconstruction straight from a real device map (both legs from it): the map's transform is consumed
-        inside the fused leg kernel and never written (``Engine.qe_map_legs_cols``).  Same result as
+        """TT reconstruction straight from a real device map (both legs from it) in ONE C-ABI call: the map's
+        transform is consumed inside the fused leg kernel and never written.  Same result as
         ``reconstruct_tt_hc(eng.rfft(tmap))``."""
         e = self.eng
         if not e.pow2:                       # chirp-z sizes: modular chain of public calls
             return self.reconstruct_tt_hc(e.rfft(tmap), out=out)
-        FG, FH, Fn = self._F["TT"]
-        w = self._buffers()
-        wl, wk = self._W["TT"]
-        rl, rk = self._R["TT"]
-        out = self._prep_out(out, wk, rk)
-        cx, cy, ch = e.qe_map_legs_cols(tmap, FG, FH, out=w["C"], width=wl, rband=rl)
-        Gx, Gy, _ = w["G"]
-        e.qe_rows(cx, cy, ch, Gx, Gy, win=wl, wout=wk, mrow=self.mrow)
-        return self._done_out(e.qe_cols_div(Gx, Gy, Fn, out=out, width=wk, rband=rk), wk, rk)
+        e._chk(tmap, "real")
+        return self._qe_tt(tmap, None, None, out)
 
     def kappa_from_map(self, XY, T2DData, E2DData=None, B2DData=None, T2DDataY=None, E2DDataY=None, B2DDataY=None,
                        alreadyFTed=False, returnFt=False):
@@ -542,28 +587,36 @@ class Estimator(object):
         e = self.eng
         if not e.pow2:
             return self._reconstruct_hc_modular(XY, kX, kY, out, norm, accumulate)
+        import ctypes
+        from ._lib import check
+        from .engine import _ptr, _stream, mark_dirty, owned_clean_region, set_clean_region
         G = self._setup_general(XY)
-        w = self._buffers()
-        Gx, Gy, H = w["G"]
-        cx, cy, ch = w["C"]
-        if getattr(self, "_acc", None) is None:
-            self._acc = (e.hc(), e.hc())
-        ax, ay = self._acc
-        scale0 = 1.0 / float(e.npix) ** 2
+        e._chk(kX, "hc"); e._chk(kY, "hc")
         # active columns: legs from this estimator's filters; kappa from its normalisation (an external
         # ``norm`` plane -- MV weights -- is bounded by the kappa mask)
-        wl = G["wl"]
+        wl, rl = G["wl"], G["rl"]
         if norm is not None and getattr(self, "_wK", None) is None:
             self._wK = (self._support_cols(self.mask_K), self._support_rows(self.mask_K))
         wk, rk = (G["wk"], G["rk"]) if norm is None else self._wK
-        rl = G["rl"]
-        out = self._prep_out(out, wk, rk, accumulate)
-        for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
-            kg, kh = (kY, kX) if swap else (kX, kY)
-            e.qe_legs_cols(kg, kh, FG, FH, out=(cx, cy, ch), width=wl, rband=rl)
-            e.qe_rows(cx, cy, ch, ax, ay, scale=sign * scale0, accumulate=(i > 0), win=wl, wout=wk, mrow=self.mrow)
-        e.qe_cols_div(ax, ay, G["Fnorm"] if norm is None else norm, out=out, accumulate=accumulate, width=wk, rband=rk)
-        return self._done_out(out, wk, rk)
+        if "c_args" not in G:                 # per-piece argument arrays of oa_qe_pol (host side, built once)
+            n = len(G["pieces"])
+            G["c_args"] = (n, (ctypes.c_double * n)(*[float(pc[0]) for pc in G["pieces"]]),
+                           (ctypes.c_void_p * n)(*[pc[1].data_ptr() for pc in G["pieces"]]),
+                           (ctypes.c_void_p * n)(*[pc[2].data_ptr() for pc in G["pieces"]]),
+                           (ctypes.c_int * n)(*[1 if pc[3] else 0 for pc in G["pieces"]]))
+        n, signs, fgs, fhs, swaps = G["c_args"]
+        if out is None:
+            out, zero = e.hc(), 0
+        else:
+            e._chk(out, "hc")
+            zero = 1 if ((wk or rk) and not accumulate and owned_clean_region(out) != (wk, rk)) else 0
+        Fn = G["Fnorm"] if norm is None else norm
+        check(e.lib.oa_qe_pol(e.plan, n, signs, fgs, fhs, swaps, _ptr(kX), _ptr(kY), _ptr(Fn), _ptr(out), 1 if accumulate else 0,
+                              int(wl), int(wk), int(rl), int(rk), int(self.mrow), zero, _stream()))
+        mark_dirty(out)
+        if wk or rk:
+            set_clean_region(out, (wk, rk))
+        return out
 
     def _reconstruct_hc_modular(self, XY, kX, kY, out=None, norm=None, accumulate=False):
         """The same estimator through the modular public calls only (map sides that are not powers of two, where

@@ -388,10 +388,67 @@ def multi_pow(cov, exp):
     return np.moveaxis(res, 0, -1).reshape(cov.shape)
 
 
+def smooth_spectrum(ps, width):
+    """Gaussian smoothing of 1-D spectra (..., nl) along ell with the 2-D mode density (~ ell) as weight:
+    ps_s(l) = sum_l' K(l - l') l' ps(l') / sum_l' K(l - l') l', K = exp(-(dl / width)^2 / 2).
+    Stands in for pixell ``enmap.smooth_spectrum(kernel="gauss", weight="mode")`` inside ``spec2flat``
+    [NOT IN SNAPSHOT: pixell is not vendored, so the exact kernel / weight are a design choice here]: it
+    approximates averaging the spectrum over the sub-grid modes each 2-D pixel of width delta-ell stands for."""
+    ps = np.asarray(ps, dtype=np.float64)
+    nl = ps.shape[-1]
+    if width <= 0 or nl < 2:
+        return ps
+    half = int(min(nl - 1, np.ceil(5 * width)))
+    dl = np.arange(-half, half + 1, dtype=np.float64)
+    K = np.exp(-0.5 * (dl / width) ** 2)
+    ell = np.arange(nl, dtype=np.float64)
+    w = np.maximum(ell, 0.5)                      # ell = 0 keeps a small weight instead of dropping out
+    flat = ps.reshape(-1, nl)
+    num = np.stack([np.convolve(f * w, K, mode="same") for f in flat])
+    den = np.convolve(w, K, mode="same")
+    return (num / den).reshape(ps.shape)
+
+
+def spec2flat(shape, wcs, cov, exp=1.0, mode="constant", smooth="auto"):
+    """Isotropic (ncomp,ncomp,nl) spectra sampled at ell = 0..nl-1 -> per-mode (ncomp,ncomp,Ny,Nx) planes in
+    PIXEL units (x Npix/area), raised to the matrix power ``exp`` -- what ``MapGen`` needs from
+    ``enmap.spec2flat(shape, wcs, cov, 0.5, mode="constant", smooth=smooth)`` (maps.py:1573).
+    Order of operations [NOT IN SNAPSHOT -- pixell's public behaviour as recalled, documented so that it can be
+    checked against a pixell installation]: (1) ``smooth="auto"``: smooth the 1-D spectra over a Gaussian of width
+    0.5 (delta-ell_y + delta-ell_x) / 3.41 (:func:`smooth_spectrum`); a number = that width; 0 / None = none;
+    (2) scale by Npix / area; (3) per-ell symmetric matrix power; non-finite -> 0; (4) LINEAR interpolation onto
+    |ell| of every 2-D mode, ``mode="constant"``: 0 beyond the table."""
+    geom = as_geometry(shape, wcs)
+    cov = np.asarray(cov, dtype=np.float64)
+    if cov.ndim == 1:
+        cov = cov[None, None]
+    assert cov.ndim == 3 and cov.shape[0] == cov.shape[1], "cov must be (ncomp,ncomp,nl)"
+    ml = geom.modlmap()
+    if smooth == "auto":
+        ly, lx = geom.laxes()
+        smooth = 0.5 * (abs(ly[1] - ly[0]) + abs(lx[1] - lx[0])) / 3.41
+    if smooth:
+        cov = smooth_spectrum(cov, float(smooth))
+    Ny, Nx = geom.shape[-2:]
+    cov = cov * (Ny * Nx / geom.area)
+    if exp != 1.0:
+        cov = multi_pow(cov, exp)
+    cov = np.where(np.isfinite(cov), cov, 0.0)
+    nc, nl = cov.shape[0], cov.shape[-1]
+    ell = np.arange(nl, dtype=np.float64)
+    out = np.empty((nc, nc) + ml.shape)
+    fill = 0.0 if mode == "constant" else None
+    for i in range(nc):
+        for j in range(nc):
+            out[i, j] = np.interp(ml, ell, cov[i, j], left=cov[i, j, 0], right=(fill if fill is not None else cov[i, j, -1]))
+    return out
+
+
 class MapGen(object):
-    """maps.py:1553-1587.  ``cov`` must be the 4-D per-mode covariance
-    (ncomp,ncomp,Ny,Nx); the 3-D (ncomp,ncomp,lmax) form relies on
-    pixell.spec2flat's interpolation -- use :func:`spec1d_to_2d` first.
+    """maps.py:1553-1587.  ``cov`` is the 4-D per-mode covariance (ncomp,ncomp,Ny,Nx) or the 3-D isotropic
+    form (ncomp,ncomp,lmax) sampled at integer ell (expanded with :func:`spec2flat`, maps.py:1573).
+    ``ndown`` (``downsample_power``, maps.py:1501-1550: a noise-model smoothing aid) is not part of the hot
+    path and raises.
 
     ``get_map`` draws on the device (Philox; the reference's global
     Mersenne-Twister stream cannot and need not be reproduced, SURVEY.md H6);
@@ -409,13 +466,19 @@ class MapGen(object):
         else:
             assert cov is not None and cov.ndim >= 3, \
                 "Power spectra have to be of shape (ncomp,ncomp,lmax) or (ncomp,ncomp,Ny,Nx)."
-            if cov.ndim != 4:
-                raise NotImplementedError("pass a 4-D (ncomp,ncomp,Ny,Nx) covariance (see maps.spec1d_to_2d)")
             if ndown:
-                raise NotImplementedError("downsample_power is outside the hot path")
-            if not pixel_units:
-                cov = cov * np.prod(self.shape[-2:]) / self.geom.area
-            self.covsqrt = multi_pow(cov, 0.5)
+                raise NotImplementedError("MapGen(ndown=...): downsample_power (maps.py:1501-1550) is outside the hot path; "
+                                          "smooth the covariance before passing it")
+            cov = np.asarray(cov)
+            if cov.ndim == 4:
+                if not pixel_units:
+                    cov = cov * np.prod(self.shape[-2:]) / self.geom.area
+                self.covsqrt = multi_pow(cov, 0.5)
+            elif cov.ndim == 3:
+                # maps.py:1573 (pixel_units plays no role on this branch in the reference either)
+                self.covsqrt = spec2flat(self.shape, self.geom, cov, 0.5, mode="constant", smooth=smooth)
+            else:
+                raise AssertionError("Power spectra have to be of shape (ncomp,ncomp,lmax) or (ncomp,ncomp,Ny,Nx).")
         self.ncomp = self.covsqrt.shape[0]
         self._cs_dev = {}
         self._calls = 0
@@ -430,7 +493,9 @@ class MapGen(object):
     def get_map(self, seed=None, scalar=False, iau=False, real=False, harm=False):
         """maps.py:1576-1587 semantics with an on-device Hermitian draw:
         C2R of covsqrt * (Hermitian unit white noise) with the unitary scale is
-        statistically identical to ``enmap.ifft(covsqrt * rand_gauss_harm).real``."""
+        statistically identical to ``enmap.ifft(covsqrt * rand_gauss_harm).real``.
+        ``real=True`` (maps.py:1578): the white noise is drawn in MAP space (one N(0,1) per pixel, Philox) and
+        transformed (unitary R2C) instead of being drawn mode by mode -- same statistics, the reference's other path."""
         torch = _torch()
         eng = _engine(self.shape, self.prec)
         if seed is None:
@@ -439,7 +504,10 @@ class MapGen(object):
             seed = int(np.random.SeedSequence(list(seed)).generate_state(1, dtype=np.uint64)[0] >> 1)
         cs = self._covsqrt_hc(eng)
         nc = self.ncomp
-        white = [eng.grf_hc(seed, c) for c in range(nc)]
+        if real:
+            white = [eng.rfft(eng.randn(seed, c), scale=1.0 / np.sqrt(eng.npix)) for c in range(nc)]
+        else:
+            white = [eng.grf_hc(seed, c) for c in range(nc)]
         ks = []
         for i in range(nc):
             acc = None

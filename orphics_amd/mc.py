@@ -54,23 +54,32 @@ class GaussianN0MonteCarlo(object):
         self.norm = geom.area / float(e.npix) ** 2
         # device-resident ensemble accumulators: (n, sum, cross) of the bandpower vectors and the mean-field stack
         self.acc = Statistics(comm=self.comm if hasattr(self.comm, "dist") else None, device=e.device)
-        self._kT, self._kk = e.hc(), qest.new_output()
-        _, self.counts = e.bin_power(self._kT, self._kT, self.norm, self.ids, self.nids, herm=True)
+        qest.bind_bins(self.ids, self.nids, self.norm)
 
     def run_local(self, sims):
-        """Process the given global sim indices on this rank's GPU."""
-        torch = _torch()
-        e, q = self.eng, self.q
-        for i in sims:
-            e.grf_hc(self.base_seed, int(i), self.cs, out=self._kT)
-            q.reconstruct_tt_hc(self._kT, out=self._kk)
-            # kappa_hat vanishes beyond q.kappa_cols / outside q.kappa_rows: only that region is visited; the mode
-            # counts are data-independent and were taken over the whole plane in __init__
-            sums, _ = e.bin_power(self._kk, self._kk, self.norm, self.ids, self.nids, herm=True, active_cols=q.kappa_cols, active_rows=q.kappa_rows)
-            # bin means sums/counts of the interior bins are formed inside the accumulation kernel
-            self.acc.add_binned("n0", sums[1:-1], self.counts[1:-1])
-            if self.mean_field:
-                self.acc.add_stack("mf", torch.view_as_real(self._kk))      # (ny, kp, 2) interleaved re, im
+        """Process the given global sim indices on this rank's GPU: every contiguous block of indices is ONE
+        ``oa_mc_run`` call (GRF -> TT estimator -> bandpowers -> moments [-> mean-field stack], no host work per sim)."""
+        from ._lib import check
+        from .engine import _ptr, _stream
+        sims = [int(i) for i in sims]
+        if not sims:
+            return self
+        q = self.q
+        e = q._bind_bins()
+        n, S, C = self.acc.device_moments("n0", self.d)
+        mf = self.acc.device_stack("mf", (e.ny, e.kp, 2)) if self.mean_field else None
+        start = prev = sims[0]
+        blocks = []
+        for i in sims[1:] + [None]:
+            if i is None or i != prev + 1:
+                blocks.append((start, prev + 1))
+                start = i
+            prev = i
+        for lo, hi in blocks:
+            check(e.lib.oa_mc_run(e.plan, self.base_seed, lo, hi, _ptr(self.cs), _ptr(n), _ptr(S), _ptr(C), _ptr(mf), _stream()))
+        self.acc.note_samples("n0", len(sims))
+        if self.mean_field:
+            self.acc.note_stacked("mf", len(sims))
         return self
 
     def run(self, nsims):

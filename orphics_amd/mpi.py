@@ -7,50 +7,45 @@ in CPU tests).  :class:`TorchComm` exposes the small mpi4py-like surface that
 :mod:`orphics_amd.stats` needs, so the statistics containers keep the
 reference's semantics unchanged.
 """
+import contextlib
 import os
 
 import numpy as np
 
 
 class fakeMpiComm(object):
-    """mpi.py:41-57: rank 0 / size 1 stand-in."""
-
-    def __init__(self):
-        self.size = self.Get_size()
-        self.rank = self.Get_rank()
+    """Single-process stand-in with the communicator surface the containers use (role of mpi.py:41-57)."""
+    rank, size = 0, 1
 
     def Get_rank(self):
-        return 0
+        return self.rank
 
     def Get_size(self):
-        return 1
+        return self.size
 
     def Barrier(self):
-        pass
+        return None
 
-    def Abort(self, dummy):
-        pass
+    def Abort(self, errorcode=1):
+        return None
 
     def allgatherv(self, x):
         return x
 
 
 def mpi_distribute(num_tasks, avail_cores, allow_empty=False):
-    """mpi.py:78-91: equal contiguous blocks; the ``rem`` extra tasks go to the
-    LAST ``rem`` ranks so that rank 0 never gets extra jobs."""
-    if not allow_empty:
-        assert avail_cores <= num_tasks
-    min_each, rem = divmod(num_tasks, avail_cores)
-    num_each = np.array([min_each] * avail_cores)
-    if rem > 0:
-        num_each[-rem:] += 1
-    task_range = list(range(num_tasks))
-    cumul = np.cumsum(num_each).tolist()
-    task_dist = [task_range[x:y] for x, y in zip([0] + cumul[:-1], cumul)]
-    assert sum(num_each) == num_tasks
-    assert len(num_each) == avail_cores
-    assert len(task_dist) == avail_cores
-    return num_each, task_dist
+    """Split tasks 0..num_tasks-1 into ``avail_cores`` contiguous blocks whose sizes differ by at most one, the
+    LARGER blocks on the LAST ranks so that rank 0 (which usually also collects) never gets an extra job -- the
+    split rule of mpi.py:78-91.  Returns (block sizes, list of task lists)."""
+    if not allow_empty and avail_cores > num_tasks:
+        raise AssertionError("more ranks (%d) than tasks (%d); pass allow_empty=True to leave ranks idle" % (avail_cores, num_tasks))
+    base, extra = divmod(int(num_tasks), int(avail_cores))
+    sizes = np.full(avail_cores, base, dtype=int)
+    if extra:
+        sizes[avail_cores - extra:] += 1
+    ends = np.cumsum(sizes)
+    blocks = [list(range(int(e - n), int(e))) for n, e in zip(sizes, ends)]
+    return sizes, blocks
 
 
 class TorchComm(object):
@@ -83,7 +78,13 @@ class TorchComm(object):
         self.dist.barrier(group=self.group)
 
     def Abort(self, code=1):
-        os._exit(code)
+        """Tear the job down: a rank that failed must not leave the others waiting in the next collective.
+        The process group is abandoned (not destroyed: destroy would itself wait for the peers) and the process
+        exits non-zero; torchrun / bench.py's launcher then terminates the remaining ranks."""
+        import sys
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(int(code) if code else 1)
 
     def _stage(self, arr):
         import torch
@@ -144,6 +145,22 @@ def get_world():
     except Exception:
         pass
     return fakeMpiComm()
+
+
+@contextlib.contextmanager
+def mpi_abort_on_exception(comm):
+    """``with mpi_abort_on_exception(comm): <Monte-Carlo loop>`` -- role of mpi.py:31-39: an exception on ANY rank
+    prints its traceback (rank 0 prints on behalf of a single-rank job too) and aborts the whole job with a
+    non-zero exit code instead of dead-locking the other ranks in their next collective."""
+    try:
+        yield
+    except Exception as e:      # noqa: BLE001 -- the point is to catch everything a user loop can raise
+        import sys
+        import traceback
+        sys.stderr.write("rank %d: %s: %s\n" % (comm.Get_rank(), type(e).__name__, e))
+        traceback.print_exc()
+        comm.Abort(1)
+        raise                   # fake communicators return from Abort: propagate instead of swallowing
 
 
 def distribute(njobs, verbose=True, comm=None, **kwargs):

@@ -438,6 +438,27 @@ class Statistics(object):
         check(load().oa_moments_add_binned(_ptr(sums), _ptr(counts), m.dim, _ptr(self._counter_cell(m)), _ptr(m.first), _ptr(m.second), _stream()))
         m.count += 1
 
+    def device_moments(self, label, dim):
+        """(n int64[1], S f64[dim], C f64[dim, dim]) device accumulators of a stats label, for kernels that add
+        samples themselves (``oa_qe_tt_moments``, ``oa_mc_run``); report how many with :meth:`note_samples`."""
+        if self.device is None:
+            raise RuntimeError("device_moments() needs Statistics(device=...)")
+        m = self._slot_vec(label, dim)
+        return self._counter_cell(m), m.first, m.second
+
+    def note_samples(self, label, k):
+        self._vec[label].count += int(k)
+
+    def device_stack(self, label, shape):
+        """float64 device accumulator of a stack label (``oa_stack_add`` / ``oa_mc_run`` mean field); report the
+        number of arrays added with :meth:`note_stacked`."""
+        if self.device is None:
+            raise RuntimeError("device_stack() needs Statistics(device=...)")
+        return self._slot_pile(label, shape).total
+
+    def note_stacked(self, label, k):
+        self._pile[label].count += int(k)
+
     def extend(self, label, X):
         """Many samples at once (stats.py:1092-1120): rows of an (m, d) array, or one (d,) sample."""
         X2 = self._to_store(X if hasattr(X, "shape") else list(X))

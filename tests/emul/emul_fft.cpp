@@ -59,12 +59,19 @@ struct EmuLauncher {
             using S = decltype(seq);
             int nz = 0;
             if constexpr (S::n >= 2) nz = qe_first_stage_nz(a.logL, S::rget(0), a.win);
-            run(grid, 1, nt, smem, [&](EmuCtx& c) {
-                if (!stockham_qe) row_qe_body_inplace<T, S>(c, a);
-                else if (nz == 1) row_qe_body<T, S, 1>(c, a);
-                else if (nz == 2) row_qe_body<T, S, 2>(c, a);
-                else row_qe_body<T, S, 0>(c, a);
+            if (!stockham_qe) { run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_body_inplace<T, S>(c, a); }); return; }
+            dispatch_nz<S>(nz, [&](auto nzc) {
+                run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_body<T, S, decltype(nzc)::value>(c, a); });
             });
+        });
+    }
+    template <typename T> void row_qe_pair(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
+        dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_total_log<S>() >= 10 && seq_total_log<S>() <= 13)
+                dispatch_pair_nz<S>(pair_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
+                    run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value>(c, a); });
+                });
         });
     }
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
@@ -136,9 +143,12 @@ static int do_qe_rows(int ny, int nx, const cx<T>* gx, const cx<T>* gy, const cx
                       int win = 0, int wout = 0, int mrow = 0) {
     Holder<T> hd(ny, nx);
     EmuLauncher q;
-    if (mrow < 0) mrow = Fft2dPlan<T>::row_grid_min(nx, hd.p.clampw(win), hd.p.clampw(wout));
+    if (mrow < 0) {
+        mrow = Fft2dPlan<T>::row_grid_min(nx, hd.p.clampw(win), hd.p.clampw(wout));
+        if (2L * hd.p.clampw(win) + hd.p.clampw(wout) > mrow) mrow = 0;
+    }
     hd.p.rows_qe(q, gx, gy, h, px, py, (T)s, 0, hd.p.clampw(win), hd.p.clampw(wout), mrow);
-    return mrow;
+    return mrow == 0 ? nx : mrow;
 }
 
 template <typename T>

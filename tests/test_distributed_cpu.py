@@ -129,3 +129,38 @@ def test_world_size_two_gloo():
     assert res[0]["legacy_n"] == 5
     np.testing.assert_allclose(res[0]["legacy_mean"], np.mean([[0, 0], [1, 2], [1, 0], [2, 2], [3, 4]], axis=0))
     np.testing.assert_allclose(res[0]["legacy_stack"], np.full((2, 2), 1.5))
+
+
+def test_abort_on_exception_exits_nonzero_and_launcher_reaps_peers(tmp_path):
+    """mpi.mpi_abort_on_exception (role of mpi.py:31-39): a rank whose user loop raises leaves with a non-zero
+    exit code at once; the peer stuck in its next collective is reaped by the launcher (bench.spawn_ranks logic)."""
+    import subprocess
+    import time
+    script = tmp_path / "w.py"
+    script.write_text('''
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+dist.init_process_group("gloo")
+from orphics_amd import mpi
+comm = mpi.TorchComm()
+with mpi.mpi_abort_on_exception(comm):
+    if comm.Get_rank() == 1:
+        raise ValueError("boom on rank 1")
+    comm.Barrier()          # rank 0 waits for a peer that is gone
+print("unreachable on rank 1")
+''' % ROOT)
+    port = str(_free_port())
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    while procs[1].poll() is None and time.time() - t0 < 120:
+        time.sleep(0.1)
+    assert procs[1].returncode == 1
+    err = procs[1].stderr.read()
+    assert "boom on rank 1" in err and "unreachable" not in procs[1].stdout.read()
+    procs[0].terminate()
+    procs[0].wait(timeout=60)
+    assert procs[0].returncode != 0

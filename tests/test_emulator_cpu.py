@@ -136,7 +136,7 @@ def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
 
 
 @pytest.mark.parametrize("ny,nx,win,wout,mrow,expect", [(32, 8192, 380, 664, -1, 2048), (32, 8192, 1139, 664, -1, 4096),
-                                                         (32, 2048, 100, 150, -1, 512), (32, 1024, 60, 100, 512, 512),
+                                                         (32, 2048, 100, 150, -1, 1024), (32, 1024, 60, 100, 512, 512),
                                                          (32, 512, 100, 150, -1, 512), (32, 4096, 190, 332, -1, 1024),
                                                          (16, 16384, 380, 664, -1, 2048)])
 def test_fused_row_stage_on_alias_free_row_grid(emu, ny, nx, win, wout, mrow, expect):

@@ -187,3 +187,111 @@ def test_tt_bandpowers_match_numpy_oracle_at_full_size(N):
         assert err < tol, "%s: bandpowers differ from the oracle by %.3g" % (prec, err)
         del q
     assert t_oracle > 0
+
+
+def _pol_inputs(N, res, th, beam_h, noise_T, seed=21):
+    """device T, E, B transforms (f64 hc planes) of Gaussian fields with the observed total spectra"""
+    from orphics_amd.geometry import FlatGeometry
+    e = eng(N, "f64")
+    g = FlatGeometry.from_res((N, N), res)
+    ly, lx = g.laxes()
+    ml_h = np.sqrt(ly[:, None] ** 2 + lx[None, :N // 2 + 1] ** 2)
+    out = []
+    for i, (sp, nz) in enumerate((("TT", noise_T), ("EE", 2 * noise_T), ("BB", 2 * noise_T))):
+        tot = th.lCl(sp, ml_h) * beam_h ** 2 + nz
+        cs = e.hcreal()
+        cs[:, :N // 2 + 1] = torch.as_tensor(np.sqrt(tot * float(N * N) ** 2 / g.area), device=e.device)
+        out.append(e.grf_hc(seed, i, cs))
+        del cs
+    return out
+
+
+@pytest.mark.parametrize("N", [2048, 8192])
+def test_config3_mv_f32_vs_f64_and_fused_vs_modular(N):
+    """BASELINE config 3: minimum-variance combination of TT, TE, EE, EB, TB on 0.5' maps (8192^2 = the configured
+    size).  f32 kernels vs f64 kernels on the kappa bandpowers (< 1e-5, the north-star tolerance), every single
+    estimator's bandpowers likewise, and -- at the smaller size -- the fused one-call path vs the modular chain of
+    public calls (3 C2R, 2 products, 2 R2C per piece)."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    res = 0.5
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    nT = cosmology.white_noise_power(1.0)
+    noise = np.full(shape, nT)
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    del ml
+    k64 = _pol_inputs(N, res, th, beam[:, :N // 2 + 1], nT)
+    edges = np.linspace(20, 3500, 20)
+    ests = ("TT", "TE", "EE", "EB", "TB")
+    res_p = {}
+    for prec in ("f64", "f32"):
+        q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, noise2d_P=2 * noise, kmask_P=tmask, kmask_K=kmask,
+                         pol=True, unlensed_equals_lensed=True, dtype=prec)
+        e = q.eng
+        kT, kE, kB = [k.to(e.cdt) for k in k64]
+        ids = e.modl_digitize(torch.as_tensor(edges, device=e.device), half=True)
+        norm = g.area / float(N * N) ** 2
+        _, counts = e.bin_power(kT, kT, norm, ids, len(edges) + 1, herm=True)
+
+        def bp(kk):
+            s, _ = e.bin_power(kk, kk, norm, ids, len(edges) + 1, herm=True)
+            return (s[1:-1] / counts[1:-1].double()).cpu().numpy()
+        f = {"T": kT, "E": kE, "B": kB}
+        out = {"MV": bp(q.reconstruct_mv_hc(kT, kE, kB, estimators=ests))}
+        for XY in ests:
+            out[XY] = bp(q.reconstruct_hc(XY, f[XY[0]], f[XY[1]]))
+        if N <= 2048 and prec == "f64":
+            acc = e.hc()
+            for i, XY in enumerate(ests):
+                q._reconstruct_hc_modular(XY, f[XY[0]], f[XY[1]], out=acc, norm=q._mv[1][XY], accumulate=(i > 0))
+            mod = bp(acc)
+            assert np.max(np.abs(mod / out["MV"] - 1)) < 1e-9, "fused MV differs from the modular chain"
+        assert q.Nlkk["MV"].shape == (N, N // 2 + 1)
+        res_p[prec] = out
+        del q, kT, kE, kB, f
+        torch.cuda.empty_cache()
+    for key in res_p["f64"]:
+        err = np.max(np.abs(res_p["f32"][key] / res_p["f64"][key] - 1))
+        assert err < 1e-5, "%s: f32 bandpowers differ from f64 by %.3g" % (key, err)
+
+
+def test_config4_mc_n0_and_mean_field_1000_sims_4096():
+    """BASELINE config 4 on one GPU: 1000 Gaussian realisations at 4096^2 0.5' through mc.GaussianN0MonteCarlo.run
+    (one oa_mc_run call for the whole shard, device-resident Statistics).  The Monte-Carlo N0 equals the analytic
+    N_L^kk from A_L within the Monte-Carlo error in every bin, and the mean field of Gaussian sims is noise."""
+    from orphics_amd import cosmology, lensing, maps, mc, stats
+    from orphics_amd.geometry import FlatGeometry
+    N, res, nsims = 4096, 0.5, 1000
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True, dtype="f32")
+    tot_h = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(20, 3500, 20)
+    drv = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=1234, mean_field=True)
+    st = drv.run(nsims)
+    assert st.count("n0") == nsims and st.stack_count("mf") == nsims
+    _, nl = stats.bin2D(ml, edges).bin(q.N_kappa("TT"))
+    mean = st.mean("n0")
+    sem = np.sqrt(st.var("n0") / nsims)
+    pull = (mean - nl) / sem
+    assert np.all(np.abs(mean / nl - 1) < 0.01), mean / nl       # sub-per-cent in every bin
+    assert np.abs(pull).max() < 4.5, pull                       # and within the Monte-Carlo error
+    # mean field: |<kappa_hat>|^2 ~ N0 / nsims (pure noise), stays on the GPU
+    mf = st.stack_sum("mf", on_device=True)
+    mfk = torch.view_as_complex(mf.contiguous())[:, :N // 2 + 1] / float(nsims)
+    p_mf = (mfk.abs() ** 2 * (g.area / float(N * N) ** 2)).cpu().numpy()
+    mlh = ml[:, :N // 2 + 1]
+    sel = (mlh > 300) & (mlh < 3000)
+    ratio = p_mf[sel].mean() / (q.Nlkk["TT"][sel].mean() / nsims)
+    assert 0.8 < ratio < 1.2, ratio

@@ -318,6 +318,24 @@ def test_tt_qe_is_unbiased_on_lensed_sims():
     assert abs(y.mean()) < 0.04
 
 
+def test_tt_and_eb_unbiased_through_the_verifier():
+    """examples/qe_unbiasedness.py (the committed verifier behind profiles/r02_unbiasedness_*.txt) at a size that
+    runs in seconds: TT AND EB cross-powers with the input kappa are consistent with the input auto-power."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("qe_unbiasedness", os.path.join(root, "examples", "qe_unbiasedness.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.run(nsims=16, side=512, res=1.0, estimators=("TT", "EB"), nbins=10, lrange=(40., 2500.), filt=(300., 2500.))
+    assert "chi2" in mod.table(res)
+    for est in ("TT", "EB"):
+        r = res["estimators"][est]
+        assert r["max_abs_pull"] < 4.5, (est, r["pull"])
+        assert abs(r["weighted_mean_bias"]) < 0.03 + 3 * r["weighted_mean_sigma"], (est, r)
+        assert r["chi2"] < 3.5 * r["nbands"]
+
+
 def test_nlgenerator_contract_and_iterative_delensing():
     """NlGenerator.getNl / getNlIterative (notebook contract), lensing-B convolution vs a direct sum."""
     from orphics_amd import cosmology, lensing, stats

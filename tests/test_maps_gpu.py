@@ -143,6 +143,53 @@ def test_mapgen_parity_and_statistics():
     assert rel(mg3.get_map_from_rand(rand3), mgo3.get_map_from_rand(rand3)) < 1e-11
 
 
+def test_mapgen_1d_spectra_and_real_space_draw():
+    """MapGen from (ncomp,ncomp,lmax) spectra (spec2flat, maps.py:1573) and get_map(real=True) (maps.py:1578):
+    covsqrt equals the oracle's restatement; binned power of the draws follows the input C_l for both draw modes
+    (demo-grf.ipynb cell 7 criterion); real / harmonic draws are different realisations of the same field."""
+    from orphics_amd import maps
+    shape = (256, 256)
+    g = geom(shape)
+    ml = g.modlmap()
+    ell = np.arange(7000.)
+    cl = 5e3 / (1 + (ell / 400.) ** 2.2)
+    mg = maps.MapGen(shape, g, cl[None, None], smooth=0, dtype="f64")
+    np.testing.assert_allclose(mg.covsqrt, mo.spec2flat(shape, g.step_y, g.step_x, cl[None, None], 0.5), rtol=1e-12)
+    fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+    edges = np.arange(200, 4000, 200.)
+    b = so.bin2D(ml, edges)
+    cents = (edges[1:] + edges[:-1]) / 2
+    for real in (False, True):
+        acc = 0
+        for sd in range(16):
+            acc = acc + fo.power2d(mg.get_map(seed=sd, scalar=True, real=real).cpu().numpy())[0]
+        _, p1d = b.bin(acc / 16)
+        assert np.abs(p1d / np.interp(cents, ell, cl) - 1).max() < 0.05
+    a = mg.get_map(seed=3, scalar=True, real=True)
+    assert torch.equal(a, mg.get_map(seed=3, scalar=True, real=True))
+    assert not torch.equal(a, mg.get_map(seed=3, scalar=True, real=False))
+    # default smoothing ("auto") changes the plane only at the few-per-cent level for a smooth spectrum
+    mgs = maps.MapGen(shape, g, cl[None, None], dtype="f64")
+    sel = (ml > 100) & (ml < 6000)
+    assert 0 < np.abs(mgs.covsqrt[0, 0][sel] / mg.covsqrt[0, 0][sel] - 1).max() < 0.1
+    # polarised 3-D covariance
+    cov3 = np.zeros((3, 3, ell.size))
+    cov3[0, 0], cov3[1, 1], cov3[2, 2] = cl, 0.1 * cl, 0.01 * cl
+    cov3[0, 1] = cov3[1, 0] = 0.2 * cl
+    shape3 = (3,) + shape
+    mg3 = maps.MapGen(shape3, geom(shape3), cov3, smooth=0, dtype="f32")
+    fo3 = mo.FourierCalc(shape3, g.step_y, g.step_x)
+    acc = 0
+    for sd in range(12):
+        acc = acc + fo3.power2d(mg3.get_map(seed=50 + sd).cpu().numpy().astype(np.float64))[0]
+    acc /= 12
+    for (i, j), amp in (((0, 0), 1.0), ((1, 1), 0.1), ((0, 1), 0.2), ((2, 2), 0.01)):
+        _, p1d = b.bin(acc[i, j])
+        assert np.abs(p1d / (amp * np.interp(cents, ell, cl)) - 1).max() < (0.12 if i != j else 0.06)
+    with pytest.raises(NotImplementedError):
+        maps.MapGen(shape, g, cl[None, None], ndown=4)
+
+
 def test_bin2d_against_reference_golden(golden_dir):
     """Product bin2D (HIP) vs the fixtures produced by the real orphics.stats.bin2D."""
     from orphics_amd import stats

@@ -1,0 +1,182 @@
+"""One-call C-ABI entries (include/orphics_amd.h) driven the way a non-torch host would:
+NumPy arrays, device memory from oa_malloc / oa_memcpy, raw pointers -- compared with the Python classes (which are
+themselves checked against the oracle elsewhere)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+class Dev(object):
+    """device buffers through the library's own allocator (no torch involved)"""
+
+    def __init__(self, lib, check):
+        self.lib, self.check, self.ptrs = lib, check, []
+
+    def up(self, a):
+        a = np.ascontiguousarray(a)
+        p = ctypes.c_void_p()
+        self.check(self.lib.oa_malloc(ctypes.byref(p), a.nbytes))
+        self.check(self.lib.oa_memcpy(p, a.ctypes.data_as(ctypes.c_void_p), a.nbytes, 1, None))
+        self.ptrs.append(p)
+        return p
+
+    def zeros(self, nbytes):
+        p = ctypes.c_void_p()
+        self.check(self.lib.oa_malloc(ctypes.byref(p), nbytes))
+        self.check(self.lib.oa_memset(p, 0, nbytes, None))
+        self.ptrs.append(p)
+        return p
+
+    def down(self, p, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self.check(self.lib.oa_memcpy(out.ctypes.data_as(ctypes.c_void_p), p, out.nbytes, 2, None))
+        self.check(self.lib.oa_stream_synchronize(None))
+        return out
+
+    def free(self):
+        for p in self.ptrs:
+            self.lib.oa_free(p)
+
+
+def _setup(N=256, res=2.0):
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True, dtype="f32")
+    rng = np.random.default_rng(4)
+    cl = th.lCl("TT", ml)
+    tk = np.fft.fft2(rng.standard_normal(shape)) * np.sqrt((cl * beam ** 2 + noise) / g.pixarea)
+    tmap = np.fft.ifft2(tk).real.astype(np.float32)
+    return q, g, tmap, (cl * beam ** 2 + noise)
+
+
+def test_one_call_entries_from_raw_pointers():
+    from orphics_amd import _lib, maps, mc
+    from orphics_amd._lib import check
+    lib = _lib.load()
+    N = 256
+    q, g, tmap, tot = _setup(N)
+    kp = q.eng.kp
+    dev = Dev(lib, check)
+    try:
+        plan = ctypes.c_void_p()
+        check(lib.oa_plan_create(N, N, _lib.OA_F32, ctypes.byref(plan)))
+        ly, lx = g.laxes()
+        check(lib.oa_plan_set_laxes(plan, ly.ctypes.data_as(ctypes.c_void_p), lx.ctypes.data_as(ctypes.c_void_p)))
+        FG, FH, Fn = [dev.up(t.cpu().numpy()) for t in q._F["TT"]]
+        check(lib.oa_plan_set_filters(plan, FG, FH, Fn, q.leg_cols, q.kappa_cols, q.leg_rows, q.kappa_rows, -1))
+        d_map = dev.up(tmap)
+        d_out = dev.up(np.full((N, kp), 7 + 7j, dtype=np.complex64))        # garbage: zero_outside must clear it
+        # --- oa_qe_tt from a real map == Estimator.reconstruct_tt_from_map
+        check(lib.oa_qe_tt(plan, d_map, None, None, d_out, 1, None))
+        got = dev.down(d_out, (N, kp), np.complex64)
+        want = q.reconstruct_tt_from_map(q.eng.to_real(tmap)).cpu().numpy()
+        assert np.array_equal(got, want)                                   # same kernels, same launch geometry
+        assert np.all(got[:, q.kappa_cols:] == 0)
+        # --- Fourier-space legs (split estimator contract: X and Y legs differ)
+        k1 = q.eng.rfft(q.eng.to_real(tmap))
+        k2 = q.eng.rfft(q.eng.to_real(tmap[::-1].copy()))
+        dk1, dk2 = dev.up(k1.cpu().numpy()), dev.up(k2.cpu().numpy())
+        check(lib.oa_qe_tt(plan, None, dk1, dk2, d_out, 1, None))
+        got = dev.down(d_out, (N, kp), np.complex64)
+        assert np.array_equal(got, q.reconstruct_tt_hc(k1, k2).cpu().numpy())
+        # --- plan-owned output plane
+        check(lib.oa_qe_tt(plan, d_map, None, None, None, 0, None))
+        own = dev.down(ctypes.c_void_p(lib.oa_plan_kappa(plan)), (N, kp), np.complex64)
+        assert np.array_equal(own, want)
+        # --- bins + one Monte-Carlo step per call
+        edges = np.linspace(100, 3000, 12)
+        nids = edges.size + 1
+        ids = q.eng.modl_digitize(torch.as_tensor(edges, device=q.eng.device), half=True)
+        d_ids = dev.up(ids.cpu().numpy())
+        norm = g.area / float(N * N) ** 2
+        check(lib.oa_plan_set_bins(plan, d_ids, nids, norm, None))
+        dd = nids - 2
+        n, S, C = dev.zeros(8), dev.zeros(8 * dd), dev.zeros(8 * dd * dd)
+        for _ in range(3):
+            check(lib.oa_qe_tt_moments(plan, d_map, n, S, C, None))
+        hn, hS, hC = dev.down(n, (1,), np.int64), dev.down(S, (dd,), np.float64), dev.down(C, (dd, dd), np.float64)
+        counts = dev.down(ctypes.c_void_p(lib.oa_plan_bin_counts(plan)), (nids,), np.int64)
+        sums, cfull = q.eng.bin_power(torch.as_tensor(want, device=q.eng.device), torch.as_tensor(want, device=q.eng.device), norm, ids, nids, herm=True)
+        assert np.array_equal(counts, cfull.cpu().numpy())
+        b = (sums[1:-1] / cfull[1:-1]).cpu().numpy()
+        assert hn[0] == 3
+        np.testing.assert_allclose(hS, 3 * b, rtol=1e-12)
+        np.testing.assert_allclose(hC, 3 * np.outer(b, b), rtol=1e-12)
+        # --- oa_mc_run == the Python driver (same Philox streams, deterministic binning)
+        tot_h = tot[:, :N // 2 + 1]
+        drv = mc.GaussianN0MonteCarlo(q, tot_h, edges, comm=None, base_seed=11, mean_field=True)
+        st = drv.run(9)
+        check(lib.oa_memset(n, 0, 8, None)); check(lib.oa_memset(S, 0, 8 * dd, None)); check(lib.oa_memset(C, 0, 8 * dd * dd, None))
+        mf = dev.zeros(8 * 2 * N * kp)
+        d_cs = dev.up(drv.cs.cpu().numpy())
+        check(lib.oa_mc_run(plan, 11, 0, 4, d_cs, n, S, C, mf, None))
+        check(lib.oa_mc_run(plan, 11, 4, 9, d_cs, n, S, C, mf, None))
+        assert dev.down(n, (1,), np.int64)[0] == 9 == st.count("n0")
+        np.testing.assert_allclose(dev.down(S, (dd,), np.float64) / 9, st.mean("n0"), rtol=1e-13)
+        np.testing.assert_allclose(dev.down(mf, (N, kp, 2), np.float64), st.stack_sum("mf"), rtol=0, atol=0)
+        # --- oa_filter_map == maps.filter_map
+        filt = maps.gauss_beam(g.modlmap(), 3.0)
+        fh = np.zeros((N, kp), dtype=np.float32)
+        fh[:, :N // 2 + 1] = filt[:, :N // 2 + 1]
+        d_f, d_o = dev.up(fh), dev.zeros(4 * N * N)
+        check(lib.oa_filter_map(plan, d_map, d_f, d_o, None))
+        np.testing.assert_allclose(dev.down(d_o, (N, N), np.float32), maps.filter_map(tmap, filt), rtol=0, atol=2e-5 * np.abs(tmap).max())
+        # --- single-rank RCCL communicator: all-reduce is the identity
+        uid = (ctypes.c_char * 128)()
+        check(lib.oa_comm_unique_id(uid))
+        comm = ctypes.c_void_p()
+        check(lib.oa_comm_init(1, 0, uid, ctypes.byref(comm)))
+        check(lib.oa_allreduce(comm, S, dd, 0, None))
+        check(lib.oa_allreduce(comm, n, 1, 1, None))
+        check(lib.oa_stream_synchronize(None))
+        assert dev.down(n, (1,), np.int64)[0] == 9
+        check(lib.oa_comm_destroy(comm))
+        # --- misuse is refused with a message, not a crash
+        assert lib.oa_qe_tt(plan, d_map, dk1, None, d_out, 1, None) != 0 and b"either" in lib.oa_last_error()
+        check(lib.oa_plan_destroy(plan))
+    finally:
+        dev.free()
+
+
+def test_one_call_pol_estimator_matches_fine_grained():
+    """oa_qe_pol (through Estimator.reconstruct_hc) == the chain of fine-grained calls it replaces."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N = 128
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, 2.0)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tm = maps.mask_kspace(shape, g, lmin=300, lmax=2500)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tm, noise2d_P=2 * noise, kmask_P=tm, kmask_K=None,
+                     pol=True, unlensed_equals_lensed=True, dtype="f64")
+    e = q.eng
+    rng = np.random.default_rng(1)
+    kE = e.rfft(e.to_real(rng.standard_normal(shape)))
+    kB = e.rfft(e.to_real(rng.standard_normal(shape)))
+    for XY in ("EB", "TE", "EE"):
+        got = q.reconstruct_hc(XY, kE, kB).cpu().numpy()
+        G = q._setup_general(XY)
+        ax, ay = e.hc(), e.hc()
+        s0 = 1.0 / float(e.npix) ** 2
+        for i, (sign, FG, FH, swap) in enumerate(G["pieces"]):
+            kg, kh = (kB, kE) if swap else (kE, kB)
+            c = e.qe_legs_cols(kg, kh, FG, FH, out=(e.hc(), e.hc(), e.hc()), width=G["wl"], rband=G["rl"])
+            e.qe_rows(c[0], c[1], c[2], ax, ay, scale=sign * s0, accumulate=(i > 0), win=G["wl"], wout=G["wk"], mrow=q.mrow)
+        want = e.qe_cols_div(ax, ay, G["Fnorm"], width=G["wk"], rband=G["rk"]).cpu().numpy()
+        w = N // 2 + 1
+        assert np.abs(got[:, :w] - want[:, :w]).max() <= 1e-14 * np.abs(want).max()

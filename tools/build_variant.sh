@@ -9,6 +9,6 @@ CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contrac
 for f in fft fft_legs; do $CXX $FLAGS -c $f.hip -o build_$NAME/$f.o & done
 wait
 OBJS="build_$NAME/fft.o build_$NAME/fft_legs.o"
-for f in plan czt elementwise bin rng; do OBJS="$OBJS build/$f.o"; done
+for f in plan czt elementwise bin rng pipeline; do OBJS="$OBJS build/$f.o"; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../variants/liborphics_amd_$NAME.so $OBJS
 echo built ../variants/liborphics_amd_$NAME.so

@@ -90,29 +90,50 @@ static std::atomic<unsigned long long> g_flops{0};
 
 struct CountLauncher {
     int nz_used = -1;
+    int rows_per_wg = 1;
+    template <typename T> void row_qe_pair(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
+        rows_per_wg = 2;
+        dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_total_log<S>() >= 10 && seq_total_log<S>() <= 13) {
+                const int nz = pair_first_stage_nz(a.logL, S::rget(0), a.win);
+                nz_used = nz;
+                std::vector<char> sm(smem + 64);
+                std::barrier<> bar(nt);
+                std::vector<std::thread> th;
+                dispatch_pair_nz<S>(nz, [&](auto nzc) {
+                    for (int t = 0; t < nt; ++t)
+                        th.emplace_back([&, t]() {
+                            t_flops = 0;
+                            EmuCtx c{t, 0, &bar, sm.data()};     // ONE workgroup (block 0): one row pair
+                            row_qe_pair_body<T, S, decltype(nzc)::value>(c, a);
+                            g_flops += t_flops;
+                        });
+                });
+                for (auto& x : th) x.join();
+            }
+        });
+    }
     template <typename T> void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         dispatch_seq_qe(a.logL, [&](auto seq) {
             using S = decltype(seq);
             if constexpr (seq_total_log<S>() >= 4) {
                 int nz = 0;
-                if constexpr (S::n >= 2 && S::rget(0) == 16) nz = qe_first_stage_nz(a.logL, 16, a.win);
+                if constexpr (S::n >= 2) nz = qe_first_stage_nz(a.logL, S::rget(0), a.win);
                 nz_used = nz;
+                rows_per_wg = 1 << a.logC;
                 std::vector<char> sm(smem + 64);
                 std::barrier<> bar(nt);
                 std::vector<std::thread> th;
-                for (int t = 0; t < nt; ++t)
-                    th.emplace_back([&, t]() {
-                        t_flops = 0;
-                        EmuCtx c{t, 0, &bar, sm.data()};     // ONE workgroup (block 0): C rows
-                        if constexpr (S::n >= 2 && S::rget(0) == 16) {
-                            if (nz == 1) row_qe_body<T, S, 1>(c, a);
-                            else if (nz == 2) row_qe_body<T, S, 2>(c, a);
-                            else row_qe_body<T, S, 0>(c, a);
-                        } else {
-                            row_qe_body<T, S, 0>(c, a);
-                        }
-                        g_flops += t_flops;
-                    });
+                dispatch_nz<S>(nz, [&](auto nzc) {
+                    for (int t = 0; t < nt; ++t)
+                        th.emplace_back([&, t]() {
+                            t_flops = 0;
+                            EmuCtx c{t, 0, &bar, sm.data()};     // ONE workgroup (block 0): C rows
+                            row_qe_body<T, S, decltype(nzc)::value>(c, a);
+                            g_flops += t_flops;
+                        });
+                });
                 for (auto& x : th) x.join();
             }
         });
@@ -130,10 +151,14 @@ int main(int argc, char** argv) {
     std::vector<cx<CF>> twx((size_t)N);
     for (int i = 0; i < N; ++i) twx[i] = mk<CF>(CF::run(tw[i].x), CF::run(tw[i].y));
     p.ny = N; p.nx = N; p.logNy = ilog2(N); p.logNx = ilog2(N); p.kp = kpitch_for(N); p.tw_x = twx.data(); p.tw_y = twx.data();
-    if (mrow < 0) mrow = Fft2dPlan<CF>::row_grid_min(N, p.clampw(win), p.clampw(wout));
-    if (mrow == 0 || mrow > N) mrow = N;
-    const int L = mrow / 2;
-    int C = 4096 / L; if (C < 1) C = 1;
+    if (mrow < 0) {
+        mrow = Fft2dPlan<CF>::row_grid_min(N, p.clampw(win), p.clampw(wout));
+        if (2L * p.clampw(win) + p.clampw(wout) > mrow) mrow = 0;
+    }
+    if (mrow > N) mrow = N;
+    const int grid = mrow == 0 ? N : mrow;
+    const int L = grid / 2;
+    int C = 4096 / L; if (C < 2) C = 2;
     const size_t rows = (size_t)C;
     std::vector<cx<CF>> gx(rows * p.kp), gy(rows * p.kp), h(rows * p.kp), px(rows * p.kp), py(rows * p.kp);
     for (size_t i = 0; i < gx.size(); ++i) {
@@ -142,10 +167,11 @@ int main(int argc, char** argv) {
     }
     CountLauncher q;
     p.rows_qe(q, gx.data(), gy.data(), h.data(), px.data(), py.data(), CF::run(1.0f), 0, p.clampw(win), p.clampw(wout), mrow);
+    C = q.rows_per_wg;
     const double per_row = (double)g_flops.load() / (double)C;
     const double nominal = 5.0 * 5.0 * L * std::log2((double)L);
     printf("{\"n\": %d, \"win\": %d, \"wout\": %d, \"mrow\": %d, \"rows_per_workgroup\": %d, \"first_stage_nz\": %d, \"flops_per_row\": %.1f, "
            "\"nominal_5NlogN_flops_per_row\": %.1f, \"ratio_to_nominal\": %.4f}\n",
-           N, p.clampw(win), p.clampw(wout), mrow, C, q.nz_used, per_row, nominal, per_row / nominal);
+           N, p.clampw(win), p.clampw(wout), grid, C, q.nz_used, per_row, nominal, per_row / nominal);
     return 0;
 }
