@@ -318,40 +318,32 @@ def per_kernel_table(torch, P, R, args):
     fl, fk = (wl or W) / float(W), (wk or W) / float(W)
     gl = (2 * rl - 1) / float(N) if rl else 1.0       # active row fractions
     gk = (2 * rk - 1) / float(N) if rk else 1.0
-    s1, s2, s3, s4, s5 = eng.hc(), eng.hc(), eng.hc(), eng.hc(), eng.hc()
+    from orphics_amd.engine import _ptr, _stream
+    from orphics_amd._lib import check
     r1 = R.tmaps[0]
-    kk = q.new_output()
-    FG, FH, Fn = q._F["TT"]
-    norm = R.norm
+    e = q._bind_bins()                       # this handle's plan knows its filters and bins
+    lib, plan = e.lib, e.plan
 
-    def map_legs():
-        eng.qe_map_legs_cols(r1, FG, FH, out=(s1, s2, s3), width=wl, rband=rl)
-
-    # name -> (launcher, bytes it must move once)
+    def stage(k):
+        # one stage of oa_qe_tt_moments on the plan's own (compact) work planes: the launches of the headline path
+        return lambda: check(lib.oa_qe_tt_stage(plan, k, _ptr(r1), _stream()))
+    scratch_moments = (R.mom_n[0].clone(), R.mom_S[0].clone(), R.mom_C[0].clone())     # fill every work plane once
+    check(lib.oa_qe_tt_moments(plan, _ptr(r1), *[_ptr(t) for t in scratch_moments], _stream()))
+    # name -> (stage, bytes it must move once: inputs + outputs on its active columns / rows)
     kern = {
-        "row_fft_kernel<R2C>": (lambda: eng.fft_pass(0, r1, s1, wl), A + fl * Ah),
-        "col_fft_kernel<fwd pass1, leg width>": (lambda: eng.fft_pass(1, s1, s2, wl), 2 * fl * Ah),
-        "map_legs_cols (whole call)": (map_legs, None),
-        "row_qe_kernel": (lambda: eng.qe_rows(s1, s2, s3, s4, s5, win=wl, wout=wk, mrow=q.mrow), (3 * fl + 2 * fk) * Ah),
+        "row_fft_kernel<R2C>": (0, A + fl * Ah),
+        "col_fft_kernel<fwd pass1, leg width>": (1, 2 * fl * Ah),
+        # col_fwdlegs (read the pass-1 plane + 2 real filter planes on the band rows, write 3) + 3-plane inverse pass 2 (r + w)
+        "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>": (2, fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah),
+        "row_qe_kernel": (3, (3 * fl + 2 * fk) * Ah),
         # one 2-plane pass-1 launch (read 2, write 2) + col_div (read 2 + Fn/2, write the band rows of 1)
-        "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel": (lambda: eng.qe_cols_div(s4, s5, Fn, out=kk, width=wk, rband=rk),
-                                                                 4 * fk * Ah + fk * (2 * Ah + gk * Ah / 2 + gk * Ah)),
-        "bin_kernel<power>": (lambda: eng.bin_power(kk, kk, norm, P["ids"], P["nids"], herm=True, active_cols=wk, active_rows=rk),
-                              1.5 * fk * gk * Ah),
+        "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel": (4, 4 * fk * Ah + fk * (2 * Ah + gk * Ah / 2 + gk * Ah)),
+        "bin_kernel<power>": (5, 1.5 * fk * gk * Ah),
     }
     per = {}
-    for name, (fn, moved) in kern.items():
-        dt = time_kernel(torch, fn)
-        per[name] = {"avg_ms": dt * 1e3}
-        if moved is not None:
-            per[name].update({"hbm_min_GB": moved / 1e9, "hbm_GBs": moved / dt / 1e9, "hbm_frac": moved / dt / 1e9 / HBM_PEAK_GBS})
-    whole = per.pop("map_legs_cols (whole call)")
-    t_fl = max(whole["avg_ms"] - per["row_fft_kernel<R2C>"]["avg_ms"] - per["col_fft_kernel<fwd pass1, leg width>"]["avg_ms"], 1e-6)
-    # col_fwdlegs (read pass-1 plane on the band rows' tiles + 2 real filter planes, write 3) + 3-plane inverse pass 2 (r+w 3)
-    m_fl = fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah
-    per["fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>"] = {
-        "avg_ms": t_fl, "hbm_min_GB": m_fl / 1e9, "hbm_GBs": m_fl / t_fl / 1e6, "hbm_frac": m_fl / t_fl / 1e6 / HBM_PEAK_GBS,
-        "derived": "whole oa_qe_map_legs_cols call minus its row and pass-1 launches"}
+    for name, (k, moved) in kern.items():
+        dt = time_kernel(torch, stage(k))
+        per[name] = {"avg_ms": dt * 1e3, "hbm_min_GB": moved / 1e9, "hbm_GBs": moved / dt / 1e9, "hbm_frac": moved / dt / 1e9 / HBM_PEAK_GBS}
     flops, mrow, how = row_qe_flops(N, wl, wk, q.mrow)
     rq = per["row_qe_kernel"]
     rq.update({"executed_GFLOP": flops / 1e9, "flop_count": how, "row_grid": mrow, "TFLOPs": flops / (rq["avg_ms"] * 1e-3) / 1e12,

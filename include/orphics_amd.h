@@ -165,6 +165,12 @@ int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void
 int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, double* C, void* stream);
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S,
               double* C, double* meanfield_acc, void* stream);
+/* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py roofline; the
+ * one-call path keeps its intermediates on COMPACT planes -- pitch = active columns rounded up to a 32-column tile
+ * -- so its kernels are not the same launches as the fine-grained calls on caller planes of pitch kpitch):
+ * 0 = row R2C, 1 = forward column pass 1, 2 = fused leg kernel + 3-plane inverse pass 2, 3 = fused row stage,
+ * 4 = 2-plane forward pass 1 + divergence kernel, 5 = binned power + moment accumulation (plan-owned dummies). */
+int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream);
 
 /* ---- device memory helpers for hosts without a GPU array library (the reference passes NumPy arrays) --------- */
 int oa_malloc(void** out, size_t bytes);

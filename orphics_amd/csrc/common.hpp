@@ -77,6 +77,16 @@ int czt_c2c(oa_plan* p, const void* in, void* out, int inverse, double scale, hi
 int czt_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, hipStream_t st);
 int czt_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStream_t st);
 void pipeline_release(oa_plan* p);
+// fused estimator passes on the plan's compact work planes (fft.hip)
+long work_pitch(const oa_plan* p, int w);
+int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
+                       int rband, long pl, hipStream_t st, int stages = 7);
+int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                   int width, int rband, long pl, hipStream_t st);
+int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
+              int win, int wout, int mrow, long pl, long pk, hipStream_t st);
+int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
+                  long pk, hipStream_t st);
 }
 #define OA_NEED_POW2(p, what) \
     OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

@@ -56,12 +56,40 @@ __device__ __forceinline__ cx<float> add_pi(cx<float> a, cx<float> b) {
 __device__ __forceinline__ cx<float> operator*(cx<float> a, cx<float> b) {
     oa_f2 t, r;
     const oa_f2 av = __builtin_bit_cast(oa_f2, a), bv = __builtin_bit_cast(oa_f2, b);
+#ifdef OA_PK_SPLIT_ASM
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));          // (a.x b.x, a.x b.y)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                  // (-a.y b.y, a.y b.x) + t
         : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+#else
+    // ONE asm statement for the dependent pair: the compiler pads every inline-asm boundary with an s_nop (it cannot
+    // see what the instruction is); the VALU -> VALU read-after-write inside is interlocked by the hardware
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0,0] op_sel_hi:[0,1]\n\t"                                     // (a.x b.x, a.x b.y)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                  // (-a.y b.y, a.y b.x) + t
+        : "=&v"(t), "=v"(r) : "v"(av), "v"(bv));
+#endif
     return __builtin_bit_cast(cx<float>, r);
 }
 #endif
+
+// streaming (use-once) global accesses of the column passes: -DOA_COL_NT marks them non-temporal
+template <typename T> OA_HD cx<T> ld_stream(const cx<T>* p) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(OA_COL_NT)
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const vec2 v = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+    return mk<T>(v.x, v.y);
+#else
+    return *p;
+#endif
+}
+template <typename T> OA_HD void st_stream(cx<T>* p, cx<T> v) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(OA_COL_NT)
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    vec2 w; w.x = v.x; w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<vec2*>(p));
+#else
+    *p = v;
+#endif
+}
 
 OA_HD int ilog2(int v) {
     int l = 0;

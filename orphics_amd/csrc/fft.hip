@@ -208,7 +208,7 @@ static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double 
 }
 template <typename T>
 static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-                        int accumulate, int win, int wout, int mrow, hipStream_t st) {
+                        int accumulate, int win, int wout, int mrow, hipStream_t st, long pin = 0, long pout = 0) {
     HipLauncher q{st};
     auto f = view<T>(p);
     const int wi = f.clampw(win), wo = f.clampw(wout);
@@ -220,22 +220,23 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
         if (!is_pow2(mrow) || mrow < 64) return fail("oa_qe_rows: mrow must be a power of two >= 64");
         if (2L * wi + wo > mrow) return fail("oa_qe_rows: mrow < 2*win + wout would alias the leg products into the kept columns");
     }
-    f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate, wi, wo, mrow);
+    f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate, wi, wo, mrow,
+              pin, pout);
     return q.rc;
 }
 
 template <typename T>
 static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy,
-                          void* h, int width, int rband, hipStream_t st) {
+                          void* h, int width, int rband, hipStream_t st, long pout = 0) {
     HipLauncher q{st};
     view<T>(p).legs_cols(q, (const cx<T>*)kX, (const cx<T>*)kY, (const T*)FG, (const T*)FH, (const T*)p->lxd,
-                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, rband);
+                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, rband, 0, pout);
     return q.rc;
 }
 // real map -> the three column-transformed leg planes (both legs from this one map)
 template <typename T>
 static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                              int width, int rband, hipStream_t st) {
+                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
@@ -243,30 +244,59 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
     const int w = f.clampw(width);
-    f.rows(q, ROW_R2C, map, p->nx / 2, tA, p->kp, (T)1, w);
+    const long pw = pwork > 0 ? pwork : p->kp;          // pitch of the two scratch planes
+    // stages (per-kernel timing, oa_qe_tt_stage): 1 = row R2C, 2 = forward column pass 1, 4 = fused legs + inverse pass 2
+    if (stages & 1) f.rows(q, ROW_R2C, map, p->nx / 2, tA, pw, (T)1, w);
     if (Fft2dPlan<T>::has_fwdlegs(p->logNy)) {
-        f.cols(q, tA, p->kp, tB, p->kp, w, false, (T)1, 1);                       // forward pass 1 only
-        f.legs_cols_from_pass1(q, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
-                               (cx<T>*)gy, (cx<T>*)h, width, rband);
-    } else {
-        f.cols(q, tA, p->kp, tB, p->kp, w, false, (T)1, 0, 1, nullptr, nullptr, rband);
+        if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 1);       // forward pass 1 only
+        if (stages & 4)
+            f.legs_cols_from_pass1(q, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
+                                   (cx<T>*)gy, (cx<T>*)h, width, rband, pw, pout);
+    } else if (stages == 7) {
+        f.cols(q, tA, pw, tB, pw, w, false, (T)1, 0, 1, nullptr, nullptr, rband);
         f.legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
-                    (cx<T>*)h, width, rband);
+                    (cx<T>*)h, width, rband, pw, pout);
     }
     return q.rc;
 }
 
 template <typename T>
 static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
-                         int width, int rband, hipStream_t st) {
+                         int width, int rband, hipStream_t st, long pin = 0) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
     view<T>(p).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
-                        (cx<T>*)out, tA, tB, accumulate, width, rband);
+                        (cx<T>*)out, tA, tB, accumulate, width, rband, pin);
     return q.rc;
+}
+
+// ---- the same passes on the plan's COMPACT work planes (pipeline.hip): pl = pitch of the leg planes and of the
+//      scratch planes while they hold the input transform, pk = pitch of the product planes (Fft2dPlan::work_pitch)
+long work_pitch(const oa_plan* p, int w) {
+    return p->dtype == OA_F32 ? view<float>(p).work_pitch(w) : view<double>(p).work_pitch(w);
+}
+int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
+                       int rband, long pl, hipStream_t st, int stages) {
+    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages)
+                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages);
+}
+int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
+                   int width, int rband, long pl, hipStream_t st) {
+    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl)
+                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl);
+}
+int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
+              int win, int wout, int mrow, long pl, long pk, hipStream_t st) {
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk);
+}
+int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
+                  long pk, hipStream_t st) {
+    return p->dtype == OA_F32 ? cols_div_impl<float>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk)
+                              : cols_div_impl<double>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk);
 }
 
 }  // namespace oa

@@ -470,7 +470,8 @@ template <typename T>
 struct RowQeArgs {
     const cx<T>* gx; const cx<T>* gy; const cx<T>* h;
     cx<T>* px; cx<T>* py;
-    long pitch;
+    long pitch;   // row pitch of gx, gy, h (complex elements)
+    long opitch;  // row pitch of px, py
     int logL, logC, NT, rowStride;
     const cx<T>* tw;
     int logTw;
@@ -619,7 +620,7 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
         stage_out<T, R0, true, false>(work, v, tid, NT, logL, logC, RS, 0, NoStore{});
         ctx.sync();
         forward_tail<T, SEQ>(ctx, work, tid, NT, logL, logC, RS, twl, logL);
-        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
+        r2c_epilogue<T>(ctx, work, dst, a.opitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
         ctx.sync();
     }
 }
@@ -730,8 +731,8 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
         ctx.sync();
         forward_tail<T, SEQ>(ctx, work, tid, NT, logM, 0, RS, twl, logM);
         // unpack the kept columns of both rows
-        cx<T>* o0 = dst + r0 * a.pitch;
-        cx<T>* o1 = o0 + a.pitch;
+        cx<T>* o0 = dst + r0 * a.opitch;
+        cx<T>* o1 = o0 + a.opitch;
         for (int k = tid; k < a.wout; k += NT) {
             const int km = (M - k) & (M - 1);
             const cx<T> Pk = work[k + (k >> 4)];
@@ -836,7 +837,7 @@ OA_HD void row_qe_body_inplace(Ctx& ctx, const RowQeArgs<T>& a) {
 #pragma unroll
         for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].x, v[t].x * hreg[t].y);
         dit_from_regs<T, SEQ>(ctx, work, v, tid, NT, logL, logC, RS, twl);   // this thread rewrites the points it just read
-        r2c_epilogue<T>(ctx, work, dst, a.pitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
+        r2c_epilogue<T>(ctx, work, dst, a.opitch, r0, logL, logC, NT, RS, a.tw, a.logTw, (T)1, a.accumulate != 0, a.wout);
         ctx.sync();
     }
 }
@@ -875,7 +876,7 @@ struct ColLoad {
     bool inv;
     template <typename U> OA_HD cx<U> get(int n, int c) const {
         cx<U> x = mk<U>((U)0, (U)0);
-        if (c < ncols) x = base[(unsigned)n * nstride + (unsigned)c];
+        if (c < ncols) x = ld_stream(base + ((unsigned)n * nstride + (unsigned)c));
         return inv ? swp(x) : x;
     }
 };
@@ -894,7 +895,7 @@ struct ColStore {
         if (rb) { const int y = row0 + k * rowstep; if (y >= rb && y <= ny - rb) return; }
         if (tw) v = v * tw[k];
         if (inv) v = swp(v);
-        base[(unsigned)k * kstride + (unsigned)c] = v * scale;
+        st_stream(base + ((unsigned)k * kstride + (unsigned)c), v * scale);
     }
 };
 
@@ -966,7 +967,9 @@ struct ColLegsArgs {
     const T* FG; const T* FH;
     const T* lxd; const T* lyd;
     cx<T>* gx; cx<T>* gy; cx<T>* h;
-    long pitch;
+    long pitch;      // row pitch of kX, kY
+    long fpitch;     // row pitch of the filter planes FG, FH
+    long opitch;     // row pitch of the three output planes (compact work planes: see Fft2dPlan::work_pitch)
     int width, logC, NT;
     const cx<T>* tw;
     int logTw;
@@ -995,9 +998,10 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     for (int i = tid; i < (1 << logL); i += NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
     ctx.sync();
     const long org = g * a.in_gs * a.pitch + c0;   // scalar tile origin; per-element offsets are 32-bit
+    const long forg = g * a.in_gs * a.fpitch + c0;
     const cx<T>* kXb = a.kX + org; const cx<T>* kYb = a.kY + org;
-    const T* FGb = a.FG + org; const T* FHb = a.FH + org;
-    const unsigned nstr = (unsigned)(a.in_ns * a.pitch);
+    const T* FGb = a.FG + forg; const T* FHb = a.FH + forg;
+    const unsigned nstr = (unsigned)(a.in_ns * a.pitch), fstr = (unsigned)(a.in_ns * a.fpitch);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -1006,18 +1010,18 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
 #pragma unroll
         for (int t = 0; t < R0; ++t) {
             const int n = j + (t << (logL - LR));
-            const unsigned i = (unsigned)n * nstr + (unsigned)c;
+            const unsigned i = (unsigned)n * nstr + (unsigned)c, fi = (unsigned)n * fstr + (unsigned)c;
             cx<T> kx = mk<T>((T)0, (T)0), ky = kx;
             T fg = 0, fh = 0;
             bool live = ok;
             if (a.rband) { const int y = (int)(g * a.in_gs) + n * (int)a.in_ns; live = ok && !(y >= a.rband && y <= a.ny - a.rband); }
-            if (live) { kx = kXb[i]; ky = kYb[i]; fg = FGb[i]; fh = FHb[i]; }
+            if (live) { kx = kXb[i]; ky = kYb[i]; fg = FGb[fi]; fh = FHb[fi]; }
             gv[u * R0 + t] = kx * fg;
             v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
     }
     {   // H = FH kY
-        const ColStore<T> st{a.h + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
+        const ColStore<T> st{a.h + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
@@ -1030,7 +1034,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
 #pragma unroll
             for (int t = 0; t < R0; ++t) v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * lx);
         }
-        const ColStore<T> st{a.gx + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
+        const ColStore<T> st{a.gx + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
@@ -1045,7 +1049,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
                 v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * a.lyd[y]);
             }
         }
-        const ColStore<T> st{a.gy + g * a.out_gs * a.pitch + c0, (unsigned)(a.out_ks * a.pitch), ncols, true,
+        const ColStore<T> st{a.gy + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
     }
@@ -1070,7 +1074,9 @@ struct ColFwdLegsArgs {
     const T* FG; const T* FH;
     const T* lxd; const T* lyd;
     cx<T>* gx; cx<T>* gy; cx<T>* h;
-    long pitch;
+    long pitch;                 // row pitch of `in`
+    long fpitch;                // row pitch of FG, FH
+    long opitch;                // row pitch of gx, gy, h
     int width;
     const cx<T>* tw;            // W_Ny^k
     int logTw;
@@ -1105,7 +1111,8 @@ OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
     const ColLoad<T> ld{a.in + org, rstr, ncols, false};
     col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, logC, twl, logL, ld);
     ctx.sync();
-    const T* FGb = a.FG + org; const T* FHb = a.FH + org;
+    const T* FGb = a.FG + (g * a.fpitch + c0); const T* FHb = a.FH + (g * a.fpitch + c0);
+    const unsigned fstr = (unsigned)(a.n1f * a.fpitch);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -1114,7 +1121,7 @@ OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
 #pragma unroll
         for (int t = 0; t < RL; ++t) {
             const int k = j + (t << logNs);
-            const unsigned i = (unsigned)k * rstr + (unsigned)c;
+            const unsigned i = (unsigned)k * fstr + (unsigned)c;
             T fg = 0, fh = 0;
             bool live = ok;
             if (a.rband) { const int y = (int)g + k * (int)a.n1f; live = ok && !(y >= a.rband && y <= a.ny - a.rband); }
@@ -1125,9 +1132,9 @@ OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
         }
     }
     // inverse pass 1 (length L, input stride n1f): outputs block-transposed at rows g*L + k, twiddled by W_Ny^(g k)
-    const long oorg = g * ((long)1 << logL) * a.pitch + c0;
+    const long oorg = g * ((long)1 << logL) * a.opitch + c0;
     {   // H = FH kT
-        const ColStore<T> st{a.h + oorg, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
+        const ColStore<T> st{a.h + oorg, (unsigned)a.opitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQI>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
     }
@@ -1139,7 +1146,7 @@ OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
 #pragma unroll
             for (int t = 0; t < RL; ++t) v[u * RL + t] = swp(mul_pi(gv[u * RL + t]) * lx);
         }
-        const ColStore<T> st{a.gx + oorg, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
+        const ColStore<T> st{a.gx + oorg, (unsigned)a.opitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQI>(ctx, s, v, tid, NT, logC, twl, logL, st);
         ctx.sync();
     }
@@ -1153,7 +1160,7 @@ OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
                 v[u * RL + t] = swp(mul_pi(gv[u * RL + t]) * a.lyd[y]);
             }
         }
-        const ColStore<T> st{a.gy + oorg, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
+        const ColStore<T> st{a.gy + oorg, (unsigned)a.opitch, ncols, true, ti, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQI>(ctx, s, v, tid, NT, logC, twl, logL, st);
     }
 }
@@ -1168,7 +1175,8 @@ struct ColDivArgs {
     const T* Fn;
     const T* lxd; const T* lyd;
     cx<T>* out;
-    long pitch;
+    long pitch;      // row pitch of A, B
+    long opitch;     // row pitch of Fn and out
     int width, logC, NT;
     const cx<T>* tw;
     int logTw;
@@ -1216,10 +1224,10 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
         ctx.sync();
         col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL, lb);
     }
-    const long oorg = g * a.out_gs * a.pitch + c0;
+    const long oorg = g * a.out_gs * a.opitch + c0;
     const T* Fnb = a.Fn + oorg;
     cx<T>* outb = a.out + oorg;
-    const unsigned ostr = (unsigned)(a.out_ks * a.pitch);
+    const unsigned ostr = (unsigned)(a.out_ks * a.opitch);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;

@@ -33,6 +33,16 @@ struct Fft2dPlan {
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
     static constexpr int COLC = COL_LOGC;  // log2 columns per column tile (kernels assume it at compile time)
 
+    // COMPACT WORK PLANES.  A plane with `w` active columns stored at the full pitch kp leaves each row's w*8 bytes
+    // 8 kp bytes apart: a column tile then touches 128 rows in 128 different DRAM pages / TLB entries for 256 bytes
+    // each, and the narrow column passes ran at 3.3-3.9 TB/s where the dense ones reach 5.2-6.1 (profiles/r02g_*).
+    // Plan-owned intermediates therefore use the smallest pitch that holds whole 32-column tiles (measured: the same
+    // passes 26-32 % faster, tools/pitch_probe.py); planes that belong to the caller keep kp.
+    long work_pitch(int w) const {
+        const long c = 1L << COLC;
+        const long p = ((long)clampw(w) + c - 1) / c * c;
+        return p < kp ? p : kp;
+    }
     // active-column count of an hc plane: <= 0 or too large means all nx/2+1 columns
     int clampw(int w) const { return (w <= 0 || w > nx / 2 + 1) ? nx / 2 + 1 : w; }
     // row band: rows y < rb or y > ny - rb are active; 0 (or a band covering every row) = all rows
@@ -81,13 +91,15 @@ struct Fft2dPlan {
     }
     template <class Launcher>
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
-                 int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0) const {
+                 int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0, long pin = 0,
+                 long pout = 0) const {
         RowQeArgs<T> a{};
         // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
         // transforms with no assumption beyond win / wout
         const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
         if (logM < logNx) scale = scale * (T)((double)nx / (double)(1 << logM));
-        a.tw = tw_x; a.logTw = logNx; a.scale = scale; a.pitch = kp;
+        a.tw = tw_x; a.logTw = logNx; a.scale = scale;
+        a.pitch = pin > 0 ? pin : kp; a.opitch = pout > 0 ? pout : kp;
         a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
         a.win = win; a.wout = wout;
         if (mrow > 0 && logM >= 10 && logM <= 13 && 2L * win + wout <= (1L << logM) && ny % 2 == 0) {
@@ -155,7 +167,8 @@ struct Fft2dPlan {
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
     template <class Launcher>
     void legs_cols(Launcher& q, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
-                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0) const {
+                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0, long pin = 0, long pout = 0) const {
+        const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -163,13 +176,14 @@ struct Fft2dPlan {
         const int tiles = (width + C - 1) / C;
         ColLegsArgs<T> a{};
         a.kX = kX; a.kY = kY; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
-        a.pitch = kp; a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
+        a.pitch = pi; a.fpitch = kp; a.opitch = po;
+        a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
         a.rband = clampr(rband); a.ny = ny;
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
-        cols(q, gx, kp, gx, kp, width, true, (T)1, 2, 3, ins, outs);      // pass 2 of the three planes, one launch
+        cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs);      // pass 2 of the three planes, one launch
     }
 
     // (A') legs straight from the forward column pass 1 of the map's row transform (both legs from ONE map):
@@ -178,8 +192,10 @@ struct Fft2dPlan {
     static bool has_fwdlegs(int logNy) { return logNy / 2 >= 5 && logNy / 2 <= 7; }
     template <class Launcher>
     bool legs_cols_from_pass1(Launcher& q, const cx<T>* p1, const T* FG, const T* FH, const T* lxd, const T* lyd,
-                              cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0) const {
+                              cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0, long pin = 0,
+                              long pout = 0) const {
         if (!has_fwdlegs(logNy)) return false;
+        const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         const int logL = logNy / 2, logN1f = logNy - logL;
         const long L = 1L << logL, N1f = 1L << logN1f;
         const int C = 1 << COLC;
@@ -187,11 +203,12 @@ struct Fft2dPlan {
         const int tiles = (width + C - 1) / C;
         ColFwdLegsArgs<T> a{};
         a.in = p1; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
-        a.pitch = kp; a.width = width; a.tw = tw_y; a.logTw = logNy; a.n1f = N1f; a.rband = clampr(rband); a.ny = ny;
+        a.pitch = pi; a.fpitch = kp; a.opitch = po;
+        a.width = width; a.tw = tw_y; a.logTw = logNy; a.n1f = N1f; a.rband = clampr(rband); a.ny = ny;
         q.col_fwdlegs(tiles, (int)N1f, (int)((L * C) / EPT), ((size_t)L * C + tw_lds_size(logL) + L) * sizeof(cx<T>), logL, a);
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
-        cols(q, gx, kp, gx, kp, width, true, (T)1, 2, 3, ins, outs, 0, true);   // inverse pass 2, split swapped
+        cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs, 0, true);   // inverse pass 2, split swapped
         return true;
     }
 
@@ -199,7 +216,8 @@ struct Fft2dPlan {
     //     tmpA, tmpB: two hc scratch planes
     template <class Launcher>
     void cols_div(Launcher& q, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
-                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0) const {
+                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0) const {
+        const long pi = pin > 0 ? pin : kp;     // pitch of pa, pb AND of the two scratch planes
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -207,9 +225,9 @@ struct Fft2dPlan {
         const int tiles = (width + C - 1) / C;
         const cx<T>* ins[2] = {pa, pb};
         cx<T>* outs[2] = {tmpA, tmpB};
-        cols(q, pa, kp, tmpA, kp, width, false, (T)1, 1, 2, ins, outs);   // pass 1 of both planes, one launch
+        cols(q, pa, pi, tmpA, pi, width, false, (T)1, 1, 2, ins, outs);   // pass 1 of both planes, one launch
         ColDivArgs<T> a{};
-        a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = kp; a.width = width;
+        a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = width;
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
         a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
         a.rband = clampr(rband); a.ny = ny;

@@ -119,13 +119,16 @@ int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, v
     void* out = out_kappa_hc ? out_kappa_hc : q->kk;
     if (out_kappa_hc && zero_outside)
         if (int rc = zero_complement(p, out, q->wk, q->rk, (hipStream_t)stream)) return rc;
+    // intermediates live on the plan's compact work planes (Fft2dPlan::work_pitch): only `out` has the caller's pitch
+    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
+    hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (real_map) rc = oa_qe_map_legs_cols(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, stream);
-    else rc = oa_qe_legs_cols(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, stream);
+    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st);
+    else rc = qe_legs_cols_w(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st);
     if (rc) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx);
-    if ((rc = oa_qe_rows(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s, 0, q->wl, q->wk, q->mrow, stream))) return rc;
-    return oa_qe_cols_div(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, stream);
+    if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s, 0, q->wl, q->wk, q->mrow, pl, pk, st))) return rc;
+    return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st);
 }
 
 int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* const* host_FG, const void* const* host_FH,
@@ -138,14 +141,16 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
     if (!accumulate && zero_outside && out != q->kk)
         if (int rc = zero_complement(p, out, kappa_cols, kappa_rows, (hipStream_t)stream)) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx);
-    // the leg planes double as the accumulators' inputs: products accumulate in g[0], g[1] over the separable pieces
+    const long pl = work_pitch(p, leg_cols), pk = work_pitch(p, kappa_cols);
+    hipStream_t st = (hipStream_t)stream;
+    // products accumulate in g[0], g[1] over the separable pieces (compact work planes)
     for (int i = 0; i < npieces; ++i) {
         const bool sw = host_swap && host_swap[i];
-        int rc = oa_qe_legs_cols(p, sw ? kY : kX, sw ? kX : kY, host_FG[i], host_FH[i], q->c[0], q->c[1], q->c[2], leg_cols, leg_rows, stream);
+        int rc = qe_legs_cols_w(p, sw ? kY : kX, sw ? kX : kY, host_FG[i], host_FH[i], q->c[0], q->c[1], q->c[2], leg_cols, leg_rows, pl, st);
         if (rc) return rc;
-        if ((rc = oa_qe_rows(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], host_signs[i] * s * s, i > 0, leg_cols, kappa_cols, mrow, stream))) return rc;
+        if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], host_signs[i] * s * s, i > 0, leg_cols, kappa_cols, mrow, pl, pk, st))) return rc;
     }
-    return oa_qe_cols_div(p, q->g[0], q->g[1], Fnorm, out, accumulate, kappa_cols, kappa_rows, stream);
+    return qe_cols_div_w(p, q->g[0], q->g[1], Fnorm, out, accumulate, kappa_cols, kappa_rows, pk, st);
 }
 
 int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream) {
@@ -172,6 +177,34 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     Pipeline* q = (Pipeline*)p->pipe;
     if (int rc = oa_qe_tt(p, real_map, nullptr, nullptr, nullptr, 0, stream)) return rc;
     return bandpower_moments(p, q, n, S, C, stream);
+}
+
+/* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py):
+ * 0 = row R2C of the map, 1 = forward column pass 1, 2 = fused forward pass 2 + leg filters + inverse pass 1 and the
+ * 3-plane inverse pass 2, 3 = fused row stage, 4 = 2-plane forward pass 1 + divergence kernel, 5 = binned power +
+ * moment accumulation (into plan-owned dummies).  Stages read what the previous ones left in the work planes. */
+int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_qe_tt_stage: call oa_plan_set_filters first");
+    Pipeline* q = (Pipeline*)p->pipe;
+    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
+    hipStream_t st = (hipStream_t)stream;
+    const double s = 1.0 / ((double)p->ny * p->nx);
+    switch (stage) {
+        case 0: case 1: case 2:
+            OA_REQUIRE(real_map, "oa_qe_tt_stage: stages 0-2 need the map");
+            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage);
+        case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s, 0, q->wl, q->wk, q->mrow, pl, pk, st);
+        case 4: return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st);
+        case 5: {
+            OA_REQUIRE(q->ids, "oa_qe_tt_stage: stage 5 needs oa_plan_set_bins");
+            // dummies: the tail of the (nids-long) sums / counts_tmp buffers is not large enough for C: use the kT plane
+            int64_t* n = (int64_t*)q->kT;
+            double* S = (double*)q->kT + 8;
+            double* C = S + q->nids;
+            return bandpower_moments(p, q, n, S, C, stream);
+        }
+        default: return fail("oa_qe_tt_stage: stage must be 0..5");
+    }
 }
 
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S, double* C,

@@ -69,6 +69,10 @@ int oa_plan_create(int ny, int nx, int dtype, oa_plan** out) {
     p->dtype = dtype; p->kp = kpitch_for(nx); p->pow2 = pow2;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail("hipGetDevice failed"); }
     int rc = pow2 ? ((dtype == OA_F32) ? upload_tables<float>(p) : upload_tables<double>(p)) : czt_setup(p);
+    // scratch for every transform of a power-of-two plan (two hc planes >= one full complex plane) is taken HERE, so
+    // that no stream-ordered entry point ever synchronises the device or frees memory (plan_ensure_scratch grows it
+    // only for the chirp-z work planes, at set-up time)
+    if (!rc && pow2) rc = plan_ensure_scratch(p, 2 * (size_t)ny * p->kp * 2 * (dtype == OA_F32 ? sizeof(float) : sizeof(double)));
     if (rc) { oa_plan_destroy(p); return rc; }
     *out = p;
     return 0;

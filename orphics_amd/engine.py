@@ -204,6 +204,7 @@ class Engine(object):
         self.pow2 = (self.ny & (self.ny - 1)) == 0 and (self.nx & (self.nx - 1)) == 0
         self._laxes = None
         self._bin_scratch = None
+        self._last_stream = None          # the plan's scratch planes are single-buffered: see _ordered()
 
     def __del__(self):
         try:
@@ -212,6 +213,16 @@ class Engine(object):
                 self.plan = None
         except Exception:
             pass
+
+    def _ordered(self):
+        """One plan = one set of scratch planes.  Calls arriving on a DIFFERENT torch stream than the previous call
+        are ordered behind it (``wait_stream``), so two streams sharing an Engine serialise on the scratch instead
+        of racing on it; handles meant to overlap use their own plan (``lensing.Estimator.fork``)."""
+        cur = torch.cuda.current_stream()
+        last = self._last_stream
+        if last is not None and last != cur:
+            cur.wait_stream(last)
+        self._last_stream = cur
 
     # ---- allocation -------------------------------------------------------
     def real(self, *lead):
@@ -255,6 +266,7 @@ class Engine(object):
         columns of ``out`` are produced (callers that filter with a band-limited mask; see ACTIVE COLUMNS in
         include/orphics_amd.h) -- the rest of ``out`` is left untouched; ``rband`` > 0: only the rows
         y < rband or y > ny - rband of those columns hold the transform, the other rows are undefined."""
+        self._ordered()
         self._chk(x, "real")
         out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), int(width), int(rband), _stream()))
@@ -263,6 +275,7 @@ class Engine(object):
     def irfft(self, k, scale=None, out=None, width=0):
         """hc -> real; default scale 1/Npix (pixell fft.ifft normalize=True, maps.py:1633).
         ``width`` > 0 asserts that columns >= width of ``k`` are zero (they are not read)."""
+        self._ordered()
         self._chk(k, "hc")
         out = self.real() if out is None else _dirty(self._chk(out, "real"))
         if scale is None:
@@ -271,6 +284,7 @@ class Engine(object):
         return out
 
     def cfft(self, z, inverse=False, scale=1.0, out=None):
+        self._ordered()
         self._chk(z, "full")
         out = self.full() if out is None else _dirty(self._chk(out, "full"))
         check(self.lib.oa_fft_c2c(self.plan, _ptr(z), _ptr(out), 1 if inverse else 0, float(scale), _stream()))
@@ -278,6 +292,7 @@ class Engine(object):
 
     def fft_cols(self, k, inverse=False, scale=1.0, out=None, width=0):
         """Column transforms only (hc -> hc, out != in); ``width`` > 0: first ``width`` columns only."""
+        self._ordered()
         self._chk(k, "hc")
         out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_fft_cols(self.plan, _ptr(k), _ptr(out), 1 if inverse else 0, float(scale), int(width), _stream()))
@@ -299,6 +314,7 @@ class Engine(object):
     def qe_legs_cols(self, kX, kY, FG, FH, out, width=0, rband=0):
         """Fused leg filters + inverse column transforms (3 planes out, ready for qe_rows); ``width`` > 0:
         the filters vanish for columns >= width, which are neither read nor produced."""
+        self._ordered()
         self._chk(kX, "hc"); self._chk(kY, "hc"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
         gx, gy, h = out
         for t in out:
@@ -309,6 +325,7 @@ class Engine(object):
     def qe_map_legs_cols(self, tmap, FG, FH, out, width=0, rband=0):
         """Real map -> the three column-transformed leg planes (both legs from this map): row R2C, forward column
         pass 1, then ONE kernel for forward pass 2 + leg filters + inverse pass 1, then the inverse pass 2."""
+        self._ordered()
         self._chk(tmap, "real"); self._chk(FG, "hcreal"); self._chk(FH, "hcreal")
         gx, gy, h = out
         for t in out:
@@ -320,6 +337,7 @@ class Engine(object):
     def qe_cols_div(self, px, py, Fnorm, out=None, accumulate=False, width=0, rband=0):
         """Fused forward column transforms + divergence * normalisation; ``width`` > 0: only the first
         ``width`` columns of ``out`` are produced (Fnorm vanishes beyond them)."""
+        self._ordered()
         self._chk(px, "hc"); self._chk(py, "hc"); self._chk(Fnorm, "hcreal")
         out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
         check(self.lib.oa_qe_cols_div(self.plan, _ptr(px), _ptr(py), _ptr(Fnorm), _ptr(out), 1 if accumulate else 0, int(width), int(rband), _stream()))

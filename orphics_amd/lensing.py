@@ -231,6 +231,35 @@ class Estimator(object):
         other._acc = None
         return other
 
+    def astype(self, dtype):
+        """The same estimator (filters, normalisations, MV weights: all computed once with the f64 kernels and kept on
+        the host) with its per-map kernels in another precision: device planes are converted, nothing is recomputed.
+        ``q64.astype("f32")`` is how a parity run and a production run share one expensive set-up."""
+        import copy
+        if dtype == self.prec:
+            return self
+        other = copy.copy(self)
+        other._token = object()
+        other.prec = dtype
+        other.eng = maps._engine(self.shape, dtype)
+        other.eng.set_laxes(*self.geom.laxes())
+        rdt = other.eng.rdt
+        other._F = {k: tuple(t.to(rdt) for t in v) for k, v in self._F.items()}
+        if getattr(self, "_gen", None) is not None:
+            other._gen = {}
+            for XY, G in self._gen.items():
+                G2 = {k: v for k, v in G.items() if k != "c_args"}
+                G2["pieces"] = [(sg, fg.to(rdt), fh.to(rdt), sw) for (sg, fg, fh, sw) in G["pieces"]]
+                G2["Fnorm"] = G["Fnorm"].to(rdt)
+                other._gen[XY] = G2
+        if getattr(self, "_mv", None) is not None:
+            other._mv = (self._mv[0], {k: v.to(rdt) for k, v in self._mv[1].items()})
+        other.AL, other.Nlkk = dict(self.AL), dict(self.Nlkk)
+        other._work = None
+        other._rwork = None
+        other._bins = None
+        return other
+
     # ---- data plumbing -----------------------------------------------------------------
     def _as_hc(self, x, alreadyFTed):
         """Map / FT in any accepted container -> hc tensor of the run precision."""
@@ -266,6 +295,7 @@ class Estimator(object):
         from ._lib import check
         from .engine import _ptr
         e = self.eng
+        e._ordered()                      # the plan's work planes are single-buffered (Engine._ordered)
         if getattr(e, "_pipe_owner", None) is not self._token:
             FG, FH, Fn = self._F["TT"]
             wl, wk = self._W["TT"]
@@ -611,6 +641,7 @@ class Estimator(object):
             e._chk(out, "hc")
             zero = 1 if ((wk or rk) and not accumulate and owned_clean_region(out) != (wk, rk)) else 0
         Fn = G["Fnorm"] if norm is None else norm
+        e._ordered()
         check(e.lib.oa_qe_pol(e.plan, n, signs, fgs, fhs, swaps, _ptr(kX), _ptr(kY), _ptr(Fn), _ptr(out), 1 if accumulate else 0,
                               int(wl), int(wk), int(rl), int(rk), int(self.mrow), zero, _stream()))
         mark_dirty(out)
