@@ -71,26 +71,6 @@ __device__ __forceinline__ cx<float> operator*(cx<float> a, cx<float> b) {
 }
 #endif
 
-// streaming (use-once) global accesses of the column passes: -DOA_COL_NT marks them non-temporal
-template <typename T> OA_HD cx<T> ld_stream(const cx<T>* p) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(OA_COL_NT)
-    typedef T vec2 __attribute__((ext_vector_type(2)));
-    const vec2 v = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
-    return mk<T>(v.x, v.y);
-#else
-    return *p;
-#endif
-}
-template <typename T> OA_HD void st_stream(cx<T>* p, cx<T> v) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(OA_COL_NT)
-    typedef T vec2 __attribute__((ext_vector_type(2)));
-    vec2 w; w.x = v.x; w.y = v.y;
-    __builtin_nontemporal_store(w, reinterpret_cast<vec2*>(p));
-#else
-    *p = v;
-#endif
-}
-
 OA_HD int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -876,7 +876,7 @@ struct ColLoad {
     bool inv;
     template <typename U> OA_HD cx<U> get(int n, int c) const {
         cx<U> x = mk<U>((U)0, (U)0);
-        if (c < ncols) x = ld_stream(base + ((unsigned)n * nstride + (unsigned)c));
+        if (c < ncols) x = base[(unsigned)n * nstride + (unsigned)c];
         return inv ? swp(x) : x;
     }
 };
@@ -895,7 +895,7 @@ struct ColStore {
         if (rb) { const int y = row0 + k * rowstep; if (y >= rb && y <= ny - rb) return; }
         if (tw) v = v * tw[k];
         if (inv) v = swp(v);
-        st_stream(base + ((unsigned)k * kstride + (unsigned)c), v * scale);
+        base[(unsigned)k * kstride + (unsigned)c] = v * scale;
     }
 };
 

@@ -21,5 +21,5 @@ for nx, w in ((8192, 380), (1024, 380), (8192, 664), (2048, 664)):
     mb = 2 * 8192 * w * 8 / 1e6
     for pid, name in ((1, "pass1"), (2, "pass2 (in place)")):
         us = t(lambda: e.fft_pass(pid, s1, s2, w))
-        print("ny=8192 nx=%5d pitch=%5d width=%4d %-16s %7.1f us  %.2f TB/s" % (nx, e.kp, w, name, us, mb / us / 1e6 * 1e6 / 1e6), flush=True)
+        print("ny=8192 nx=%5d pitch=%5d width=%4d %-16s %7.1f us  %.2f TB/s" % (nx, e.kp, w, name, us, mb / us), flush=True)
     del e, s1, s2
