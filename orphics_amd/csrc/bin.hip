@@ -92,6 +92,41 @@ OA_D void wave_accum(bool valid, int id, double v, double cw, int ci, double* ro
     }
 }
 
+// Sorted fast path.  Radial ids are non-decreasing along a row of the half plane, so the keys of a wave-instruction are
+// (almost always) SORTED over the lanes: one segmented inclusive scan (6 shuffle steps for every id at once) replaces
+// the match loop above (6+ dependent shuffle steps PER DISTINCT ID -- the latency that dominated the active-region
+// launch).  Every lane passes a key, also lanes without a value (`valid` false: they contribute zero and must carry a
+// key that keeps the sequence sorted); the last lane of each run of equal keys adds the run total to the wave's
+// private LDS row -- distinct keys, distinct addresses, fixed order: deterministic.  Returns false (nothing done)
+// when the keys are not sorted; the caller then falls back to wave_accum.
+template <bool WEIGHTED>
+OA_D bool wave_accum_sorted(bool valid, int key, double v, double cw, int ci, int nids, double* row_sum, double* row_w,
+                            unsigned long long* row_cnt, int lane) {
+    const int prev = __shfl_up(key, 1, 64);
+    if (__ballot(lane > 0 && prev > key)) return false;
+    if (!valid) { v = 0.0; cw = 0.0; ci = 0; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int pk = __shfl_up(key, d, 64);
+        const double pv = __shfl_up(v, d, 64);
+        const bool same = lane >= d && pk == key;
+        if (WEIGHTED) {
+            const double pw = __shfl_up(cw, d, 64);
+            if (same) { v += pv; cw += pw; }
+        } else {
+            const int pc = __shfl_up(ci, d, 64);
+            if (same) { v += pv; ci += pc; }
+        }
+    }
+    const int next = __shfl_down(key, 1, 64);
+    const bool tail = lane == 63 || next != key;
+    if (tail && key >= 0 && key < nids) {
+        if (WEIGHTED) { row_sum[key] += v; row_w[key] += cw; }
+        else { row_sum[key] += v; row_cnt[key] += (unsigned long long)ci; }
+    }
+    return true;
+}
+
 // POWER: `data`/`data2` are complex planes and the binned value is Re(conj(k1) k2) * pnorm
 // (FourierCalc.f2power fused into the histogram: the 2-D power plane never exists in HBM)
 template <typename T, bool WEIGHTED, bool POWER>
@@ -116,15 +151,23 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
     // only the rows of the band |ky index| < rb, i.e. y < rb or y > ny - rb  (2 rb - 1 rows)
     const long nyf = n / hp;
     const long nrows = (wq && rb && 2L * rb - 1 < nyf) ? 2L * rb - 1 : nyf;
-    const long nchunks = wq ? nrows * (long)wq : (n + 3) / 4;
+    // Hermitian (row-structured) planes: the chunks of a visited row are padded to a whole number of waves in the
+    // VIRTUAL index, so a wave never straddles two rows and its ids stay sorted (wave_accum_sorted)
+    const unsigned rowc = wq ? wq : (nxh >= 0 ? (hp >> 2) : 0u);     // chunks per visited row (0: flat data)
+    const unsigned rowp = (rowc + 63u) & ~63u;
+    const long nchunks = rowc ? nrows * (long)rowp : (n + 3) / 4;
     for (long base = (long)blockIdx.x * BIN_BLOCK; base < nchunks; base += (long)gridDim.x * BIN_BLOCK) {
         const long cv = base + tid;      // virtual chunk index over the visited region
-        const bool cin = cv < nchunks;
+        bool cin = cv < nchunks;
         long c = cv;
-        if (wq) {
-            const long r = cv / wq;
-            const long y = (nrows == nyf || r < (long)rb) ? r : nyf - nrows + r;
-            c = y * (long)(hp >> 2) + (cv - r * wq);
+        unsigned col0 = 0;               // column of the chunk's first element
+        if (rowc) {
+            const unsigned r = (unsigned)(cv / rowp);      // < 2^31 rows x padded chunks: the quotient fits 32 bits
+            const unsigned q = (unsigned)(cv - (long)r * rowp);
+            const long y = (nrows == nyf || (long)r < (long)rb) ? (long)r : nyf - nrows + (long)r;
+            c = y * (long)(hp >> 2) + q;
+            cin = cin && q < rowc;
+            col0 = q * 4u;
         }
         const long i0 = c * 4;
         int id[4];
@@ -162,8 +205,6 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
                 cw[j] = (WEIGHTED && ok[j]) ? (double)w[i0 + j] : 1.0;
             }
         }
-        unsigned col0 = 0;
-        if (nxh >= 0) col0 = (unsigned)((unsigned long long)i0 % hp);  // hp % 4 == 0: the chunk stays in one row
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int m = 1;
@@ -178,19 +219,39 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
             else v[j] = v[j] * (double)m;
             ci[j] = m;
         }
-        // per-lane run merge, then wave-level flushes
-        bool cur_ok = ok[0];
-        int cur_id = id[0], cur_ci = ci[0];
-        double cur_v = v[0], cur_w = cw[0];
+        // per-lane run merge: up to 4 runs of equal ids (a lane holds 4 consecutive columns: usually 1 run, 2 where
+        // a bin edge falls inside the chunk)
+        // (all indices below are compile-time after unrolling: a runtime-indexed local array would live in scratch)
+        int rid[4], rc[4], nr = 0, last = 0;
+        double rv[4], rw[4];
 #pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            const bool same = cur_ok && ok[j] && id[j] == cur_id;
-            const bool flush = cur_ok && !same;
-            wave_accum<WEIGHTED>(flush, cur_id, cur_v, cur_w, cur_ci, row_sum, row_w, row_cnt, lane);
-            if (same) { cur_v += v[j]; cur_w += cw[j]; cur_ci += ci[j]; }
-            else { cur_ok = ok[j]; cur_id = id[j]; cur_v = v[j]; cur_w = cw[j]; cur_ci = ci[j]; }
+        for (int j = 0; j < 4; ++j) { rid[j] = 0; rc[j] = 0; rv[j] = 0.0; rw[j] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ok[j]) {
+                if (!(nr > 0 && last == id[j])) { ++nr; last = id[j]; }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (nr - 1 == t) { rid[t] = id[j]; rv[t] += v[j]; rw[t] += cw[j]; rc[t] += ci[j]; }
+            }
         }
-        wave_accum<WEIGHTED>(cur_ok, cur_id, cur_v, cur_w, cur_ci, row_sum, row_w, row_cnt, lane);
+        // run k of every lane in one wave-level step: sorted keys -> segmented scan, anything else -> match loop.
+        // A lane without a k-th run passes its last key (keeps the sequence sorted) and no value; a lane without any
+        // run sits beyond the end of its row: key = INT_MAX.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!__ballot(nr > k)) break;
+            const bool has = k < nr;
+            int key = 0x7fffffff, kc = 0;
+            double kv = 0.0, kw = 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool pick = has ? (t == k) : (t == nr - 1);     // own k-th run, else the lane's last run (key only)
+                if (pick) { key = rid[t]; kv = rv[t]; kw = rw[t]; kc = rc[t]; }
+            }
+            if (!wave_accum_sorted<WEIGHTED>(has, key, kv, kw, kc, nids, row_sum, row_w, row_cnt, lane))
+                wave_accum<WEIGHTED>(has, key, kv, kw, kc, row_sum, row_w, row_cnt, lane);
+        }
     }
     __syncthreads();
     for (int i = tid; i < nids; i += BIN_BLOCK) {
@@ -249,7 +310,9 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
     unsigned wq = 0;                                  // 4-element chunks visited per row (0 = whole rows)
     if (active_cols > 0 && nxh >= 0 && hp > 0 && (long)active_cols < hp && n % hp == 0) wq = (unsigned)((active_cols + 3) / 4);
     const unsigned rb = (wq && active_rows > 0 && 2L * active_rows - 1 < n / hp) ? (unsigned)active_rows : 0u;
-    const long nchunks = wq ? (rb ? 2L * rb - 1 : n / hp) * (long)wq : (n + 3) / 4;
+    const unsigned rowc = wq ? wq : ((nxh >= 0 && hp > 0) ? (unsigned)(hp >> 2) : 0u);   // as in the kernel
+    const long rowp = (long)((rowc + 63u) & ~63u);
+    const long nchunks = rowc ? (rb ? 2L * rb - 1 : n / hp) * rowp : (n + 3) / 4;
     int G = (int)((nchunks + BIN_BLOCK - 1) / BIN_BLOCK);
     if (G < 1) G = 1;
     if (G > BIN_GMAX) G = BIN_GMAX;

@@ -144,10 +144,13 @@ class bin2D(object):
         return E.dev_bin(d.reshape(-1), self._ids, self._nids, weights=None if w is None else w.reshape(-1), aux=aux,
                          mode=mode, skip_nan=skip_nan)
 
-    def bin(self, data2d, weights=None, err=False, get_count=False, mask_nan=False):
-        """stats.py:790-811.  ``err=True`` returns the standard error of the
-        bin mean sqrt(sum (x-mu_b)^2/(c-1)/c); the reference shifts mu_b by one bin
-        (loop index bug, stats.py:799-801) -- the intended statistic is computed."""
+    def bin(self, data2d, weights=None, err=False, get_count=False, mask_nan=False, err_reference_indexing=False):
+        """stats.py:790-811.  ``err=True`` returns the standard error of the bin mean
+        sqrt(sum_b (x - mu_b)^2 / (c_b - 1) / c_b).  DEVIATION, on purpose: the reference's loop runs its index over
+        0..nbins-1 against the 1-based bin ids (stats.py:799-801), so it subtracts the mean of the NEXT bin from
+        the members of bin i (constant-per-bin data does not give 0 there).  The intended statistic is the default;
+        ``err_reference_indexing=True`` reproduces the reference's shifted one (pinned by the fixture
+        ``a_err_ref_shifted`` made from the real orphics.stats.bin2D)."""
         torch = _torch()
         if weights is None:
             sums, counts = self._raw(data2d, skip_nan=mask_nan)
@@ -157,6 +160,14 @@ class bin2D(object):
             if err:
                 cfull = counts.to(torch.float64)
                 mean = torch.where(cfull > 0, sums / cfull, torch.zeros_like(sums))
+                if err_reference_indexing:
+                    # reference: meanmap[digitized == i] = res[i], res = bincount[1:-1]  ->  members of id i get the
+                    # mean of id i + 1 (ids 0..nbins-1 only); everything else keeps meanmap = 0
+                    nb = self.bin_edges.size - 1
+                    shifted = torch.zeros_like(mean)
+                    hi = min(nb, self._maxid - 1)
+                    shifted[:hi] = mean[1:hi + 1]
+                    mean = shifted
                 ssq, _ = self._raw(data2d, aux=mean, mode=1, skip_nan=mask_nan)
                 with np.errstate(divide="ignore", invalid="ignore"):
                     std = np.sqrt(self._slice(ssq.cpu().numpy()) / (count - 1) / count)

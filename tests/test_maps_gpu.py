@@ -206,6 +206,11 @@ def test_bin2d_against_reference_golden(golden_dir):
     np.testing.assert_allclose(r, g["a_res_nan"], rtol=1e-13)
     _, _, s = b.bin(g["a_data"], err=True)
     np.testing.assert_allclose(s, so.bin2D(g["a_modlmap"], g["a_edges"]).bin(g["a_data"], err=True)[2], rtol=1e-10)
+    # the documented deviation: the reference's err loop is shifted by one bin (stats.py:799-801); the flag reproduces
+    # the real reference's output (fixture), the default does not
+    _, _, s_ref = b.bin(g["a_data"], err=True, err_reference_indexing=True)
+    np.testing.assert_allclose(s_ref, g["a_err_ref_shifted"], rtol=1e-10)
+    assert np.max(np.abs(s / g["a_err_ref_shifted"] - 1)) > 1e-3
     bt = stats.bin2D(g["t_modlmap"], g["t_edges"])
     assert np.array_equal(bt.digitized, g["t_digitized"])  # exact ties on integer edges
     _, r, cnt = bt.bin(g["t_data"], get_count=True)
