@@ -50,11 +50,16 @@ def steps_from(rows, key_time):
 
 
 def steady(steps, keep=8):
-    """the last `keep` steps whose kernel-name sequence equals the final step's"""
+    """the last `keep` steps of the dominant kernel-name sequence (most dispatches in total): the timed loop's full
+    pipeline, not the per-stage timing calls bench.py makes after it"""
     if not steps:
         return []
-    sig = [r["Kernel_Name"] for r in steps[-1]]
-    good = [s for s in steps if [r["Kernel_Name"] for r in s] == sig]
+    weight = {}
+    for s in steps:
+        sig = tuple(r["Kernel_Name"] for r in s)
+        weight[sig] = weight.get(sig, 0) + len(sig)
+    sig = max(weight, key=weight.get)
+    good = [s for s in steps if tuple(r["Kernel_Name"] for r in s) == sig]
     return good[-keep:]
 
 
