@@ -153,6 +153,19 @@ int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const v
  *                        interleaved re/im doubles, if meanfield_acc != NULL).  No host synchronisation. */
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
                         int leg_rows, int kappa_rows, int mrow);
+/* COLUMN GRID of the one-call TT path (the y-axis counterpart of the ROW GRID above).  Legs confined to the rows
+ * |ky index| < leg_rows have real-space products confined to |ky index| <= 2 (leg_rows - 1); evaluated on
+ * mcol >= max(2 leg_rows + kappa_rows, 2 kappa_rows) rows (a power of two < ny) no aliased product frequency reaches
+ * the kept rows |ky index| < kappa_rows, which therefore equal the full-resolution result (the grid-size factor is
+ * folded into the scale).  The input transform is still taken at full resolution (every map pixel is read); the
+ * inverse column transforms of the legs, the row stage and the forward column transforms of the products run on
+ * mcol instead of ny rows.  Filters, ly axis, kX / kY and the kappa output stay on the full-resolution grid (the
+ * kernels address row y + (y >= mcol/2 ? ny - mcol : 0)).  oa_plan_set_filters selects -1 (auto: the smallest such
+ * power of two, or none if that is >= ny or the filters have no row band) unless mrow == 0, which selects 0 (the map's
+ * own rows, as for the row grid).  oa_plan_set_col_grid overrides: -1 auto, 0 off, > 0 explicit (checked against the
+ * bound); oa_plan_col_grid returns the resolved grid (0 = ny). */
+int oa_plan_set_col_grid(oa_plan* p, int mcol);
+int oa_plan_col_grid(const oa_plan* p);
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);
 void* oa_plan_kappa(oa_plan* p);
 const int64_t* oa_plan_bin_counts(oa_plan* p);

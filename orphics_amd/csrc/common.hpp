@@ -67,6 +67,7 @@ struct oa_plan {
     void* cz_bhat; void* cz_a; void* cz_f;   // cx<T>[My*Mx]: chirp-kernel transform, two work planes
     void* cz_full;                           // cx<T>[ny*nx]
     void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
+    void* tw_y_small; int my_small;          // COLUMN GRID of the one-call estimator path: cx<T>[my_small] = W_my^k
 };
 
 namespace oa {
@@ -79,14 +80,16 @@ int czt_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStre
 void pipeline_release(oa_plan* p);
 // fused estimator passes on the plan's compact work planes (fft.hip)
 long work_pitch(const oa_plan* p, int w);
+// my > 0: COLUMN GRID -- legs, row stage and divergence run on my < ny rows (plan_ensure_col_grid(p, my) first)
+int plan_ensure_col_grid(oa_plan* p, int my);
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
-                       int rband, long pl, hipStream_t st, int stages = 7);
+                       int rband, long pl, hipStream_t st, int stages = 7, int my = 0);
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                   int width, int rband, long pl, hipStream_t st);
+                   int width, int rband, long pl, hipStream_t st, int my = 0);
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
-              int win, int wout, int mrow, long pl, long pk, hipStream_t st);
+              int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0);
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
-                  long pk, hipStream_t st);
+                  long pk, hipStream_t st, int my = 0);
 }
 #define OA_NEED_POW2(p, what) \
     OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

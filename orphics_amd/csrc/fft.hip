@@ -161,6 +161,31 @@ static Fft2dPlan<T> view(const oa_plan* p) {
     f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y;
     return f;
 }
+// COLUMN GRID view: the same map transformed on my < ny rows (plan_ensure_col_grid made the W_my table)
+template <typename T>
+static Fft2dPlan<T> coarse_view(const oa_plan* p, int my) {
+    Fft2dPlan<T> f = view<T>(p);
+    if (my > 0 && my < p->ny && my == p->my_small) {
+        f.ny = my; f.logNy = ilog2(my); f.tw_y = (const cx<T>*)p->tw_y_small; f.ny_full = p->ny;
+    }
+    return f;
+}
+int plan_ensure_col_grid(oa_plan* p, int my) {
+    if (my <= 0 || my >= p->ny || p->my_small == my) return 0;
+    if (!is_pow2(my) || my < 32) return fail("column grid must be a power of two >= 32");
+    if (p->tw_y_small) { OA_HIP(hipDeviceSynchronize()); OA_HIP(hipFree(p->tw_y_small)); p->tw_y_small = nullptr; p->my_small = 0; }
+    if (p->dtype == OA_F32) {
+        auto t = make_twiddles<float>(my);
+        OA_HIP(hipMalloc(&p->tw_y_small, t.size() * sizeof(cx<float>)));
+        OA_HIP(hipMemcpy(p->tw_y_small, t.data(), t.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+    } else {
+        auto t = make_twiddles<double>(my);
+        OA_HIP(hipMalloc(&p->tw_y_small, t.size() * sizeof(cx<double>)));
+        OA_HIP(hipMemcpy(p->tw_y_small, t.data(), t.size() * sizeof(cx<double>), hipMemcpyHostToDevice));
+    }
+    p->my_small = my;
+    return 0;
+}
 
 template <typename T>
 static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, int width, int rband, hipStream_t st) {
@@ -208,9 +233,9 @@ static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double 
 }
 template <typename T>
 static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-                        int accumulate, int win, int wout, int mrow, hipStream_t st, long pin = 0, long pout = 0) {
+                        int accumulate, int win, int wout, int mrow, hipStream_t st, long pin = 0, long pout = 0, int my = 0) {
     HipLauncher q{st};
-    auto f = view<T>(p);
+    auto f = coarse_view<T>(p, my);
     const int wi = f.clampw(win), wo = f.clampw(wout);
     if (mrow < 0) {                                                         // auto: smallest alias-free grid
         mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo);
@@ -227,16 +252,16 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
 
 template <typename T>
 static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy,
-                          void* h, int width, int rband, hipStream_t st, long pout = 0) {
+                          void* h, int width, int rband, hipStream_t st, long pout = 0, int my = 0, long pin = 0) {
     HipLauncher q{st};
-    view<T>(p).legs_cols(q, (const cx<T>*)kX, (const cx<T>*)kY, (const T*)FG, (const T*)FH, (const T*)p->lxd,
-                         (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, rband, 0, pout);
+    coarse_view<T>(p, my).legs_cols(q, (const cx<T>*)kX, (const cx<T>*)kY, (const T*)FG, (const T*)FH, (const T*)p->lxd,
+                                    (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, rband, pin, pout, true);
     return q.rc;
 }
 // real map -> the three column-transformed leg planes (both legs from this one map)
 template <typename T>
 static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7) {
+                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7, int my = 0) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
@@ -247,7 +272,16 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
     const long pw = pwork > 0 ? pwork : p->kp;          // pitch of the two scratch planes
     // stages (per-kernel timing, oa_qe_tt_stage): 1 = row R2C, 2 = forward column pass 1, 4 = fused legs + inverse pass 2
     if (stages & 1) f.rows(q, ROW_R2C, map, p->nx / 2, tA, pw, (T)1, w);
-    if (Fft2dPlan<T>::has_fwdlegs(p->logNy)) {
+    if (my > 0 && my < p->ny) {
+        // COLUMN GRID: the map's transform is needed on the leg band only (forward pass 2 stores just those rows, at
+        // their full-resolution positions); legs and inverse transform then run on my rows
+        if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 1);
+        if (stages & 4) {
+            f.cols(q, tA, pw, tB, pw, w, false, (T)1, 2, 1, nullptr, nullptr, rband);
+            coarse_view<T>(p, my).legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
+                                            (cx<T>*)gy, (cx<T>*)h, width, rband, pw, pout, true);
+        }
+    } else if (Fft2dPlan<T>::has_fwdlegs(p->logNy)) {
         if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 1);       // forward pass 1 only
         if (stages & 4)
             f.legs_cols_from_pass1(q, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
@@ -262,14 +296,14 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
 
 template <typename T>
 static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
-                         int width, int rband, hipStream_t st, long pin = 0) {
+                         int width, int rband, hipStream_t st, long pin = 0, int my = 0) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
-    view<T>(p).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
-                        (cx<T>*)out, tA, tB, accumulate, width, rband, pin);
+    coarse_view<T>(p, my).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
+                                   (cx<T>*)out, tA, tB, accumulate, width, rband, pin);
     return q.rc;
 }
 
@@ -279,24 +313,24 @@ long work_pitch(const oa_plan* p, int w) {
     return p->dtype == OA_F32 ? view<float>(p).work_pitch(w) : view<double>(p).work_pitch(w);
 }
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
-                       int rband, long pl, hipStream_t st, int stages) {
-    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages)
-                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages);
+                       int rband, long pl, hipStream_t st, int stages, int my) {
+    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my)
+                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my);
 }
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                   int width, int rband, long pl, hipStream_t st) {
-    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl)
-                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl);
+                   int width, int rband, long pl, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl, my)
+                              : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl, my);
 }
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
-              int win, int wout, int mrow, long pl, long pk, hipStream_t st) {
-    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk)
-                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk);
+              int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my);
 }
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
-                  long pk, hipStream_t st) {
-    return p->dtype == OA_F32 ? cols_div_impl<float>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk)
-                              : cols_div_impl<double>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk);
+                  long pk, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? cols_div_impl<float>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk, my)
+                              : cols_div_impl<double>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk, my);
 }
 
 }  // namespace oa

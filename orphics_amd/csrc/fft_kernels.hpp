@@ -976,6 +976,10 @@ struct ColLegsArgs {
     long in_gs, in_ns, out_gs, out_ks;
     int twiddle;
     int rband, ny;   // rband > 0: the filters vanish on input rows rband <= y <= ny - rband, which are not read
+    // COLUMN GRID (include/orphics_amd.h): this transform runs on ny = My < ny_full rows; its input row y stands for
+    // row y + (y >= ny/2 ? yshift : 0) of the full-resolution grid, where the filters, the ly axis and -- when
+    // xfull -- kX / kY live.  yshift = ny_full - My; 0 = the plan's own grid.
+    int yshift, xfull;
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -1002,6 +1006,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     const cx<T>* kXb = a.kX + org; const cx<T>* kYb = a.kY + org;
     const T* FGb = a.FG + forg; const T* FHb = a.FH + forg;
     const unsigned nstr = (unsigned)(a.in_ns * a.pitch), fstr = (unsigned)(a.in_ns * a.fpitch);
+    const unsigned fsh = (unsigned)a.yshift * (unsigned)a.fpitch, xsh = a.xfull ? (unsigned)a.yshift * (unsigned)a.pitch : 0u;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -1014,8 +1019,11 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             cx<T> kx = mk<T>((T)0, (T)0), ky = kx;
             T fg = 0, fh = 0;
             bool live = ok;
-            if (a.rband) { const int y = (int)(g * a.in_gs) + n * (int)a.in_ns; live = ok && !(y >= a.rband && y <= a.ny - a.rband); }
-            if (live) { kx = kXb[i]; ky = kYb[i]; fg = FGb[fi]; fh = FHb[fi]; }
+            const int y = (int)(g * a.in_gs) + n * (int)a.in_ns;
+            if (a.rband) live = ok && !(y >= a.rband && y <= a.ny - a.rband);
+            const unsigned up = (a.yshift && y >= (a.ny >> 1)) ? 1u : 0u;     // upper half: rows of negative ky
+            const unsigned ix = i + up * xsh, ifl = fi + up * fsh;
+            if (live) { kx = kXb[ix]; ky = kYb[ix]; fg = FGb[ifl]; fh = FHb[ifl]; }
             gv[u * R0 + t] = kx * fg;
             v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
@@ -1045,7 +1053,8 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             const int j = (tid + u * NT) >> logC;
 #pragma unroll
             for (int t = 0; t < R0; ++t) {
-                const unsigned y = (unsigned)(g * a.in_gs) + (unsigned)(j + (t << (logL - LR))) * (unsigned)a.in_ns;
+                unsigned y = (unsigned)(g * a.in_gs) + (unsigned)(j + (t << (logL - LR))) * (unsigned)a.in_ns;
+                if (a.yshift && y >= (unsigned)(a.ny >> 1)) y += (unsigned)a.yshift;
                 v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * a.lyd[y]);
             }
         }
@@ -1183,6 +1192,7 @@ struct ColDivArgs {
     long in_gs, in_ns, out_gs, out_ks;
     int accumulate;
     int rband, ny;   // rband > 0: Fn vanishes on output rows rband <= y <= ny - rband, which are not written
+    int yshift;      // COLUMN GRID: output row y of this My-row transform is row y + (y >= ny/2 ? yshift : 0) of Fn, ly, out
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -1241,8 +1251,9 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
             const int k = base + (t << logNs);
             const unsigned y = (unsigned)(g * a.out_gs) + (unsigned)k * (unsigned)a.out_ks;
             if (a.rband && (int)y >= a.rband && (int)y <= a.ny - a.rband) continue;
-            const unsigned i = (unsigned)k * ostr + (unsigned)c;
-            cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y]) * Fnb[i];
+            const unsigned up = (a.yshift && y >= (unsigned)(a.ny >> 1)) ? (unsigned)a.yshift : 0u;
+            const unsigned i = (unsigned)k * ostr + (unsigned)c + up * (unsigned)a.opitch;
+            cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * Fnb[i];
             if (a.accumulate) d = d + outb[i];
             outb[i] = d;
         }

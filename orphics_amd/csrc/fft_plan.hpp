@@ -31,6 +31,10 @@ struct Fft2dPlan {
     long kp = 0;                 // half-complex pitch (complex elements)
     const cx<T>* tw_x = nullptr; // W_nx^k, k < nx
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
+    // COLUMN GRID view (fft.hip coarse_view): this plan describes ny = My rows of a map with ny_full rows; filters, ly
+    // axis and caller-owned planes are addressed at the full-resolution rows (ColLegsArgs::yshift).  0 = own grid.
+    int ny_full = 0;
+    int yshift() const { return ny_full > ny ? ny_full - ny : 0; }
     static constexpr int COLC = COL_LOGC;  // log2 columns per column tile (kernels assume it at compile time)
 
     // COMPACT WORK PLANES.  A plane with `w` active columns stored at the full pitch kp leaves each row's w*8 bytes
@@ -167,7 +171,8 @@ struct Fft2dPlan {
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
     template <class Launcher>
     void legs_cols(Launcher& q, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
-                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0, long pin = 0, long pout = 0) const {
+                   cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0, long pin = 0, long pout = 0,
+                   bool in_full = true) const {   // in_full: kX, kY are stored on the full-resolution rows (column grid views)
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
@@ -179,7 +184,7 @@ struct Fft2dPlan {
         a.pitch = pi; a.fpitch = kp; a.opitch = po;
         a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
-        a.rband = clampr(rband); a.ny = ny;
+        a.rband = clampr(rband); a.ny = ny; a.yshift = yshift(); a.xfull = in_full ? 1 : 0;
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
@@ -230,7 +235,7 @@ struct Fft2dPlan {
         a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = width;
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
         a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
-        a.rband = clampr(rband); a.ny = ny;
+        a.rband = clampr(rband); a.ny = ny; a.yshift = yshift();
         q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a);
     }
 

@@ -4,6 +4,7 @@
 // rng.hip (the same kernels the fine-grained calls launch), plus an RCCL all-reduce for hosts that do not bring
 // torch.distributed (librccl is dlopen'ed on first use, so the library has no link-time dependency on it).
 #include <dlfcn.h>
+#include <algorithm>
 #include <vector>
 #include "common.hpp"
 #include "fft_plan.hpp"
@@ -14,6 +15,8 @@ struct Pipeline {
     // filters (caller-owned device planes) + active region of the TT estimator
     const void* FG = nullptr; const void* FH = nullptr; const void* Fn = nullptr;
     int wl = 0, wk = 0, rl = 0, rk = 0, mrow = -1;
+    int mcol = -1;   // requested column grid (-1 auto, 0 = the map's own ny rows, > 0 explicit)
+    int my = 0;      // resolved: rows the legs / row stage / divergence run on (0 = ny)
     // plan-owned work planes (hc): legs x3, products x2, input transform, kappa
     void* work = nullptr;
     void* c[3] = {nullptr, nullptr, nullptr};
@@ -72,11 +75,38 @@ static int zero_complement(oa_plan* p, void* out, int wk, int rk, hipStream_t st
     return 0;
 }
 
+// COLUMN GRID.  Legs confined to rows |ky| < rl have real-space products confined to |ky| <= 2 (rl - 1); sampled on
+// my >= 2 rl + rk rows no aliased product frequency reaches the kept kappa rows |ky| < rk (same argument as the row
+// grid, include/orphics_amd.h), so the inverse column transforms, the row stage and the forward column transforms run
+// on my instead of ny rows and return the same kappa_hat rows.
+static int resolve_col_grid(oa_plan* p, Pipeline* q) {
+    q->my = 0;
+    if (q->mcol == 0 || q->rl <= 0 || q->rk <= 0) return 0;
+    const long need = std::max(2L * q->rl + q->rk, 2L * q->rk);
+    int my = q->mcol;
+    if (my < 0) { my = 64; while (my < need && my < p->ny) my <<= 1; }
+    else if (my < need) return fail("column grid < max(2*leg_rows + kappa_rows, 2*kappa_rows) would alias the leg products into the kept rows");
+    if (my >= p->ny) return 0;
+    if (int rc = plan_ensure_col_grid(p, my)) return rc;
+    q->my = my;
+    return 0;
+}
+
 }  // namespace oa
 
 using namespace oa;
 
 extern "C" {
+
+int oa_plan_set_col_grid(oa_plan* p, int mcol) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_plan_set_col_grid: call oa_plan_set_filters first");
+    OA_REQUIRE(mcol <= 0 || is_pow2(mcol), "oa_plan_set_col_grid: mcol must be -1 (auto), 0 (off) or a power of two");
+    Pipeline* q = (Pipeline*)p->pipe;
+    q->mcol = mcol;
+    return resolve_col_grid(p, q);
+}
+
+int oa_plan_col_grid(const oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->my : 0; }
 
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
                         int leg_rows, int kappa_rows, int mrow) {
@@ -86,7 +116,9 @@ int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* 
     Pipeline* q = pipe_of(p);
     q->FG = FG; q->FH = FH; q->Fn = Fnorm;
     q->wl = leg_cols; q->wk = kappa_cols; q->rl = leg_rows; q->rk = kappa_rows; q->mrow = mrow;
-    return ensure_work(p, q);
+    q->mcol = mrow == 0 ? 0 : -1;             // the map's own grid in x means the map's own grid in y too
+    if (int rc = ensure_work(p, q)) return rc;
+    return resolve_col_grid(p, q);
 }
 
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream) {
@@ -123,12 +155,13 @@ int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, v
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st);
-    else rc = qe_legs_cols_w(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st);
+    const int my = q->my;
+    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 7, my);
+    else rc = qe_legs_cols_w(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, my);
     if (rc) return rc;
-    const double s = 1.0 / ((double)p->ny * p->nx);
-    if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s, 0, q->wl, q->wk, q->mrow, pl, pk, st))) return rc;
-    return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st);
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;   // DFT on my rows = my/ny x the full one
+    if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my))) return rc;
+    return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st, my);
 }
 
 int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* const* host_FG, const void* const* host_FH,
@@ -188,13 +221,14 @@ int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
     Pipeline* q = (Pipeline*)p->pipe;
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     hipStream_t st = (hipStream_t)stream;
-    const double s = 1.0 / ((double)p->ny * p->nx);
+    const int my = q->my;
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
     switch (stage) {
         case 0: case 1: case 2:
             OA_REQUIRE(real_map, "oa_qe_tt_stage: stages 0-2 need the map");
-            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage);
-        case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s, 0, q->wl, q->wk, q->mrow, pl, pk, st);
-        case 4: return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st);
+            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my);
+        case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my);
+        case 4: return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st, my);
         case 5: {
             OA_REQUIRE(q->ids, "oa_qe_tt_stage: stage 5 needs oa_plan_set_bins");
             // dummies: the tail of the (nids-long) sums / counts_tmp buffers is not large enough for C: use the kT plane

@@ -53,7 +53,7 @@ class Estimator(object):
 
     def __init__(self, shape, wcs, theory, noise2d=None, beam2d=None, kmask=None, noise2d_P=None, kmask_P=None,
                  kmask_K=None, pol=False, grad_cut=None, unlensed_equals_lensed=False, bigell=9000, dtype="f32",
-                 theory_norm=None, prune=True, iau=False, row_grid="auto"):
+                 theory_norm=None, prune=True, iau=False, row_grid="auto", col_grid="auto"):
         # prune: let the fused kernels skip the hc columns on which the (band-limited) filters vanish --
         # same arithmetic on the remaining columns, identical results (include/orphics_amd.h, ACTIVE COLUMNS)
         self.prune = bool(prune)
@@ -62,6 +62,9 @@ class Estimator(object):
         # >= 2 leg_cols + kappa_cols -- exact for band-limited filters (include/orphics_amd.h, ROW GRID); None / "full":
         # always the map's own nx points.
         self.mrow = -1 if (self.prune and row_grid == "auto") else (0 if row_grid in (None, "full", "auto") else int(row_grid))
+        # col_grid: the same for the y axis of the one-call TT path (include/orphics_amd.h, COLUMN GRID): "auto" = the
+        # smallest power of two >= max(2 leg_rows + kappa_rows, 2 kappa_rows) when that is < ny; "full" = the map's ny rows
+        self.mcol = -1 if (self.prune and col_grid == "auto" and self.mrow != 0) else (0 if col_grid in (None, "full", "auto") else int(col_grid))
         self.iau = bool(iau)          # polarisation angle convention of the E/B inputs (FourierCalc(iau=...), maps.py:1600)
         self.shape = tuple(shape)
         self.wcs = wcs
@@ -153,6 +156,11 @@ class Estimator(object):
         y = np.nonzero(nz)[0]
         rb = int(np.minimum(y, Ny - y).max()) + 1
         return 0 if 2 * rb - 1 >= Ny else rb
+
+    @property
+    def col_grid(self):
+        """Rows the one-call TT path runs its inverse-column / row / forward-column stages on (0 = the map's ny)."""
+        return int(self._bind().lib.oa_plan_col_grid(self.eng.plan))
 
     @property
     def kappa_rows(self):
@@ -301,6 +309,7 @@ class Estimator(object):
             wl, wk = self._W["TT"]
             rl, rk = self._R["TT"]
             check(e.lib.oa_plan_set_filters(e.plan, _ptr(FG), _ptr(FH), _ptr(Fn), int(wl), int(wk), int(rl), int(rk), int(self.mrow)))
+            check(e.lib.oa_plan_set_col_grid(e.plan, int(self.mcol)))
             e._pipe_owner = self._token
             e._bins_owner = None
         return e

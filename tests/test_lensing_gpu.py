@@ -472,6 +472,48 @@ def test_active_column_pruning_is_exact():
         assert bool((c_b[1:-1] <= c_w[1:-1]).all())
 
 
+def test_column_grid_is_exact():
+    """col_grid="auto" (default): legs, row stage and divergence of the one-call TT path run on the smallest alias-free
+    power-of-two number of rows (include/orphics_amd.h, COLUMN GRID).  kappa_hat must equal the col_grid="full"
+    result (f64: rounding only), from a real map and from Fourier-space legs, with garbage outside the leg band of the
+    input and in the output plane; a grid below the alias bound is refused."""
+    from orphics_amd import lensing
+    from orphics_amd._lib import OrphicsAmdError
+    N, res = 1024, 1.0
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, res, seed=11)
+    kw = dict(noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True)
+    for prec, tol in (("f64", 1e-12), ("f32", 2e-6)):
+        qc = lensing.qest(shape, g, th, dtype=prec, **kw)
+        qf = lensing.qest(shape, g, th, dtype=prec, col_grid="full", **kw)
+        e = qc.eng
+        x = e.to_real(t1)
+        full = qf.reconstruct_tt_from_map(x).clone()
+        assert qf.col_grid == 0
+        dirty = e.hc(); dirty[:] = 3.0
+        rec = qc.reconstruct_tt_from_map(x, out=dirty).clone()
+        my = qc.col_grid
+        rl, rk = qc.leg_rows, qc.kappa_rows
+        assert 0 < my < N and my >= max(2 * rl + rk, 2 * rk) and my // 2 < max(2 * rl + rk, 2 * rk)
+        scale = float(full.abs().max())
+        assert float((rec - full).abs().max()) / scale < tol
+        assert bool((rec[rk:N - rk + 1] == 0).all()) and bool((rec[:, qc.kappa_cols:] == 0).all())
+        # Fourier-space legs (distinct X and Y), garbage outside the leg band
+        kX, kY = e.rfft(x), e.rfft(e.to_real(t2))
+        full2 = qf.reconstruct_tt_hc(kX, kY).clone()
+        kXg, kYg = kX.clone(), kY.clone()
+        kXg[rl:N - rl + 1] = 1e30; kYg[rl:N - rl + 1] = 1e30
+        kXg[:, qc.leg_cols:] = 1e30; kYg[:, qc.leg_cols:] = 1e30
+        rec2 = qc.reconstruct_tt_hc(kXg, kYg, out=dirty)
+        assert float((rec2 - full2).abs().max()) / float(full2.abs().max()) < tol
+        # explicit grids: twice the minimum is fine, half of it aliases and is refused
+        q2 = lensing.qest(shape, g, th, dtype=prec, col_grid=2 * my if 2 * my < N else my, **kw)
+        rec3 = q2.reconstruct_tt_from_map(x)
+        assert float((rec3 - full).abs().max()) / scale < tol
+        qbad = lensing.qest(shape, g, th, dtype=prec, col_grid=my // 2, **kw)
+        with pytest.raises(OrphicsAmdError):
+            qbad.reconstruct_tt_from_map(x)
+
+
 @pytest.mark.parametrize("N,res", [(1024, 1.0), (2048, 1.0)])
 def test_reconstruct_from_map_fused_forward_legs(N, res):
     """reconstruct_tt_from_map (forward column pass 2 + leg filters + inverse pass 1 in one kernel; kT never
