@@ -1,5 +1,6 @@
 // HIP launchers for the LDS-staged 2-D FFT passes (K1) + oa_fft_* entry points.
 #include "fft_launch.hpp"
+#include "fft_r2c_w64.hpp"
 
 namespace oa {
 
@@ -7,6 +8,21 @@ template <typename T, int MODE, class SEQ>
 __global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_kernel(RowArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_fft_body<T, MODE, SEQ>(c, a);
+}
+
+// one wave per row, 64 points per lane: a single wave per SIMD (LDS-limited), so the whole register file is its own
+__global__ __launch_bounds__(64, 1) void row_r2c_w64_kernel(RowW64Args a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_w64_body(c, a);
+}
+
+#ifndef OA_STREAM_WAVES_PER_EU
+#define OA_STREAM_WAVES_PER_EU 3     // two row blocks of registers (current + prefetched): 128 VGPRs spill, 168 do not
+#endif
+template <typename T, class SEQ>
+__global__ __launch_bounds__(row_maxnt<SEQ>(), OA_STREAM_WAVES_PER_EU) void row_r2c_stream_kernel(RowArgs<T> a, int ny, int nwg) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_stream_body<T, SEQ>(c, a, ny, nwg);
 }
 
 #ifndef OA_QE_WAVES_PER_EU
@@ -69,10 +85,56 @@ struct HipLauncher {
         if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
         go(row_fft_kernel<T, MODE, S>, dim3(grid), nt, smem, a);
     }
+    // resident workgroups of the streaming R2C pass: LDS-limited (160 KB per CU)
+    static int stream_wgs(size_t smem, int nt) {
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        int per = (int)(LDS_MAX / (smem ? smem : 1));
+        // workgroups of 256 threads = one wave per SIMD each: the register budget allows OA_STREAM_WAVES_PER_EU of them
+        const int wps = (nt + 255) / 256;          // waves per SIMD of one workgroup
+        if (per > OA_STREAM_WAVES_PER_EU / wps) per = OA_STREAM_WAVES_PER_EU / wps;
+        if (per < 1) per = 1;
+        return cus * per;
+    }
+    static int r2c_stream_mode() {
+        static const int m = [] { const char* e = getenv("OA_R2C_STREAM"); return e ? atoi(e) : 0; }();
+        return m;
+    }
+    static int r2c_w64_mode() {
+        static const int m = [] { const char* e = getenv("OA_R2C_W64"); return e ? atoi(e) : 1; }();
+        return m;
+    }
+    // band-limited R2C of 8192-point rows (f32): one wave per row (fft_r2c_w64.hpp)
+    bool row_w64(int ny, const RowArgs<float>& a) {
+        if (a.mode != ROW_R2C || a.logL != 12 || a.wcols > 512 || !r2c_w64_mode() || rc) return false;
+        RowW64Args w{};
+        w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
+        w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = ny;
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        w.nwg = cus * (int)(LDS_MAX / W64_LDS_BYTES);      // resident waves: one per SIMD
+        if (w.nwg > ny) w.nwg = ny;
+        hipLaunchKernelGGL(row_r2c_w64_kernel, dim3(w.nwg), dim3(64), W64_LDS_BYTES, st, w);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+        return true;
+    }
+    bool row_w64(int, const RowArgs<double>&) { return false; }
     template <typename T>
     void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (row_w64(grid << a.logC, a)) return;
         const bool ok = dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
+            if constexpr (sizeof(T) == 4 && seq_logl<S>() >= 10) {
+                const int nwg = stream_wgs(smem, nt);
+                if (a.mode == ROW_R2C && r2c_stream_mode() && grid >= 2 * nwg) {
+                    if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
+                    if (rc) return;
+                    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(row_r2c_stream_kernel<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    hipLaunchKernelGGL((row_r2c_stream_kernel<T, S>), dim3(nwg), dim3(nt), smem, st, a, grid << a.logC, nwg);
+                    hipError_t e = hipGetLastError();
+                    if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+                    return;
+                }
+            }
             switch (a.mode) {
                 case ROW_R2C: row_mode<T, ROW_R2C, S>(grid, nt, smem, a); break;
                 case ROW_C2R: row_mode<T, ROW_C2R, S>(grid, nt, smem, a); break;

@@ -11,7 +11,16 @@ struct GpuCtx {
     OA_D int bid_x() const { return blockIdx.x; }
     OA_D int bid_y() const { return blockIdx.y; }
     OA_D int bid_z() const { return blockIdx.z; }
+    // Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt: every outstanding GLOBAL load and
+    // store of the wave would have to land before the barrier -- the stores of one fused pipeline stage would stall
+    // the next stage, and loads prefetched for the next row could not stay in flight across the FFT stages.  These
+    // kernels exchange data between threads through LDS only (global data is never re-read inside a launch), so the
+    // barrier waits for this wave's LDS operations (lgkmcnt) and nothing else.
+#ifdef OA_FULL_BARRIER
     OA_D void sync() const { __syncthreads(); }
+#else
+    OA_D void sync() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
     OA_D void* smem() const { return sm; }
 };
 

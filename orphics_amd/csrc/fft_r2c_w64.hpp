@@ -1,0 +1,138 @@
+// One-wave-per-row R2C pass for band-limited consumers (f32, rows of 8192 reals = 4096 packed complex points).
+//
+// The general row pass (row_fft_body) spends its time in LDS and barriers, not in HBM: 16 points per thread means three
+// radix-16 stages = three full-row LDS round trips (192 KB per row against 128 B/clk/CU) and seven workgroup barriers
+// per row; with the global loads removed it still takes 54 of its 66 us at 8192^2 (tools/r2c_bench.py, OA_R2C_NOLOAD).
+// Here ONE wave owns a row and every lane holds 64 points: 4096 = 64 x 64 is two in-register radix-64 stages (each
+// 8 x 8, constants W64^m) around ONE LDS transpose, with no workgroup barrier at all (a single wave's LDS operations
+// execute in order).  The second stage computes only the output bins the consumers keep (columns < 512 and their
+// mirror images, which the real-transform untangle needs): 2 of the 8 outputs of each outer radix-8.
+// Lane j:  stage 1: B_j[k1] = sum_t z[j + 64 t] W64^(t k1), times W4096^(j k1)  -> LDS[k1][j]
+//          stage 2 (lane k1): Z[k1 + 64 k2] = sum_j LDS[k1][j] W64^(j k2),  k2 in [0,8) and [56,64)
+//          untangle: X[k] = E + W8192^k O,  E = (Z[k] + conj Z[4096-k]) / 2,  O = -i (Z[k] - conj Z[4096-k]) / 2
+#pragma once
+#include "fft_kernels.hpp"
+
+namespace oa {
+
+struct W64Tab {
+    static constexpr float c[64] = {1.0f, 0.9951847266721969f, 0.9807852804032304f, 0.9569403357322088f, 0.9238795325112867f, 0.881921264348355f, 0.8314696123025452f, 0.773010453362737f, 0.7071067811865476f, 0.6343932841636455f, 0.5555702330196023f, 0.4713967368259978f, 0.38268343236508984f, 0.29028467725446233f, 0.19509032201612833f, 0.09801714032956077f, 6.123233995736766e-17f, -0.09801714032956065f, -0.1950903220161282f, -0.29028467725446216f, -0.3826834323650897f, -0.4713967368259977f, -0.555570233019602f, -0.6343932841636454f, -0.7071067811865475f, -0.773010453362737f, -0.8314696123025453f, -0.8819212643483549f, -0.9238795325112867f, -0.9569403357322088f, -0.9807852804032304f, -0.9951847266721968f, -1.0f, -0.9951847266721969f, -0.9807852804032304f, -0.9569403357322089f, -0.9238795325112868f, -0.881921264348355f, -0.8314696123025455f, -0.7730104533627371f, -0.7071067811865477f, -0.6343932841636459f, -0.5555702330196022f, -0.47139673682599786f, -0.38268343236509034f, -0.29028467725446244f, -0.19509032201612866f, -0.09801714032956045f, -1.8369701987210297e-16f, 0.09801714032956009f, 0.1950903220161283f, 0.29028467725446205f, 0.38268343236509f, 0.4713967368259976f, 0.5555702330196018f, 0.6343932841636456f, 0.7071067811865474f, 0.7730104533627367f, 0.8314696123025452f, 0.8819212643483548f, 0.9238795325112865f, 0.9569403357322088f, 0.9807852804032303f, 0.9951847266721969f};
+    static constexpr float s[64] = {0.0f, 0.0980171403295606f, 0.19509032201612825f, 0.29028467725446233f, 0.3826834323650898f, 0.47139673682599764f, 0.5555702330196022f, 0.6343932841636455f, 0.7071067811865475f, 0.773010453362737f, 0.8314696123025452f, 0.8819212643483549f, 0.9238795325112867f, 0.9569403357322089f, 0.9807852804032304f, 0.9951847266721968f, 1.0f, 0.9951847266721969f, 0.9807852804032304f, 0.9569403357322089f, 0.9238795325112867f, 0.881921264348355f, 0.8314696123025455f, 0.7730104533627371f, 0.7071067811865476f, 0.6343932841636455f, 0.5555702330196022f, 0.47139673682599786f, 0.3826834323650899f, 0.2902846772544624f, 0.1950903220161286f, 0.09801714032956083f, 1.2246467991473532e-16f, -0.09801714032956059f, -0.19509032201612836f, -0.2902846772544621f, -0.38268343236508967f, -0.47139673682599764f, -0.555570233019602f, -0.6343932841636453f, -0.7071067811865475f, -0.7730104533627367f, -0.8314696123025452f, -0.8819212643483549f, -0.9238795325112865f, -0.9569403357322088f, -0.9807852804032303f, -0.9951847266721969f, -1.0f, -0.9951847266721969f, -0.9807852804032304f, -0.9569403357322089f, -0.9238795325112866f, -0.881921264348355f, -0.8314696123025455f, -0.7730104533627369f, -0.7071067811865477f, -0.6343932841636459f, -0.5555702330196022f, -0.4713967368259979f, -0.3826834323650904f, -0.2902846772544625f, -0.19509032201612872f, -0.0980171403295605f};
+};
+
+// W64^m = exp(-2 pi i m / 64), m a compile-time constant after unrolling
+OA_HD cx<float> w64(int m) { return mk<float>(W64Tab::c[m & 63], -W64Tab::s[m & 63]); }
+
+// In-register DFT of 64 points, in place.  Input natural order; output bin k = a + 8 b is left in v[8 a + b].
+// PRUNE: only the bins k in [0,8) (v[8 a]) and [56,64) (v[8 a + 7]) are produced.
+template <bool PRUNE>
+OA_HD void dft64(cx<float>* v) {
+    // inner layer: for each s0, DFT-8 over s1 of v[8 s1 + s0] -> bin a, times W64^(s0 a), stored at v[8 a + s0]
+#pragma unroll
+    for (int s0 = 0; s0 < 8; ++s0) {
+        cx<float> t[8];
+#pragma unroll
+        for (int s1 = 0; s1 < 8; ++s1) t[s1] = v[8 * s1 + s0];
+        Dft<float, 8>::run(t);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) v[8 * a + s0] = (s0 * a) ? t[a] * w64(s0 * a) : t[a];
+    }
+    // outer layer: for each a, DFT-8 over s0 of v[8 a + s0] -> bin b, i.e. output k = a + 8 b, stored at v[8 a + b]
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        cx<float>* t = v + 8 * a;
+        if (!PRUNE) {
+            Dft<float, 8>::run(t);
+        } else {
+            const float h = 0.70710678118654752440f;
+            // b = 0: plain sum;  b = 7: sum_s t[s] W8^(-s)
+            const cx<float> p04 = t[0] + t[4], m04 = t[0] - t[4], p26 = t[2] + t[6], m26 = t[2] - t[6];
+            const cx<float> p15 = t[1] + t[5], m15 = t[1] - t[5], p37 = t[3] + t[7], m37 = t[3] - t[7];
+            const cx<float> x0 = (p04 + p26) + (p15 + p37);
+            // W8^-1 = (1+i)h, W8^-2 = i, W8^-3 = (-1+i)h:  m15 (1+i) h + m37 (-1+i) h = h [(m15 - m37) + i (m15 + m37)]
+            const cx<float> d = m15 - m37, e = m15 + m37;
+            const cx<float> x7 = add_pi(m04, m26) + add_pi(d, e) * h;
+            t[0] = x0;
+            t[7] = x7;
+        }
+    }
+}
+
+struct RowW64Args {
+    const cx<float>* in;      // real rows viewed as packed complex: z[n] = x[2n] + i x[2n+1]
+    cx<float>* out;
+    long in_pitch, out_pitch; // complex elements
+    const cx<float>* tw;      // W_M^k, M = 2^logTw >= 8192
+    int logTw;
+    float scale;
+    int wcols;                // columns produced (<= 512)
+    int ny, nwg;
+};
+
+// LDS: the 64 x 64 transpose, rows of 65 complex elements (the b64 writes of consecutive lanes and the row-strided
+// reads are both conflict-free).  33 KB per wave = one wave per SIMD, which therefore owns the whole register file
+// (512): a variant that halves the LDS (transpose in two halves) to fit two waves per SIMD needs v and u live together
+// within 256 registers and spills (176 us at 8192^2).  Prefetching the next row -- all of it into 128 more registers,
+// or into the first stage's registers once they are dead -- measured slower than not prefetching (68.6 / 68.9 us vs
+// 61.1; the four waves of a CU cover each other's load phases), so each row simply loads, transforms, stores.
+constexpr int W64_LDS_STRIDE = 65;
+constexpr size_t W64_LDS_BYTES = (size_t)64 * W64_LDS_STRIDE * sizeof(cx<float>);
+
+template <class Ctx>
+OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
+    cx<float>* s = reinterpret_cast<cx<float>*>(ctx.smem());
+    const int j = ctx.tid();                       // lane = point residue (stage 1) = bin residue k1 (stage 2)
+    const int sh = a.logTw - 12;                   // W4096^e = tw[e << sh]
+    const int jm = (64 - j) & 63;
+    // per-lane twiddle bases, kept across the rows of this wave: P[a] = W4096^(j a), Q[b] = W4096^(8 j b);
+    // untangle factors U[m] = W8192^(j + 64 m)
+    cx<float> P[8], Q[8], U[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        P[i] = a.tw[(unsigned)((j * i) & 4095) << sh];
+        Q[i] = a.tw[(unsigned)((8 * j * i) & 4095) << sh];
+        U[i] = a.tw[(unsigned)(j + 64 * i) << (sh - 1)];
+    }
+    for (long row = ctx.bid_x(); row < a.ny; row += a.nwg) {
+        cx<float> v[64];
+        const cx<float>* src = a.in + row * a.in_pitch + j;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) v[t] = src[64 * t];
+        dft64<false>(v);                           // bin k1 = aa + 8 b sits in v[8 aa + b]
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int k1 = aa + 8 * b;
+                cx<float> x = v[8 * aa + b];
+                if (k1) x = x * ((aa && b) ? P[aa] * Q[b] : (aa ? P[aa] : Q[b]));
+                s[k1 * W64_LDS_STRIDE + j] = x;
+            }
+        }
+        ctx.sync();
+#pragma unroll
+        for (int t = 0; t < 64; ++t) v[t] = s[j * W64_LDS_STRIDE + t];
+        ctx.sync();                                // every read of the transpose precedes the writes below
+        dft64<true>(v);                            // lane k1 = j: Z[k1 + 64 m] in v[8 m], Z[k1 + 64 (56 + m)] in v[8 m + 7]
+#pragma unroll
+        for (int m = 0; m < 8; ++m) s[m * 64 + j] = v[8 * m + 7];
+        ctx.sync();
+        cx<float>* dst = a.out + row * a.out_pitch + j;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int k = j + 64 * m;
+            const cx<float> Zk = v[8 * m];
+            // partner Z[4096 - k]: lane (64 - j) & 63, high slot 63 - m (j > 0) or 64 - m (j = 0; m = 0: Z[0] itself)
+            const int idx = j ? (7 - m) : (8 - m);
+            cx<float> Zm = Zk;
+            if (m > 0 || j) Zm = s[(idx & 7) * 64 + jm];
+            const cx<float> E = (Zk + conj(Zm)) * 0.5f;
+            const cx<float> O = mul_mi(Zk - conj(Zm)) * 0.5f;
+            const cx<float> X = (E + U[m] * O) * a.scale;
+            if (k < a.wcols) dst[64 * m] = X;
+        }
+        ctx.sync();                                // the partner reads precede the next row's transpose writes
+    }
+}
+
+}  // namespace oa
