@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 #include "../../orphics_amd/csrc/fft_plan.hpp"
+#include "../../orphics_amd/csrc/fft_r2c_w64.hpp"
 
 using namespace oa;
 
@@ -183,7 +184,47 @@ static int do_map_legs_cols(int ny, int nx, const T* map, const T* FG, const T* 
     return hd.p.legs_cols_from_pass1(q, tB.data(), FG, FH, lxd, lyd, gx, gy, h, width, rband) ? 0 : 1;
 }
 
+// COLUMN GRID view of a (ny_full, nx) map: the column passes run on my rows, filters / ly / kX / out stay full-resolution
+template <typename T>
+struct CoarseHolder {
+    std::vector<cx<T>> twx, twy;
+    Fft2dPlan<T> p;
+    CoarseHolder(int ny_full, int my, int nx) {
+        twx = make_twiddles<T>(nx);
+        twy = make_twiddles<T>(my);
+        p.ny = my; p.nx = nx; p.logNy = ilog2(my); p.logNx = ilog2(nx);
+        p.kp = kpitch_for(nx); p.tw_x = twx.data(); p.tw_y = twy.data(); p.ny_full = ny_full;
+    }
+};
+
 extern "C" {
+// one-wave-per-row R2C pass (fft_r2c_w64.hpp): nx must be 8192; out has pitch nx/2+16
+int emu_r2c_rows_w64_f32(int ny, int nx, const float* in, void* out, double scale, int width, int nwg) {
+    if (nx != 8192 || width > 512) return 1;
+    auto tw = make_twiddles<float>(nx);
+    RowW64Args a{};
+    a.in = (const cx<float>*)in; a.out = (cx<float>*)out; a.in_pitch = nx / 2; a.out_pitch = kpitch_for(nx);
+    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (float)scale; a.wcols = width; a.ny = ny; a.nwg = nwg;
+    EmuLauncher q;
+    q.run(nwg, 1, 64, W64_LDS_BYTES, [&](EmuCtx& c) { row_r2c_w64_body(c, a); });
+    return 0;
+}
+int emu_legs_cols_cg_f64(int ny_full, int my, int nx, const void* kX, const void* kY, const double* FG, const double* FH,
+                         const double* lxd, const double* lyd, void* gx, void* gy, void* h, int width, int rband) {
+    CoarseHolder<double> hd(ny_full, my, nx);
+    EmuLauncher q;
+    hd.p.legs_cols(q, (const cx<double>*)kX, (const cx<double>*)kY, FG, FH, lxd, lyd, (cx<double>*)gx, (cx<double>*)gy,
+                   (cx<double>*)h, width, rband, 0, 0, true);
+    return 0;
+}
+int emu_cols_div_cg_f64(int ny_full, int my, int nx, const void* pa, const void* pb, const double* Fn, const double* lxd,
+                        const double* lyd, void* out, int width, int rband) {
+    CoarseHolder<double> hd(ny_full, my, nx);
+    std::vector<cx<double>> tA((size_t)my * hd.p.kp), tB((size_t)my * hd.p.kp);
+    EmuLauncher q;
+    hd.p.cols_div(q, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out, tA.data(), tB.data(), 0, width, rband);
+    return 0;
+}
 int emu_map_legs_cols_f64(int ny, int nx, const double* map, const double* FG, const double* FH, const double* lxd,
                           const double* lyd, void* gx, void* gy, void* h, int width, int rband) {
     return do_map_legs_cols<double>(ny, nx, map, FG, FH, lxd, lyd, (cx<double>*)gx, (cx<double>*)gy, (cx<double>*)h, width, rband);

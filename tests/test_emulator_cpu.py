@@ -17,8 +17,9 @@ EMUL = os.path.join(HERE, "emul")
 def emu():
     so = os.path.join(EMUL, "libemul_fft.so")
     src = os.path.join(EMUL, "emul_fft.cpp")
-    hdr = os.path.join(HERE, "..", "orphics_amd", "csrc", "fft_kernels.hpp")
-    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    csrc = os.path.join(HERE, "..", "orphics_amd", "csrc")
+    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "cx.hpp")]
+    if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.emu_kpitch.restype = ctypes.c_long
@@ -248,3 +249,70 @@ def test_fused_forward_pass2_legs(emu, ny, nx, w, rb):
         assert np.abs(got[:, :wv] - want[:, :wv]).max() < 1e-10 * np.abs(want).max()
         if w:
             assert np.all(got[:, wv:W] == 3.0)
+
+
+@pytest.mark.parametrize("ny_full,my,w,rb", [(256, 64, 21, 9), (512, 128, 0, 20), (256, 128, 30, 33)])
+def test_column_grid_views(emu, ny_full, my, w, rb):
+    """COLUMN GRID (include/orphics_amd.h): col_legs / col_div run on my < ny rows while filters, the ly axis, kX / kY
+    and the output keep the full-resolution row layout -- row y of the my-row transform is row
+    y + (y >= my/2 ? ny - my : 0) of the full planes."""
+    nx = 64
+    rng = np.random.default_rng(ny_full + my + w)
+    W = nx // 2 + 1
+    wv = w if w else W
+    kp = emu.emu_kpitch(nx)
+    ly = 2 * np.pi * np.fft.fftfreq(ny_full) * 100
+    lx = 2 * np.pi * np.fft.fftfreq(nx) * 100
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[ny_full // 2] = 0
+    lxd[nx // 2] = 0
+    rows = np.r_[0:my // 2, ny_full - my // 2:ny_full]            # full-resolution row of each coarse row
+    band = np.r_[0:rb, ny_full - rb + 1:ny_full]
+    kX = _hc(emu, ny_full, nx, fill=1e30); kY = _hc(emu, ny_full, nx, fill=1e30)    # garbage wherever it must not be read
+    kX[band, :wv] = rng.standard_normal((band.size, wv)) + 1j * rng.standard_normal((band.size, wv))
+    kY[band, :wv] = rng.standard_normal((band.size, wv)) + 1j * rng.standard_normal((band.size, wv))
+    FG = np.zeros((ny_full, kp)); FH = np.zeros((ny_full, kp)); Fn = np.zeros((ny_full, kp))
+    FG[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv))
+    FH[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv))
+    Fn[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv))
+    outs = [_hc(emu, my, nx, fill=3.0) for _ in range(3)]
+    assert emu.emu_legs_cols_cg_f64(ny_full, my, nx, _p(kX), _p(kY), _p(FG), _p(FH), _p(lxd), _p(lyd), _p(outs[0]), _p(outs[1]),
+                                    _p(outs[2]), w, rb) == 0
+    kXc = np.where(FG[rows][:, :W] != 0, kX[rows][:, :W], 0)      # the coarse spectrum: band rows, zero elsewhere
+    kYc = np.where(FH[rows][:, :W] != 0, kY[rows][:, :W], 0)
+    lx2, ly2 = lxd[None, :W], lyd[rows][:, None]
+    refs = [_col_ifft(1j * lx2 * FG[rows][:, :W] * kXc, my), _col_ifft(1j * ly2 * FG[rows][:, :W] * kXc, my),
+            _col_ifft(FH[rows][:, :W] * kYc, my)]
+    for got, want in zip(outs, refs):
+        assert np.abs(got[:, :wv] - want[:, :wv]).max() < 1e-11 * np.abs(want).max()
+        if w:
+            assert np.all(got[:, wv:W] == 3.0)
+    A = _hc(emu, my, nx); B = _hc(emu, my, nx)
+    A[:, :W] = rng.standard_normal((my, W)) + 1j * rng.standard_normal((my, W))
+    B[:, :W] = rng.standard_normal((my, W)) + 1j * rng.standard_normal((my, W))
+    out = _hc(emu, ny_full, nx, fill=3.0)
+    assert emu.emu_cols_div_cg_f64(ny_full, my, nx, _p(A), _p(B), _p(Fn), _p(lxd), _p(lyd), _p(out), w, rb) == 0
+    want = Fn[rows][:, :W] * (1j * lx2 * np.fft.fft(A[:, :W], axis=0) + 1j * ly2 * np.fft.fft(B[:, :W], axis=0))
+    coarse_band = np.r_[0:rb, my - rb + 1:my]
+    assert np.abs(out[rows[coarse_band]][:, :wv] - want[coarse_band][:, :wv]).max() < 1e-11 * np.abs(want).max()
+    untouched = np.setdiff1d(np.arange(ny_full), rows[coarse_band])
+    assert np.all(out[untouched] == 3.0)                         # nothing outside kappa's band rows is written
+    if w:
+        assert np.all(out[:, wv:W] == 3.0)
+
+
+def test_one_wave_per_row_r2c(emu):
+    """row_r2c_w64_body (fft_r2c_w64.hpp): 8192-point real rows, one 64-lane wave per row, two radix-64 stages around
+    one LDS transpose, pruned second stage -> the first `width` columns of numpy.fft.rfft."""
+    ny, nx, width = 5, 8192, 380
+    rng = np.random.default_rng(64)
+    x = rng.standard_normal((ny, nx)).astype(np.float32)
+    kp = emu.emu_kpitch(nx)
+    out = np.full((ny, kp), 3.0 + 0j, dtype=np.complex64)
+    assert emu.emu_r2c_rows_w64_f32(ny, nx, _p(x), _p(out), ctypes.c_double(0.5), width, 2) == 0
+    ref = 0.5 * np.fft.rfft(x.astype(np.float64), axis=1)
+    assert np.abs(out[:, :width] - ref[:, :width]).max() < 2e-6 * np.abs(ref).max()
+    assert np.all(out[:, width:] == 3.0)
+    out2 = np.full((ny, kp), 3.0 + 0j, dtype=np.complex64)
+    assert emu.emu_r2c_rows_w64_f32(ny, nx, _p(x), _p(out2), ctypes.c_double(1.0), 512, 3) == 0
+    assert np.abs(out2[:, :512] - 2 * ref[:, :512]).max() < 2e-6 * 2 * np.abs(ref).max()
