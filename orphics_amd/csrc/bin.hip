@@ -127,6 +127,19 @@ OA_D bool wave_accum_sorted(bool valid, int key, double v, double cw, int ci, in
     return true;
 }
 
+// Tail of the one-call Monte-Carlo step (pipeline.hip): the workgroup of bin_final_kernel that finishes LAST (a ticket
+// counter over its nids workgroups; nobody waits for anybody) also does what moments_add_binned_kernel would do in one
+// more launch: n += 1, S += b, C += b b^T with b = sums / mode counts.  The final sums travel write-through (sc1
+// stores, agent-scope loads) instead of behind a device-scope fence: on this multi-XCD part a release fence writes back
+// the XCD's whole L2.  Measured and dropped: the same ticket in bin_kernel itself (~1000 workgroups: 95 us with
+// __threadfence(), 30 us of same-address atomics without) and a one-workgroup tail kernel (30 us: one CU cannot keep
+// enough of the strided partial loads in flight).
+struct BinTail {
+    unsigned* ticket;            // zero before the launch; reset to zero by the last workgroup.  nullptr: no tail
+    const int64_t* mcounts;      // moments: data-independent mode counts per id (nullptr: no moments)
+    int64_t* n; double* S; double* C;
+};
+
 // POWER: `data`/`data2` are complex planes and the binned value is Re(conj(k1) k2) * pnorm
 // (FourierCalc.f2power fused into the histogram: the 2-D power plane never exists in HBM)
 template <typename T, bool WEIGHTED, bool POWER>
@@ -277,10 +290,11 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
 __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict__ part_sum, const double* __restrict__ part_w,
                                                         const unsigned long long* __restrict__ part_cnt, int nblocks,
                                                         int nids, int weighted, double* __restrict__ sums,
-                                                        int64_t* __restrict__ counts, double* __restrict__ wsums) {
+                                                        int64_t* __restrict__ counts, double* __restrict__ wsums, BinTail tail) {
     __shared__ double sh_s[256];
     __shared__ double sh_q[256];
     __shared__ unsigned long long sh_c[256];
+    __shared__ int s_last;
     const int i = blockIdx.x, t = threadIdx.x;
     double s = 0.0, q = 0.0;
     unsigned long long c = 0;
@@ -296,9 +310,40 @@ __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict
         __syncthreads();
     }
     if (t == 0) {
-        sums[i] = sh_s[0];
+        if (tail.ticket) __hip_atomic_store(sums + i, sh_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else sums[i] = sh_s[0];
         if (weighted) { if (wsums) wsums[i] = sh_q[0]; }
         else if (counts) counts[i] = (int64_t)sh_c[0];
+    }
+    if (!tail.ticket) return;
+    if (t == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through store of sums[i] has been acknowledged
+        s_last = (__hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // moments of the bandpower vector b[a] = sums[1 + a] / mcounts[1 + a], a < d = nids - 2 (stats.bin2D [1:-1])
+    const int d = nids - 2;
+    for (int a0 = 0; a0 < d; a0 += 256) {              // S, and b staged through LDS in chunks of 256
+        const int a = a0 + t;
+        double bv = 0.0;
+        if (a < d) {
+            bv = __hip_atomic_load(sums + 1 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)tail.mcounts[1 + a];
+            tail.S[a] += bv;
+        }
+        __syncthreads();
+        sh_s[t] = bv;
+        __syncthreads();
+        // C rows a0 .. a0+255 need every b: column values are re-read from global (write-through, agent scope)
+        for (long e = t; e < (long)((d - a0 < 256) ? d - a0 : 256) * d; e += 256) {
+            const int ra = (int)(e / d), cb = (int)(e - (long)ra * d);
+            const double bb = __hip_atomic_load(sums + 1 + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)tail.mcounts[1 + cb];
+            tail.C[(long)(a0 + ra) * d + cb] += sh_s[ra] * bb;
+        }
+    }
+    if (t == 0) {
+        tail.n[0] += 1;
+        __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
 }
 
@@ -306,7 +351,7 @@ template <typename T>
 static int bin_impl(const void* data, const void* data2, double pnorm, bool power, const int32_t* ids, const void* weights,
                     const double* aux, long n, int nids, int mode,
                     int skip_nan, long hp, int nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
-                    hipStream_t st, int active_cols = 0, int active_rows = 0) {
+                    hipStream_t st, int active_cols = 0, int active_rows = 0, const BinTail* fused = nullptr) {
     unsigned wq = 0;                                  // 4-element chunks visited per row (0 = whole rows)
     if (active_cols > 0 && nxh >= 0 && hp > 0 && (long)active_cols < hp && n % hp == 0) wq = (unsigned)((active_cols + 3) / 4);
     const unsigned rb = (wq && active_rows > 0 && 2L * active_rows - 1 < n / hp) ? (unsigned)active_rows : 0u;
@@ -321,6 +366,8 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
     unsigned long long* part_cnt = reinterpret_cast<unsigned long long*>(part_w);
     const size_t smem = (size_t)2 * BIN_WAVES * nids * sizeof(double);
     const bool weighted = weights != nullptr;
+    BinTail tail{};
+    if (fused && !weighted) tail = *fused;
 #define OA_BIN_LAUNCH(W, P)                                                                                          \
     {                                                                                                                \
         auto k = bin_kernel<T, W, P>;                                                                                \
@@ -338,9 +385,21 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
 #undef OA_BIN_LAUNCH
     OA_LAUNCH_CHECK();
     hipLaunchKernelGGL(bin_final_kernel, dim3(nids), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
-                       weighted ? 1 : 0, sums, counts, wsums);
+                       weighted ? 1 : 0, sums, counts, wsums, tail);
     OA_LAUNCH_CHECK();
     return 0;
+}
+
+// kappa_hat -> binned auto-power -> moment accumulation in ONE launch (pipeline.hip)
+int bin_power_moments(int dtype, const void* k, double norm, const int32_t* ids, long n, int nids, long hp, int nxh, double* sums,
+                      int64_t* counts, void* scratch, int active_cols, int active_rows, unsigned* ticket,
+                      const int64_t* mcounts, int64_t* mn, double* S, double* C, hipStream_t st) {
+    BinTail t{ticket, mcounts, mn, S, C};
+    if (dtype == OA_F32)
+        return bin_impl<float>(k, k, norm, true, ids, nullptr, nullptr, n, nids, 0, 0, hp, nxh, sums, counts, nullptr, scratch, st,
+                               active_cols, active_rows, &t);
+    return bin_impl<double>(k, k, norm, true, ids, nullptr, nullptr, n, nids, 0, 0, hp, nxh, sums, counts, nullptr, scratch, st,
+                            active_cols, active_rows, &t);
 }
 
 }  // namespace oa

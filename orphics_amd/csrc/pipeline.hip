@@ -31,6 +31,7 @@ struct Pipeline {
     double* sums = nullptr;
     int64_t* counts_full = nullptr;   // data-independent mode counts over the whole plane
     int64_t* counts_tmp = nullptr;
+    unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
 };
 
 static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
@@ -48,6 +49,7 @@ void pipeline_release(oa_plan* p) {
     if (q->sums) (void)hipFree(q->sums);
     if (q->counts_full) (void)hipFree(q->counts_full);
     if (q->counts_tmp) (void)hipFree(q->counts_tmp);
+    if (q->ticket) (void)hipFree(q->ticket);
     delete q;
     p->pipe = nullptr;
 }
@@ -134,6 +136,10 @@ int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, v
         OA_HIP(hipMalloc((void**)&q->counts_full, nids * sizeof(int64_t)));
         OA_HIP(hipMalloc((void**)&q->counts_tmp, nids * sizeof(int64_t)));
     }
+    if (!q->ticket) {
+        OA_HIP(hipMalloc((void**)&q->ticket, sizeof(unsigned)));
+        OA_HIP(hipMemset(q->ticket, 0, sizeof(unsigned)));
+    }
     q->ids = ids_hc; q->nids = nids; q->norm = norm;
     // mode counts per bin over the WHOLE plane (the per-call binning visits only kappa's active region)
     return oa_bin_power(p->dtype, q->c[0], q->c[0], norm, ids_hc, nullptr, (long)p->ny * p->kp, nids, p->kp, p->nx / 2, q->sums,
@@ -198,10 +204,9 @@ int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void
 
 // kappa_hat (plan-owned plane) -> bandpower sums over its active region -> n += 1, S += b, C += b b^T (b = bin means)
 static int bandpower_moments(oa_plan* p, Pipeline* q, int64_t* n, double* S, double* C, void* stream) {
-    int rc = oa_bin_power(p->dtype, q->kk, q->kk, q->norm, q->ids, nullptr, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums,
-                          q->counts_tmp, nullptr, q->bin_scratch, q->wk, q->rk, stream);
-    if (rc) return rc;
-    return oa_moments_add_binned(q->sums + 1, q->counts_full + 1, q->nids - 2, n, S, C, stream);
+    // one launch: the last workgroup of the histogram reduces the partials and adds the bandpower vector to n, S, C
+    return bin_power_moments(p->dtype, q->kk, q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
+                             q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, (hipStream_t)stream);
 }
 
 int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, double* C, void* stream) {

@@ -2,7 +2,7 @@
 """Per-step summary of rocprofv3 output for bench.py's timed loop (one HIP stream).
 
 One reconstruction ("step") of the headline pipeline is a fixed kernel sequence that ends with
-``moments_add_binned_kernel``; this tool cuts the dispatch list of each profiler run at those markers, keeps the
+``bin_final_kernel`` (whose last workgroup also updates the moments); this tool cuts the dispatch list of each profiler run at those markers, keeps the
 steady-state steps (the last ones of the run) and reports, per position in the sequence, the median duration
 (kernel trace), FETCH_SIZE and WRITE_SIZE (two separate --pmc runs).  HBM bytes = FETCH_SIZE x 1024 x 2
 (gfx950 tallies the 128-byte requests of wide coalesced reads as 64 B: MI355X_MICROARCH.md, HBM section)
@@ -22,7 +22,7 @@ import shutil
 import statistics
 import sys
 
-MARK = "moments_add_binned_kernel"
+MARK = "bin_final_kernel"
 
 
 def find(d, suffix):

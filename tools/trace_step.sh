@@ -14,7 +14,7 @@ rows = []
 for f in glob.glob(O + '/p_trace/**/*kernel_trace.csv', recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-MARK = 'moments_add_binned_kernel'
+MARK = 'bin_final_kernel'
 steps, cur = [], []
 for r in rows:
     cur.append(r)
