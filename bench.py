@@ -329,27 +329,57 @@ def per_kernel_table(torch, P, R, args):
         return lambda: check(lib.oa_qe_tt_stage(plan, k, _ptr(r1), _stream()))
     scratch_moments = (R.mom_n[0].clone(), R.mom_S[0].clone(), R.mom_C[0].clone())     # fill every work plane once
     check(lib.oa_qe_tt_moments(plan, _ptr(r1), *[_ptr(t) for t in scratch_moments], _stream()))
+    # column grid: the legs / row stage / divergence run on my of the N rows (include/orphics_amd.h, COLUMN GRID)
+    my = int(lib.oa_plan_col_grid(plan))
+    cg = my / float(N) if my else 1.0
     # name -> (stage, bytes it must move once: inputs + outputs on its active columns / rows)
+    if my:
+        legs_name = "fwdlegs_cols = col_fft_kernel<fwd pass2> + col_legs_kernel + col_fft_kernel<inv pass2 x3> on the %d-row column grid" % my
+        # forward pass 2 (read the pass-1 plane, write the band rows) + col_legs (read the band rows + 2 real filter planes there,
+        # write 3 planes of my rows) + 3-plane inverse pass 2 on my rows (r + w)
+        legs_bytes = fl * (Ah + gl * Ah) + fl * (gl * Ah + gl * Ah + 3 * cg * Ah) + 6 * fl * cg * Ah
+    else:
+        legs_name = "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>"
+        # col_fwdlegs (read the pass-1 plane + 2 real filter planes on the band rows, write 3) + 3-plane inverse pass 2 (r + w)
+        legs_bytes = fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah
     kern = {
         "row_fft_kernel<R2C>": (0, A + fl * Ah),
         "col_fft_kernel<fwd pass1, leg width>": (1, 2 * fl * Ah),
-        # col_fwdlegs (read the pass-1 plane + 2 real filter planes on the band rows, write 3) + 3-plane inverse pass 2 (r + w)
-        "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>": (2, fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah),
-        "row_qe_kernel": (3, (3 * fl + 2 * fk) * Ah),
+        legs_name: (2, legs_bytes),
+        "row_qe_kernel": (3, (3 * fl + 2 * fk) * Ah * cg),
         # one 2-plane pass-1 launch (read 2, write 2) + col_div (read 2 + Fn/2, write the band rows of 1)
-        "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel": (4, 4 * fk * Ah + fk * (2 * Ah + gk * Ah / 2 + gk * Ah)),
+        "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel": (4, 4 * fk * Ah * cg + fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah)),
         "bin_kernel<power>": (5, 1.5 * fk * gk * Ah),
     }
+    # Stage durations IN SEQUENCE: whole steps (stages 0..5 back to back on this stream, alternating between the two
+    # input maps as the timed loop does) with a HIP event between consecutive stages.  Timing one stage in a tight
+    # loop of its own would let its inputs sit in the 256 MB infinity cache / L2 (the 268 MB map re-read 20 times
+    # measured 49 us for the row pass against 60 us inside the step) -- these are the durations rocprofv3 reports for
+    # the same kernels inside the timed loop (profiles/<tag>_step.txt).
+    reps, warm = 24, 4
+    names = sorted(kern, key=lambda n: kern[n][0])
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(reps)]
+    for it in range(warm + reps):
+        rmap = _ptr(R.tmaps[it & 1])
+        for si, name in enumerate(names):
+            if it >= warm:
+                evs[it - warm][si].record()
+            check(lib.oa_qe_tt_stage(plan, kern[name][0], rmap, _stream()))
+        if it >= warm:
+            evs[it - warm][len(names)].record()
+    torch.cuda.synchronize()
     per = {}
-    for name, (k, moved) in kern.items():
-        dt = time_kernel(torch, stage(k))
+    for si, name in enumerate(names):
+        dt = float(np.median([evs[r][si].elapsed_time(evs[r][si + 1]) for r in range(reps)])) * 1e-3
+        moved = kern[name][1]
         per[name] = {"avg_ms": dt * 1e3, "hbm_min_GB": moved / 1e9, "hbm_GBs": moved / dt / 1e9, "hbm_frac": moved / dt / 1e9 / HBM_PEAK_GBS}
     flops, mrow, how = row_qe_flops(N, wl, wk, q.mrow)
+    flops *= cg                                   # the row stage visits my of the N rows
     rq = per["row_qe_kernel"]
     rq.update({"executed_GFLOP": flops / 1e9, "flop_count": how, "row_grid": mrow, "TFLOPs": flops / (rq["avg_ms"] * 1e-3) / 1e12,
                "valu_frac": flops / (rq["avg_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                "arithmetic_intensity_flop_per_B": flops / (rq["hbm_min_GB"] * 1e9)})
-    return per, dict(A=A, Ah=Ah, fl=fl, fk=fk, W=W, wl=wl, wk=wk, rl=rl, rk=rk, mrow=mrow)
+    return per, dict(A=A, Ah=Ah, fl=fl, fk=fk, W=W, wl=wl, wk=wk, rl=rl, rk=rk, mrow=mrow, mcol=my)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -431,7 +461,7 @@ def main():
     ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
                     help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
                          "(exact for band-limited filters; library default), full = the map's nx points")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams: independent realisations are issued round-robin "
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams: independent realisations are issued round-robin "
                     "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
     args = ap.parse_args()
 
@@ -547,6 +577,10 @@ def main():
         roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
         roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
                                 "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}
+        roofline["col_grid"] = {"rows": G["mcol"] or N, "of": N, "note": "the same argument along y: inverse column transforms of the legs, row stage "
+                                "and forward column transforms of the products run on the smallest alias-free power-of-two number of rows "
+                                ">= max(2 leg_rows + kappa_rows, 2 kappa_rows) (exact; include/orphics_amd.h COLUMN GRID); extra.fullres_rows "
+                                "is the same job with both grids at the map's own resolution"}
         roofline["active_rows"] = {"legs": (2 * G["rl"] - 1) if G["rl"] else N, "kappa": (2 * G["rk"] - 1) if G["rk"] else N, "of": N}
         roofline["share_of_recon_ms"] = share
         roofline["per_kernel"] = per

@@ -1,0 +1,12 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out; bash tools/collect_profiles.sh r02z > gpurun_out/r02z_collect.log 2>&1
+cat gpurun_out/r02z/summary/r02z_step.txt
+bash tools/pmc_step.sh r02z > /dev/null 2>&1
+timeout -k 10 500 python bench.py > gpurun_out/r02z/bench.json 2> gpurun_out/r02z/bench.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r02z/bench.json'))
+print(d['value'], d['ms_per_step'], d['roofline']['bound'], d['roofline']['kernel'], d['roofline']['frac'], d['roofline']['traffic'])
+print({k:(round(v.get('reconstructions_per_s',0)), v.get('max_rel_bandpower_diff')) for k,v in d['extra'].items()})
+PY

@@ -94,26 +94,33 @@ def counter_table(pmc_dir, counter):
 
 
 def bench_keys(table):
-    """Map the step's positions onto bench.py's per-kernel names (composites = sums)."""
-    keys = {}
-    colfft = [i for i, r in enumerate(table) if r["kernel"].startswith("col_fft_kernel")]
+    """Map the step's positions onto bench.py's per-kernel names (composites = sums): landmarks are the row R2C, the
+    first column pass, the fused row stage and the divergence kernel; whatever sits between them belongs to the
+    composite stage in front of the next landmark."""
+    names = [r["kernel"] for r in table]
 
-    def idx(prefix):
-        return [i for i, r in enumerate(table) if r["kernel"].startswith(prefix)]
-    if idx("row_fft_kernel"):
-        keys["row_fft_kernel<R2C>"] = idx("row_fft_kernel")[:1]
-    if len(colfft) >= 1:
-        keys["col_fft_kernel<fwd"] = colfft[:1]
-    fl = idx("col_fwdlegs_kernel") + idx("col_legs_kernel")
-    if fl and len(colfft) >= 2:
-        keys["fwdlegs_cols"] = fl[:1] + colfft[1:2]
-    if idx("row_qe_kernel"):
-        keys["row_qe_kernel"] = idx("row_qe_kernel")[:1]
-    if idx("col_div_kernel") and len(colfft) >= 3:
-        keys["cols_div"] = colfft[2:3] + idx("col_div_kernel")[:1]
-    b = idx("bin_kernel") + idx("bin_final_kernel")
-    if b:
-        keys["bin_kernel<power>"] = b
+    def first(*prefixes):
+        for i, n in enumerate(names):
+            if any(n.startswith(p) for p in prefixes):
+                return i
+        return None
+    keys = {}
+    r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_stream_kernel")
+    c0 = first("col_fft_kernel")
+    q = first("row_qe_pair_kernel", "row_qe_kernel")
+    d = first("col_div_kernel")
+    if r0 is not None:
+        keys["row_fft_kernel<R2C>"] = [r0]
+    if c0 is not None:
+        keys["col_fft_kernel<fwd"] = [c0]
+    if c0 is not None and q is not None and q > c0 + 1:
+        keys["fwdlegs_cols"] = list(range(c0 + 1, q))
+    if q is not None:
+        keys["row_qe_kernel"] = [q]
+    if q is not None and d is not None and d > q:
+        keys["cols_div"] = list(range(q + 1, d + 1))
+    if d is not None and d + 1 < len(names):
+        keys["bin_kernel<power>"] = list(range(d + 1, len(names)))
     return keys
 
 
