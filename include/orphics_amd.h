@@ -163,7 +163,8 @@ int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* 
  * kernels address row y + (y >= mcol/2 ? ny - mcol : 0)).  oa_plan_set_filters selects -1 (auto: the smallest such
  * power of two, or none if that is >= ny or the filters have no row band) unless mrow == 0, which selects 0 (the map's
  * own rows, as for the row grid).  oa_plan_set_col_grid overrides: -1 auto, 0 off, > 0 explicit (checked against the
- * bound); oa_plan_col_grid returns the resolved grid (0 = ny). */
+ * bound); oa_plan_col_grid returns the grid resolved for the TT filters (0 = ny).  oa_qe_pol follows the same policy
+ * with the row bands of each call (mrow == 0 switches it off there too). */
 int oa_plan_set_col_grid(oa_plan* p, int mcol);
 int oa_plan_col_grid(const oa_plan* p);
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);

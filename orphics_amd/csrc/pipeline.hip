@@ -81,18 +81,19 @@ static int zero_complement(oa_plan* p, void* out, int wk, int rk, hipStream_t st
 // my >= 2 rl + rk rows no aliased product frequency reaches the kept kappa rows |ky| < rk (same argument as the row
 // grid, include/orphics_amd.h), so the inverse column transforms, the row stage and the forward column transforms run
 // on my instead of ny rows and return the same kappa_hat rows.
-static int resolve_col_grid(oa_plan* p, Pipeline* q) {
-    q->my = 0;
-    if (q->mcol == 0 || q->rl <= 0 || q->rk <= 0) return 0;
-    const long need = std::max(2L * q->rl + q->rk, 2L * q->rk);
-    int my = q->mcol;
+static int resolve_my(oa_plan* p, int mcol, int rl, int rk, int* my_out) {
+    *my_out = 0;
+    if (mcol == 0 || rl <= 0 || rk <= 0) return 0;
+    const long need = std::max(2L * rl + rk, 2L * rk);
+    int my = mcol;
     if (my < 0) { my = 64; while (my < need && my < p->ny) my <<= 1; }
     else if (my < need) return fail("column grid < max(2*leg_rows + kappa_rows, 2*kappa_rows) would alias the leg products into the kept rows");
     if (my >= p->ny) return 0;
     if (int rc = plan_ensure_col_grid(p, my)) return rc;
-    q->my = my;
+    *my_out = my;
     return 0;
 }
+static int resolve_col_grid(oa_plan* p, Pipeline* q) { return resolve_my(p, q->mcol, q->rl, q->rk, &q->my); }
 
 }  // namespace oa
 
@@ -101,11 +102,12 @@ using namespace oa;
 extern "C" {
 
 int oa_plan_set_col_grid(oa_plan* p, int mcol) {
-    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_plan_set_col_grid: call oa_plan_set_filters first");
+    OA_REQUIRE(p, "oa_plan_set_col_grid: NULL plan");
+    OA_NEED_POW2(p, "oa_plan_set_col_grid");
     OA_REQUIRE(mcol <= 0 || is_pow2(mcol), "oa_plan_set_col_grid: mcol must be -1 (auto), 0 (off) or a power of two");
-    Pipeline* q = (Pipeline*)p->pipe;
+    Pipeline* q = pipe_of(p);
     q->mcol = mcol;
-    return resolve_col_grid(p, q);
+    return q->FG ? resolve_col_grid(p, q) : 0;     // oa_qe_pol resolves it per call from its own row bands
 }
 
 int oa_plan_col_grid(const oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->my : 0; }
@@ -179,17 +181,19 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
     if (int rc = ensure_work(p, q)) return rc;
     if (!accumulate && zero_outside && out != q->kk)
         if (int rc = zero_complement(p, out, kappa_cols, kappa_rows, (hipStream_t)stream)) return rc;
-    const double s = 1.0 / ((double)p->ny * p->nx);
     const long pl = work_pitch(p, leg_cols), pk = work_pitch(p, kappa_cols);
     hipStream_t st = (hipStream_t)stream;
+    int my = 0;                                     // column grid from this call's row bands (policy: oa_plan_set_col_grid)
+    if (int rc = resolve_my(p, mrow == 0 ? 0 : q->mcol, leg_rows, kappa_rows, &my)) return rc;
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
     // products accumulate in g[0], g[1] over the separable pieces (compact work planes)
     for (int i = 0; i < npieces; ++i) {
         const bool sw = host_swap && host_swap[i];
-        int rc = qe_legs_cols_w(p, sw ? kY : kX, sw ? kX : kY, host_FG[i], host_FH[i], q->c[0], q->c[1], q->c[2], leg_cols, leg_rows, pl, st);
+        int rc = qe_legs_cols_w(p, sw ? kY : kX, sw ? kX : kY, host_FG[i], host_FH[i], q->c[0], q->c[1], q->c[2], leg_cols, leg_rows, pl, st, my);
         if (rc) return rc;
-        if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], host_signs[i] * s * s, i > 0, leg_cols, kappa_cols, mrow, pl, pk, st))) return rc;
+        if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], host_signs[i] * s * s * sy, i > 0, leg_cols, kappa_cols, mrow, pl, pk, st, my))) return rc;
     }
-    return qe_cols_div_w(p, q->g[0], q->g[1], Fnorm, out, accumulate, kappa_cols, kappa_rows, pk, st);
+    return qe_cols_div_w(p, q->g[0], q->g[1], Fnorm, out, accumulate, kappa_cols, kappa_rows, pk, st, my);
 }
 
 int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream) {

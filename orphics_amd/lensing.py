@@ -651,6 +651,7 @@ class Estimator(object):
             zero = 1 if ((wk or rk) and not accumulate and owned_clean_region(out) != (wk, rk)) else 0
         Fn = G["Fnorm"] if norm is None else norm
         e._ordered()
+        check(e.lib.oa_plan_set_col_grid(e.plan, int(self.mcol)))       # plans are shared per geometry: policy per call
         check(e.lib.oa_qe_pol(e.plan, n, signs, fgs, fhs, swaps, _ptr(kX), _ptr(kY), _ptr(Fn), _ptr(out), 1 if accumulate else 0,
                               int(wl), int(wk), int(rl), int(rk), int(self.mrow), zero, _stream()))
         mark_dirty(out)

@@ -76,48 +76,51 @@ def fwhm_from_sigma(sigma):
 
 
 def mask_kspace(shape, wcs, lxcut=None, lycut=None, lmin=None, lmax=None):
-    """maps.py:1936-1948: int ones/zeros; zero where ell<=lmin, ell>=lmax,
-    |lx|<lxcut, |ly|<lycut."""
+    """0/1 (int64) mode mask of maps.py:1936-1948.  A mode SURVIVES only under strict inequalities: lmin < ell < lmax,
+    |lx| >= lxcut, |ly| >= lycut; cuts that are None do not apply."""
     geom = as_geometry(shape, wcs)
-    output = np.ones(shape[-2:], dtype=int)
-    if (lmin is not None) or (lmax is not None):
-        modlmap = geom.modlmap()
-    if (lxcut is not None) or (lycut is not None):
+    keep = np.ones(tuple(shape[-2:]), dtype=bool)
+    if lmin is not None or lmax is not None:
+        ell = geom.modlmap()
+        if lmin is not None:
+            keep &= ell > lmin
+        if lmax is not None:
+            keep &= ell < lmax
+    if lxcut is not None or lycut is not None:
         ly, lx = geom.laxes()
-    if lmin is not None:
-        output[np.where(modlmap <= lmin)] = 0
-    if lmax is not None:
-        output[np.where(modlmap >= lmax)] = 0
-    if lxcut is not None:
-        output[:, np.where(np.abs(lx) < lxcut)] = 0
-    if lycut is not None:
-        output[np.where(np.abs(ly) < lycut), :] = 0
-    return output
+        if lxcut is not None:
+            keep &= (np.abs(lx) >= lxcut)[None, :]
+        if lycut is not None:
+            keep &= (np.abs(ly) >= lycut)[:, None]
+    return keep.astype(int)
+
+
+def _edge_taper(n, width, pad):
+    """The two one-sided raised-cosine factors of an n-pixel axis (leading edge, trailing edge): 1 outside their
+    ranges `x <= width + pad` and `x >= n - 1 - width - pad`, (1 - cos(pi d / width)) / 2 inside, d = distance from the
+    padded edge (negative inside the pad, as in the reference, which zeroes the pad afterwards)."""
+    x = np.arange(n)
+    lead, trail = np.ones(n), np.ones(n)
+    if width > 0:
+        ramp = lambda d: 1. / 2 * (1 - np.cos(-np.pi * d / width))       # noqa: E731  (the reference's rounding)
+        lo = x <= width + pad
+        hi = x >= (n - 1) - width - pad
+        lead[lo] = ramp((x - pad).astype(float)[lo])
+        trail[hi] = ramp(((n - 1) - x - pad).astype(float)[hi])
+    return lead, trail, (lo if width > 0 else np.zeros(n, bool)), (hi if width > 0 else np.zeros(n, bool))
 
 
 def cosine_window(Ny, Nx, lenApodY=30, lenApodX=30, padY=0, padX=0):
-    """maps.py:1891-1920 (host-side, one-off)."""
-    win = np.ones((Ny, Nx))
-    i = np.arange(Nx)
-    j = np.arange(Ny)
-    ii, jj = np.meshgrid(i, j)
-    if lenApodX > 0:
-        r = ii.astype(float) - padX
-        sel = np.where(ii <= (lenApodX + padX))
-        win[sel] = 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodX))
-        sel = np.where(ii >= ((Nx - 1) - lenApodX - padX))
-        r = ((Nx - 1) - ii - padX).astype(float)
-        win[sel] = 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodX))
-    if lenApodY > 0:
-        r = jj.astype(float) - padY
-        sel = np.where(jj <= (lenApodY + padY))
-        win[sel] *= 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodY))
-        sel = np.where(jj >= ((Ny - 1) - lenApodY - padY))
-        r = ((Ny - 1) - jj - padY).astype(float)
-        win[sel] *= 1. / 2 * (1 - np.cos(-np.pi * r[sel] / lenApodY))
-    win[0:padY, :] = 0
-    win[:, 0:padX] = 0
-    win[Ny - padY:, :] = 0
+    """Separable raised-cosine apodisation with zeroed pads (maps.py:1891-1920), built from two 1-D profiles.
+    Faithful to the reference where the two edge ramps of an axis overlap (narrow maps): along x the trailing ramp
+    REPLACES the leading one, along y the two MULTIPLY."""
+    xl, xt, _, xhi = _edge_taper(Nx, lenApodX, padX)
+    yl, yt, _, _ = _edge_taper(Ny, lenApodY, padY)
+    wx = np.where(xhi, xt, xl)
+    win = (wx[None, :] * yl[:, None]) * yt[:, None]
+    win[:padY] = 0
+    win[Ny - padY:] = 0
+    win[:, :padX] = 0
     win[:, Nx - padX:] = 0
     return win
 
