@@ -110,7 +110,8 @@ struct HipLauncher {
         w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
         w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = ny;
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        w.nwg = cus * (int)(LDS_MAX / W64_LDS_BYTES);      // resident waves: one per SIMD
+        static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (int)(LDS_MAX / W64_LDS_BYTES); }();
+        w.nwg = cus * per_cu;                              // resident waves: one per SIMD (LDS-limited)
         if (w.nwg > ny) w.nwg = ny;
         hipLaunchKernelGGL(row_r2c_w64_kernel, dim3(w.nwg), dim3(64), W64_LDS_BYTES, st, w);
         hipError_t e = hipGetLastError();
