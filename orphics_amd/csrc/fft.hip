@@ -16,6 +16,12 @@ __global__ __launch_bounds__(64, 1) void row_r2c_w64_kernel(RowW64Args a) {
     row_r2c_w64_body(c, a);
 }
 
+// 16384-point rows: two waves per row (even / odd packed samples), one workgroup of 128 threads per row in flight
+__global__ __launch_bounds__(128, 1) void row_r2c_w64x2_kernel(RowW64Args a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_w64x2_body(c, a);
+}
+
 #ifndef OA_STREAM_WAVES_PER_EU
 #define OA_STREAM_WAVES_PER_EU 3     // two row blocks of registers (current + prefetched): 128 VGPRs spill, 168 do not
 #endif
@@ -105,14 +111,23 @@ struct HipLauncher {
     }
     // band-limited R2C of 8192-point rows (f32): one wave per row (fft_r2c_w64.hpp)
     bool row_w64(int ny, const RowArgs<float>& a) {
-        if (a.mode != ROW_R2C || a.logL != 12 || a.wcols > 512 || !r2c_w64_mode() || rc) return false;
+        if (a.mode != ROW_R2C || !r2c_w64_mode() || rc) return false;
+        const bool one = a.logL == 12 && a.wcols <= 512, two = a.logL == 13 && a.wcols <= 64 * W64X2_KEEP;
+        if (!one && !two) return false;
         RowW64Args w{};
         w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
         w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = ny;
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (int)(LDS_MAX / W64_LDS_BYTES); }();
         w.nwg = cus * per_cu;                              // resident waves: one per SIMD (LDS-limited)
+        if (two) w.nwg = cus * (int)(LDS_MAX / W64X2_LDS_BYTES);
         if (w.nwg > ny) w.nwg = ny;
+        if (two) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(row_r2c_w64x2_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)W64X2_LDS_BYTES);
+            if (attr != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(attr)); return true; }
+            hipLaunchKernelGGL(row_r2c_w64x2_kernel, dim3(w.nwg), dim3(128), W64X2_LDS_BYTES, st, w);
+        } else
         hipLaunchKernelGGL(row_r2c_w64_kernel, dim3(w.nwg), dim3(64), W64_LDS_BYTES, st, w);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));

@@ -24,7 +24,9 @@ struct W64Tab {
 OA_HD cx<float> w64(int m) { return mk<float>(W64Tab::c[m & 63], -W64Tab::s[m & 63]); }
 
 // In-register DFT of 64 points, in place.  Input natural order; output bin k = a + 8 b is left in v[8 a + b].
-// PRUNE: only the bins k in [0,8) (v[8 a]) and [56,64) (v[8 a + 7]) are produced.
+// PRUNE: only the bins k in [0,8) (v[8 a]) and [56,64) (v[8 a + 7]) are produced.  (Callers that need a few more
+// bins -- b = 1, 6 -- use the full transform and simply do not read the rest: after unrolling the unused butterfly
+// outputs are dead code.)
 template <bool PRUNE>
 OA_HD void dft64(cx<float>* v) {
     // inner layer: for each s0, DFT-8 over s1 of v[8 s1 + s0] -> bin a, times W64^(s0 a), stored at v[8 a + s0]
@@ -132,6 +134,89 @@ OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
             if (k < a.wcols) dst[64 * m] = X;
         }
         ctx.sync();                                // the partner reads precede the next row's transpose writes
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16384-point rows (8192 packed complex points): TWO waves per row.  Wave 0 transforms the even packed samples, wave 1
+// the odd ones -- each exactly the 4096-point two-stage transform above -- and a radix-2 combine
+//   Z[k] = Ze[k] + W8192^k Zo[k],   Z[8192 - k] = Ze[4096 - k] + conj(W8192^k) Zo[4096 - k]
+// in front of the untangle  X[k] = E + W16384^k O  finishes the row.  Columns k < 768 only (bins k2 <= 11 and their
+// mirror images k2 >= 52 of each half transform).  One workgroup barrier per exchange (two waves).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr size_t W64X2_LDS_BYTES = 2 * W64_LDS_BYTES;
+constexpr int W64X2_KEEP = 12;     // kept bins k2 per side of each half transform
+
+template <class Ctx>
+OA_HD void row_r2c_w64x2_body(Ctx& ctx, const RowW64Args& a) {
+    cx<float>* s = reinterpret_cast<cx<float>*>(ctx.smem());
+    const int tid = ctx.tid(), w = tid >> 6, j = tid & 63;
+    cx<float>* T = s + w * (64 * W64_LDS_STRIDE);          // this wave's transpose buffer
+    const int sh = a.logTw - 12;                            // W4096^e = tw[e << sh]
+    const int jm = (64 - j) & 63;
+    constexpr int NM = W64X2_KEEP / 2;                      // output column groups m per wave
+    cx<float> P[8], Q[8], Wk[NM], U[NM];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        P[i] = a.tw[(unsigned)((j * i) & 4095) << sh];
+        Q[i] = a.tw[(unsigned)((8 * j * i) & 4095) << sh];
+    }
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        const int k = j + 64 * (w * NM + i);
+        Wk[i] = a.tw[(unsigned)k << (sh - 1)];             // W8192^k
+        U[i] = a.tw[(unsigned)k << (sh - 2)];              // W16384^k
+    }
+    for (long row = ctx.bid_x(); row < a.ny; row += a.nwg) {
+        cx<float> v[64];
+        const cx<float>* src = a.in + row * a.in_pitch + w + 2 * j;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) v[t] = src[128 * t];  // packed sample 2 (j + 64 t) + w
+        dft64<false>(v);
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int k1 = aa + 8 * b;
+                cx<float> x = v[8 * aa + b];
+                if (k1) x = x * ((aa && b) ? P[aa] * Q[b] : (aa ? P[aa] : Q[b]));
+                T[k1 * W64_LDS_STRIDE + j] = x;
+            }
+        }
+        ctx.sync();
+#pragma unroll
+        for (int t = 0; t < 64; ++t) v[t] = T[j * W64_LDS_STRIDE + t];
+        ctx.sync();                                        // every read of the transposes precedes the writes below
+        dft64<false>(v);                                   // lane k1 = j: Zw[k1 + 64 k2], k2 = a + 8 b, in v[8 a + b]
+        // exchange area (aliases the transposes): EX[half][slot][lane]; slots 0..11 = bins k2 0..11, 12..23 = bins 52..63
+        cx<float>* EX = s + w * (2 * W64X2_KEEP * 64);
+#pragma unroll
+        for (int k2 = 0; k2 < W64X2_KEEP; ++k2) EX[k2 * 64 + j] = v[8 * (k2 & 7) + (k2 >> 3)];
+#pragma unroll
+        for (int q = 0; q < W64X2_KEEP; ++q) {
+            const int k2 = 64 - W64X2_KEEP + q;
+            EX[(W64X2_KEEP + q) * 64 + j] = v[8 * (k2 & 7) + (k2 >> 3)];
+        }
+        ctx.sync();
+        const cx<float>* Ee = s;                           // even-sample half
+        const cx<float>* Eo = s + 2 * W64X2_KEEP * 64;     // odd-sample half
+        cx<float>* dst = a.out + row * a.out_pitch + j;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int m = w * NM + i, k = j + 64 * m;
+            const cx<float> Zk = Ee[m * 64 + j] + Wk[i] * Eo[m * 64 + j];
+            // partner bin 4096 - k of the half transforms: lane (64 - j) & 63, bin 63 - m (j > 0) or 64 - m (j = 0)
+            const int k2p = j ? (63 - m) : (64 - m);
+            const int sp = W64X2_KEEP + (k2p - (64 - W64X2_KEEP));
+            cx<float> Zm = Zk;
+            if (m > 0 || j) Zm = Ee[(sp % (2 * W64X2_KEEP)) * 64 + jm] + conj(Wk[i]) * Eo[(sp % (2 * W64X2_KEEP)) * 64 + jm];
+            const cx<float> E = (Zk + conj(Zm)) * 0.5f;
+            const cx<float> O = mul_mi(Zk - conj(Zm)) * 0.5f;
+            const cx<float> X = (E + U[i] * O) * a.scale;
+            if (k < a.wcols) dst[64 * m] = X;
+        }
+        ctx.sync();                                        // the exchange reads precede the next row's transpose writes
     }
 }
 

@@ -209,6 +209,17 @@ int emu_r2c_rows_w64_f32(int ny, int nx, const float* in, void* out, double scal
     q.run(nwg, 1, 64, W64_LDS_BYTES, [&](EmuCtx& c) { row_r2c_w64_body(c, a); });
     return 0;
 }
+// two-waves-per-row R2C pass for 16384-point rows
+int emu_r2c_rows_w64x2_f32(int ny, int nx, const float* in, void* out, double scale, int width, int nwg) {
+    if (nx != 16384 || width > 64 * W64X2_KEEP) return 1;
+    auto tw = make_twiddles<float>(nx);
+    RowW64Args a{};
+    a.in = (const cx<float>*)in; a.out = (cx<float>*)out; a.in_pitch = nx / 2; a.out_pitch = kpitch_for(nx);
+    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (float)scale; a.wcols = width; a.ny = ny; a.nwg = nwg;
+    EmuLauncher q;
+    q.run(nwg, 1, 128, W64X2_LDS_BYTES, [&](EmuCtx& c) { row_r2c_w64x2_body(c, a); });
+    return 0;
+}
 int emu_legs_cols_cg_f64(int ny_full, int my, int nx, const void* kX, const void* kY, const double* FG, const double* FH,
                          const double* lxd, const double* lyd, void* gx, void* gy, void* h, int width, int rband) {
     CoarseHolder<double> hd(ny_full, my, nx);

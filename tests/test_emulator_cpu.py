@@ -316,3 +316,16 @@ def test_one_wave_per_row_r2c(emu):
     out2 = np.full((ny, kp), 3.0 + 0j, dtype=np.complex64)
     assert emu.emu_r2c_rows_w64_f32(ny, nx, _p(x), _p(out2), ctypes.c_double(1.0), 512, 3) == 0
     assert np.abs(out2[:, :512] - 2 * ref[:, :512]).max() < 2e-6 * 2 * np.abs(ref).max()
+
+
+def test_two_waves_per_row_r2c(emu):
+    """row_r2c_w64x2_body: 16384-point real rows, even / odd packed samples in two waves, radix-2 combine + untangle."""
+    ny, nx, width = 3, 16384, 760
+    rng = np.random.default_rng(65)
+    x = rng.standard_normal((ny, nx)).astype(np.float32)
+    kp = emu.emu_kpitch(nx)
+    out = np.full((ny, kp), 3.0 + 0j, dtype=np.complex64)
+    assert emu.emu_r2c_rows_w64x2_f32(ny, nx, _p(x), _p(out), ctypes.c_double(1.0), width, 2) == 0
+    ref = np.fft.rfft(x.astype(np.float64), axis=1)
+    assert np.abs(out[:, :width] - ref[:, :width]).max() < 2e-6 * np.abs(ref).max()
+    assert np.all(out[:, width:] == 3.0)
