@@ -303,6 +303,11 @@ int oa_bin_power(int dtype, const void* k1, const void* k2, double norm, const i
  * enmap.ifft(covsqrt*rand_gauss_harm).real.  Counter-based Philox4x32-10,
  * key = (seed, stream_id), so realisations are independent of launch geometry. */
 int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream);
+/* The same draw restricted to the ACTIVE region (columns < width, rows y < rband or y > ny - rband; 0 = all): a
+ * bit-identical subset of oa_grf_hc's plane (every mode keeps its Philox counter), the rest of hc_out is not written.
+ * A Monte-Carlo loop whose estimator reads only its leg band (oa_mc_run does this itself) draws ~1 % of the modes. */
+int oa_grf_hc_band(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, int width, int rband,
+                   void* stream);
 /* real white noise N(0,1) plane of n elements (enmap.rand_gauss) */
 int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, void* stream);
 

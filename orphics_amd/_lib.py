@@ -82,6 +82,7 @@ SIGNATURES = {
     "oa_bin_power": (c_int, [c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_long, c_int, c_long, c_int,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "oa_grf_hc": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
+    "oa_grf_hc_band": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "oa_randn": (c_int, [c_int, c_u64, c_u64, c_void_p, c_long, c_void_p]),
     "oa_moments_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_moments_add_binned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

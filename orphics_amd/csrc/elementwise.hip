@@ -79,6 +79,18 @@ __global__ __launch_bounds__(256) void stack_add_kernel(const T* __restrict__ x,
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc[i] += (double)x[i];
 }
 
+// the same over the active region of an hc plane only (columns < w, band rows): kappa_hat is exactly zero elsewhere
+template <typename T>
+__global__ __launch_bounds__(256) void stack_add_region_kernel(const T* __restrict__ x, double* __restrict__ acc, int ny, long kp,
+                                                               int w, int rb) {
+    int y = blockIdx.y;
+    if (rb > 0 && y >= rb) y += ny - (2 * rb - 1);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;      // real-valued element within the row (2 per complex column)
+    if (c >= 2 * w) return;
+    const long i = 2 * (long)y * kp + c;
+    acc[i] += (double)x[i];
+}
+
 // ---------------------------------------------------------------- layout helpers
 // hc -> full complex plane by X(-l) = conj X(l)
 template <typename T>
@@ -238,6 +250,19 @@ __global__ __launch_bounds__(256) void lens_gather_kernel(const T* __restrict__ 
     out[i] = accumulate ? out[i] + v : v;
 }
 
+}  // namespace oa
+
+namespace oa {
+// mean-field stack of the one-call Monte-Carlo driver (pipeline.hip)
+int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st) {
+    if (w <= 0 || w > kp) w = (int)kp;
+    if (!(rb > 0 && 2L * rb - 1 < ny)) rb = 0;
+    dim3 grid((2 * w + 255) / 256, rb ? 2 * rb - 1 : ny);
+    if (dtype == OA_F32) hipLaunchKernelGGL(stack_add_region_kernel<float>, grid, dim3(256), 0, st, (const float*)x, acc, ny, kp, w, rb);
+    else hipLaunchKernelGGL(stack_add_region_kernel<double>, grid, dim3(256), 0, st, (const double*)x, acc, ny, kp, w, rb);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
 }  // namespace oa
 
 using namespace oa;

@@ -256,11 +256,13 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     OA_REQUIRE(covsqrt_hc && n && S && C && sim_hi >= sim_lo, "oa_mc_run: bad argument");
     Pipeline* q = (Pipeline*)p->pipe;
     for (long i = sim_lo; i < sim_hi; ++i) {
-        int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
+        // only the leg band of the realisation is ever read (col_legs: columns < wl, rows |ky index| < rl)
+        int rc = oa_grf_hc_band(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, q->wl, q->rl, stream);
         if (rc) return rc;
         if ((rc = oa_qe_tt(p, nullptr, q->kT, nullptr, nullptr, 0, stream))) return rc;
         if ((rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
-        if (meanfield_acc && (rc = oa_stack_add(p->dtype, q->kk, meanfield_acc, 2L * p->ny * p->kp, stream))) return rc;
+        // kappa_hat vanishes outside its active region (the plan-owned plane was zero-filled once): stack only that
+        if (meanfield_acc && (rc = stack_add_region(p->dtype, q->kk, meanfield_acc, p->ny, p->kp, q->wk, q->rk, (hipStream_t)stream))) return rc;
     }
     return 0;
 }

@@ -48,12 +48,15 @@ OA_D void normals4(uint64_t seed, uint64_t sid, uint64_t idx, float* n) {
 // One Philox call serves 2 modes: (row y', column pair p) -> columns 2p, 2p+1.
 template <typename T>
 __global__ __launch_bounds__(256) void grf_hc_kernel(uint64_t seed, uint64_t sid, const T* __restrict__ cs,
-                                                     cx<T>* __restrict__ out, int ny, int nx, long kp) {
+                                                     cx<T>* __restrict__ out, int ny, int nx, long kp, int wpairs, int rband) {
     const int nxh = nx / 2;
     const int npair = nxh / 2 + 1;  // pairs cover columns 0..nxh(+1)
     const int pr = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (pr >= npair) return;
+    // region draws (oa_grf_hc_band): grid y enumerates the band rows y < rband, y > ny - rband; every mode keeps the
+    // Philox counter of the full-plane draw, so the region is a bit-identical subset of it
+    int y = blockIdx.y;
+    if (rband > 0 && y >= rband) y += ny - (2 * rband - 1);
+    if (pr >= (wpairs > 0 ? wpairs : npair)) return;
     const T rs2 = (T)0.70710678118654752440;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -123,18 +126,28 @@ using namespace oa;
 
 extern "C" {
 
-int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream) {
+int oa_grf_hc_band(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, int width, int rband,
+                   void* stream) {
     OA_REQUIRE(p && hc_out, "oa_grf_hc: NULL argument");
     const int npair = p->nx / 4 + 1;
-    dim3 grid((npair + 255) / 256, p->ny);
+    int wpairs = (width > 0 && width < p->nx / 2 + 1) ? (width + 1) / 2 : 0;          // column pairs drawn (0 = all)
+    if (wpairs >= npair) wpairs = 0;
+    const int rb = (rband > 0 && 2L * rband - 1 < p->ny) ? rband : 0;
+    const int np = wpairs ? wpairs : npair;
+    const int bs = np >= 256 ? 256 : 64;
+    dim3 grid((np + bs - 1) / bs, rb ? 2 * rb - 1 : p->ny);
     if (p->dtype == OA_F32)
-        hipLaunchKernelGGL(grf_hc_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, seed, stream_id,
-                           (const float*)covsqrt_hc, (cx<float>*)hc_out, p->ny, p->nx, p->kp);
+        hipLaunchKernelGGL(grf_hc_kernel<float>, grid, dim3(bs), 0, (hipStream_t)stream, seed, stream_id,
+                           (const float*)covsqrt_hc, (cx<float>*)hc_out, p->ny, p->nx, p->kp, wpairs, rb);
     else
-        hipLaunchKernelGGL(grf_hc_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, seed, stream_id,
-                           (const double*)covsqrt_hc, (cx<double>*)hc_out, p->ny, p->nx, p->kp);
+        hipLaunchKernelGGL(grf_hc_kernel<double>, grid, dim3(bs), 0, (hipStream_t)stream, seed, stream_id,
+                           (const double*)covsqrt_hc, (cx<double>*)hc_out, p->ny, p->nx, p->kp, wpairs, rb);
     OA_LAUNCH_CHECK();
     return 0;
+}
+
+int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream) {
+    return oa_grf_hc_band(p, seed, stream_id, covsqrt_hc, hc_out, 0, 0, stream);
 }
 
 int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, void* stream) {

@@ -486,11 +486,14 @@ class Engine(object):
                              active_cols=active_cols if herm else 0, active_rows=active_rows if herm else 0)
 
     # ---- random fields / accumulators ---------------------------------------------------
-    def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None):
+    def grf_hc(self, seed, stream_id, covsqrt_hc=None, out=None, width=0, rband=0):
+        """Hermitian-consistent Gaussian draw on the hc grid (Philox key = (seed, stream_id)).  width / rband > 0: only
+        the active region (columns < width, rows |ky index| < rband) is drawn -- the same values as the full draw
+        there, the rest of ``out`` untouched (zero for a fresh plane)."""
         if covsqrt_hc is not None:
             self._chk(covsqrt_hc, "hcreal")
         out = self.hc() if out is None else _dirty(self._chk(out, "hc"))
-        check(self.lib.oa_grf_hc(self.plan, int(seed), int(stream_id), _ptr(covsqrt_hc), _ptr(out), _stream()))
+        check(self.lib.oa_grf_hc_band(self.plan, int(seed), int(stream_id), _ptr(covsqrt_hc), _ptr(out), int(width), int(rband), _stream()))
         return out
 
     def randn(self, seed, stream_id, shape=None):

@@ -173,6 +173,23 @@ def test_bin_hermitian_half_plane(prec):
     np.testing.assert_allclose(sh.cpu().numpy(), sf.cpu().numpy(), rtol=1e-12)
 
 
+def test_grf_band_is_a_subset_of_the_full_draw():
+    """oa_grf_hc_band draws only the active region, with the same Philox counters as the full plane."""
+    from orphics_amd.engine import Engine
+    for prec in ("f32", "f64"):
+        e = Engine.get(256, 512, prec)
+        cs = torch.rand(256, e.kp, device="cuda", dtype=e.rdt)
+        full = e.grf_hc(99, 7, cs)
+        for (w, rb) in ((37, 20), (0, 9), (64, 0), (300, 200)):
+            out = e.hc(); out[:] = 5.0
+            e.grf_hc(99, 7, cs, out=out, width=w, rband=rb)
+            rows = np.r_[0:rb, 256 - rb + 1:256] if (rb and 2 * rb - 1 < 256) else np.arange(256)
+            wv = ((w + 1) // 2) * 2 if (0 < w < 257 and (w + 1) // 2 < 129) else 257      # whole column pairs are drawn
+            assert torch.equal(out[rows][:, :min(wv, 257)], full[rows][:, :min(wv, 257)])
+            other = np.setdiff1d(np.arange(256), rows)
+            assert bool((out[other] == 5.0).all()) and bool((out[:, min(wv, 257):257] == 5.0).all())
+
+
 def test_grf_statistics():
     ny, nx = 256, 256
     e = eng(ny, nx, "f32")
