@@ -33,10 +33,14 @@ class GaussianN0MonteCarlo(object):
     C_l^TT B_l^2 + N_l, generated on the device in harmonic space
     (MapGen semantics, maps.py:1576-1587, with the Philox stream (base_seed, sim index))."""
 
-    def __init__(self, qest, total_power_half, bin_edges, comm=None, base_seed=1234, mean_field=False):
+    def __init__(self, qest, total_power_half, bin_edges, comm=None, base_seed=1234, mean_field=False, streams=1):
         """qest: lensing.Estimator; total_power_half: (Ny, Nx/2+1) host array of the
-        observed-map power (C B^2 + N); bin_edges: kappa bandpower edges."""
+        observed-map power (C B^2 + N); bin_edges: kappa bandpower edges.
+        streams > 1: this rank's simulations are split into that many contiguous blocks, each issued on its own HIP
+        stream through a forked estimator handle (private plan and accumulators, summed at the end): the small
+        latency-bound launches of independent realisations overlap."""
         torch = _torch()
+        self.streams = max(1, int(streams))
         self.q = qest
         self.eng = qest.eng
         self.comm = comm if comm is not None else _mpi.get_world()
@@ -75,12 +79,67 @@ class GaussianN0MonteCarlo(object):
                 blocks.append((start, prev + 1))
                 start = i
             prev = i
-        for lo, hi in blocks:
-            check(e.lib.oa_mc_run(e.plan, self.base_seed, lo, hi, _ptr(self.cs), _ptr(n), _ptr(S), _ptr(C), _ptr(mf), _stream()))
+        # (with the mean-field stack the one-stream loop measured faster -- 16.0k vs 14.1k sims/s at 4096^2 -- so the
+        # lanes are used for the bandpower moments only)
+        if self.streams > 1 and len(sims) >= 4 * self.streams and not self.mean_field:
+            self._run_blocks_on_streams(blocks, n, S, C, mf)
+        else:
+            for lo, hi in blocks:
+                check(e.lib.oa_mc_run(e.plan, self.base_seed, lo, hi, _ptr(self.cs), _ptr(n), _ptr(S), _ptr(C), _ptr(mf), _stream()))
         self.acc.note_samples("n0", len(sims))
         if self.mean_field:
             self.acc.note_stacked("mf", len(sims))
         return self
+
+    def _run_blocks_on_streams(self, blocks, n, S, C, mf):
+        """The blocks cut into ``self.streams`` pieces of (nearly) equal size; piece j runs on stream j with its own
+        estimator handle and accumulators, which are added to (n, S, C, mf) in stream order at the end."""
+        torch = _torch()
+        from ._lib import check
+        from .engine import _ptr
+        K = self.streams
+        if getattr(self, "_lanes", None) is None:
+            lanes = []
+            for j in range(K):
+                qj = self.q if j == 0 else self.q.fork()
+                qj.bind_bins(self.ids, self.nids, self.norm)
+                own = None
+                if j:     # private accumulators of this lane, allocated once and kept zero between calls
+                    own = [torch.zeros_like(n), torch.zeros_like(S), torch.zeros_like(C), torch.zeros_like(mf) if mf is not None else None]
+                lanes.append((qj, torch.cuda.Stream() if j else None, own))
+            self._lanes = lanes
+        sims = [i for lo, hi in blocks for i in range(lo, hi)]
+        per = (len(sims) + K - 1) // K
+        cur = torch.cuda.current_stream()
+        parts = []
+        for j, (qj, st, own) in enumerate(self._lanes):
+            mine = sims[j * per:(j + 1) * per]
+            if not mine:
+                continue
+            if j == 0:
+                nj, Sj, Cj, mfj, stream = n, S, C, mf, cur
+            else:
+                nj, Sj, Cj, mfj = own
+                stream = st
+                stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                ej = qj._bind_bins()
+                lo = prev = mine[0]
+                for i in mine[1:] + [None]:
+                    if i is None or i != prev + 1:
+                        check(ej.lib.oa_mc_run(ej.plan, self.base_seed, lo, prev + 1, _ptr(self.cs), _ptr(nj), _ptr(Sj), _ptr(Cj),
+                                               _ptr(mfj), stream.cuda_stream))
+                        lo = i
+                    prev = i
+            if j:
+                parts.append((stream, nj, Sj, Cj, mfj))
+        for stream, nj, Sj, Cj, mfj in parts:
+            cur.wait_stream(stream)
+            n += nj; S += Sj; C += Cj
+            nj.zero_(); Sj.zero_(); Cj.zero_()
+            if mf is not None:
+                mf += mfj
+                mfj.zero_()
 
     def run(self, nsims):
         """Shard ``nsims`` with mpi.mpi_distribute (mpi.py:78-91), run, reduce once; returns the reduced

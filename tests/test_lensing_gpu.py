@@ -181,6 +181,24 @@ def test_mc_driver_n0_and_mean_field():
     assert 0.7 < ratio < 1.3
 
 
+def test_mc_driver_on_several_streams_equals_one_stream():
+    """streams=3 splits a rank's simulations over three HIP streams (forked estimator handles, private accumulators
+    summed at the end): same realisations, same moments and mean-field stack up to summation order."""
+    from orphics_amd import lensing, mc
+    N, res = 512, 1.0
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(N, res, seed=2)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True, dtype="f32")
+    tot_h = (cl * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(100, 3000, 12)
+    a = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=5).run(40)
+    drv = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=5, streams=3)
+    b = drv.run(40)
+    assert getattr(drv, "_lanes", None) is not None and len(drv._lanes) == 3
+    assert a.count("n0") == b.count("n0") == 40
+    np.testing.assert_allclose(b.mean("n0"), a.mean("n0"), rtol=1e-12)
+    np.testing.assert_allclose(b.cov("n0"), a.cov("n0"), rtol=1e-9, atol=1e-30)
+
+
 def pol_setup(N, res_arcmin, seed=0):
     from orphics_amd import cosmology, maps
     from orphics_amd.geometry import FlatGeometry

@@ -55,21 +55,21 @@ def mv(N=8192, res=0.5):
         torch.cuda.empty_cache()
 
 
-def mcn0(N=4096, res=0.5, nsims=200):
+def mcn0(N=4096, res=0.5, nsims=600):
     shape, g, th, ml, beam, noise, q = setup(N, res, False)
     nxh = N // 2
     tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :nxh + 1]
     edges = np.linspace(20, 3500, 20)
-    for mf in (False, True):
-        drv = mc.GaussianN0MonteCarlo(q, tot, edges, mean_field=mf)
-        drv.run_local(range(5))
+    for mf, ns in ((False, 1), (True, 1), (False, 3), (True, 3)):
+        drv = mc.GaussianN0MonteCarlo(q, tot, edges, mean_field=mf, streams=ns)
+        drv.run_local(range(24))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        drv.run_local(range(5, 5 + nsims))
+        drv.run_local(range(24, 24 + nsims))
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / nsims
-        print("config 4: %d^2 MC N0%s: %.3f ms per simulated realisation = %.0f sims/s per GPU (1000 sims on 8 GPUs ~ %.2f s)"
-              % (N, " + mean-field stack" if mf else "", dt * 1e3, 1 / dt, 125 * dt), flush=True)
+        print("config 4: %d^2 MC N0%s, %d stream(s): %.3f ms per simulated realisation = %.0f sims/s per GPU (1000 sims on 8 GPUs ~ %.3f s)"
+              % (N, " + mean-field stack" if mf else "", ns, dt * 1e3, 1 / dt, 125 * dt), flush=True)
 
 
 if __name__ == "__main__":
