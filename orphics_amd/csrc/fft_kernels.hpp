@@ -328,6 +328,22 @@ struct RowLoad {
         return SWAP ? swp(x) : x;
     }
 };
+// R2C input rows: read exactly once per transform -> non-temporal (does not displace the small planes in L2 / MALL)
+template <typename T>
+struct RowLoadOnce {
+    static constexpr bool reads_lds = false;
+    const cx<T>* in;
+    unsigned pitch;
+    template <typename U> OA_HD cx<U> get(int n, int c) const {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_W64_PLAIN_LOADS)
+        typedef U v2 __attribute__((ext_vector_type(2)));
+        const v2 v = __builtin_nontemporal_load(reinterpret_cast<const v2*>(in + (unsigned)c * pitch + (unsigned)n));
+        return mk<U>(v.x, v.y);
+#else
+        return in[(unsigned)c * pitch + (unsigned)n];
+#endif
+    }
+};
 template <typename T, bool SWAP>
 struct RowStore {
     cx<T>* out;        // pre-offset to the first row of this workgroup
@@ -464,7 +480,7 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
         }
 #else
         fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL,
-                                                RowLoad<T, false>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
+                                                RowLoadOnce<T>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
 #endif
         r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale, false, a.wcols);
     } else {

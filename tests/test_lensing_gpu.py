@@ -551,6 +551,29 @@ def test_column_grid_is_exact():
             qbad.reconstruct_tt_from_map(x)
 
 
+@pytest.mark.parametrize("ny,nx,tl,kl", [(256, 256, 500, 800), (512, 256, 700, 1200), (1024, 256, 700, 1300), (256, 1024, 900, 1200)])
+def test_column_grid_small_and_rectangular(ny, nx, tl, kl):
+    """Tiny column grids (64 ... 256 rows: sub-lengths down to 8 points) and rectangular maps.  (The kappa mask stays
+    below twice the leg band limit: beyond it no pair of leg modes reaches L, the response is rounding noise and
+    A_L = 1/R amplifies it -- in every path, the modular one included.)"""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    shape = (ny, nx)
+    g = FlatGeometry.from_res(shape, 2.0)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    kw = dict(noise2d=np.full(shape, cosmology.white_noise_power(1.0)), beam2d=maps.gauss_beam(ml, 1.5),
+              kmask=maps.mask_kspace(shape, g, lmin=100, lmax=tl), kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=kl),
+              unlensed_equals_lensed=True, dtype="f64")
+    qc = lensing.qest(shape, g, th, **kw)
+    qf = lensing.qest(shape, g, th, col_grid="full", **kw)
+    x = qc.eng.to_real(np.random.default_rng(ny + nx).standard_normal(shape))
+    full = qf.reconstruct_tt_from_map(x).clone()
+    rec = qc.reconstruct_tt_from_map(x)
+    assert 0 < qc.col_grid < ny, (qc.col_grid, qc.leg_rows, qc.kappa_rows)
+    assert float((rec - full).abs().max()) / float(full.abs().max()) < 1e-12
+
+
 def test_column_grid_is_exact_for_pol_and_mv():
     """The polarised one-call path (oa_qe_pol) and the MV accumulation on the column grid equal the full-row results."""
     from orphics_amd import cosmology, lensing, maps
