@@ -1074,6 +1074,9 @@ struct ColLegsArgs {
     // row y + (y >= ny/2 ? yshift : 0) of the full-resolution grid, where the filters, the ly axis and -- when
     // xfull -- kX / kY live.  yshift = ny_full - My; 0 = the plan's own grid.
     int yshift, xfull;
+    // split != 0: launched with grid z = 3, workgroup z computes ONE leg plane (0 = H, 1 = Gx, 2 = Gy): three times the
+    // workgroups for the small latency-bound launches of the column grid (the tile's inputs are re-read per leg)
+    int split;
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -1122,13 +1125,14 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
     }
-    {   // H = FH kY
+    const int only = a.split ? ctx.bid_z() : -1;       // uniform per workgroup
+    if (only < 0 || only == 0) {   // H = FH kY
         const ColStore<T> st{a.h + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
-        ctx.sync();
+        if (only < 0) ctx.sync();
     }
-    {   // Gx = i lx FG kX   (lx is constant along a column)
+    if (only < 0 || only == 1) {   // Gx = i lx FG kX   (lx is constant along a column)
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int c = (tid + u * NT) & ((1 << logC) - 1);
@@ -1139,9 +1143,9 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
         const ColStore<T> st{a.gx + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
-        ctx.sync();
+        if (only < 0) ctx.sync();
     }
-    {   // Gy = i ly FG kX   (ly follows the input row of each tap)
+    if (only < 0 || only == 2) {   // Gy = i ly FG kX   (ly follows the input row of each tap)
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             const int j = (tid + u * NT) >> logC;

@@ -185,6 +185,7 @@ struct Fft2dPlan {
         a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
         a.rband = clampr(rband); a.ny = ny; a.yshift = yshift(); a.xfull = in_full ? 1 : 0;
+        a.split = (yshift() && (long)tiles * N2 < 1024) ? 1 : 0;     // small launches of the column grid: one leg per workgroup
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
