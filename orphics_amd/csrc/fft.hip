@@ -207,6 +207,11 @@ struct HipLauncher {
         rc = launch_col_fwdlegs<T>(st, gx, gy, nt, smem, logL, a);
     }
     template <typename T>
+    void col_fwdlegs_cg(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a) {
+        if (rc) return;
+        rc = launch_col_fwdlegs_cg<T>(st, gx, gy, nt, smem, logL, a);
+    }
+    template <typename T>
     void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
         const bool ok = dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
@@ -355,9 +360,14 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
         // their full-resolution positions); legs and inverse transform then run on my rows
         if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 1);
         if (stages & 4) {
-            f.cols(q, tA, pw, tB, pw, w, false, (T)1, 2, 1, nullptr, nullptr, rband);
-            coarse_view<T>(p, my).legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
-                                            (cx<T>*)gy, (cx<T>*)h, width, rband, pw, pout, true);
+            static const bool nofuse = getenv("OA_NO_FWDLEGS_CG") != nullptr;        // A/B switch
+            const auto cv = coarse_view<T>(p, my);
+            if (nofuse || !f.legs_cols_from_pass1_cg(q, cv, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd,
+                                                     (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, pw, pout)) {
+                f.cols(q, tA, pw, tB, pw, w, false, (T)1, 2, 1, nullptr, nullptr, rband);
+                cv.legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
+                             (cx<T>*)h, width, rband, pw, pout, true);
+            }
         }
     } else if (Fft2dPlan<T>::has_fwdlegs(p->logNy)) {
         if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 1);       // forward pass 1 only

@@ -1273,6 +1273,104 @@ OA_HD void col_fwdlegs_body(Ctx& ctx, const ColFwdLegsArgs<T>& a) {
 }
 
 // ===========================================================================
+// (A'') COLUMN GRID version of (A'): forward column pass 2 of the map's transform (length L, all ny rows) + leg filter +
+//       inverse pass 1 of the My-row transform in ONE kernel.
+//       ny = N1f * L and My = N1f * Lq: the tile of group g = k1 holds X[k1 + N1f k2], k2 < L; the My-row spectrum is
+//       X'[k1 + N1f k2'] with k2' = k2 (k2 < Lq/2) or k2 - (L - Lq) (k2 >= L - Lq/2), the rest of the band being empty.
+//       The inverse splits My = Lq (pass 1, over k2', here) x N1f (pass 2, over k1, a plain column pass afterwards):
+//         x[y_lo + Lq y_hi] = sum_k1 W_N1f^(-k1 y_hi) [ W_My^(-k1 y_lo) sum_k2' X'[k1 + N1f k2'] W_Lq^(-k2' y_lo) ].
+//       Built for Lq = 16 = L / (last forward radix): after the forward pass every butterfly of a thread holds exactly one
+//       kept bin, k2' = j (j = its position, j < 16): a thread owns j = q + 4 u (q = tid / 32, u = 0..3) of one column,
+//       so the 16-point inverse is a DFT-4 over u in registers, a W16 twiddle, and a DFT-4 over q through 4 KB of LDS.
+// ===========================================================================
+template <typename T>
+struct ColFwdLegsCgArgs {
+    const cx<T>* in;            // forward pass-1 output of the map's row transform (full resolution, ny rows)
+    const T* FG; const T* FH;   // full-resolution filter planes
+    const T* lxd; const T* lyd;
+    cx<T>* gx; cx<T>* gy; cx<T>* h;   // My-row planes, block-transposed pass-1 layout: row k1 * Lq + y_lo
+    long pitch, fpitch, opitch;
+    int width;
+    const cx<T>* tw;            // W_ny^k   (forward stage twiddles)
+    int logTw;
+    const cx<T>* twc;           // W_My^k   (inverse inter-pass twiddle)
+    long n1f;                   // row stride of the tile: rows g + n1f * n, n < L
+};
+
+template <typename T, class SEQF, class Ctx>
+OA_HD void col_fwdlegs_cg_body(Ctx& ctx, const ColFwdLegsCgArgs<T>& a) {
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    constexpr int logL = seq_total_log<SEQF>();
+    constexpr int L = 1 << logL;
+    constexpr int RL = SEQF::get(SEQF::n - 1), LRL = Log2x<RL>::v, NB = EPT / RL;
+    constexpr int Ns = L >> LRL;
+    constexpr int LQ = 16;
+    static_assert(Ns == LQ && NB == 4, "col_fwdlegs_cg: needs 16 positions per butterfly and 4 butterflies per thread");
+    constexpr int logC = COL_LOGC;
+    constexpr int NT = (1 << (logL + COL_LOGC)) / EPT;
+    static_assert(NT == 4 << COL_LOGC, "col_fwdlegs_cg: a thread owns positions q + 4 u of one column");
+    const int tid = ctx.tid();
+    const int c0 = ctx.bid_x() << logC;
+    const long g = ctx.bid_y();
+    int ncols = a.width - c0;
+    if (ncols > (1 << logC)) ncols = 1 << logC;
+    cx<T> gv[EPT];
+    cx<T>* twl = s + (1 << (logL + logC));
+    cx<T>* ex = twl + tw_lds_size(logL);                  // [4 q][4 a][C] exchange of the 16-point inverse
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    ctx.sync();
+    const ColLoad<T> ld{a.in + g * a.pitch + c0, (unsigned)(a.n1f * a.pitch), ncols, false};
+    col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, logC, twl, logL, ld);
+    const int c = tid & ((1 << logC) - 1), q = tid >> logC;
+    const bool ok = c < ncols;
+    const T lx = ok ? a.lxd[c0 + c] : (T)0;
+    // the forward pass is done ONCE per tile; the three legs follow from its registers (tripling the workgroups so
+    // that each redoes the forward pass measured slower: 24.8 us vs 19.1 us for the two launches this kernel replaces)
+    for (int leg = 0; leg < 3; ++leg) {                   // 0 = H, 1 = Gx, 2 = Gy
+        cx<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = q + 4 * u;                      // kept bin k2' of this butterfly
+            const bool low = j < LQ / 2;
+            const cx<T> x = low ? gv[u * RL] : gv[u * RL + RL - 1];
+            const int k2 = low ? j : (L - LQ) + j;
+            const unsigned y = (unsigned)g + (unsigned)k2 * (unsigned)a.n1f;      // full-resolution row of this mode
+            cx<T> val = mk<T>((T)0, (T)0);
+            if (ok) {
+                const unsigned fi = y * (unsigned)a.fpitch + (unsigned)(c0 + c);
+                if (leg == 0) val = x * a.FH[fi];
+                else if (leg == 1) val = mul_pi(x * a.FG[fi]) * lx;
+                else val = mul_pi(x * a.FG[fi]) * a.lyd[y];
+            }
+            v[u] = swp(val);                              // inverse transform = forward transform of the swapped data
+        }
+        Dft<T, 4>::run(v);                                // over u: B[a] = sum_u v[q + 4 u] W4^(u a)
+#pragma unroll
+        for (int aa = 1; aa < 4; ++aa) {                  // W16^(q a), q a in {0,1,2,3,4,6,9}; W16^(8 + k) = -W16^k
+            const int e = q * aa;
+            const cx<T> w = w16<T>(e & 7);
+            v[aa] = v[aa] * (e >= 8 ? mk<T>(-w.x, -w.y) : w);
+        }
+        if (leg) ctx.sync();                              // the previous leg's exchange reads are complete
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) ex[((q * 4 + aa) << logC) + c] = v[aa];
+        ctx.sync();
+        cx<T>* out = (leg == 0 ? a.h : (leg == 1 ? a.gx : a.gy)) + (g * LQ) * a.opitch + c0;
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            cx<T> t[4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) t[qq] = ex[((qq * 4 + aa) << logC) + c];
+            Dft<T, 4>::run(t);                            // over q: X[a + 4 b] = sum_q B'[q][a] W4^(q b); this thread keeps b = q
+            const int y = aa + 4 * q;
+            cx<T> r = (q == 0 ? t[0] : (q == 1 ? t[1] : (q == 2 ? t[2] : t[3])));
+            r = swp(r * a.twc[(unsigned)g * (unsigned)y]);    // inter-pass twiddle W_My^(g y_lo), then back from the swapped domain
+            if (ok) out[(unsigned)y * (unsigned)a.opitch + (unsigned)c] = r;
+        }
+    }
+}
+
+// ===========================================================================
 // (B) divergence * normalisation fused into the forward column pass 2:
 //     out = Fn * (i lx FFTcol[A] + i ly FFTcol[B])   (+ out if accumulate)
 // ===========================================================================

@@ -133,9 +133,10 @@ struct Fft2dPlan {
     template <class Launcher>
     void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
               T scale, int which = 0, int nb = 1, const cx<T>* const* ins = nullptr, cx<T>* const* outs = nullptr,
-              int rband = 0, bool swap = false) const {   // rband: the natural-order result (pass 2) is stored on the band rows only
+              int rband = 0, bool swap = false, int logn1 = -1) const {   // rband: the natural-order result (pass 2) is stored on the band rows only
         // swap: split Ny the other way round (pass 1 the SHORTER length) -- the inverse after legs_cols_from_pass1
-        const int logN1 = swap ? logNy / 2 : (logNy + 1) / 2, logN2 = logNy - logN1;
+        // logn1 >= 0: explicit pass-1 length (the inverse after legs_cols_from_pass1_cg: 16 x Ny/16)
+        const int logN1 = logn1 >= 0 ? logn1 : (swap ? logNy / 2 : (logNy + 1) / 2), logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
         const int tiles = (width + C - 1) / C;
@@ -215,6 +216,33 @@ struct Fft2dPlan {
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
         cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs, 0, true);   // inverse pass 2, split swapped
+        return true;
+    }
+
+    // (A'') COLUMN GRID: legs from the forward column pass 1 of the map's transform on THIS (full-resolution) plan, outputs
+    //       on `my` rows: forward pass 2 + filter + 16-point inverse pass 1 in one kernel (one leg per workgroup), then the
+    //       3-plane inverse pass 2 of length ny / L on the coarse view `cv`.  false: geometry without this kernel.
+    static bool has_fwdlegs_cg(int logNy, int my) {
+        const int logL = logNy / 2;
+        return logL == 6 && my > 0 && (my >> (logNy - logL)) == 16;
+    }
+    template <class Launcher>
+    bool legs_cols_from_pass1_cg(Launcher& q, const Fft2dPlan<T>& cv, const cx<T>* p1, const T* FG, const T* FH, const T* lxd,
+                                 const T* lyd, cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax, long pin, long pout) const {
+        if (!has_fwdlegs_cg(logNy, cv.ny)) return false;
+        const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
+        const int logL = logNy / 2, logN1f = logNy - logL;
+        const long L = 1L << logL, N1f = 1L << logN1f;
+        const int C = 1 << COLC;
+        const int width = clampw(wmax);
+        const int tiles = (width + C - 1) / C;
+        ColFwdLegsCgArgs<T> a{};
+        a.in = p1; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
+        a.pitch = pi; a.fpitch = kp; a.opitch = po; a.width = width; a.tw = tw_y; a.logTw = logNy; a.twc = cv.tw_y; a.n1f = N1f;
+        q.col_fwdlegs_cg(tiles, (int)N1f, (int)((L * C) / EPT), ((size_t)L * C + tw_lds_size(logL) + 16 * C) * sizeof(cx<T>), logL, a);
+        cx<T>* outs[3] = {gx, gy, h};
+        const cx<T>* ins[3] = {gx, gy, h};
+        cv.cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs, 0, false, 4);   // inverse pass 2: length My / 16 at row stride 16
         return true;
     }
 

@@ -88,6 +88,9 @@ struct EmuLauncher {
                 run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fwdlegs_body<T, S>(c, a); });
         });
     }
+    template <typename T> void col_fwdlegs_cg(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a) {
+        if (logL == 6) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fwdlegs_cg_body<T, Seq<16, 4>>(c, a); });
+    }
     template <typename T> void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
@@ -218,6 +221,22 @@ int emu_r2c_rows_w64x2_f32(int ny, int nx, const float* in, void* out, double sc
     a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (float)scale; a.wcols = width; a.ny = ny; a.nwg = nwg;
     EmuLauncher q;
     q.run(nwg, 1, 128, W64X2_LDS_BYTES, [&](EmuCtx& c) { row_r2c_w64x2_body(c, a); });
+    return 0;
+}
+// real map -> leg planes on the my-row column grid: fused (fwd pass 2 + legs + 16-point inverse pass 1) vs the three-launch path
+int emu_map_legs_cols_cg_f64(int ny, int my, int nx, const double* map, const double* FG, const double* FH, const double* lxd,
+                             const double* lyd, void* gx, void* gy, void* h, int width, int rband, int fused) {
+    Holder<double> hd(ny, nx);
+    CoarseHolder<double> cv(ny, my, nx);
+    std::vector<cx<double>> tA((size_t)ny * hd.p.kp), tB((size_t)ny * hd.p.kp);
+    EmuLauncher q;
+    const int w = hd.p.clampw(width);
+    hd.p.rows(q, ROW_R2C, map, nx / 2, tA.data(), hd.p.kp, 1.0, w);
+    hd.p.cols(q, tA.data(), hd.p.kp, tB.data(), hd.p.kp, w, false, 1.0, 1);
+    if (fused)
+        return hd.p.legs_cols_from_pass1_cg(q, cv.p, tB.data(), FG, FH, lxd, lyd, (cx<double>*)gx, (cx<double>*)gy, (cx<double>*)h, width, 0, 0) ? 0 : 1;
+    hd.p.cols(q, tA.data(), hd.p.kp, tB.data(), hd.p.kp, w, false, 1.0, 2, 1, nullptr, nullptr, rband);
+    cv.p.legs_cols(q, tB.data(), tB.data(), FG, FH, lxd, lyd, (cx<double>*)gx, (cx<double>*)gy, (cx<double>*)h, width, rband, 0, 0, true);
     return 0;
 }
 int emu_legs_cols_cg_f64(int ny_full, int my, int nx, const void* kX, const void* kY, const double* FG, const double* FH,

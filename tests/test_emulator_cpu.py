@@ -329,3 +329,38 @@ def test_two_waves_per_row_r2c(emu):
     ref = np.fft.rfft(x.astype(np.float64), axis=1)
     assert np.abs(out[:, :width] - ref[:, :width]).max() < 2e-6 * np.abs(ref).max()
     assert np.all(out[:, width:] == 3.0)
+
+
+@pytest.mark.parametrize("ny,my,w,rb", [(4096, 1024, 20, 190), (8192, 2048, 33, 300), (4096, 1024, 0, 100)])
+def test_fused_forward_pass2_legs_on_the_column_grid(emu, ny, my, w, rb):
+    """col_fwdlegs_cg_body (forward pass 2 + leg filter + 16-point inverse pass 1, one leg per workgroup) followed by the
+    16 x My/16 inverse pass 2 equals the three-launch column-grid path AND the NumPy inverse transform of the leg band."""
+    nx = 64
+    rng = np.random.default_rng(ny + w)
+    W = nx // 2 + 1
+    wv = w if w else W
+    kp = emu.emu_kpitch(nx)
+    ly = 2 * np.pi * np.fft.fftfreq(ny) * 100
+    lx = 2 * np.pi * np.fft.fftfreq(nx) * 100
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[ny // 2] = 0
+    lxd[nx // 2] = 0
+    x = rng.standard_normal((ny, nx))
+    band = np.r_[0:rb, ny - rb + 1:ny]
+    FG = np.zeros((ny, kp)); FH = np.zeros((ny, kp))
+    FG[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv))
+    FH[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv))
+    outs = {}
+    for fused in (1, 0):
+        o = [_hc(emu, my, nx, fill=3.0) for _ in range(3)]
+        assert emu.emu_map_legs_cols_cg_f64(ny, my, nx, _p(x), _p(FG), _p(FH), _p(lxd), _p(lyd), _p(o[0]), _p(o[1]), _p(o[2]), w, rb, fused) == 0
+        outs[fused] = o
+    rows = np.r_[0:my // 2, ny - my // 2:ny]
+    kT = np.fft.rfft2(x)[rows]
+    lx2, ly2 = lxd[None, :W], lyd[rows][:, None]
+    refs = [_col_ifft(1j * lx2 * FG[rows][:, :W] * kT, my), _col_ifft(1j * ly2 * FG[rows][:, :W] * kT, my), _col_ifft(FH[rows][:, :W] * kT, my)]
+    for a, b, want in zip(outs[1], outs[0], refs):
+        assert np.abs(a[:, :wv] - want[:, :wv]).max() < 1e-11 * np.abs(want).max()
+        assert np.abs(a[:, :wv] - b[:, :wv]).max() < 1e-11 * np.abs(want).max()
+        if w:
+            assert np.all(a[:, wv:W] == 3.0)
