@@ -333,7 +333,13 @@ def per_kernel_table(torch, P, R, args):
     my = int(lib.oa_plan_col_grid(plan))
     cg = my / float(N) if my else 1.0
     # name -> (stage, bytes it must move once: inputs + outputs on its active columns / rows)
-    if my:
+    logn = int(round(np.log2(N)))
+    if my and logn // 2 == 6 and (my >> (logn - 6)) == 16 and not os.environ.get("OA_NO_FWDLEGS_CG"):
+        legs_name = "fwdlegs_cols = col_fwdlegs_cg_kernel (fwd pass2 + legs + inv pass1) + col_fft_kernel<inv pass2 x3> on the %d-row column grid" % my
+        # fused kernel: read the pass-1 plane + 2 real filter planes on the band rows, write 3 planes of my rows; then the
+        # 3-plane inverse pass 2 on my rows (r + w)
+        legs_bytes = fl * (Ah + gl * Ah + 3 * cg * Ah) + 6 * fl * cg * Ah
+    elif my:
         legs_name = "fwdlegs_cols = col_fft_kernel<fwd pass2> + col_legs_kernel + col_fft_kernel<inv pass2 x3> on the %d-row column grid" % my
         # forward pass 2 (read the pass-1 plane, write the band rows) + col_legs (read the band rows + 2 real filter planes there,
         # write 3 planes of my rows) + 3-plane inverse pass 2 on my rows (r + w)
