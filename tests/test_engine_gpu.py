@@ -173,6 +173,21 @@ def test_bin_hermitian_half_plane(prec):
     np.testing.assert_allclose(sh.cpu().numpy(), sf.cpu().numpy(), rtol=1e-12)
 
 
+@pytest.mark.parametrize("ny,nx,width", [(64, 8192, 300), (32, 8192, 512), (64, 8192, 1), (32, 16384, 760), (64, 16384, 37)])
+def test_band_limited_r2c_row_kernels_on_short_maps(ny, nx, width):
+    """The one-wave-per-row (8192-point rows) and two-waves-per-row (16384-point rows) R2C kernels on maps with few
+    rows (fewer rows than resident waves) and extreme widths: rfft(width=...) equals torch.fft.rfft2 on the kept columns."""
+    from orphics_amd.engine import Engine
+    e = Engine.get(ny, nx, "f32")
+    x = torch.randn(ny, nx, device="cuda", dtype=torch.float32)
+    ref = torch.fft.rfft2(x.double())
+    out = e.hc(); out[:] = 7.0
+    e.rfft(x, out=out, width=width)
+    err = float((out[:, :width].to(torch.complex128) - ref[:, :width]).abs().max() / ref.abs().max())
+    assert err < 3e-6, err
+    assert bool((out[:, width:] == 7.0).all())
+
+
 def test_grf_band_is_a_subset_of_the_full_draw():
     """oa_grf_hc_band draws only the active region, with the same Philox counters as the full plane."""
     from orphics_amd.engine import Engine
