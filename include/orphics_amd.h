@@ -224,10 +224,12 @@ int oa_hc_resample(int dtype, const void* in, int ny_in, int nx_in, long kp_in, 
  * oa_f2power    : out = Re(conj(k1)*k2)*norm        (FourierCalc.f2power, maps.py:1620-1624)
  * oa_cmul_real  : out = k * f (complex * real)      (filter_map's `* kfilter`, maps.py:1923;
  *                                                   MapGen covsqrt*rand scalar case, maps.py:1579)
+ * oa_cmul       : out = k * f (complex * complex)   (filter_map with a complex kfilter, maps.py:1923)
  * oa_mul_real   : out = a * b (real)                (QE real-space product)
  * oa_axpby_real : out = alpha*a + beta*b (real)     (observed = beamed + noise, lensing.py:516) */
 int oa_f2power(int dtype, const void* k1, const void* k2, void* out_real, double norm, long n, void* stream);
 int oa_cmul_real(int dtype, const void* k_in, const void* filt_real, void* k_out, long n, void* stream);
+int oa_cmul(int dtype, const void* k_in, const void* filt_complex, void* k_out, long n, void* stream);
 int oa_mul_real(int dtype, const void* a, const void* b, void* out, long n, void* stream);
 int oa_axpby_real(int dtype, const void* a, const void* b, void* out, double alpha, double beta, long n, void* stream);
 /* per-mode 2x2 rotation of two complex planes: [o1;o2] = [[c,-s],[s,c]] [i1;i2]

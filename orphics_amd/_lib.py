@@ -67,6 +67,7 @@ SIGNATURES = {
     "oa_hc_resample": (c_int, [c_int, c_void_p, c_int, c_int, c_long, c_void_p, c_int, c_int, c_long, c_double, c_void_p]),
     "oa_f2power": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p]),
     "oa_cmul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_cmul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_mul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_axpby_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_double, c_long, c_void_p]),
     "oa_rot2": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),

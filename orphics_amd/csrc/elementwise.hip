@@ -25,6 +25,16 @@ __global__ __launch_bounds__(256) void f2power_kernel(const cx<T>* __restrict__ 
     if (t0 < n) out[t0] = (k1[t0].x * k2[t0].x + k1[t0].y * k2[t0].y) * norm;
 }
 
+// out = k * f, both complex (filter_map with a complex k-space filter, maps.py:1923)
+template <typename T>
+__global__ __launch_bounds__(256) void cmul_kernel(const cx<T>* __restrict__ k, const cx<T>* __restrict__ f, cx<T>* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const cx<T> a = k[i], b = f[i];
+        out[i] = mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void cmul_real_kernel(const cx<T>* __restrict__ k, const T* __restrict__ f,
                                                         cx<T>* __restrict__ out, long n4, long n) {
@@ -296,6 +306,17 @@ int oa_cmul_real(int dtype, const void* k, const void* f, void* out, long n, voi
                                 (cx<float>*)out, n4, n),
              hipLaunchKernelGGL(cmul_real_kernel<double>, dim3(g), dim3(256), 0, st, (const cx<double>*)k, (const double*)f,
                                 (cx<double>*)out, n4, n));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_cmul(int dtype, const void* k, const void* f, void* out, long n, void* stream) {
+    OA_REQUIRE(k && f && out && n >= 0, "oa_cmul: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = flat_grid(n > 0 ? n : 1);
+    DISPATCH(dtype,
+             hipLaunchKernelGGL(cmul_kernel<float>, dim3(g), dim3(256), 0, st, (const cx<float>*)k, (const cx<float>*)f, (cx<float>*)out, n),
+             hipLaunchKernelGGL(cmul_kernel<double>, dim3(g), dim3(256), 0, st, (const cx<double>*)k, (const cx<double>*)f, (cx<double>*)out, n));
     OA_LAUNCH_CHECK();
     return 0;
 }

@@ -396,6 +396,15 @@ class Engine(object):
         check(self.lib.oa_cmul_real(self.code, _ptr(k), _ptr(f), _ptr(out), n, _stream()))
         return out
 
+    def cmul(self, k, f, out=None):
+        """complex * complex, elementwise (k-space filters with a phase)"""
+        n = self._same(k, f)
+        if k.dtype != self.cdt or f.dtype != self.cdt:
+            raise ValueError("cmul: dtype mismatch")
+        out = torch.empty_like(k) if out is None else _dirty(out)
+        check(self.lib.oa_cmul(self.code, _ptr(k), _ptr(f), _ptr(out), n, _stream()))
+        return out
+
     def mul_real(self, a, b, out=None):
         n = self._same(a, b)
         if a.dtype != self.rdt or b.dtype != self.rdt:

@@ -348,17 +348,25 @@ class FourierCalc(object):
 
 def filter_map(imap, kfilter):
     """maps.py:1922-1923: Re(IFFT(FFT(m) * F)), IFFT / Npix.  ``kfilter`` is a
-    real (or int) full-plane (Ny,Nx) array; an even-symmetric filter keeps the
+    full-plane (Ny,Nx) array: an even-symmetric real (or int) filter keeps the
     result exactly real and allows the half-plane R2C/C2R path, a general real
-    filter takes the C2C path like the reference."""
+    or a complex filter takes the C2C path like the reference."""
     torch = _torch()
     from .engine import precision_of
     shape = tuple(imap.shape)
     eng = _engine(shape, precision_of(imap))
     x = eng.to_real(imap)
     f = kfilter
-    if isinstance(f, np.ndarray) and np.iscomplexobj(f):
-        raise NotImplementedError("complex k-space filters are outside the reference's hot path")
+    if (isinstance(f, np.ndarray) and np.iscomplexobj(f)) or (_is_tensor(f) and f.is_complex()):
+        # complex filter (a phase: shifts, derivative operators): full-plane C2C like the reference
+        fc = eng.to_complex(np.broadcast_to(np.asarray(f), shape[-2:]) if not _is_tensor(f) else f)
+        planes, lead = _planes(x)
+        outs = []
+        for p in planes:
+            k = eng.hc_to_full(eng.rfft(p.contiguous()))
+            k = eng.cmul(k, fc, out=k)
+            outs.append(torch.real(eng.cfft(k, inverse=True, scale=1.0 / eng.npix)).contiguous())
+        return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), imap)
     fdev = eng.to_real(np.broadcast_to(np.asarray(f, dtype=np.float64), shape[-2:]) if not _is_tensor(f) else f)
     planes, lead = _planes(x)
     # even-symmetry test decides the fast path

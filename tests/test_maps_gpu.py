@@ -102,6 +102,25 @@ def test_filter_map_beam_mask():
     assert np.array_equal(t, to) and w2 == w2o
 
 
+def test_filter_map_complex_filter_is_a_shift():
+    """maps.filter_map with a COMPLEX k-space filter (maps.py:1923 takes any array): the phase ramp exp(-i l.dx) of a
+    whole-pixel shift reproduces np.roll; a general complex filter equals the NumPy expression Re(IFFT(FFT(m) F))."""
+    from orphics_amd import maps
+    from orphics_amd.geometry import FlatGeometry
+    ny, nx = 128, 256
+    rng = np.random.default_rng(9)
+    m = rng.standard_normal((ny, nx))
+    ky = np.fft.fftfreq(ny)[:, None]; kx = np.fft.fftfreq(nx)[None, :]
+    shift = np.exp(-2j * np.pi * (3 * ky + 5 * kx))
+    out = maps.filter_map(m, shift)
+    assert np.abs(out - np.roll(m, (3, 5), axis=(0, 1))).max() < 1e-10
+    F = rng.standard_normal((ny, nx)) + 1j * rng.standard_normal((ny, nx))
+    want = np.real(np.fft.ifft2(np.fft.fft2(m) * F))
+    assert np.abs(maps.filter_map(m, F) - want).max() < 1e-10 * np.abs(want).max()
+    out32 = maps.filter_map(m.astype(np.float32), shift)
+    assert out32.dtype == np.float32 and np.abs(out32 - np.roll(m, (3, 5), axis=(0, 1))).max() < 2e-5
+
+
 def test_mapgen_parity_and_statistics():
     from orphics_amd import maps
     shape = (128, 128)
