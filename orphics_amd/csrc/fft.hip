@@ -22,15 +22,6 @@ __global__ __launch_bounds__(128, 1) void row_r2c_w64x2_kernel(RowW64Args a) {
     row_r2c_w64x2_body(c, a);
 }
 
-#ifndef OA_STREAM_WAVES_PER_EU
-#define OA_STREAM_WAVES_PER_EU 3     // two row blocks of registers (current + prefetched): 128 VGPRs spill, 168 do not
-#endif
-template <typename T, class SEQ>
-__global__ __launch_bounds__(row_maxnt<SEQ>(), OA_STREAM_WAVES_PER_EU) void row_r2c_stream_kernel(RowArgs<T> a, int ny, int nwg) {
-    GpuCtx c{oa_dyn_smem};
-    row_r2c_stream_body<T, SEQ>(c, a, ny, nwg);
-}
-
 #ifndef OA_QE_WAVES_PER_EU
 #define OA_QE_WAVES_PER_EU 3
 #endif
@@ -91,20 +82,6 @@ struct HipLauncher {
         if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
         go(row_fft_kernel<T, MODE, S>, dim3(grid), nt, smem, a);
     }
-    // resident workgroups of the streaming R2C pass: LDS-limited (160 KB per CU)
-    static int stream_wgs(size_t smem, int nt) {
-        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        int per = (int)(LDS_MAX / (smem ? smem : 1));
-        // workgroups of 256 threads = one wave per SIMD each: the register budget allows OA_STREAM_WAVES_PER_EU of them
-        const int wps = (nt + 255) / 256;          // waves per SIMD of one workgroup
-        if (per > OA_STREAM_WAVES_PER_EU / wps) per = OA_STREAM_WAVES_PER_EU / wps;
-        if (per < 1) per = 1;
-        return cus * per;
-    }
-    static int r2c_stream_mode() {
-        static const int m = [] { const char* e = getenv("OA_R2C_STREAM"); return e ? atoi(e) : 0; }();
-        return m;
-    }
     static int r2c_w64_mode() {
         static const int m = [] { const char* e = getenv("OA_R2C_W64"); return e ? atoi(e) : 1; }();
         return m;
@@ -139,18 +116,6 @@ struct HipLauncher {
         if (row_w64(grid << a.logC, a)) return;
         const bool ok = dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
-            if constexpr (sizeof(T) == 4 && seq_logl<S>() >= 10) {
-                const int nwg = stream_wgs(smem, nt);
-                if (a.mode == ROW_R2C && r2c_stream_mode() && grid >= 2 * nwg) {
-                    if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
-                    if (rc) return;
-                    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(row_r2c_stream_kernel<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                    hipLaunchKernelGGL((row_r2c_stream_kernel<T, S>), dim3(nwg), dim3(nt), smem, st, a, grid << a.logC, nwg);
-                    hipError_t e = hipGetLastError();
-                    if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
-                    return;
-                }
-            }
             switch (a.mode) {
                 case ROW_R2C: row_mode<T, ROW_R2C, S>(grid, nt, smem, a); break;
                 case ROW_C2R: row_mode<T, ROW_C2R, S>(grid, nt, smem, a); break;

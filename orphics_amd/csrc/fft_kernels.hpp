@@ -491,69 +491,6 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// Streaming R2C row pass: a resident grid of workgroups walks the rows (row block b, b + G, ...), and the global
-// loads of the NEXT row block are issued into registers before the current one goes through its FFT stages, so HBM
-// reads stay in flight under the arithmetic / LDS phases (the barriers wait for LDS traffic only: GpuCtx::sync).
-// Same arithmetic, same results as row_fft_body<ROW_R2C>: the first stage takes its taps from registers.
-// ---------------------------------------------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-template <typename T> __device__ __forceinline__ void keep_live(cx<T>& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
-#else
-template <typename T> inline void keep_live(cx<T>&) {}
-#endif
-template <typename T, class SEQ, class Ctx>
-OA_HD void row_r2c_stream_body(Ctx& ctx, const RowArgs<T>& a, int ny, int nwg) {
-    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
-    const int tid = ctx.tid(), NT = a.NT;
-    constexpr int logL = seq_total_log<SEQ>();
-    constexpr int R0 = SEQ::r0, LR0 = Log2x<R0>::v, NB = EPT / R0, logLR = logL - LR0;
-    const int C = 1 << a.logC, RS = a.rowStride;
-    const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
-    cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
-    cx<T>* twl = s + C * RS;
-    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
-    cx<T> cur[EPT], nxt[EPT];
-    // element u*R0+t of this thread <-> point j_u + t*L/R0 of row c_u (as stage_in<ROWMAJOR, SRC_G>)
-    auto fetch = [&](cx<T>* v, long r0) {
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int b = tid + u * NT;
-            const int j = b & ((1 << logLR) - 1), c = b >> logLR;
-            const cx<T>* row = in + (r0 + c) * a.in_pitch + j;
-#pragma unroll
-            for (int t = 0; t < R0; ++t) v[u * R0 + t] = row[t << logLR];
-        }
-    };
-    long r0 = (long)ctx.bid_x() * C;
-    const long step = (long)nwg * C;
-    if (r0 >= ny) return;                             // whole workgroup (uniform): no barrier is skipped by a subset
-    fetch(cur, r0);
-    // The first block's loads complete HERE, so that no load of `cur` is pending on any path into the loop: with a
-    // pending load merging in at the loop header the compiler's static s_waitcnt placement would wait for vmcnt(0)
-    // after the prefetch has been issued, i.e. for the prefetch itself.
-#pragma unroll
-    for (int i = 0; i < EPT; ++i) keep_live(cur[i]);
-    ctx.sync();
-    constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
-    for (; r0 < ny; r0 += step) {
-        // unconditional prefetch (no control flow around the loads): the last trip re-reads its own block
-        const long rn = (r0 + step < ny) ? r0 + step : r0;
-        fetch(nxt, rn);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) Dft<T, R0>::run(cur + u * R0);
-        stage_out<T, R0, true, false>(s, cur, tid, NT, logL, a.logC, RS, 0, NoStore{});
-        ctx.sync();
-        if constexpr (SEQ::n >= 2) { stage<T, SEQ::r1, true, false, false>(ctx, s, tid, NT, logL, a.logC, RS, l0, twl, logL, NoLoad{}, NoStore{}); ctx.sync(); }
-        if constexpr (SEQ::n >= 3) { stage<T, SEQ::r2, true, false, false>(ctx, s, tid, NT, logL, a.logC, RS, l1, twl, logL, NoLoad{}, NoStore{}); ctx.sync(); }
-        if constexpr (SEQ::n >= 4) { stage<T, SEQ::r3, true, false, false>(ctx, s, tid, NT, logL, a.logC, RS, l2, twl, logL, NoLoad{}, NoStore{}); ctx.sync(); }
-        r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale, false, a.wcols);
-        ctx.sync();                                   // the epilogue's LDS reads precede the next block's first-stage writes
-#pragma unroll
-        for (int i = 0; i < EPT; ++i) cur[i] = nxt[i];
-    }
-}
-
 // ===========================================================================
 // Fused QE row stage (TT and every other estimator term): for each row
 //   h = C2R(H),  for leg in (Gx, Gy):  P_leg = R2C( C2R(leg) * h )
