@@ -151,10 +151,11 @@ class Runner(object):
     """`ns` estimator handles on `ns` HIP streams (shared filters, private plan + work buffers), device-side
     bandpower moments per stream: step(i) = map -> kappa_hat -> 19 bandpowers -> (n, S, C) accumulation."""
 
-    def __init__(self, P, torch, tmaps, ns):
+    def __init__(self, P, torch, tmaps, ns, pair=True):
         from orphics_amd.engine import _ptr, _stream
         from orphics_amd._lib import check
         self.P, self.torch, self.tmaps, self.ns = P, torch, tmaps, max(1, ns)
+        self.pair = bool(pair)        # two realisations per C-ABI call (oa_qe_tt_moments2): they share every launch behind the row R2C
         q, eng = P["q"], P["eng"]
         self.q, self.eng = q, eng
         self.d = P["nids"] - 2
@@ -180,6 +181,19 @@ class Runner(object):
         with self.torch.cuda.stream(self.streams[j]):
             self.qs[j].tt_moments(self.tmaps[i & 1], self.mom_n[j], self.mom_S[j], self.mom_C[j])
 
+    def run(self, first, count):
+        """`count` reconstructions starting at step index `first`: in pair mode two steps (maps 0 and 1) per call."""
+        if not self.pair:
+            for i in range(first, first + count):
+                self.step(i)
+            return
+        for c in range(count // 2):
+            j = (first // 2 + c) % self.ns
+            with self.torch.cuda.stream(self.streams[j]):
+                self.qs[j].tt_moments2(self.tmaps[0], self.tmaps[1], self.mom_n[j], self.mom_S[j], self.mom_C[j])
+        if count & 1:
+            self.step(first + count - 1)
+
     def bandpowers(self, which=0):
         """bandpowers of map `which` through this runner's path (public fine-grained calls, same kernels)"""
         q, P, e = self.q, self.P, self.eng
@@ -194,12 +208,10 @@ class Runner(object):
             self.mom_n[j].zero_(); self.mom_S[j].zero_(); self.mom_C[j].zero_()
 
     def rate(self, nsteps, nwarm=10):
-        for i in range(nwarm):
-            self.step(i)
+        self.run(0, nwarm)
         self.torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(nsteps):
-            self.step(i)
+        self.run(0, nsteps)
         self.torch.cuda.synchronize()
         return nsteps / (time.perf_counter() - t0)
 
@@ -467,6 +479,7 @@ def main():
     ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
                     help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
                          "(exact for band-limited filters; library default), full = the map's nx points")
+    ap.add_argument("--no-pair", action="store_true", help="one realisation per C-ABI call (oa_qe_tt_moments) instead of two (oa_qe_tt_moments2)")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams: independent realisations are issued round-robin "
                     "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
     args = ap.parse_args()
@@ -497,18 +510,16 @@ def main():
     q, eng = P["q"], P["eng"]
     seed = 1234 + rank                                    # distinct realisations per rank
     tmaps = make_maps(P, torch, seed)
-    R = Runner(P, torch, tmaps, args.streams)
+    R = Runner(P, torch, tmaps, args.streams, pair=not args.no_pair)
     ns = R.ns
 
     # pre-roll: a fresh box idles at ~550 MHz sclk and needs a few hundred ms of load to reach its sustained
     # clocks; W warm-up steps alone (~10 ms) would leave the ramp inside the timed region.  Untimed, uncounted.
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < args.preroll:
-        for i in range(8):
-            R.step(i)
+        R.run(0, 8)
         torch.cuda.synchronize()
-    for i in range(args.warmup):
-        R.step(i)
+    R.run(0, args.warmup)
     torch.cuda.synchronize()
     # rehearse the end-of-job reduction once (first use of a torch op / of the RCCL communicator loads code
     # objects and opens connections: tens of ms that belong to start-up, not to the K timed steps)
@@ -523,12 +534,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     evs = []
-    for i in range(args.steps):
-        R.step(i)
-        if args.trace_steps:
+    if args.trace_steps:
+        for i in range(args.steps):
+            R.step(i)
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(R.streams[i % ns])
             evs.append(ev)
+    else:
+        R.run(0, args.steps)          # exactly K reconstructions (pair mode: K // 2 two-map calls + one single if K is odd)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic: must stay < elapsed)
     torch.cuda.synchronize()
     if args.trace_steps and rank == 0:
@@ -608,13 +621,20 @@ def main():
                                    "incl. R2C of the input map and 19-bin kappa auto-bandpowers; T filter ell in (300,%d), "
                                    "kappa mask (20,3500), 1.5' beam, 1 uK' noise" % (N, N, args.res, int(args.tlmax)),
                        "map_side": N, "res_arcmin": args.res, "estimator": "TT", "nbins": R.d,
-                       "streams_per_gpu": ns,
+                       "streams_per_gpu": ns, "realisations_per_call": 2 if R.pair else 1,
                        "parallelism": "independent realisations per GPU + 1 all-reduce of bandpower moments"},
             "roofline": roofline,
         }
         hbm = {"peak_GBs": HBM_PEAK_GBS,
                "kernels_on_own_bytes": {k: {"GBs": v["hbm_GBs"], "frac": v["hbm_frac"]} for k, v in per.items() if "hbm_GBs" in v and k != "row_qe_kernel"},
                "survey_8d_bytes_per_recon_dense": 37.25 * A}
+        if traffic_tab and traffic_tab.get("bytes_per_recon"):
+            # every launch of a reconstruction together: PMC bytes through the L2 <-> fabric interface x reconstructions/s.
+            # (Kernel boundaries flush the per-XCD L2s, so every intermediate plane makes the round trip even when the
+            # infinity cache holds it; a plain device copy moves 5.4 TB/s through the same interface: tools/hbm_read_probe.py.)
+            bpr = float(traffic_tab["bytes_per_recon"])
+            hbm["whole_pipeline_on_pmc_bytes"] = {"bytes_per_recon": bpr, "GBs": bpr * rate / 1e9, "frac": bpr * rate / 1e9 / HBM_PEAK_GBS,
+                                                  "plain_copy_GBs_on_this_part": 5400.0}
         if world == 1 and not args.no_extras and not args.no_prune:
             want = [w for w in args.extras.split(",") if w]
             ref_p1d = R.bandpowers(0)

@@ -177,6 +177,9 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
               int leg_cols, int kappa_cols, int leg_rows, int kappa_rows, int mrow, int zero_outside, void* stream);
 int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream);
 int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, double* C, void* stream);
+/* Two Monte-Carlo steps per call (two independent maps): identical results to two oa_qe_tt_moments calls; on the
+ * column-grid path every launch behind the two row transforms is shared by both maps. */
+int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, int64_t* n, double* S, double* C, void* stream);
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S,
               double* C, double* meanfield_acc, void* stream);
 /* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py roofline; the

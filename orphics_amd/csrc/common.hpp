@@ -94,6 +94,10 @@ int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* p
               int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0);
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
                   long pk, hipStream_t st, int my = 0);
+// two maps at once (fft.hip); -1 = not available for this geometry
+int qe_tt_pair_w(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0, void* c1,
+                 void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow, int my, long pl, long pk,
+                 hipStream_t st);
 }
 #define OA_NEED_POW2(p, what) \
     OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

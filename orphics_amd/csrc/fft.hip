@@ -172,17 +172,17 @@ struct HipLauncher {
         rc = launch_col_fwdlegs<T>(st, gx, gy, nt, smem, logL, a);
     }
     template <typename T>
-    void col_fwdlegs_cg(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a) {
+    void col_fwdlegs_cg(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a, int gz = 1) {
         if (rc) return;
-        rc = launch_col_fwdlegs_cg<T>(st, gx, gy, nt, smem, logL, a);
+        rc = launch_col_fwdlegs_cg<T>(st, gx, gy, nt, smem, logL, a, gz);
     }
     template <typename T>
-    void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
+    void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
         const bool ok = dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
             if constexpr (seq_logl<S>() <= 8) {
                 if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
-                go(col_div_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+                go(col_div_kernel<T, S>, dim3(gx, gy, gz), nt, smem, a);
             } else if (!rc) rc = fail("fft: unsupported column sub-length");
         });
         if (!ok && !rc) rc = fail("fft: unsupported column length");
@@ -358,6 +358,49 @@ static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void*
     coarse_view<T>(p, my).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
                                    (cx<T>*)out, tA, tB, accumulate, width, rband, pin);
     return q.rc;
+}
+
+// ---- TWO real maps -> two kappa_hat planes with every coarse-grid stage launched once for both (pipeline.hip,
+//      oa_qe_tt_moments2).  The small launches behind the row R2C are latency-bound and far from filling the chip: doing
+//      two realisations' worth of work per launch costs little more than one.  Returns -1 when this geometry lacks one
+//      of the pieces (column grid with the fused forward-legs kernel, two-rows-per-transform row stage): the caller
+//      then runs the maps one after the other.
+template <typename T>
+static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0,
+                           void* c1, void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow,
+                           int my, long pl, long pk, hipStream_t st) {
+    auto f = view<T>(p);
+    if (!(my > 0 && my < p->ny && my == p->my_small) || !Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my)) return -1;
+    const auto cv = coarse_view<T>(p, my);
+    const int wi = f.clampw(wl), wo = f.clampw(wk);
+    if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo); if (2L * wi + wo > mrow) mrow = 0; }
+    if (!cv.rows_qe_is_pair(wi, wo, mrow)) return -1;
+    const long ms = (long)p->ny * pl, cms = (long)my * pl, gms = (long)my * pk;      // second-map offsets of the plane families
+    if (2 * ms > (long)p->ny * p->kp || 2 * gms > (long)p->ny * p->kp) return -1;
+    const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
+    if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
+    HipLauncher q{st};
+    cx<T>* tA = (cx<T>*)p->scratch;
+    cx<T>* tB = tA + (size_t)p->ny * p->kp;
+    f.rows(q, ROW_R2C, map0, p->nx / 2, tA, pl, (T)1, wi);
+    f.rows(q, ROW_R2C, map1, p->nx / 2, tA + ms, pl, (T)1, wi);
+    const cx<T>* ins[2] = {tA, tA + ms};
+    cx<T>* outs[2] = {tB, tB + ms};
+    f.cols(q, tA, pl, tB, pl, wi, false, (T)1, 1, 2, ins, outs);                      // forward pass 1 of both maps, one launch
+    if (!f.legs_cols_from_pass1_cg(q, cv, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)c0, (cx<T>*)c1,
+                                   (cx<T>*)c2, wl, pl, pl, 2, ms, cms))
+        return -1;
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = (double)p->ny / my;
+    cv.rows_qe(q, (const cx<T>*)c0, (const cx<T>*)c1, (const cx<T>*)c2, (cx<T>*)g0, (cx<T>*)g1, (T)(s * s * sy), 0, wi, wo, mrow, pl, pk, 2, cms, gms);
+    cv.cols_div(q, (const cx<T>*)g0, (const cx<T>*)g1, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)out0, tA, tB, 0, wk, rk, pk, 2,
+                gms, gms, (long)((cx<T>*)out1 - (cx<T>*)out0));
+    return q.rc;
+}
+int qe_tt_pair_w(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0, void* c1,
+                 void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow, int my, long pl, long pk,
+                 hipStream_t st) {
+    return p->dtype == OA_F32 ? qe_tt_pair_impl<float>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st)
+                              : qe_tt_pair_impl<double>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st);
 }
 
 // ---- the same passes on the plan's COMPACT work planes (pipeline.hip): pl = pitch of the leg planes and of the

@@ -509,6 +509,9 @@ struct RowQeArgs {
     T scale;      // product scale: (1/Npix)^2 for two normalised inverse transforms
     int accumulate;  // != 0: add the (scaled) result to the existing contents of px, py
     int win, wout;   // leg columns >= win are zero (not read); only product columns < wout are written
+    // TWO MAPS PER LAUNCH (pair row stage only): workgroups >= npairs work on the second map, whose planes sit in_moff /
+    // out_moff elements behind the first one's.  npairs = 0: one map.
+    int npairs; long in_moff, out_moff;
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -737,20 +740,23 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     constexpr int logM = seq_total_log<SEQ>();
     constexpr int M = 1 << logM;
     const int RS = a.rowStride;
-    const long r0 = (long)ctx.bid_x() * 2;
+    long wg = ctx.bid_x();
+    long imo = 0, omo = 0;
+    if (a.npairs && wg >= a.npairs) { wg -= a.npairs; imo = a.in_moff; omo = a.out_moff; }
+    const long r0 = wg * 2;
     constexpr int R0 = SEQ::get(0);
     cx<T> hreg[EPT], v[EPT];
     cx<T>* twl = work + RS;
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
-    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, a.h + r0 * a.pitch, a.h + (r0 + 1) * a.pitch, a.win);
+    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, a.h + imo + r0 * a.pitch, a.h + imo + (r0 + 1) * a.pitch, a.win);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * a.scale;
     ctx.sync();
     for (int leg = 0; leg < 2; ++leg) {
-        const cx<T>* src = leg ? a.gy : a.gx;
-        cx<T>* dst = leg ? a.py : a.px;
+        const cx<T>* src = (leg ? a.gy : a.gx) + imo;
+        cx<T>* dst = (leg ? a.py : a.px) + omo;
         pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
         // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
 #pragma unroll
@@ -886,6 +892,7 @@ struct ColArgs {
     // select on purpose: a ?: chain over pointer members is turned into an indexed read of the by-value
     // argument struct, which drags the whole struct into scratch memory (2x slower passes)
     long in_off1, in_off2, out_off1, out_off2;
+    int nbz; long in_moff, out_moff;   // two maps per launch: z = map * nbz + plane, the second map's planes sit *_moff behind (nbz = 0: one map)
     int rband, ny;             // rband > 0: output rows outside the band (rband <= y <= ny - rband) are not stored
     long in_pitch, out_pitch;  // complex elements
     int width;                 // valid columns
@@ -1232,6 +1239,7 @@ struct ColFwdLegsCgArgs {
     int logTw;
     const cx<T>* twc;           // W_My^k   (inverse inter-pass twiddle)
     long n1f;                   // row stride of the tile: rows g + n1f * n, n < L
+    long in_moff, out_moff;     // two maps per launch (grid z = map): offsets of the second map's `in` and leg planes
 };
 
 template <typename T, class SEQF, class Ctx>
@@ -1256,7 +1264,8 @@ OA_HD void col_fwdlegs_cg_body(Ctx& ctx, const ColFwdLegsCgArgs<T>& a) {
     cx<T>* ex = twl + tw_lds_size(logL);                  // [4 q][4 a][C] exchange of the 16-point inverse
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
     ctx.sync();
-    const ColLoad<T> ld{a.in + g * a.pitch + c0, (unsigned)(a.n1f * a.pitch), ncols, false};
+    const long imo = ctx.bid_z() ? a.in_moff : 0, omo = ctx.bid_z() ? a.out_moff : 0;
+    const ColLoad<T> ld{a.in + imo + g * a.pitch + c0, (unsigned)(a.n1f * a.pitch), ncols, false};
     col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, logC, twl, logL, ld);
     const int c = tid & ((1 << logC) - 1), q = tid >> logC;
     const bool ok = c < ncols;
@@ -1292,7 +1301,7 @@ OA_HD void col_fwdlegs_cg_body(Ctx& ctx, const ColFwdLegsCgArgs<T>& a) {
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) ex[((q * 4 + aa) << logC) + c] = v[aa];
         ctx.sync();
-        cx<T>* out = (leg == 0 ? a.h : (leg == 1 ? a.gx : a.gy)) + (g * LQ) * a.opitch + c0;
+        cx<T>* out = (leg == 0 ? a.h : (leg == 1 ? a.gx : a.gy)) + omo + (g * LQ) * a.opitch + c0;
 #pragma unroll
         for (int aa = 0; aa < 4; ++aa) {
             cx<T> t[4];
@@ -1326,6 +1335,7 @@ struct ColDivArgs {
     int accumulate;
     int rband, ny;   // rband > 0: Fn vanishes on output rows rband <= y <= ny - rband, which are not written
     int yshift;      // COLUMN GRID: output row y of this My-row transform is row y + (y >= ny/2 ? yshift : 0) of Fn, ly, out
+    long in_moff, out_moff;   // two maps per launch (grid z = map): offsets of the second map's A / B planes and of its `out`
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -1346,8 +1356,9 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     cx<T>* twl = s + (1 << (logL + logC));
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
     ctx.sync();
-    const ColLoad<T> la{a.A + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
-    const ColLoad<T> lb{a.B + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
+    const long imo = ctx.bid_z() ? a.in_moff : 0, omo = ctx.bid_z() ? a.out_moff : 0;
+    const ColLoad<T> la{a.A + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
+    const ColLoad<T> lb{a.B + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     if constexpr (n == 2) {
         // both tiles' global loads are issued back to back (twice the bytes in flight per workgroup) before either
         // plane goes through LDS
@@ -1369,7 +1380,7 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     }
     const long oorg = g * a.out_gs * a.opitch + c0;
     const T* Fnb = a.Fn + oorg;
-    cx<T>* outb = a.out + oorg;
+    cx<T>* outb = a.out + omo + oorg;
     const unsigned ostr = (unsigned)(a.out_ks * a.opitch);
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
@@ -1410,9 +1421,11 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     if (a.twiddle)
         for (int i = tid; i < (1 << logL); i += CNT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
     ctx.sync();
-    const int z = ctx.bid_z();
-    const cx<T>* in = a.in + (long)(z & 1) * a.in_off1 + (long)(z >> 1) * a.in_off2;
-    cx<T>* out = a.out + (long)(z & 1) * a.out_off1 + (long)(z >> 1) * a.out_off2;
+    int z = ctx.bid_z();
+    long imo = 0, omo = 0;
+    if (a.nbz && z >= a.nbz) { z -= a.nbz; imo = a.in_moff; omo = a.out_moff; }
+    const cx<T>* in = a.in + imo + (long)(z & 1) * a.in_off1 + (long)(z >> 1) * a.in_off2;
+    cx<T>* out = a.out + omo + (long)(z & 1) * a.out_off1 + (long)(z >> 1) * a.out_off2;
     const ColLoad<T> ld{in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};
     const ColStore<T> st{out + g * a.out_gs * a.out_pitch + c0, (unsigned)(a.out_ks * a.out_pitch), ncols, a.inverse != 0,
                          a.twiddle ? ti : nullptr, (unsigned)g, a.scale, a.rband, (int)(g * a.out_gs), (int)a.out_ks, a.ny};

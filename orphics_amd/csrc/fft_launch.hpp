@@ -75,6 +75,6 @@ int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int log
 template <typename T>
 int launch_col_fwdlegs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a);
 template <typename T>
-int launch_col_fwdlegs_cg(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a);
+int launch_col_fwdlegs_cg(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a, int gz = 1);
 
 }  // namespace oa

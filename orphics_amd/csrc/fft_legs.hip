@@ -56,16 +56,16 @@ __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void
 }
 
 template <typename T>
-int launch_col_fwdlegs_cg(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a) {
+int launch_col_fwdlegs_cg(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a, int gz) {
     int rc = 0;
     if (logL != 6) return fail("fft: col_fwdlegs_cg is built for 64-point forward sub-lengths");
     using S = Seq<16, 4>;
     if (nt != (1 << (6 + COL_LOGC)) / EPT) return fail("fft: col_fwdlegs_cg launched with the wrong workgroup size");
-    launch_go(rc, st, col_fwdlegs_cg_kernel<T, S>, dim3(gx, gy), nt, smem, a);
+    launch_go(rc, st, col_fwdlegs_cg_kernel<T, S>, dim3(gx, gy, gz), nt, smem, a);
     return rc;
 }
-template int launch_col_fwdlegs_cg<float>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsCgArgs<float>&);
-template int launch_col_fwdlegs_cg<double>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsCgArgs<double>&);
+template int launch_col_fwdlegs_cg<float>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsCgArgs<float>&, int);
+template int launch_col_fwdlegs_cg<double>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsCgArgs<double>&, int);
 
 template int launch_col_fwdlegs<float>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsArgs<float>&);
 template int launch_col_fwdlegs<double>(hipStream_t, int, int, int, size_t, int, const ColFwdLegsArgs<double>&);

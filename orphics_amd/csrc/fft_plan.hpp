@@ -81,6 +81,11 @@ struct Fft2dPlan {
     // have products band-limited to 2 (win - 1), so the row stage evaluated on ANY grid of mrow >= 2 win + wout
     // points yields the same product columns k < wout (no aliasing reaches them) times mrow / nx -- folded into the
     // scale here.  The real-space planes exist only in LDS, so the sampling grid is not observable.
+    // does rows_qe run the two-rows-per-transform kernel (the only row stage that takes two maps per launch)?
+    bool rows_qe_is_pair(int win, int wout, int mrow) const {
+        const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
+        return mrow > 0 && logM >= 10 && logM <= 13 && 2L * win + wout <= (1L << logM) && ny % 2 == 0;
+    }
     static int row_grid_min(int nx, int win, int wout) {
         long need = 2L * win + wout;
         int m = 1024;                                   // shortest grid the two-rows-per-transform kernel is built for
@@ -96,7 +101,7 @@ struct Fft2dPlan {
     template <class Launcher>
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
                  int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0, long pin = 0,
-                 long pout = 0) const {
+                 long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0) const {
         RowQeArgs<T> a{};
         // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
         // transforms with no assumption beyond win / wout
@@ -110,7 +115,8 @@ struct Fft2dPlan {
             // alias-free row grid: two rows per complex transform of length M (row_qe_pair_body)
             const int M = 1 << logM;
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
-            q.row_qe_pair(ny / 2, a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
+            if (nmaps > 1) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; }
+            q.row_qe_pair(ny / 2 * (nmaps > 1 ? 2 : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
             return;
         }
         a.logL = logM - 1;
@@ -133,7 +139,9 @@ struct Fft2dPlan {
     template <class Launcher>
     void cols(Launcher& q, const cx<T>* in, long in_pitch, cx<T>* out, long out_pitch, int width, bool inverse,
               T scale, int which = 0, int nb = 1, const cx<T>* const* ins = nullptr, cx<T>* const* outs = nullptr,
-              int rband = 0, bool swap = false, int logn1 = -1) const {   // rband: the natural-order result (pass 2) is stored on the band rows only
+              int rband = 0, bool swap = false, int logn1 = -1, int nmaps = 1, long in_moff = 0, long out_moff = 0) const {
+        // rband: the natural-order result (pass 2) is stored on the band rows only
+        // nmaps = 2: the same pass over a second set of planes *_moff elements behind the first (two maps per launch)
         // swap: split Ny the other way round (pass 1 the SHORTER length) -- the inverse after legs_cols_from_pass1
         // logn1 >= 0: explicit pass-1 length (the inverse after legs_cols_from_pass1_cg: 16 x Ny/16)
         const int logN1 = logn1 >= 0 ? logn1 : (swap ? logNy / 2 : (logNy + 1) / 2), logN2 = logNy - logN1;
@@ -153,7 +161,8 @@ struct Fft2dPlan {
             a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1;
             a.twiddle = (logN2 > 0) ? 1 : 0;
             a.scale = (logN2 > 0) ? (T)1 : scale;
-            q.col(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), a, nb);
+            a.nbz = nmaps > 1 ? nb : 0; a.in_moff = in_moff; a.out_moff = out_moff;
+            q.col(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), a, nb * nmaps);
         }
         if (logN2 == 0 || which == 1) return;
         // pass 2: length N2 over y2 (stride N1), in place, natural order out
@@ -166,7 +175,8 @@ struct Fft2dPlan {
         if (a.NT < 1) a.NT = 1;
         a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1;
         a.twiddle = 0; a.scale = scale; a.rband = clampr(rband); a.ny = ny;
-        q.col(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), a, nb);
+        a.nbz = nmaps > 1 ? nb : 0; a.in_moff = out_moff; a.out_moff = out_moff;       // in place
+        q.col(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), a, nb * nmaps);
     }
 
     // (A) legs + inverse column transform of the three leg planes (outputs ready for rows_qe)
@@ -228,7 +238,8 @@ struct Fft2dPlan {
     }
     template <class Launcher>
     bool legs_cols_from_pass1_cg(Launcher& q, const Fft2dPlan<T>& cv, const cx<T>* p1, const T* FG, const T* FH, const T* lxd,
-                                 const T* lyd, cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax, long pin, long pout) const {
+                                 const T* lyd, cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax, long pin, long pout, int nmaps = 1,
+                                 long in_moff = 0, long out_moff = 0) const {
         if (!has_fwdlegs_cg(logNy, cv.ny)) return false;
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         const int logL = logNy / 2, logN1f = logNy - logL;
@@ -239,10 +250,13 @@ struct Fft2dPlan {
         ColFwdLegsCgArgs<T> a{};
         a.in = p1; a.FG = FG; a.FH = FH; a.lxd = lxd; a.lyd = lyd; a.gx = gx; a.gy = gy; a.h = h;
         a.pitch = pi; a.fpitch = kp; a.opitch = po; a.width = width; a.tw = tw_y; a.logTw = logNy; a.twc = cv.tw_y; a.n1f = N1f;
-        q.col_fwdlegs_cg(tiles, (int)N1f, (int)((L * C) / EPT), ((size_t)L * C + tw_lds_size(logL) + 16 * C) * sizeof(cx<T>), logL, a);
+        a.in_moff = in_moff; a.out_moff = out_moff;
+        q.col_fwdlegs_cg(tiles, (int)N1f, (int)((L * C) / EPT), ((size_t)L * C + tw_lds_size(logL) + 16 * C) * sizeof(cx<T>), logL, a,
+                         nmaps > 1 ? 2 : 1);
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
-        cv.cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs, 0, false, 4);   // inverse pass 2: length My / 16 at row stride 16
+        // inverse pass 2: length My / 16 at row stride 16
+        cv.cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs, 0, false, 4, nmaps, out_moff, out_moff);
         return true;
     }
 
@@ -250,7 +264,8 @@ struct Fft2dPlan {
     //     tmpA, tmpB: two hc scratch planes
     template <class Launcher>
     void cols_div(Launcher& q, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
-                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0) const {
+                  cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0, int nmaps = 1,
+                  long in_moff = 0, long tmp_moff = 0, long out_moff = 0) const {
         const long pi = pin > 0 ? pin : kp;     // pitch of pa, pb AND of the two scratch planes
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
@@ -259,13 +274,14 @@ struct Fft2dPlan {
         const int tiles = (width + C - 1) / C;
         const cx<T>* ins[2] = {pa, pb};
         cx<T>* outs[2] = {tmpA, tmpB};
-        cols(q, pa, pi, tmpA, pi, width, false, (T)1, 1, 2, ins, outs);   // pass 1 of both planes, one launch
+        cols(q, pa, pi, tmpA, pi, width, false, (T)1, 1, 2, ins, outs, 0, false, -1, nmaps, in_moff, tmp_moff);   // pass 1 of both planes, one launch
         ColDivArgs<T> a{};
         a.A = tmpA; a.B = tmpB; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = width;
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
         a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
         a.rband = clampr(rband); a.ny = ny; a.yshift = yshift();
-        q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a);
+        a.in_moff = tmp_moff; a.out_moff = out_moff;
+        q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a, nmaps > 1 ? 2 : 1);
     }
 
     // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane

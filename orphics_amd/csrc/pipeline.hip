@@ -226,9 +226,9 @@ int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void
 }
 
 // kappa_hat (plan-owned plane) -> bandpower sums over its active region -> n += 1, S += b, C += b b^T (b = bin means)
-static int bandpower_moments(oa_plan* p, Pipeline* q, int64_t* n, double* S, double* C, void* stream) {
+static int bandpower_moments(oa_plan* p, Pipeline* q, int64_t* n, double* S, double* C, void* stream, const void* kappa = nullptr) {
     // one launch: the last workgroup of the histogram reduces the partials and adds the bandpower vector to n, S, C
-    return bin_power_moments(p->dtype, q->kk, q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
+    return bin_power_moments(p->dtype, kappa ? kappa : q->kk, q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
                              q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, (hipStream_t)stream);
 }
 
@@ -238,6 +238,26 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     Pipeline* q = (Pipeline*)p->pipe;
     if (int rc = oa_qe_tt(p, real_map, nullptr, nullptr, nullptr, 0, stream)) return rc;
     return bandpower_moments(p, q, n, S, C, stream);
+}
+
+/* Two Monte-Carlo steps in one call: both maps share every launch behind their row transforms (fft.hip qe_tt_pair_impl);
+ * geometries without that path run the two steps one after the other.  n += 2, S += b0 + b1, C += b0 b0^T + b1 b1^T. */
+int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, int64_t* n, double* S, double* C, void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_qe_tt_moments2: call oa_plan_set_filters and oa_plan_set_bins first");
+    OA_REQUIRE(real_map0 && real_map1 && n && S && C, "oa_qe_tt_moments2: NULL argument");
+    Pipeline* q = (Pipeline*)p->pipe;
+    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
+    // second kappa plane: the plan-owned input-transform plane (unused on the from-map path); only kappa's active region of
+    // it is ever read back (binning)
+    int rc = qe_tt_pair_w(p, real_map0, real_map1, q->FG, q->FH, q->Fn, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], q->kk, q->kT, q->wl,
+                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream);
+    if (rc > 0) return rc;
+    if (rc < 0) {
+        if ((rc = oa_qe_tt_moments(p, real_map0, n, S, C, stream))) return rc;
+        return oa_qe_tt_moments(p, real_map1, n, S, C, stream);
+    }
+    if ((rc = bandpower_moments(p, q, n, S, C, stream, q->kk))) return rc;
+    return bandpower_moments(p, q, n, S, C, stream, q->kT);
 }
 
 /* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py):

@@ -343,6 +343,15 @@ class Estimator(object):
         e._chk(tmap, "real")
         check(e.lib.oa_qe_tt_moments(e.plan, _ptr(tmap), _ptr(n), _ptr(S), _ptr(C), _stream()))
 
+    def tt_moments2(self, tmap0, tmap1, n, S, C):
+        """Two Monte-Carlo steps in one C-ABI call (``oa_qe_tt_moments2``): the same accumulations as two
+        :meth:`tt_moments` calls; on the column-grid path the two maps share every launch behind their row transforms."""
+        from ._lib import check
+        from .engine import _ptr, _stream
+        e = self._bind_bins()
+        e._chk(tmap0, "real"); e._chk(tmap1, "real")
+        check(e.lib.oa_qe_tt_moments2(e.plan, _ptr(tmap0), _ptr(tmap1), _ptr(n), _ptr(S), _ptr(C), _stream()))
+
     def bin_counts(self):
         """int64[nids] mode counts per bin over the whole plane (taken by ``oa_plan_set_bins``)."""
         import ctypes

@@ -88,13 +88,13 @@ struct EmuLauncher {
                 run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fwdlegs_body<T, S>(c, a); });
         });
     }
-    template <typename T> void col_fwdlegs_cg(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a) {
-        if (logL == 6) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fwdlegs_cg_body<T, Seq<16, 4>>(c, a); });
+    template <typename T> void col_fwdlegs_cg(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a, int gz = 1) {
+        if (logL == 6) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fwdlegs_cg_body<T, Seq<16, 4>>(c, a); }, gz);
     }
-    template <typename T> void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a) {
+    template <typename T> void col_div(int gx, int gy, int nt, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
         dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
-            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_div_body<T, S>(c, a); });
+            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_div_body<T, S>(c, a); }, gz);
         });
     }
     template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a, int nz = 1) {

@@ -180,3 +180,37 @@ def test_one_call_pol_estimator_matches_fine_grained():
         want = e.qe_cols_div(ax, ay, G["Fnorm"], width=G["wk"], rband=G["rk"]).cpu().numpy()
         w = N // 2 + 1
         assert np.abs(got[:, :w] - want[:, :w]).max() <= 1e-14 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (4096, 0.5, "f64"), (1024, 1.0, "f32")])
+def test_two_maps_per_call_equals_two_calls(N, res, prec):
+    """oa_qe_tt_moments2: two realisations sharing every launch behind their row transforms (4096-point columns: the
+    fused pair path; 1024: the sequential fall-back) accumulate exactly what two oa_qe_tt_moments calls do."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    q = lensing.qest(shape, g, th, noise2d=np.full(shape, cosmology.white_noise_power(1.0)), beam2d=maps.gauss_beam(ml, 1.5),
+                     kmask=maps.mask_kspace(shape, g, lmin=300, lmax=2000), kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=3500),
+                     unlensed_equals_lensed=True, dtype=prec)
+    e = q.eng
+    edges = torch.as_tensor(np.linspace(20, 3500, 20), device=e.device)
+    ids = e.modl_digitize(edges, half=True)
+    q.bind_bins(ids, 21, g.area / float(N * N) ** 2)
+    m0 = e.irfft(e.grf_hc(5, 0), scale=1.0 / N)
+    m1 = e.irfft(e.grf_hc(5, 1), scale=1.0 / N)
+
+    def acc():
+        return (torch.zeros(1, dtype=torch.int64, device=e.device), torch.zeros(19, dtype=torch.float64, device=e.device),
+                torch.zeros(19, 19, dtype=torch.float64, device=e.device))
+    a, b = acc(), acc()
+    q.tt_moments(m0, *a); q.tt_moments(m1, *a)
+    q.tt_moments2(m0, m1, *b)
+    q.tt_moments2(m1, m0, *b); q.tt_moments(m0, *a); q.tt_moments(m1, *a)      # again: work planes are reused correctly
+    torch.cuda.synchronize()
+    assert int(a[0]) == int(b[0]) == 4
+    assert float(a[1].abs().min()) > 0
+    np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-13)
+    np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-12)
