@@ -67,7 +67,8 @@ struct oa_plan {
     void* cz_bhat; void* cz_a; void* cz_f;   // cx<T>[My*Mx]: chirp-kernel transform, two work planes
     void* cz_full;                           // cx<T>[ny*nx]
     void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
-    void* tw_y_small; int my_small;          // COLUMN GRID of the one-call estimator path: cx<T>[my_small] = W_my^k
+    void* tw_y_small[16];                    // COLUMN GRID: cx<T>[my] = W_my^k for my = 2^i (made on first use, kept: estimators
+                                             // with different row bands may alternate on one plan)
 };
 
 namespace oa {

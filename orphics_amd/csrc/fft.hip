@@ -213,25 +213,25 @@ static Fft2dPlan<T> view(const oa_plan* p) {
 template <typename T>
 static Fft2dPlan<T> coarse_view(const oa_plan* p, int my) {
     Fft2dPlan<T> f = view<T>(p);
-    if (my > 0 && my < p->ny && my == p->my_small) {
-        f.ny = my; f.logNy = ilog2(my); f.tw_y = (const cx<T>*)p->tw_y_small; f.ny_full = p->ny;
+    if (my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) {
+        f.ny = my; f.logNy = ilog2(my); f.tw_y = (const cx<T>*)p->tw_y_small[ilog2(my)]; f.ny_full = p->ny;
     }
     return f;
 }
 int plan_ensure_col_grid(oa_plan* p, int my) {
-    if (my <= 0 || my >= p->ny || p->my_small == my) return 0;
+    if (my <= 0 || my >= p->ny) return 0;
     if (!is_pow2(my) || my < 32) return fail("column grid must be a power of two >= 32");
-    if (p->tw_y_small) { OA_HIP(hipDeviceSynchronize()); OA_HIP(hipFree(p->tw_y_small)); p->tw_y_small = nullptr; p->my_small = 0; }
+    void*& slot = p->tw_y_small[ilog2(my)];
+    if (slot) return 0;                       // tables are kept: no allocation / synchronisation after the first use of a grid
     if (p->dtype == OA_F32) {
         auto t = make_twiddles<float>(my);
-        OA_HIP(hipMalloc(&p->tw_y_small, t.size() * sizeof(cx<float>)));
-        OA_HIP(hipMemcpy(p->tw_y_small, t.data(), t.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
+        OA_HIP(hipMalloc(&slot, t.size() * sizeof(cx<float>)));
+        OA_HIP(hipMemcpy(slot, t.data(), t.size() * sizeof(cx<float>), hipMemcpyHostToDevice));
     } else {
         auto t = make_twiddles<double>(my);
-        OA_HIP(hipMalloc(&p->tw_y_small, t.size() * sizeof(cx<double>)));
-        OA_HIP(hipMemcpy(p->tw_y_small, t.data(), t.size() * sizeof(cx<double>), hipMemcpyHostToDevice));
+        OA_HIP(hipMalloc(&slot, t.size() * sizeof(cx<double>)));
+        OA_HIP(hipMemcpy(slot, t.data(), t.size() * sizeof(cx<double>), hipMemcpyHostToDevice));
     }
-    p->my_small = my;
     return 0;
 }
 
@@ -370,7 +370,7 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
                            void* c1, void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow,
                            int my, long pl, long pk, hipStream_t st) {
     auto f = view<T>(p);
-    if (!(my > 0 && my < p->ny && my == p->my_small) || !Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my)) return -1;
+    if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my)) return -1;
     const auto cv = coarse_view<T>(p, my);
     const int wi = f.clampw(wl), wo = f.clampw(wk);
     if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo); if (2L * wi + wo > mrow) mrow = 0; }

@@ -85,7 +85,7 @@ int oa_plan_destroy(oa_plan* p) {
     czt_release(p);
     if (p->tw_x) (void)hipFree(p->tw_x);
     if (p->tw_y) (void)hipFree(p->tw_y);
-    if (p->tw_y_small) (void)hipFree(p->tw_y_small);
+    for (void* t : p->tw_y_small) if (t) (void)hipFree(t);
     if (p->scratch) (void)hipFree(p->scratch);
     if (p->ly) (void)hipFree(p->ly);
     if (p->lx) (void)hipFree(p->lx);
