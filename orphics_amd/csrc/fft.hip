@@ -64,6 +64,13 @@ __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void
     col_div_body<T, SEQ>(c, a);
 }
 
+// single-pass forward column transform + divergence on short (coarse-grid) columns: 1024 threads hold a whole column tile
+template <typename T, class SEQ, int LOGC>
+__global__ __launch_bounds__(1024, 4) void col_div_sp_kernel(ColDivArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_div_body<T, SEQ, GpuCtx, LOGC>(c, a);
+}
+
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_fft_kernel(ColArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -186,6 +193,16 @@ struct HipLauncher {
             } else if (!rc) rc = fail("fft: unsupported column sub-length");
         });
         if (!ok && !rc) rc = fail("fft: unsupported column length");
+    }
+    // single pass: logL = whole column length (10 or 11), tile of 2^(14 - logL) columns, 1024 threads
+    template <typename T>
+    bool col_div_sp(int gx, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
+        if constexpr (sizeof(T) == 4) {
+            if (rc) return true;
+            if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, 3>, dim3(gx, 1, gz), 1024, smem, a); return true; }
+            if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, 4>, dim3(gx, 1, gz), 1024, smem, a); return true; }
+        }
+        return false;
     }
     template <typename T>
     void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a, int nz = 1) {

@@ -1040,7 +1040,8 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     cx<T>* twl = s + (1 << (logL + logC));        // stage twiddles, then the inter-pass twiddles W_N^(g k)
     cx<T>* ti = twl + tw_lds_size(logL);
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
-    for (int i = tid; i < (1 << logL); i += NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
+    if (a.twiddle)
+        for (int i = tid; i < (1 << logL); i += NT) ti[i] = a.tw[(unsigned)g * (unsigned)i];
     ctx.sync();
     const long org = g * a.in_gs * a.pitch + c0;   // scalar tile origin; per-element offsets are 32-bit
     const long forg = g * a.in_gs * a.fpitch + c0;
@@ -1338,15 +1339,18 @@ struct ColDivArgs {
     long in_moff, out_moff;   // two maps per launch (grid z = map): offsets of the second map's A / B planes and of its `out`
 };
 
-template <typename T, class SEQ, class Ctx>
+// LOGC: log2 of the tile width.  The default (32 columns) is the two-pass layout; with a WHOLE column in the tile (SEQ = the
+// full column length, 8 or 16 columns, 1024 threads, in_ns = out_ks = 1, one group) the same body is a SINGLE-PASS forward
+// column transform + divergence: the product planes are read once, no pass-1 plane is written and read back.
+template <typename T, class SEQ, class Ctx, int LOGC = COL_LOGC>
 OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
     constexpr int n = SEQ::n;
     constexpr int RL = SEQ::get(n - 1), LRL = Log2x<RL>::v, NB = EPT / RL;
     constexpr int logNs = logL - LRL;
-    constexpr int logC = COL_LOGC;
-    constexpr int NT = ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) : 1;
+    constexpr int logC = LOGC;
+    constexpr int NT = ((1 << (seq_total_log<SEQ>() + LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + LOGC)) / EPT) : 1;
     const int tid = ctx.tid();
     const int c0 = ctx.bid_x() << logC;
     const long g = ctx.bid_y();

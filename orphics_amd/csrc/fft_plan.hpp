@@ -260,6 +260,10 @@ struct Fft2dPlan {
         return true;
     }
 
+    static bool single_pass_div() {
+        static const bool on = [] { const char* e = getenv("OA_SINGLE_PASS_DIV"); return e ? atoi(e) != 0 : true; }();
+        return on;
+    }
     // (B) forward column transforms of two row-transformed planes + divergence * Fnorm
     //     tmpA, tmpB: two hc scratch planes
     template <class Launcher>
@@ -267,6 +271,18 @@ struct Fft2dPlan {
                   cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0, int nmaps = 1,
                   long in_moff = 0, long tmp_moff = 0, long out_moff = 0) const {
         const long pi = pin > 0 ? pin : kp;     // pitch of pa, pb AND of the two scratch planes
+        if (single_pass_div() && (logNy == 10 || logNy == 11) && sizeof(T) == 4) {
+            // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column tile in LDS, the product planes
+            // are read once and nothing is written back but kappa's band rows
+            const int lc = 14 - logNy, Cs = 1 << lc;
+            ColDivArgs<T> a{};
+            a.A = pa; a.B = pb; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = clampw(wmax);
+            a.logC = lc; a.NT = 1024; a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = 1; a.out_gs = 1; a.out_ks = 1;
+            a.accumulate = accumulate; a.rband = clampr(rband); a.ny = ny; a.yshift = yshift();
+            a.in_moff = in_moff; a.out_moff = out_moff;
+            const int tl = (a.width + Cs - 1) / Cs;
+            if (q.col_div_sp(tl, ((size_t)(1 << 14) + tw_lds_size(logNy)) * sizeof(cx<T>), logNy, a, nmaps > 1 ? 2 : 1)) return;
+        }
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;

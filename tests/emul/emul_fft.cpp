@@ -97,6 +97,13 @@ struct EmuLauncher {
             run(gx, gy, nt, smem, [&](EmuCtx& c) { col_div_body<T, S>(c, a); }, gz);
         });
     }
+    template <typename T> bool col_div_sp(int gx, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
+        if constexpr (sizeof(T) == 4) {
+            if (logL == 11) { run(gx, 1, 1024, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 8>, EmuCtx, 3>(c, a); }, gz); return true; }
+            if (logL == 10) { run(gx, 1, 1024, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 4>, EmuCtx, 4>(c, a); }, gz); return true; }
+        }
+        return false;
+    }
     template <typename T> void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a, int nz = 1) {
         dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
@@ -253,6 +260,14 @@ int emu_cols_div_cg_f64(int ny_full, int my, int nx, const void* pa, const void*
     std::vector<cx<double>> tA((size_t)my * hd.p.kp), tB((size_t)my * hd.p.kp);
     EmuLauncher q;
     hd.p.cols_div(q, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out, tA.data(), tB.data(), 0, width, rband);
+    return 0;
+}
+int emu_cols_div_cg_f32(int ny_full, int my, int nx, const void* pa, const void* pb, const float* Fn, const float* lxd,
+                        const float* lyd, void* out, int width, int rband) {
+    CoarseHolder<float> hd(ny_full, my, nx);
+    std::vector<cx<float>> tA((size_t)my * hd.p.kp), tB((size_t)my * hd.p.kp);
+    EmuLauncher q;
+    hd.p.cols_div(q, (const cx<float>*)pa, (const cx<float>*)pb, Fn, lxd, lyd, (cx<float>*)out, tA.data(), tB.data(), 0, width, rband);
     return 0;
 }
 int emu_map_legs_cols_f64(int ny, int nx, const double* map, const double* FG, const double* FH, const double* lxd,
