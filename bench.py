@@ -360,13 +360,18 @@ def per_kernel_table(torch, P, R, args):
         legs_name = "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>"
         # col_fwdlegs (read the pass-1 plane + 2 real filter planes on the band rows, write 3) + 3-plane inverse pass 2 (r + w)
         legs_bytes = fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah
+    if my in (1024, 2048) and P["prec"] == "f32" and os.environ.get("OA_SINGLE_PASS_DIV", "1") != "0":
+        # single pass: read the 2 product planes of my rows + Fn/2 on the band rows, write the band rows of kappa_hat
+        div_name, div_bytes = "cols_div = col_div_sp_kernel (single-pass forward columns + divergence)", fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah)
+    else:
+        # one 2-plane pass-1 launch (read 2, write 2) + col_div (read 2 + Fn/2, write the band rows of 1)
+        div_name, div_bytes = "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel", 4 * fk * Ah * cg + fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah)
     kern = {
         "row_fft_kernel<R2C>": (0, A + fl * Ah),
         "col_fft_kernel<fwd pass1, leg width>": (1, 2 * fl * Ah),
         legs_name: (2, legs_bytes),
         "row_qe_kernel": (3, (3 * fl + 2 * fk) * Ah * cg),
-        # one 2-plane pass-1 launch (read 2, write 2) + col_div (read 2 + Fn/2, write the band rows of 1)
-        "cols_div = col_fft_kernel<pass1 x2> + col_div_kernel": (4, 4 * fk * Ah * cg + fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah)),
+        div_name: (4, div_bytes),
         "bin_kernel<power>": (5, 1.5 * fk * gk * Ah),
     }
     # Stage durations IN SEQUENCE: whole steps (stages 0..5 back to back on this stream, alternating between the two
