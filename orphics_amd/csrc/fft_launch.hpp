@@ -11,6 +11,7 @@ struct GpuCtx {
     OA_D int bid_x() const { return blockIdx.x; }
     OA_D int bid_y() const { return blockIdx.y; }
     OA_D int bid_z() const { return blockIdx.z; }
+    OA_D int grid_x() const { return gridDim.x; }
     // Workgroup barrier for LDS traffic only.  __syncthreads() also drains vmcnt: every outstanding GLOBAL load and
     // store of the wave would have to land before the barrier -- the stores of one fused pipeline stage would stall
     // the next stage, and loads prefetched for the next row could not stay in flight across the FFT stages.  These

@@ -13,13 +13,14 @@
 using namespace oa;
 
 struct EmuCtx {
-    int tid_, bx_, by_, bz_;
+    int tid_, bx_, by_, bz_, gx_ = 1;
     std::barrier<>* bar;
     char* sm;
     int tid() const { return tid_; }
     int bid_x() const { return bx_; }
     int bid_y() const { return by_; }
     int bid_z() const { return bz_; }
+    int grid_x() const { return gx_; }
     void sync() const { bar->arrive_and_wait(); }
     void* smem() const { return sm; }
 };
@@ -37,7 +38,7 @@ struct EmuLauncher {
                 for (int bz = 0; bz < gz; ++bz)
                   for (int by = 0; by < gy; ++by)
                     for (int bx = 0; bx < gx; ++bx) {
-                        EmuCtx c{t, bx, by, bz, &bar, sm.data()};
+                        EmuCtx c{t, bx, by, bz, gx, &bar, sm.data()};
                         body(c);
                         bar.arrive_and_wait();
                     }

@@ -366,11 +366,11 @@ def test_fused_forward_pass2_legs_on_the_column_grid(emu, ny, my, w, rb):
             assert np.all(a[:, wv:W] == 3.0)
 
 
-@pytest.mark.parametrize("ny_full,my,w,rb", [(4096, 1024, 20, 150), (8192, 2048, 0, 300)])
-def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb):
+@pytest.mark.parametrize("ny_full,my,w,rb,nx", [(4096, 1024, 20, 150, 64), (8192, 2048, 0, 300, 64), (8192, 2048, 200, 300, 512)])
+def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb, nx):
     """col_div_body with a whole 1024- / 2048-point column in the tile (16 / 8 columns, 1024 threads): forward column
-    transform + divergence in ONE pass (f32), with the column-grid row mapping of Fn, ly and the output."""
-    nx = 64
+    transform + divergence in ONE pass (f32), with the column-grid row mapping of Fn, ly and the output; the 512-column
+    case has more than 16 tiles, i.e. exercises the XCD-pairing tile order."""
     rng = np.random.default_rng(my + w)
     W = nx // 2 + 1
     wv = w if w else W
