@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Golden vectors for the PURE-NumPy host helpers of the reference's maps.py (run in the build container only).
+
+`import orphics.maps` fails here (pixell is absent), but `gauss_beam`, `cosine_window` and the body of
+`FourierCalc.f2power` do not touch pixell: their function definitions are taken out of /root/reference/orphics/maps.py
+with `ast` and executed as they stand (no stand-in for any missing module is written), on seeded inputs; inputs + outputs are stored in
+maps_host_reference.npz next to this script.  The fixture is data; no reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_maps_host.py
+"""
+import ast
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = "/root/reference/orphics/maps.py"
+
+
+def reference_functions(names):
+    tree = ast.parse(open(SRC).read())
+    ns = {"np": np}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module(body=[node], type_ignores=[]), SRC, "exec"), ns)
+    missing = [n for n in names if n not in ns]
+    assert not missing, missing
+    return ns
+
+
+def reference_method(cls, name):
+    tree = ast.parse(open(SRC).read())
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == name:
+                    ns = {"np": np}
+                    exec(compile(ast.Module(body=[sub], type_ignores=[]), SRC, "exec"), ns)
+                    return ns[name]
+    raise KeyError((cls, name))
+
+
+def main():
+    import types
+    ns = reference_functions(["gauss_beam", "cosine_window"])
+    out = {}
+    rng = np.random.default_rng(3)
+    ell = np.abs(rng.standard_normal((16, 24))) * 3000.
+    for i, fwhm in enumerate((1.5, 7.0)):
+        out["beam_ell"] = ell
+        out["beam_fwhm_%d" % i] = np.float64(fwhm)
+        out["beam_out_%d" % i] = ns["gauss_beam"](ell, fwhm)
+    cases = [(64, 80, 10, 12, 3, 2), (32, 32, 30, 30, 0, 0), (20, 16, 12, 9, 2, 3), (50, 40, 0, 7, 0, 1), (40, 40, 5, 0, 2, 0), (16, 16, 30, 30, 1, 1)]
+    out["win_cases"] = np.array(cases)
+    for i, (Ny, Nx, ay, ax, py, px) in enumerate(cases):
+        out["win_out_%d" % i] = ns["cosine_window"](Ny, Nx, lenApodY=ay, lenApodX=ax, padY=py, padX=px)
+    # FourierCalc.f2power's body (maps.py:1620-1624) is one NumPy expression of its arguments
+    k1 = rng.standard_normal((12, 10)) + 1j * rng.standard_normal((12, 10))
+    k2 = rng.standard_normal((12, 10)) + 1j * rng.standard_normal((12, 10))
+    out["f2_k1"], out["f2_k2"], out["f2_norm"] = k1, k2, np.float64(0.37)
+    f2power = reference_method("FourierCalc", "f2power")
+    fake_self = types.SimpleNamespace(normfact=0.37)
+    out["f2_out"] = f2power(fake_self, k1, k2)
+    out["f2_out_pixel_units"] = f2power(fake_self, k1, k2, pixel_units=True)
+    np.savez_compressed(os.path.join(HERE, "maps_host_reference.npz"), **out)
+    print("wrote maps_host_reference.npz with", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

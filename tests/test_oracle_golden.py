@@ -291,3 +291,25 @@ def test_oracle_estimators_unbiased_on_fully_lensed_sims_incl_EB():
     for est, v in acc.items():
         mean, sem = np.mean(v), np.std(v) / np.sqrt(len(v))
         assert abs(mean - 1) < 0.05 + 3 * sem, (est, mean, sem)
+
+
+def test_maps_host_helpers_match_the_reference_functions():
+    """gauss_beam, cosine_window and FourierCalc.f2power's body: outputs of the REFERENCE's own function definitions
+    (executed out of maps.py by tests/golden/make_golden_maps_host.py) vs the oracle and vs the product's host helpers."""
+    import os
+    from oracle import maps_oracle as mo
+    from orphics_amd import maps
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maps_host_reference.npz"))
+    for i in range(2):
+        fw = float(g["beam_fwhm_%d" % i])
+        assert np.array_equal(mo.gauss_beam(g["beam_ell"], fw), g["beam_out_%d" % i])
+        assert np.array_equal(maps.gauss_beam(g["beam_ell"], fw), g["beam_out_%d" % i])
+    for i, (Ny, Nx, ay, ax, py, px) in enumerate(g["win_cases"]):
+        want = g["win_out_%d" % i]
+        assert np.array_equal(mo.cosine_window(int(Ny), int(Nx), int(ay), int(ax), int(py), int(px)), want)
+        assert np.array_equal(maps.cosine_window(int(Ny), int(Nx), lenApodY=int(ay), lenApodX=int(ax), padY=int(py), padX=int(px)), want)
+    k1, k2, norm = g["f2_k1"], g["f2_k2"], float(g["f2_norm"])
+    fc = mo.FourierCalc(k1.shape, 1e-3, -1e-3)
+    fc.normfact = norm
+    assert np.array_equal(fc.f2power(k1, k2), g["f2_out"])
+    assert np.array_equal(fc.f2power(k1, k2, pixel_units=True), g["f2_out_pixel_units"])
