@@ -370,6 +370,14 @@ def brute_force_gf(q, gterms, fterms, Lyi, Lxi):
 
 
 # ---- flat-sky lensing of simulated maps (lensing.py:395-454, 651-665), signed-coordinate restatement -----
+def fkappa_to_fphi(fkappa, modlmap):
+    """lensing.py:662-665: phi_l = 2 kappa_l / (l (l + 1)), zero below l = 2 (same operation order as the reference)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        k = np.nan_to_num(2. * fkappa / modlmap / (modlmap + 1.))
+    k[modlmap < 2.] = 0.
+    return k
+
+
 def alpha_from_kappa(kappa, step_y, step_x):
     shape = kappa.shape
     ly, lx = mo.laxes(shape, step_y, step_x)
@@ -377,10 +385,7 @@ def alpha_from_kappa(kappa, step_y, step_x):
     lyd[shape[0] // 2] = 0.0
     lxd[shape[1] // 2] = 0.0
     ml = np.sqrt(ly[:, None] ** 2 + lx[None, :] ** 2)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        f = np.nan_to_num(2. / ml / (ml + 1.))
-    f[ml < 2.] = 0.
-    fphi = _fft(kappa) * f
+    fphi = fkappa_to_fphi(_fft(kappa), ml)
     return _ifftn(1j * lyd[:, None] * fphi).real, _ifftn(1j * lxd[None, :] * fphi).real
 
 

@@ -42,7 +42,7 @@ def reference_method(cls, name):
 
 def main():
     import types
-    ns = reference_functions(["gauss_beam", "cosine_window"])
+    ns = reference_functions(["gauss_beam", "cosine_window", "kspace_coadd"])
     out = {}
     rng = np.random.default_rng(3)
     ell = np.abs(rng.standard_normal((16, 24))) * 3000.
@@ -62,6 +62,28 @@ def main():
     fake_self = types.SimpleNamespace(normfact=0.37)
     out["f2_out"] = f2power(fake_self, k1, k2)
     out["f2_out_pixel_units"] = f2power(fake_self, k1, k2, pixel_units=True)
+    # kspace_coadd (maps.py:1098-1114), with zero-noise and zero-beam modes to exercise the non-finite handling
+    km = rng.standard_normal((3, 12, 10)) + 1j * rng.standard_normal((3, 12, 10))
+    kb = rng.uniform(0.2, 1.0, (3, 12, 10))
+    kn = rng.uniform(0.5, 2.0, (3, 12, 10))
+    kn[0, 2, 3] = 0.0
+    kn[:, 5, 5] = 0.0
+    kb[:, 7, 1] = 0.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out["coadd_kmaps"], out["coadd_kbeams"], out["coadd_kncovs"] = km, kb, kn
+        out["coadd_out"] = ns["kspace_coadd"](km.copy(), kb.copy(), kn.copy(), fkbeam=0.8)
+    # lensing.fkappa_to_fphi (lensing.py:662-665): phi = 2 kappa / (l (l + 1)), zero below l = 2
+    global SRC
+    SRC_MAPS = SRC
+    SRC = "/root/reference/orphics/lensing.py"
+    f2p = reference_functions(["fkappa_to_fphi"])["fkappa_to_fphi"]
+    SRC = SRC_MAPS
+    ml = np.abs(rng.standard_normal((12, 10))) * 500.
+    ml[0, 0] = 0.0
+    ml[1, 1] = 1.5
+    fk = rng.standard_normal((12, 10)) + 1j * rng.standard_normal((12, 10))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out["fphi_modlmap"], out["fphi_fkappa"], out["fphi_out"] = ml, fk, f2p(fk.copy(), ml.copy())
     np.savez_compressed(os.path.join(HERE, "maps_host_reference.npz"), **out)
     print("wrote maps_host_reference.npz with", len(out), "arrays")
 

@@ -338,3 +338,27 @@ def test_split_calc_and_noise_from_splits():
     cross = sum(fo.f2power(k32[i], k32[j]) for i in range(4) for j in range(i + 1, 4)) / 6.
     assert rel(noise, (auto - cross) / 4) < 2e-5          # the reference casts splits to float32 (maps.py:2354)
     assert rel(cross_teb, cross) < 2e-5
+
+
+def test_coadd_and_kappa_to_phi_match_the_reference_functions():
+    """The product's kspace_coadd and FlatLenser.kappa_to_phi vs outputs of the REFERENCE's own kspace_coadd
+    (maps.py:1098-1114) and fkappa_to_fphi (lensing.py:662-665), tests/golden/maps_host_reference.npz (12 x 10 planes:
+    zero-noise and zero-beam modes; modes below l = 2)."""
+    from orphics_amd import maps, lensing
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maps_host_reference.npz"))
+    got = maps.kspace_coadd(gd["coadd_kmaps"], gd["coadd_kbeams"], gd["coadd_kncovs"], fkbeam=0.8)
+    want = gd["coadd_out"]
+    assert np.array_equal(got == 0, want == 0)            # the non-finite -> 0 modes are the same modes
+    assert rel(got, want) < 1e-13
+    # kappa -> phi on a real map: the reference function applied to the oracle's DFT of kappa, inverted on the host
+    shape = (64, 128)
+    g = geom(shape)
+    rng = np.random.default_rng(3)
+    kappa = rng.standard_normal(shape)
+    ml = g.modlmap()
+    from oracle import qe_oracle as qo
+    phi_ref = np.fft.ifft2(qo.fkappa_to_fphi(np.fft.fft2(kappa), ml)).real
+    fl = lensing.FlatLenser(shape, g, dtype="f64")
+    phi = fl.kappa_to_phi(kappa)
+    phi = phi.cpu().numpy() if hasattr(phi, "cpu") else np.asarray(phi)
+    assert rel(phi, phi_ref) < 1e-12

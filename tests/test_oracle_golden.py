@@ -313,3 +313,8 @@ def test_maps_host_helpers_match_the_reference_functions():
     fc.normfact = norm
     assert np.array_equal(fc.f2power(k1, k2), g["f2_out"])
     assert np.array_equal(fc.f2power(k1, k2, pixel_units=True), g["f2_out_pixel_units"])
+    # kspace_coadd (maps.py:1098-1114) with zero-noise / zero-beam modes, and lensing.fkappa_to_fphi (lensing.py:662-665)
+    from oracle import qe_oracle as qo
+    assert np.array_equal(mo.kspace_coadd(g["coadd_kmaps"], g["coadd_kbeams"], g["coadd_kncovs"], fkbeam=0.8), g["coadd_out"])
+    assert np.array_equal(qo.fkappa_to_fphi(g["fphi_fkappa"], g["fphi_modlmap"]), g["fphi_out"])
+    assert np.all(g["fphi_out"][g["fphi_modlmap"] < 2.] == 0)
