@@ -180,6 +180,18 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
 /* Two Monte-Carlo steps per call (two independent maps): identical results to two oa_qe_tt_moments calls; on the
  * column-grid path every launch behind the two row transforms is shared by both maps. */
 int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, int64_t* n, double* S, double* C, void* stream);
+/* SplitLensing.cross_estimator (lensing.py:980-1003) needs the TT reconstruction of every ordered pair of
+ * splits (X / gradient leg from split i, Y leg from split j).  One call: the three filtered leg planes of each split are
+ * transformed ONCE (nsplits leg stages instead of nsplits^2), then the row stage + divergence run per pair.
+ * host_kmaps: nsplits device hc planes (the splits' transforms); host_out: nsplits^2 device hc planes, [i*nsplits + j];
+ * zero_outside as in oa_qe_tt.  Needs oa_plan_set_filters.
+ * oa_split_cross_power: the estimator's combination of those planes per mode, in f64 (the QE is bilinear, so the
+ * reference's reconstructions involving the split mean are means of the pairwise ones):
+ *   out = (n^4 P(kc) - 4 n^2 sum_i P(kic) + 4 sum_{i<j} P(kij)) / (n (n-1)(n-2)(n-3)),  P(x) = |x|^2 norm,
+ * written over columns < active_cols and the band rows of the real half-plane `out_hcreal` only (4 <= nsplits <= 8). */
+int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void* const* host_out, int zero_outside, void* stream);
+int oa_split_cross_power(int dtype, int nsplits, const void* const* host_kappa, void* out_hcreal, double norm, int ny, long kpitch,
+                         int active_cols, int active_rows, void* stream);
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S,
               double* C, double* meanfield_acc, void* stream);
 /* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py roofline; the

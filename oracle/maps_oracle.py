@@ -389,6 +389,29 @@ def kspace_coadd(kmaps, kbeams, kncovs, fkbeam=1):
     return f
 
 
+def split_calc(isplits, jsplits, icoadd, jcoadd, f2power, alt=True):
+    """maps.py:2296-2333: (total, mean cross, noise) 2-D power from split transforms; ``f2power(k1, k2)`` is the power
+    function (FourierCalc.f2power)."""
+    isplits, jsplits = np.asarray(isplits), np.asarray(jsplits)
+    total = f2power(icoadd, jcoadd)
+    ni, nj = isplits.shape[0], jsplits.shape[0]
+    if alt:
+        assert ni == nj
+        noise = 0.
+        for a, b in zip(isplits, jsplits):
+            noise = noise + f2power(a - icoadd, b - jcoadd)
+        noise = noise / ((1. - 1. / ni) * ni ** 2)
+        return total, total - noise, noise
+    acc, count = 0., 0.
+    for i in range(ni):
+        for j in range(nj):
+            if i != j:
+                acc = acc + f2power(isplits[i], jsplits[j])
+                count += 1.
+    crosses = acc / count
+    return total, crosses, total - crosses
+
+
 def matched_filter_apply(ktemp, kmap, n2d, normfact, kmask=None):
     """MatchedFilter.apply, maps.py:2587-2604."""
     if kmask is None:

@@ -369,6 +369,31 @@ def brute_force_gf(q, gterms, fterms, Lyi, Lxi):
 
 
 
+# ---- split-based 4-point estimator (lensing.py:980-1003), evaluated exactly as the reference orders it ---------
+def split_cross_estimator(qfrag, qpower, splits):
+    """``qfrag(a, b)``: kappa FT from X-leg a and Y-leg b; ``qpower(k1, k2)``: 2-D cross power.  1 + 3n + n(n-1) qfrag
+    calls, including the ones on the mean split (the product derives those from the pairwise ones by bilinearity)."""
+    splits = np.asarray(splits)
+    n = splits.shape[0]
+    fn = float(n)
+    mean = splits.mean(axis=0)
+    k_mean = qfrag(mean, mean)
+    diag_sum = 0.
+    p_single = 0.
+    p_pairs = 0.
+    for i in range(n):
+        sym_i = (qfrag(splits[i], mean) + qfrag(mean, splits[i])) / 2.
+        k_ii = qfrag(splits[i], splits[i])
+        diag_sum = diag_sum + k_ii
+        resid = sym_i - k_ii / fn
+        p_single = p_single + qpower(resid, resid)
+        for j in range(i + 1, n):
+            sym_ij = (qfrag(splits[i], splits[j]) + qfrag(splits[j], splits[i])) / 2.
+            p_pairs = p_pairs + qpower(sym_ij, sym_ij)
+    k_c = k_mean - diag_sum / fn ** 2.
+    return (fn ** 4. * qpower(k_c, k_c) - 4. * fn ** 2. * p_single + 4. * p_pairs) / fn / (fn - 1.) / (fn - 2.) / (fn - 3.)
+
+
 # ---- flat-sky lensing of simulated maps (lensing.py:395-454, 651-665), signed-coordinate restatement -----
 def fkappa_to_fphi(fkappa, modlmap):
     """lensing.py:662-665: phi_l = 2 kappa_l / (l (l + 1)), zero below l = 2 (same operation order as the reference)."""

@@ -50,6 +50,8 @@ SIGNATURES = {
     "oa_filter_map": (c_int, [c_void_p] * 5),
     "oa_qe_tt_moments": (c_int, [c_void_p] * 6),
     "oa_qe_tt_moments2": (c_int, [c_void_p] * 7),
+    "oa_qe_tt_splits": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "oa_split_cross_power": (c_int, [c_int, c_int, c_void_p, c_void_p, c_double, c_int, c_long, c_int, c_int, c_void_p]),
     "oa_qe_tt_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "oa_mc_run": (c_int, [c_void_p, c_u64, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_malloc": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_size_t]),

@@ -101,6 +101,66 @@ __global__ __launch_bounds__(256) void stack_add_region_kernel(const T* __restri
     acc[i] += (double)x[i];
 }
 
+// ---------------------------------------------------------------- split-based 4-point combination
+// SplitLensing.cross_estimator (lensing.py:980-1003) per Fourier mode from the N^2 pairwise reconstructions
+// K[i*N+j] = QE(X leg from split i, Y leg from split j).  The QE is bilinear, so with s = mean of the splits
+//   QE(s,s) = mean_ij K_ij,   (QE(m_i,s) + QE(s,m_i))/2 = sum_j (K_ij + K_ji) / (2N),
+// and every term of the estimator is a linear combination of the K's: one pass, arithmetic in f64.
+struct SplitPlanes { const void* k[64]; };
+
+template <typename T, int N>
+__global__ __launch_bounds__(256) void split_cross_power_kernel(SplitPlanes P, T* __restrict__ out, double norm, int ny, long kp,
+                                                                int w, int rb) {
+    int y = blockIdx.y;
+    if (rb > 0 && y >= rb) y += ny - (2 * rb - 1);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const long at = (long)y * kp + x;
+    double rcr[N], rci[N], dr[N], di[N];           // rc_i = sum_j (K_ij + K_ji), d_i = K_ii
+#pragma unroll
+    for (int i = 0; i < N; ++i) rcr[i] = rci[i] = 0.0;
+    double tr = 0.0, ti = 0.0, pij = 0.0;         // sum of all K, sum_{i<j} |K_ij + K_ji|^2
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const cx<T> d = ((const cx<T>*)P.k[i * N + i])[at];
+        dr[i] = (double)d.x; di[i] = (double)d.y;
+        rcr[i] += 2.0 * dr[i]; rci[i] += 2.0 * di[i];
+        tr += dr[i]; ti += di[i];
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) {
+            const cx<T> a = ((const cx<T>*)P.k[i * N + j])[at], b = ((const cx<T>*)P.k[j * N + i])[at];
+            const double sr = (double)a.x + (double)b.x, si = (double)a.y + (double)b.y;
+            rcr[i] += sr; rci[i] += si; rcr[j] += sr; rci[j] += si;
+            tr += sr; ti += si;
+            pij += sr * sr + si * si;
+        }
+    }
+    const double n = (double)N, n2 = n * n;
+    double sdr = 0.0, sdi = 0.0, pic = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        sdr += dr[i]; sdi += di[i];
+        const double cr = rcr[i] / (2.0 * n) - dr[i] / n, ci = rci[i] / (2.0 * n) - di[i] / n;    // k_i - k_ii / N
+        pic += cr * cr + ci * ci;
+    }
+    const double kcr = (tr - sdr) / n2, kci = (ti - sdi) / n2;                                   // QE(s,s) - sum_i k_ii / N^2
+    const double v = (n2 * n2 * (kcr * kcr + kci * kci) - 4.0 * n2 * pic + pij) * norm / (n * (n - 1.0) * (n - 2.0) * (n - 3.0));
+    out[at] = (T)v;
+}
+
+template <typename T>
+static int split_cross_power_launch(int n, const SplitPlanes& P, T* out, double norm, int ny, long kp, int w, int rb, hipStream_t st) {
+    dim3 grid((w + 255) / 256, rb ? 2 * rb - 1 : ny);
+#define OA_SPLIT_CASE(NN) case NN: hipLaunchKernelGGL((split_cross_power_kernel<T, NN>), grid, dim3(256), 0, st, P, out, norm, ny, kp, w, rb); break
+    switch (n) {
+        OA_SPLIT_CASE(4); OA_SPLIT_CASE(5); OA_SPLIT_CASE(6); OA_SPLIT_CASE(7); OA_SPLIT_CASE(8);
+        default: return fail("oa_split_cross_power: 4 <= nsplits <= 8");
+    }
+#undef OA_SPLIT_CASE
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---------------------------------------------------------------- layout helpers
 // hc -> full complex plane by X(-l) = conj X(l)
 template <typename T>
@@ -294,6 +354,23 @@ int oa_f2power(int dtype, const void* k1, const void* k2, void* out, double norm
                                 (const cx<double>*)k2, (double*)out, norm, n4, n));
     OA_LAUNCH_CHECK();
     return 0;
+}
+
+int oa_split_cross_power(int dtype, int nsplits, const void* const* host_kappa, void* out_hcreal, double norm, int ny, long kp,
+                         int active_cols, int active_rows, void* stream) {
+    OA_REQUIRE(host_kappa && out_hcreal && ny > 0 && kp > 0, "oa_split_cross_power: bad argument");
+    OA_REQUIRE(nsplits >= 4 && nsplits <= 8, "oa_split_cross_power: 4 <= nsplits <= 8");
+    SplitPlanes P;
+    for (int i = 0; i < nsplits * nsplits; ++i) {
+        OA_REQUIRE(host_kappa[i], "oa_split_cross_power: NULL plane");
+        P.k[i] = host_kappa[i];
+    }
+    int w = active_cols, rb = active_rows;
+    if (w <= 0 || w > kp) w = (int)kp;
+    if (!(rb > 0 && 2L * rb - 1 < ny)) rb = 0;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(dtype, return split_cross_power_launch<float>(nsplits, P, (float*)out_hcreal, norm, ny, kp, w, rb, st),
+             return split_cross_power_launch<double>(nsplits, P, (double*)out_hcreal, norm, ny, kp, w, rb, st));
 }
 
 int oa_cmul_real(int dtype, const void* k, const void* f, void* out, long n, void* stream) {

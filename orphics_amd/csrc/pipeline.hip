@@ -32,6 +32,8 @@ struct Pipeline {
     int64_t* counts_full = nullptr;   // data-independent mode counts over the whole plane
     int64_t* counts_tmp = nullptr;
     unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
+    void* split_legs = nullptr;       // oa_qe_tt_splits: 3 compact leg planes per split
+    int split_cap = 0;
 };
 
 static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
@@ -50,6 +52,7 @@ void pipeline_release(oa_plan* p) {
     if (q->counts_full) (void)hipFree(q->counts_full);
     if (q->counts_tmp) (void)hipFree(q->counts_tmp);
     if (q->ticket) (void)hipFree(q->ticket);
+    if (q->split_legs) (void)hipFree(q->split_legs);
     delete q;
     p->pipe = nullptr;
 }
@@ -238,6 +241,37 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     Pipeline* q = (Pipeline*)p->pipe;
     if (int rc = oa_qe_tt(p, real_map, nullptr, nullptr, nullptr, 0, stream)) return rc;
     return bandpower_moments(p, q, n, S, C, stream);
+}
+
+int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void* const* host_out, int zero_outside, void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_qe_tt_splits: call oa_plan_set_filters first");
+    OA_REQUIRE(nsplits >= 1 && nsplits <= 64 && host_kmaps && host_out, "oa_qe_tt_splits: bad argument");
+    Pipeline* q = (Pipeline*)p->pipe;
+    hipStream_t st = (hipStream_t)stream;
+    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
+    const size_t lb = (size_t)pl * p->ny * 2 * (p->dtype == OA_F32 ? 4 : 8);      // one compact leg plane
+    if (q->split_cap < nsplits) {
+        if (q->split_legs) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->split_legs); q->split_legs = nullptr; q->split_cap = 0; }
+        OA_HIP(hipMalloc(&q->split_legs, 3 * lb * nsplits));
+        q->split_cap = nsplits;
+    }
+    const int my = q->my;
+    auto leg = [&](int i, int c) { return (void*)((char*)q->split_legs + (3 * (size_t)i + c) * lb); };
+    for (int i = 0; i < nsplits; ++i) {
+        OA_REQUIRE(host_kmaps[i], "oa_qe_tt_splits: NULL split plane");
+        if (int rc = qe_legs_cols_w(p, host_kmaps[i], host_kmaps[i], q->FG, q->FH, leg(i, 0), leg(i, 1), leg(i, 2), q->wl, q->rl, pl, st, my)) return rc;
+    }
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
+    for (int i = 0; i < nsplits; ++i)
+        for (int j = 0; j < nsplits; ++j) {
+            void* out = host_out[i * nsplits + j];
+            OA_REQUIRE(out, "oa_qe_tt_splits: NULL output plane");
+            int rc;
+            if (zero_outside && (rc = zero_complement(p, out, q->wk, q->rk, st))) return rc;
+            if ((rc = qe_rows_w(p, leg(i, 0), leg(i, 1), leg(j, 2), q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my))) return rc;
+            if ((rc = qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st, my))) return rc;
+        }
+    return 0;
 }
 
 /* Two Monte-Carlo steps in one call: both maps share every launch behind their row transforms (fft.hip qe_tt_pair_impl);

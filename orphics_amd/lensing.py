@@ -421,6 +421,31 @@ class Estimator(object):
         e._chk(tmap, "real")
         return self._qe_tt(tmap, None, None, out)
 
+    def tt_pairs(self, ksplits, out=None):
+        """TT reconstructions of every ordered pair of maps in ONE C-ABI call (``oa_qe_tt_splits``): ``ksplits`` = n hc
+        transforms; returns an (n, n, Ny, kp) complex tensor K with K[i, j] = QE(X leg from map i, Y leg from map j).
+        The three filtered leg planes of each map are transformed once (n leg stages, not n^2)."""
+        import ctypes
+        torch = _torch()
+        from ._lib import check
+        from .engine import _stream, mark_dirty
+        e = self._bind()
+        n = len(ksplits)
+        for k in ksplits:
+            e._chk(k, "hc")
+        zero = 0
+        if out is None:
+            out = torch.zeros((n, n, e.ny, e.kp), dtype=e.cdt, device=e.device)
+        else:
+            if tuple(out.shape) != (n, n, e.ny, e.kp) or out.dtype != e.cdt or not out.is_contiguous():
+                raise ValueError("tt_pairs: out must be a contiguous (n, n, Ny, kp) complex tensor of the estimator's precision")
+            zero = 1
+        ins = (ctypes.c_void_p * n)(*[k.data_ptr() for k in ksplits])
+        outs = (ctypes.c_void_p * (n * n))(*[out[i, j].data_ptr() for i in range(n) for j in range(n)])
+        check(e.lib.oa_qe_tt_splits(e.plan, n, ins, outs, zero, _stream()))
+        mark_dirty(out)
+        return out
+
     def kappa_from_map(self, XY, T2DData, E2DData=None, B2DData=None, T2DDataY=None, E2DDataY=None, B2DDataY=None,
                        alreadyFTed=False, returnFt=False):
         """qest.kappa_from_map (lensing.py:973-976; notebook cell 4).  The X
@@ -860,47 +885,71 @@ class SplitLensing(object):
         raise NotImplementedError("SplitLensing: the reference's EE branch is marked wrong (lensing.py:975)")
 
     def cross_estimator(self, ksplits):
-        """lensing.py:980-1003."""
-        torch = _torch()
-        if isinstance(ksplits, HalfPlane):
+        """lensing.py:980-1003: the split-based 4-point estimate of the kappa power, 2-D.
+
+        The QE is bilinear in its two legs, so everything the reference evaluates -- QE(s, s), QE(m_i, s), QE(s, m_i)
+        with s the mean split -- is a mean of the n^2 pairwise reconstructions K_ij = QE(m_i, m_j):
+
+            kc  = mean_ij K_ij - sum_i K_ii / n^2,   kic = sum_j (K_ij + K_ji) / (2n) - K_ii / n,   kij = (K_ij + K_ji) / 2
+            result = (n^4 P(kc) - 4 n^2 sum_i P(kic) + 4 sum_{i<j} P(kij)) / (n (n-1)(n-2)(n-3))
+
+        n^2 reconstructions instead of the reference's 1 + 3n + n(n-1).  With this package's TT :class:`Estimator`
+        (power-of-two sides, 4 <= n <= 8) the whole matrix is ONE ``oa_qe_tt_splits`` call that transforms each split's
+        leg planes once, and the combination is one ``oa_split_cross_power`` launch (f64 arithmetic per mode).  Any
+        other ``qest`` object (duck-typed ``kappa_from_map``) goes through ``qfrag`` pair by pair."""
+        half = isinstance(ksplits, HalfPlane)
+        if half:
             splits = [ksplits[i] for i in range(ksplits.t.shape[0])]
-            mean = HalfPlane(ksplits.t.mean(dim=0), ksplits.eng)
-            wrap = lambda t: t  # noqa: E731
-            arith = "half"
         else:
             arr = np.asanyarray(ksplits)
             splits = [arr[i] for i in range(arr.shape[0])]
-            mean = np.mean(arr, axis=0)
-            arith = "np"
-        insplits = len(splits)
-        nsplits = float(insplits)
+        n = len(splits)
+        q = self.qest
+        if self.est == "TT" and isinstance(q, Estimator) and q.eng.pow2 and 4 <= n <= 8:
+            return self._cross_estimator_device(splits, ksplits)
+        # generic: pairwise reconstructions through the public qfrag, combined on whatever array type it returns
+        val = lambda x: x.t if isinstance(x, HalfPlane) else x      # noqa: E731
+        raw = [[self.qfrag(splits[i], splits[j]) for j in range(n)] for i in range(n)]
+        K = [[val(x) for x in row] for row in raw]
+        like = raw[0][0] if half else None
 
-        def val(x):
-            return x.t if isinstance(x, HalfPlane) else x
+        def power(x):
+            return val(self.qpower(HalfPlane(x, like.eng), HalfPlane(x, like.eng)) if half else self.qpower(x, x))
 
-        def mk(t, like):
-            return HalfPlane(t, like.eng) if isinstance(like, HalfPlane) else t
+        fn = float(n)
+        diag = sum(K[i][i] for i in range(n))
+        kc = sum(K[i][j] for i in range(n) for j in range(n)) / fn ** 2 - diag / fn ** 2
+        pic = 0.
+        pij = 0.
+        for i in range(n):
+            kic = sum(K[i][j] + K[j][i] for j in range(n)) / (2. * fn) - K[i][i] / fn
+            pic = pic + power(kic)
+            for j in range(i + 1, n):
+                pij = pij + power((K[i][j] + K[j][i]) / 2.)
+        res = (fn ** 4. * power(kc) - 4. * fn ** 2. * pic + 4. * pij) / fn / (fn - 1.) / (fn - 2.) / (fn - 3.)
+        return HalfPlane(res, like.eng) if half else res
 
-        s = mean
-        k = self.qfrag(s, s)
-        kiisum = 0.
-        psum = 0.
-        psum2 = 0.
-        for i in range(insplits):
-            mi = splits[i]
-            ki = mk((val(self.qfrag(mi, s)) + val(self.qfrag(s, mi))) / 2., k)
-            kii = self.qfrag(mi, mi)
-            kiisum = kiisum + val(kii)
-            kic = mk(val(ki) - (1. / nsplits) * val(kii), k)
-            psum = psum + val(self.qpower(kic, kic))
-            for j in range(i + 1, int(insplits)):
-                mj = splits[j]
-                kij = mk((val(self.qfrag(mi, mj)) + val(self.qfrag(mj, mi))) / 2., k)
-                psum2 = psum2 + val(self.qpower(kij, kij))
-        kc = mk(val(k) - (1. / nsplits ** 2.) * kiisum, k)
-        res = (nsplits ** 4. * val(self.qpower(kc, kc)) - 4. * nsplits ** 2. * psum + 4. * psum2) \
-            / nsplits / (nsplits - 1.) / (nsplits - 2.) / (nsplits - 3.)
-        return mk(res, self.qpower(kc, kc)) if arith == "half" else res
+    def _cross_estimator_device(self, splits, like):
+        import ctypes
+        from ._lib import check
+        from .engine import _ptr, _stream
+        q = self.qest
+        e = q.eng
+        n = len(splits)
+        hcs = []
+        kind = "half"
+        for m in splits:
+            k, kind = q._as_hc(m, True)
+            hcs.append(k)
+        K = q.tt_pairs(hcs)
+        wk, rk = q._W["TT"][1], q._R["TT"][1]
+        out = e.hcreal()                              # zero outside kappa's active region, like every K_ij
+        planes = (ctypes.c_void_p * (n * n))(*[K[i, j].data_ptr() for i in range(n) for j in range(n)])
+        check(e.lib.oa_split_cross_power(e.code, n, planes, _ptr(out), float(self.fc.normfact), e.ny, e.kp, int(wk), int(rk), _stream()))
+        if kind == "half":
+            return HalfPlane(out, e)
+        full = e.hcreal_to_full(out)
+        return full.cpu().numpy() if kind == "np" else full
 
 
 # ---- kappa -> phi -> deflection, flat-sky Taylens (SURVEY.md section 8f-1) -------------------------------

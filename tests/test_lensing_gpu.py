@@ -103,6 +103,8 @@ def test_n0_of_gaussian_sims_matches_AL():
 
 
 def test_split_lensing_cross_estimator_matches_numpy():
+    """Device path (one oa_qe_tt_splits call + oa_split_cross_power) vs the reference's ordering of the estimator
+    (oracle/qe_oracle.split_cross_estimator, pinned by tests/golden/splits_reference.npz) evaluated with the oracle QE."""
     from orphics_amd import lensing
     shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(128, 4.0, seed=7)
     q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask,
@@ -110,30 +112,86 @@ def test_split_lensing_cross_estimator_matches_numpy():
     qr = qo.QEOracleTT(shape, g.step_y, g.step_x, cl, cl, noise, beam, tmask, kmask_K=kmask)
     fo = mo.FourierCalc(shape, g.step_y, g.step_x)
     rng = np.random.default_rng(8)
-    splits = np.array([np.fft.fft2(t1 + 0.3 * rng.standard_normal(shape)) for _ in range(4)])
-    sl = lensing.SplitLensing(shape, g, q, "TT")
-    got = sl.cross_estimator(splits)
+    for n in (4, 5):
+        splits = np.array([np.fft.fft2(t1 + 0.3 * rng.standard_normal(shape)) for _ in range(n)])
+        sl = lensing.SplitLensing(shape, g, q, "TT")
+        got = sl.cross_estimator(splits)
+        assert isinstance(got, np.ndarray) and got.shape == shape
+        ref = qo.split_cross_estimator(lambda a, b: qr.kappa_from_map("TT", a, T2DDataY=b, alreadyFTed=True, returnFt=True),
+                                       fo.f2power, splits)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-8
 
-    # reference algebra (lensing.py:980-1003) evaluated with the oracle QE
-    def qfrag(a, b):
-        return qr.kappa_from_map("TT", a, T2DDataY=b, alreadyFTed=True, returnFt=True)
-    n = 4.
-    s = splits.mean(0)
-    k = qfrag(s, s)
-    kiisum = 0; psum = 0; psum2 = 0
-    for i in range(4):
-        mi = splits[i]
-        ki = (qfrag(mi, s) + qfrag(s, mi)) / 2.
-        kii = qfrag(mi, mi)
-        kiisum = kiisum + kii
-        kic = ki - kii / n
-        psum = psum + fo.f2power(kic, kic)
-        for j in range(i + 1, 4):
-            kij = (qfrag(mi, splits[j]) + qfrag(splits[j], mi)) / 2.
-            psum2 = psum2 + fo.f2power(kij, kij)
-    kc = k - kiisum / n ** 2
-    ref = (n ** 4 * fo.f2power(kc, kc) - 4 * n ** 2 * psum + 4 * psum2) / n / (n - 1) / (n - 2) / (n - 3)
-    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-8
+
+class _DuckQest(object):
+    """Any object with kappa_from_map is a valid qest for SplitLensing (lensing.py:961-976)."""
+
+    def __init__(self, fn):
+        self.fn = fn
+        self.calls = 0
+
+    def kappa_from_map(self, XY, T2DData=None, T2DDataY=None, alreadyFTed=False, returnFt=False, **unused):
+        assert XY == "TT" and alreadyFTed and returnFt
+        self.calls += 1
+        return self.fn(T2DData, T2DDataY)
+
+
+def test_split_estimators_match_the_reference_functions():
+    """SplitLensing.cross_estimator with a caller-supplied qest, and maps.split_calc, vs outputs of the REFERENCE's own
+    definitions (tests/golden/splits_reference.npz; lensing.py:980-1003, maps.py:2296-2333)."""
+    import os
+    from orphics_amd import lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "splits_reference.npz"))
+    U, V = gd["U"], gd["V"]
+    shape = U.shape
+    geo = FlatGeometry.from_res(shape, 2.0)
+    for n in (4, 5, 6):
+        duck = _DuckQest(lambda a, b: U * a * b + V * a * np.roll(b, (1, 2), (0, 1)))
+        sl = lensing.SplitLensing(shape, geo, duck, "TT")
+        sl.fc.normfact = float(gd["normfact"])
+        got = sl.cross_estimator(gd["cross_splits_%d" % n])
+        want = gd["cross_out_%d" % n]
+        assert duck.calls == n * n                         # pairwise reconstructions only (reference: 1 + 3n + n(n-1))
+        assert np.abs(got - want).max() < 1e-11 * np.abs(want).max()
+    fc = maps.FourierCalc(shape, geo)
+    fc.normfact = float(gd["normfact"])
+    isp, jsp = gd["sc_isplits"], gd["sc_jsplits"]
+    for alt, tag in ((True, "alt"), (False, "loop")):
+        t, c, nz = maps.split_calc(isp, jsp, isp.mean(0), jsp.mean(0), fourier_calc=fc, alt=alt)
+        for got, key in ((t, "sc_total_"), (c, "sc_crosses_"), (nz, "sc_noise_")):
+            want = gd[key + tag]
+            assert np.abs(np.asarray(got) - want).max() < 1e-12 * np.abs(want).max(), (tag, key)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-9), ("f32", 2e-3)])
+def test_split_device_path_equals_pairwise_calls(prec, tol):
+    """oa_qe_tt_splits (each split's leg planes transformed once) returns the same K_ij as n^2 separate two-leg
+    reconstructions, and the one-launch combination equals the generic host combination of those planes."""
+    from orphics_amd import lensing
+    from orphics_amd.stats import HalfPlane
+    shape, g, th, ml, beam, noise, tmask, kmask, cl, t1, t2 = setup(256, 2.0, seed=5)
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask,
+                     unlensed_equals_lensed=True, dtype=prec)
+    e = q.eng
+    rng = np.random.default_rng(9)
+    n = 5
+    maps_ = [t1 + 0.3 * rng.standard_normal(shape) for _ in range(n)]
+    hcs = [e.rfft(e.to_real(m)) for m in maps_]
+    K = q.tt_pairs(hcs)
+    for i, j in ((0, 0), (1, 3), (4, 2)):
+        one = q.reconstruct_tt_hc(hcs[i], hcs[j]).clone()
+        assert torch.equal(K[i, j], one)                   # same kernels on the same inputs: bit-identical
+    buf = torch.full_like(K, 7.0)                          # a caller-owned (dirty) output block is zero-filled outside
+    assert torch.equal(q.tt_pairs(hcs, out=buf), K)
+    sl = lensing.SplitLensing(shape, g, q, "TT")
+    half = HalfPlane(torch.stack(hcs), e)
+    dev = sl.cross_estimator(half)
+    assert isinstance(dev, HalfPlane)
+    duck = _DuckQest(lambda a, b: q.kappa_from_map("TT", T2DData=a, T2DDataY=b, alreadyFTed=True, returnFt=True))
+    gen = lensing.SplitLensing(shape, g, duck, "TT").cross_estimator(half)
+    assert duck.calls == n * n
+    a, b = dev.t.double(), gen.t.double()
+    assert float((a - b).abs().max() / b.abs().max()) < tol
 
 
 @pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 2e-5)])

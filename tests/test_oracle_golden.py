@@ -318,3 +318,30 @@ def test_maps_host_helpers_match_the_reference_functions():
     assert np.array_equal(mo.kspace_coadd(g["coadd_kmaps"], g["coadd_kbeams"], g["coadd_kncovs"], fkbeam=0.8), g["coadd_out"])
     assert np.array_equal(qo.fkappa_to_fphi(g["fphi_fkappa"], g["fphi_modlmap"]), g["fphi_out"])
     assert np.all(g["fphi_out"][g["fphi_modlmap"] < 2.] == 0)
+
+
+def _bilinear_qfrag(U, V):
+    """The data-defined two-leg map of tests/golden/make_golden_splits.py."""
+    return lambda a, b: U * a * b + V * a * np.roll(b, (1, 2), (0, 1))
+
+
+def test_split_estimators_match_the_reference_functions():
+    """SplitLensing.cross_estimator (lensing.py:980-1003) and split_calc (maps.py:2296-2333): outputs of the REFERENCE's
+    own definitions (tests/golden/make_golden_splits.py) vs the oracle restatements."""
+    import os
+    from oracle import maps_oracle as mo
+    from oracle import qe_oracle as qo
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "splits_reference.npz"))
+    norm = float(g["normfact"])
+    power = lambda a, b: np.real(np.conj(a) * b) * norm       # noqa: E731  (f2power, pinned above)
+    qfrag = _bilinear_qfrag(g["U"], g["V"])
+    for n in (4, 5, 6):
+        got = qo.split_cross_estimator(qfrag, power, g["cross_splits_%d" % n])
+        want = g["cross_out_%d" % n]
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    isp, jsp = g["sc_isplits"], g["sc_jsplits"]
+    for alt, tag in ((True, "alt"), (False, "loop")):
+        t, c, nz = mo.split_calc(isp, jsp, isp.mean(0), jsp.mean(0), power, alt=alt)
+        for got, key in ((t, "sc_total_"), (c, "sc_crosses_"), (nz, "sc_noise_")):
+            want = g[key + tag]
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), (tag, key)

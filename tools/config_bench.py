@@ -2,7 +2,9 @@
 """Timings of the BASELINE.json configs that are not bench.py's headline (run on the GPU box):
    config 3: 8192^2 0.5' full TT/TE/EE/EB/TB minimum-variance reconstruction on one GPU
    config 4: Monte-Carlo N0 + mean-field on 4096^2 maps (per-GPU rate of the sharded job)
-usage: python tools/config_bench.py [mv|mc|all] [--n N]"""
+   splits  : SURVEY 8f-2, SplitLensing.cross_estimator on 4 splits: the one-call device path against the reference's
+             ordering of 1 + 3n + n(n-1) two-leg reconstructions through kappa_from_map
+usage: python tools/config_bench.py [mv|mc|splits|all] [--n N]"""
 import os
 import sys
 import time
@@ -74,9 +76,32 @@ def mcn0(N=4096, res=0.5, nsims=600):
               % (N, " + mean-field stack" if mf else "", ns, dt * 1e3, 1 / dt, 125 * dt), flush=True)
 
 
+def splits(N=8192, res=0.5, n=4):
+    from orphics_amd.stats import HalfPlane
+    shape, g, th, ml, beam, noise, q = setup(N, res, False)
+    e = q.eng
+    half = HalfPlane(torch.stack([e.grf_hc(11, i) for i in range(n)]), e)
+    sl = lensing.SplitLensing(shape, g, q, "TT")
+    dt = timeit(lambda: sl.cross_estimator(half), 10)
+
+    def reference_order():                     # the calls the reference's loop makes (lensing.py:980-1003), on device planes
+        s = HalfPlane(half.t.mean(dim=0), e)
+        sl.qfrag(s, s)
+        for i in range(n):
+            sl.qfrag(half[i], s); sl.qfrag(s, half[i]); sl.qfrag(half[i], half[i])
+            for j in range(i + 1, n):
+                sl.qfrag(half[i], half[j]); sl.qfrag(half[j], half[i])
+    dt_ref = timeit(reference_order, 5)
+    print("splits: %d^2 SplitLensing.cross_estimator on %d splits: %.2f ms per estimate (one oa_qe_tt_splits call + combination) = %.0f /s;"
+          " the reference's %d reconstructions one by one (without its power / combination arithmetic): %.2f ms"
+          % (N, n, dt * 1e3, 1 / dt, 1 + 3 * n + n * (n - 1), dt_ref * 1e3), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("mv", "all"):
         mv()
     if what in ("mc", "all"):
         mcn0()
+    if what in ("splits", "all"):
+        splits()
