@@ -63,9 +63,9 @@ def main():
     out["f2_out"] = f2power(fake_self, k1, k2)
     out["f2_out_pixel_units"] = f2power(fake_self, k1, k2, pixel_units=True)
     # kspace_coadd (maps.py:1098-1114), with zero-noise and zero-beam modes to exercise the non-finite handling
-    km = rng.standard_normal((3, 12, 10)) + 1j * rng.standard_normal((3, 12, 10))
-    kb = rng.uniform(0.2, 1.0, (3, 12, 10))
-    kn = rng.uniform(0.5, 2.0, (3, 12, 10))
+    km = rng.standard_normal((3, 32, 36)) + 1j * rng.standard_normal((3, 32, 36))
+    kb = rng.uniform(0.2, 1.0, (3, 32, 36))
+    kn = rng.uniform(0.5, 2.0, (3, 32, 36))
     kn[0, 2, 3] = 0.0
     kn[:, 5, 5] = 0.0
     kb[:, 7, 1] = 0.0

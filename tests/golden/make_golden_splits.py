@@ -52,7 +52,7 @@ def bilinear_qest(U, V):
 
 def main():
     rng = np.random.default_rng(11)
-    shape = (10, 12)
+    shape = (32, 36)            # the product's engines need even sides >= 32
     cplx = lambda *lead: rng.standard_normal(lead + shape) + 1j * rng.standard_normal(lead + shape)   # noqa: E731
     out = {}
     normfact = 0.83

@@ -342,7 +342,7 @@ def test_split_calc_and_noise_from_splits():
 
 def test_coadd_and_kappa_to_phi_match_the_reference_functions():
     """The product's kspace_coadd and FlatLenser.kappa_to_phi vs outputs of the REFERENCE's own kspace_coadd
-    (maps.py:1098-1114) and fkappa_to_fphi (lensing.py:662-665), tests/golden/maps_host_reference.npz (12 x 10 planes:
+    (maps.py:1098-1114) and fkappa_to_fphi (lensing.py:662-665), tests/golden/maps_host_reference.npz (32 x 36 planes:
     zero-noise and zero-beam modes; modes below l = 2)."""
     from orphics_amd import maps, lensing
     gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "maps_host_reference.npz"))

@@ -84,13 +84,16 @@ def splits(N=8192, res=0.5, n=4):
     sl = lensing.SplitLensing(shape, g, q, "TT")
     dt = timeit(lambda: sl.cross_estimator(half), 10)
 
+    own = q.new_output()                       # estimator-owned plane: no zero-fill per reconstruction on either path
+
     def reference_order():                     # the calls the reference's loop makes (lensing.py:980-1003), on device planes
-        s = HalfPlane(half.t.mean(dim=0), e)
-        sl.qfrag(s, s)
+        m = [half.t[i] for i in range(n)]
+        s = half.t.mean(dim=0)
+        q.reconstruct_tt_hc(s, s, out=own)
         for i in range(n):
-            sl.qfrag(half[i], s); sl.qfrag(s, half[i]); sl.qfrag(half[i], half[i])
+            q.reconstruct_tt_hc(m[i], s, out=own); q.reconstruct_tt_hc(s, m[i], out=own); q.reconstruct_tt_hc(m[i], m[i], out=own)
             for j in range(i + 1, n):
-                sl.qfrag(half[i], half[j]); sl.qfrag(half[j], half[i])
+                q.reconstruct_tt_hc(m[i], m[j], out=own); q.reconstruct_tt_hc(m[j], m[i], out=own)
     dt_ref = timeit(reference_order, 5)
     print("splits: %d^2 SplitLensing.cross_estimator on %d splits: %.2f ms per estimate (one oa_qe_tt_splits call + combination) = %.0f /s;"
           " the reference's %d reconstructions one by one (without its power / combination arithmetic): %.2f ms"
