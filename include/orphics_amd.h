@@ -175,6 +175,15 @@ int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, v
 int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* const* host_FG, const void* const* host_FH,
               const int* host_swap, const void* kX, const void* kY, const void* Fnorm, void* out, int accumulate,
               int leg_cols, int kappa_cols, int leg_rows, int kappa_rows, int mrow, int zero_outside, void* stream);
+/* oa_qe_pol for several estimators accumulated into ONE kappa plane (the minimum-variance combination: Fnorm[e] carries
+ * weight x normalisation of estimator e), pieces flattened in estimator order (host_npieces[e] each; host_kX/kY/Fnorm per
+ * estimator).  Every distinct filtered field -- identified by its (source plane, filter plane) POINTERS -- is transformed
+ * once, all in one inverse pass-2 launch: 17 leg planes instead of 30 for TT+TE+EE+EB+TB when the caller shares its filter
+ * plane objects.  Same arithmetic per piece as oa_qe_pol, same results. */
+int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_signs, const void* const* host_FG,
+             const void* const* host_FH, const int* host_swap, const void* const* host_kX, const void* const* host_kY,
+             const void* const* host_Fnorm, void* out, int accumulate, int leg_cols, int kappa_cols, int leg_rows, int kappa_rows,
+             int mrow, int zero_outside, void* stream);
 int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream);
 int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, double* C, void* stream);
 /* Two Monte-Carlo steps per call (two independent maps): identical results to two oa_qe_tt_moments calls; on the

@@ -47,6 +47,7 @@ SIGNATURES = {
     "oa_qe_tt": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     "oa_qe_pol": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oa_qe_mv": (c_int, [c_void_p, c_int] + [c_void_p] * 9 + [c_int] * 7 + [c_void_p]),
     "oa_filter_map": (c_int, [c_void_p] * 5),
     "oa_qe_tt_moments": (c_int, [c_void_p] * 6),
     "oa_qe_tt_moments2": (c_int, [c_void_p] * 7),

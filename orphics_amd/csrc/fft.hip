@@ -435,6 +435,36 @@ int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, c
     return p->dtype == OA_F32 ? legs_cols_impl<float>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl, my)
                               : legs_cols_impl<double>(p, kX, kY, FG, FH, gx, gy, h, width, rband, st, pl, my);
 }
+// oa_qe_mv: one filtered field per call -- subset 1: src, F -> a (H plane); subset 2: src, F -> a, b (gradient pair) -- pass 1
+// only; then ONE inverse pass 2 over `nplanes` compact planes `stride` elements apart
+template <typename T>
+static int legs_subset_impl(oa_plan* p, const void* src, const void* F, void* a, void* b, int subset, int width, int rband,
+                            hipStream_t st, long pout, int my) {
+    HipLauncher q{st};
+    const cx<T>* k = (const cx<T>*)src;
+    const T* f = (const T*)F;
+    coarse_view<T>(p, my).legs_cols(q, k, k, f, f, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)a, (cx<T>*)b, (cx<T>*)a, width, rband, 0,
+                                    pout, true, subset);
+    return q.rc;
+}
+template <typename T>
+static int legs_pass2_impl(oa_plan* p, void* pool, int nplanes, long stride, int width, hipStream_t st, long pout, int my) {
+    HipLauncher q{st};
+    const auto f = coarse_view<T>(p, my);
+    const long po = pout > 0 ? pout : p->kp;
+    f.cols(q, (const cx<T>*)pool, po, (cx<T>*)pool, po, f.clampw(width), true, (T)1, 2, 1, nullptr, nullptr, 0, false, -1, nplanes, stride,
+           stride);
+    return q.rc;
+}
+int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* b, int subset, int width, int rband, long pl,
+                     hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? legs_subset_impl<float>(p, src, F, a, b, subset, width, rband, st, pl, my)
+                              : legs_subset_impl<double>(p, src, F, a, b, subset, width, rband, st, pl, my);
+}
+int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? legs_pass2_impl<float>(p, pool, nplanes, stride, width, st, pl, my)
+                              : legs_pass2_impl<double>(p, pool, nplanes, stride, width, st, pl, my);
+}
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
               int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my) {
     return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my)

@@ -1021,6 +1021,9 @@ struct ColLegsArgs {
     // split != 0: launched with grid z = 3, workgroup z computes ONE leg plane (0 = H, 1 = Gx, 2 = Gy): three times the
     // workgroups for the small latency-bound launches of the column grid (the tile's inputs are re-read per leg)
     int split;
+    // with split: legs zbase .. zbase + zcount - 1 only (zcount = 0: all three).  H alone (0, 1) or the gradient pair alone
+    // (1, 2): estimators that share a filtered field transform it once (oa_qe_mv)
+    int zbase, zcount;
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -1065,12 +1068,15 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             if (a.rband) live = ok && !(y >= a.rband && y <= a.ny - a.rband);
             const unsigned up = (a.yshift && y >= (a.ny >> 1)) ? 1u : 0u;     // upper half: rows of negative ky
             const unsigned ix = i + up * xsh, ifl = fi + up * fsh;
-            if (live) { kx = kXb[ix]; ky = kYb[ix]; fg = FGb[ifl]; fh = FHb[ifl]; }
+            if (live) {
+                if (a.zcount == 0 || a.zbase) { kx = kXb[ix]; fg = FGb[ifl]; }      // the gradient leg's operands
+                if (a.zbase == 0) { ky = kYb[ix]; fh = FHb[ifl]; }
+            }
             gv[u * R0 + t] = kx * fg;
             v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
     }
-    const int only = a.split ? ctx.bid_z() : -1;       // uniform per workgroup
+    const int only = a.split ? ctx.bid_z() + a.zbase : -1;       // uniform per workgroup
     if (only < 0 || only == 0) {   // H = FH kY
         const ColStore<T> st{a.h + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
@@ -1435,7 +1441,7 @@ OA_HD void col_fft_body(Ctx& ctx, const ColArgs<T>& a) {
     ctx.sync();
     int z = ctx.bid_z();
     long imo = 0, omo = 0;
-    if (a.nbz && z >= a.nbz) { z -= a.nbz; imo = a.in_moff; omo = a.out_moff; }
+    while (a.nbz && z >= a.nbz) { z -= a.nbz; imo += a.in_moff; omo += a.out_moff; }    // map index = z / nbz (2 maps: one step)
     const cx<T>* in = a.in + imo + (long)(z & 1) * a.in_off1 + (long)(z >> 1) * a.in_off2;
     cx<T>* out = a.out + omo + (long)(z & 1) * a.out_off1 + (long)(z >> 1) * a.out_off2;
     const ColLoad<T> ld{in + g * a.in_gs * a.in_pitch + c0, (unsigned)(a.in_ns * a.in_pitch), ncols, a.inverse != 0};

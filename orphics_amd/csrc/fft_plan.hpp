@@ -183,7 +183,9 @@ struct Fft2dPlan {
     template <class Launcher>
     void legs_cols(Launcher& q, const cx<T>* kX, const cx<T>* kY, const T* FG, const T* FH, const T* lxd, const T* lyd,
                    cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax = 0x7fffffff, int rband = 0, long pin = 0, long pout = 0,
-                   bool in_full = true) const {   // in_full: kX, kY are stored on the full-resolution rows (column grid views)
+                   bool in_full = true, int subset = 0) const {   // in_full: kX, kY are stored on the full-resolution rows (column grid views)
+        // subset: 1 = H only (kY, FH -> h), 2 = the gradient pair only (kX, FG -> gx, gy); pass 1 only -- the caller runs
+        // the inverse pass 2 over all its planes in one launch (oa_qe_mv)
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
@@ -197,7 +199,9 @@ struct Fft2dPlan {
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
         a.rband = clampr(rband); a.ny = ny; a.yshift = yshift(); a.xfull = in_full ? 1 : 0;
         a.split = (yshift() && (long)tiles * N2 < 1024) ? 1 : 0;     // small launches of the column grid: one leg per workgroup
+        if (subset) { a.split = 1; a.zbase = subset == 1 ? 0 : 1; a.zcount = subset == 1 ? 1 : 2; }
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
+        if (subset) return;
         cx<T>* outs[3] = {gx, gy, h};
         const cx<T>* ins[3] = {gx, gy, h};
         cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs);      // pass 2 of the three planes, one launch

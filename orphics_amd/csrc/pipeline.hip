@@ -32,8 +32,8 @@ struct Pipeline {
     int64_t* counts_full = nullptr;   // data-independent mode counts over the whole plane
     int64_t* counts_tmp = nullptr;
     unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
-    void* split_legs = nullptr;       // oa_qe_tt_splits: 3 compact leg planes per split
-    int split_cap = 0;
+    void* split_legs = nullptr;       // oa_qe_tt_splits / oa_qe_mv: pool of compact leg planes
+    int split_cap = 0;                // planes / 3
 };
 
 static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
@@ -241,6 +241,71 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     Pipeline* q = (Pipeline*)p->pipe;
     if (int rc = oa_qe_tt(p, real_map, nullptr, nullptr, nullptr, 0, stream)) return rc;
     return bandpower_moments(p, q, n, S, C, stream);
+}
+
+/* Several estimators accumulated into one kappa plane (minimum-variance combination) with every distinct filtered field
+ * transformed once: a leg plane is identified by (source transform, filter plane) pointers, so estimators that share a
+ * filter plane object share the transform (TE / TB: the gradient of W^TE T cos, sin; EE / EB; TE / EE: E / C^EE cos, sin ...). */
+int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_signs, const void* const* host_FG,
+             const void* const* host_FH, const int* host_swap, const void* const* host_kX, const void* const* host_kY,
+             const void* const* host_Fnorm, void* out, int accumulate, int leg_cols, int kappa_cols, int leg_rows, int kappa_rows,
+             int mrow, int zero_outside, void* stream) {
+    OA_REQUIRE(p && nest >= 1 && host_npieces && host_signs && host_FG && host_FH && host_kX && host_kY && host_Fnorm && out,
+               "oa_qe_mv: bad argument");
+    OA_NEED_POW2(p, "oa_qe_mv");
+    Pipeline* q = pipe_of(p);
+    if (int rc = ensure_work(p, q)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate && zero_outside && out != q->kk)
+        if (int rc = zero_complement(p, out, kappa_cols, kappa_rows, st)) return rc;
+    const long pl = work_pitch(p, leg_cols), pk = work_pitch(p, kappa_cols);
+    int my = 0;
+    if (int rc = resolve_my(p, mrow == 0 ? 0 : q->mcol, leg_rows, kappa_rows, &my)) return rc;
+    // distinct leg planes: gradient pairs (source, FG) and H planes (source, FH)
+    struct Key { const void* src; const void* f; };
+    std::vector<Key> grad, hpl;
+    std::vector<int> gslot, hslot;
+    auto slot_of = [](std::vector<Key>& v, const void* src, const void* f) {
+        for (size_t i = 0; i < v.size(); ++i) if (v[i].src == src && v[i].f == f) return (int)i;
+        v.push_back(Key{src, f});
+        return (int)v.size() - 1;
+    };
+    int total = 0;
+    for (int e = 0; e < nest; ++e) {
+        OA_REQUIRE(host_npieces[e] >= 1 && host_kX[e] && host_kY[e] && host_Fnorm[e], "oa_qe_mv: bad estimator entry");
+        for (int i = 0; i < host_npieces[e]; ++i, ++total) {
+            OA_REQUIRE(host_FG[total] && host_FH[total], "oa_qe_mv: NULL filter plane");
+            const bool sw = host_swap && host_swap[total];
+            gslot.push_back(slot_of(grad, sw ? host_kY[e] : host_kX[e], host_FG[total]));
+            hslot.push_back(slot_of(hpl, sw ? host_kX[e] : host_kY[e], host_FH[total]));
+        }
+    }
+    const int ng = (int)grad.size(), nh = (int)hpl.size(), nplanes = 2 * ng + nh;
+    const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8);
+    const size_t lb = (size_t)pl * p->ny * es;                      // one compact leg plane
+    if (3 * q->split_cap < nplanes) {
+        if (q->split_legs) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->split_legs); q->split_legs = nullptr; q->split_cap = 0; }
+        const int cap = (nplanes + 2) / 3;
+        OA_HIP(hipMalloc(&q->split_legs, 3 * lb * cap));
+        q->split_cap = cap;
+    }
+    auto plane = [&](int k) { return (void*)((char*)q->split_legs + (size_t)k * lb); };      // gradient pair g: 2g, 2g + 1; H plane h: 2 ng + h
+    for (int g = 0; g < ng; ++g)
+        if (int rc = qe_legs_subset_w(p, grad[g].src, grad[g].f, plane(2 * g), plane(2 * g + 1), 2, leg_cols, leg_rows, pl, st, my)) return rc;
+    for (int h = 0; h < nh; ++h)
+        if (int rc = qe_legs_subset_w(p, hpl[h].src, hpl[h].f, plane(2 * ng + h), nullptr, 1, leg_cols, leg_rows, pl, st, my)) return rc;
+    if (int rc = qe_legs_pass2_w(p, q->split_legs, nplanes, (long)(lb / es), leg_cols, pl, st, my)) return rc;
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
+    int at = 0;
+    for (int e = 0; e < nest; ++e) {
+        for (int i = 0; i < host_npieces[e]; ++i, ++at) {
+            int rc = qe_rows_w(p, plane(2 * gslot[at]), plane(2 * gslot[at] + 1), plane(2 * ng + hslot[at]), q->g[0], q->g[1],
+                               host_signs[at] * s * s * sy, i > 0, leg_cols, kappa_cols, mrow, pl, pk, st, my);
+            if (rc) return rc;
+        }
+        if (int rc = qe_cols_div_w(p, q->g[0], q->g[1], host_Fnorm[e], out, (accumulate || e > 0) ? 1 : 0, kappa_cols, kappa_rows, pk, st, my)) return rc;
+    }
+    return 0;
 }
 
 int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void* const* host_out, int zero_outside, void* stream) {

@@ -615,6 +615,8 @@ class Estimator(object):
     def _setup_general(self, XY):
         if XY in self._gen:
             return self._gen[XY]
+        if getattr(self, "_fdev", None) is None:
+            self._fdev = {}
         if not self.pol and XY != "TT":
             raise ValueError("construct the estimator with pol=True for %s" % XY)
         P = self._planes()
@@ -644,10 +646,18 @@ class Estimator(object):
                 tl = [(1., c, c), (1., s_, s_)]
             else:  # sin(a2 - a1): gradient leg at l1 (p==1) or at l2 (p==2)
                 tl = [(1., c, s_), (-1., s_, c)] if p == 1 else [(1., s_, c), (-1., c, s_)]
+            nG, nH = (A, B) if p == 1 else (B, A)
             for (sg, tg, th) in tl:
                 fg = FGh if tg is None else FGh * tg
                 fh = FHh if th is None else FHh * th
-                pieces.append((cg * sg, self._hcreal(self.eng, fg), self._hcreal(self.eng, fh), p == 2))
+                # one device plane per distinct (weight name, trig factor): estimators that use the same filtered field
+                # hand the SAME plane object to the C-ABI, which then transforms that field once (oa_qe_mv)
+                tagG = (nG, None if tg is None else ("c" if tg is c else "s"))
+                tagH = (nH, None if th is None else ("c" if th is c else "s"))
+                for tag, arr in ((tagG, fg), (tagH, fh)):
+                    if tag not in self._fdev:
+                        self._fdev[tag] = self._hcreal(self.eng, arr)
+                pieces.append((cg * sg, self._fdev[tagG], self._fdev[tagH], p == 2))
                 hostf += [fg, fh]
         self._gen[XY] = dict(pieces=pieces, Fnorm=self._hcreal(self.eng, Fnorm), R=R,
                              wl=self._support_cols(*hostf), wk=self._support_cols(Fnorm),
@@ -733,8 +743,10 @@ class Estimator(object):
         self.Nlkk["MV"] = _safe_div(np.ones_like(tot), tot)
         return w
 
-    def reconstruct_mv_hc(self, kT, kE, kB, estimators=("TT", "TE", "EE", "EB", "TB"), out=None):
-        """kappa_hat^MV = sum_a w_a kappa_hat^a, accumulated in the divergence kernel."""
+    def reconstruct_mv_hc(self, kT, kE, kB, estimators=("TT", "TE", "EE", "EB", "TB"), out=None, fused=True):
+        """kappa_hat^MV = sum_a w_a kappa_hat^a, accumulated in the divergence kernel.  fused (default): one ``oa_qe_mv``
+        call in which every distinct filtered field is transformed once (TT+TE+EE+EB+TB: 17 leg planes, not 30);
+        fused=False: one ``oa_qe_pol`` call per estimator."""
         e = self.eng
         key = tuple(estimators)
         if getattr(self, "_mv", None) is None or self._mv[0] != key:
@@ -745,10 +757,50 @@ class Estimator(object):
                 AL = self.AL[XY]
                 planes[XY] = self._hcreal(e, -(L * (L + 1.) / 2.) * AL * self.mask_K * w[XY])
             self._mv = (key, planes)
-        out = e.hc() if out is None else out
         f = {"T": kT, "E": kE, "B": kB}
-        for i, XY in enumerate(estimators):
-            self.reconstruct_hc(XY, f[XY[0]], f[XY[1]], out=out, norm=self._mv[1][XY], accumulate=(i > 0))
+        if not e.pow2 or not fused:
+            out = e.hc() if out is None else out
+            for i, XY in enumerate(estimators):
+                self.reconstruct_hc(XY, f[XY[0]], f[XY[1]], out=out, norm=self._mv[1][XY], accumulate=(i > 0))
+            return out
+        # ONE C-ABI call (oa_qe_mv): distinct filtered fields transformed once, estimators accumulated in the divergence
+        import ctypes
+        from ._lib import check
+        from .engine import _ptr, _stream, mark_dirty, owned_clean_region, set_clean_region
+        if len(self._mv) < 3:
+            G = [self._setup_general(XY) for XY in estimators]
+            pcs = [pc for g_ in G for pc in g_["pieces"]]
+            n = len(pcs)
+            if getattr(self, "_wK", None) is None:
+                self._wK = (self._support_cols(self.mask_K), self._support_rows(self.mask_K))
+            # common active region: filters vanish outside their own, so the widest one is exact for all (0 = everything)
+            widest = lambda vals: 0 if any(v == 0 for v in vals) else max(vals)      # noqa: E731
+            args = dict(ne=len(G), npieces=(ctypes.c_int * len(G))(*[len(g_["pieces"]) for g_ in G]),
+                        signs=(ctypes.c_double * n)(*[float(pc[0]) for pc in pcs]),
+                        fgs=(ctypes.c_void_p * n)(*[pc[1].data_ptr() for pc in pcs]),
+                        fhs=(ctypes.c_void_p * n)(*[pc[2].data_ptr() for pc in pcs]),
+                        swaps=(ctypes.c_int * n)(*[1 if pc[3] else 0 for pc in pcs]),
+                        fns=(ctypes.c_void_p * len(G))(*[self._mv[1][XY].data_ptr() for XY in estimators]),
+                        wl=widest([g_["wl"] for g_ in G]), rl=widest([g_["rl"] for g_ in G]))
+            self._mv = (self._mv[0], self._mv[1], args)
+        a = self._mv[2]
+        for XY in estimators:
+            e._chk(f[XY[0]], "hc"); e._chk(f[XY[1]], "hc")
+        wk, rk = self._wK
+        if out is None:
+            out, zero = e.hc(), 0
+        else:
+            e._chk(out, "hc")
+            zero = 1 if ((wk or rk) and owned_clean_region(out) != (wk, rk)) else 0
+        kxs = (ctypes.c_void_p * a["ne"])(*[f[XY[0]].data_ptr() for XY in estimators])
+        kys = (ctypes.c_void_p * a["ne"])(*[f[XY[1]].data_ptr() for XY in estimators])
+        e._ordered()
+        check(e.lib.oa_plan_set_col_grid(e.plan, int(self.mcol)))
+        check(e.lib.oa_qe_mv(e.plan, a["ne"], a["npieces"], a["signs"], a["fgs"], a["fhs"], a["swaps"], kxs, kys, a["fns"], _ptr(out), 0,
+                             int(a["wl"]), int(wk), int(a["rl"]), int(rk), int(self.mrow), zero, _stream()))
+        mark_dirty(out)
+        if wk or rk:
+            set_clean_region(out, (wk, rk))
         return out
 
     # full-plane views of the normalisation (host, float64)

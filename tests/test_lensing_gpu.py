@@ -333,6 +333,31 @@ def test_mv_combination_matches_oracle():
         assert np.all(nmv[sel] <= q.N_kappa("TT")[sel] * (1 + 1e-9))   # MV is never noisier than TT
 
 
+@pytest.mark.parametrize("N,res,prune,masks", [(128, 2.0, True, "same"), (512, 1.0, True, "differ"), (256, 2.0, False, "same"), (1024, 1.0, True, "same")])
+def test_mv_one_call_equals_per_estimator_calls(N, res, prune, masks):
+    """oa_qe_mv (every distinct filtered field transformed once, one inverse pass-2 launch over all leg planes) vs one
+    oa_qe_pol call per estimator: the same kernels on the same operands piece by piece."""
+    from orphics_amd import lensing
+    shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup(N, res, seed=4)
+    pmask = tmask if masks == "same" else ((ml > 200) & (ml < 1400)).astype(tmask.dtype)      # different T / P leg bands
+    for prec, tol in (("f64", 1e-12), ("f32", 1e-5)):
+        q = lensing.qest(shape, g, th, noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=pmask, kmask_K=kmask,
+                         pol=True, unlensed_equals_lensed=True, dtype=prec, prune=prune)
+        e = q.eng
+        hk = {X: e.full_to_hc(e.to_complex(k[X])) for X in "TEB"}
+        one = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"]).clone()
+        per = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], fused=False).clone()
+        assert float((one - per).abs().max() / per.abs().max()) < tol
+        shared = len({pc[1].data_ptr() for XY in ("TT", "TE", "EE", "EB", "TB") for pc in q._gen[XY]["pieces"]})
+        assert shared == 6                                  # W^TT T; W^TE T cos, sin; W^EE E cos, sin; W^ET E: 6 gradient fields for 10 pieces
+        dirty = torch.full_like(one, 3.0)                   # caller-owned plane: zero-filled outside kappa's region
+        again = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], out=dirty)
+        assert torch.equal(again[:, :e.nxh + 1], one[:, :e.nxh + 1])       # (columns beyond nx/2 are row padding)
+        sub = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], estimators=("TT", "EB")).clone()
+        sub_per = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], estimators=("TT", "EB"), fused=False).clone()
+        assert float((sub - sub_per).abs().max() / sub_per.abs().max()) < tol
+
+
 def test_flat_lensing_op_matches_oracle_and_remaps():
     """kappa -> phi -> alpha and the FFT-only Taylens (lensing.py:395-454,651-665) vs the NumPy restatement;
     a constant one-pixel displacement is an exact roll."""
