@@ -94,6 +94,9 @@ int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, c
 // one filtered field (subset 1: H plane into a; 2: gradient pair into a, b), inverse pass 1 only; then pass 2 over a pool of planes
 int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* b, int subset, int width, int rband, long pl,
                      hipStream_t st, int my = 0);
+// all leg planes of several estimators in one inverse pass-1 launch (ColLegsArgs::batch); offsets in complex elements
+int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
+                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my = 0);
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my = 0);
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
               int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0);

@@ -448,6 +448,14 @@ static int legs_subset_impl(oa_plan* p, const void* src, const void* F, void* a,
     return q.rc;
 }
 template <typename T>
+static int legs_batch_impl(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
+                           int ngrad, int nh, void* pool, long ostride, int width, int rband, hipStream_t st, long pout, int my) {
+    HipLauncher q{st};
+    coarse_view<T>(p, my).legs_cols_batch(q, (const cx<T>*)src0, off1, off2, srcsel, (const T* const*)ftab, ngrad, nh, (const T*)p->lxd,
+                                          (const T*)p->lyd, (cx<T>*)pool, ostride, width, rband, 0, pout);
+    return q.rc;
+}
+template <typename T>
 static int legs_pass2_impl(oa_plan* p, void* pool, int nplanes, long stride, int width, hipStream_t st, long pout, int my) {
     HipLauncher q{st};
     const auto f = coarse_view<T>(p, my);
@@ -460,6 +468,11 @@ int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* 
                      hipStream_t st, int my) {
     return p->dtype == OA_F32 ? legs_subset_impl<float>(p, src, F, a, b, subset, width, rband, st, pl, my)
                               : legs_subset_impl<double>(p, src, F, a, b, subset, width, rband, st, pl, my);
+}
+int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
+                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? legs_batch_impl<float>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my)
+                              : legs_batch_impl<double>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my);
 }
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my) {
     return p->dtype == OA_F32 ? legs_pass2_impl<float>(p, pool, nplanes, stride, width, st, pl, my)

@@ -1024,6 +1024,14 @@ struct ColLegsArgs {
     // with split: legs zbase .. zbase + zcount - 1 only (zcount = 0: all three).  H alone (0, 1) or the gradient pair alone
     // (1, 2): estimators that share a filtered field transform it once (oa_qe_mv)
     int zbase, zcount;
+    // batch > 0 (oa_qe_mv): grid z = batch leg planes in ONE launch.  Plane z < 2 ngrad: Gx (z even) / Gy (z odd) of gradient
+    // field z / 2; plane z >= 2 ngrad: H of field z - ngrad.  Field f is filter plane ftab[f] (device table of the caller's
+    // h + z * ostride.  (Offsets and bit fields, not by-value pointer tables: see ColArgs; the filter pointers sit in a small
+    // DEVICE table, read with a uniform index.)
+    int batch, ngrad;
+    unsigned long long srcsel;
+    long src_off1, src_off2, ostride;
+    const T* const* ftab;
 };
 
 template <typename T, class SEQ, class Ctx>
@@ -1050,6 +1058,22 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     const long forg = g * a.in_gs * a.fpitch + c0;
     const cx<T>* kXb = a.kX + org; const cx<T>* kYb = a.kY + org;
     const T* FGb = a.FG + forg; const T* FHb = a.FH + forg;
+    int only = a.split ? ctx.bid_z() + a.zbase : -1;       // uniform per workgroup
+    bool ldx = a.zcount == 0 || a.zbase, ldy = a.zbase == 0;
+    cx<T>* ogx = a.gx; cx<T>* ogy = a.gy; cx<T>* oh = a.h;
+    if (a.batch) {
+        const int z = ctx.bid_z();
+        const bool grad = z < 2 * a.ngrad;
+        const int f = grad ? (z >> 1) : z - a.ngrad;
+        const unsigned sel = (unsigned)(a.srcsel >> (2 * f)) & 3u;
+        kXb += (long)(sel == 1u) * a.src_off1 + (long)(sel == 2u) * a.src_off2;
+        kYb = kXb;
+        FGb = a.ftab[f] + forg;
+        FHb = FGb;
+        only = grad ? 1 + (z & 1) : 0;
+        ldx = grad; ldy = !grad;
+        ogx = ogy = oh = a.h + (long)z * a.ostride;
+    }
     const unsigned nstr = (unsigned)(a.in_ns * a.pitch), fstr = (unsigned)(a.in_ns * a.fpitch);
     const unsigned fsh = (unsigned)a.yshift * (unsigned)a.fpitch, xsh = a.xfull ? (unsigned)a.yshift * (unsigned)a.pitch : 0u;
 #pragma unroll
@@ -1069,16 +1093,15 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
             const unsigned up = (a.yshift && y >= (a.ny >> 1)) ? 1u : 0u;     // upper half: rows of negative ky
             const unsigned ix = i + up * xsh, ifl = fi + up * fsh;
             if (live) {
-                if (a.zcount == 0 || a.zbase) { kx = kXb[ix]; fg = FGb[ifl]; }      // the gradient leg's operands
-                if (a.zbase == 0) { ky = kYb[ix]; fh = FHb[ifl]; }
+                if (ldx) { kx = kXb[ix]; fg = FGb[ifl]; }      // the gradient leg's operands
+                if (ldy) { ky = kYb[ix]; fh = FHb[ifl]; }
             }
             gv[u * R0 + t] = kx * fg;
             v[u * R0 + t] = swp(ky * fh);  // inverse transform = forward transform of the swapped data
         }
     }
-    const int only = a.split ? ctx.bid_z() + a.zbase : -1;       // uniform per workgroup
     if (only < 0 || only == 0) {   // H = FH kY
-        const ColStore<T> st{a.h + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
+        const ColStore<T> st{oh + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         if (only < 0) ctx.sync();
@@ -1091,7 +1114,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
 #pragma unroll
             for (int t = 0; t < R0; ++t) v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * lx);
         }
-        const ColStore<T> st{a.gx + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
+        const ColStore<T> st{ogx + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
         if (only < 0) ctx.sync();
@@ -1107,7 +1130,7 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
                 v[u * R0 + t] = swp(mul_pi(gv[u * R0 + t]) * a.lyd[y]);
             }
         }
-        const ColStore<T> st{a.gy + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
+        const ColStore<T> st{ogy + g * a.out_gs * a.opitch + c0, (unsigned)(a.out_ks * a.opitch), ncols, true,
                              a.twiddle ? ti : nullptr, (unsigned)g, (T)1, 0, 0, 0, 0};
         col_pipeline_from_regs<T, SEQ>(ctx, s, v, tid, NT, logC, twl, logL, st);
     }

@@ -18,7 +18,7 @@ int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int log
         using S = decltype(seq);
         if constexpr (seq_logl<S>() <= 8) {
             if (nt > col_maxnt<S>()) { rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
-            launch_go(rc, st, col_legs_kernel<T, S>, dim3(gx, gy, a.split ? (a.zcount ? a.zcount : 3) : 1), nt, smem, a);
+            launch_go(rc, st, col_legs_kernel<T, S>, dim3(gx, gy, a.batch ? a.batch : (a.split ? (a.zcount ? a.zcount : 3) : 1)), nt, smem, a);
         } else {
             rc = fail("fft: unsupported column sub-length");
         }

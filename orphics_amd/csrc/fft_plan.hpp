@@ -207,6 +207,29 @@ struct Fft2dPlan {
         cols(q, gx, po, gx, po, width, true, (T)1, 2, 3, ins, outs);      // pass 2 of the three planes, one launch
     }
 
+    // (A-batch) oa_qe_mv: ngrad gradient fields (2 planes each) and nh H fields in ONE inverse pass-1 launch (grid z = plane);
+    //      field f = filter plane ftab[f] (device table) applied to source src0 + {0, off1, off2}[(srcsel >> 2f) & 3]; plane z is
+    //      stored at pool + z * ostride.  The caller runs the inverse pass 2 over the pool.
+    template <class Launcher>
+    void legs_cols_batch(Launcher& q, const cx<T>* src0, long off1, long off2, unsigned long long srcsel, const T* const* ftab, int ngrad, int nh, const T* lxd, const T* lyd, cx<T>* pool, long ostride, int wmax,
+                         int rband, long pin, long pout) const {
+        const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
+        const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
+        const long N1 = 1L << logN1, N2 = 1L << logN2;
+        const int C = 1 << COLC;
+        const int width = clampw(wmax);
+        const int tiles = (width + C - 1) / C;
+        ColLegsArgs<T> a{};
+        a.kX = src0; a.kY = src0; a.FG = nullptr; a.FH = nullptr; a.ftab = ftab; a.lxd = lxd; a.lyd = lyd; a.gx = pool; a.gy = pool; a.h = pool;
+        a.pitch = pi; a.fpitch = kp; a.opitch = po;
+        a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
+        a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
+        a.rband = clampr(rband); a.ny = ny; a.yshift = yshift(); a.xfull = 1;
+        a.split = 1; a.batch = 2 * ngrad + nh; a.ngrad = ngrad; a.srcsel = srcsel; a.src_off1 = off1; a.src_off2 = off2;
+        a.ostride = ostride;
+        q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
+    }
+
     // (A') legs straight from the forward column pass 1 of the map's row transform (both legs from ONE map):
     //      forward pass 2 + filters + inverse pass 1 in one kernel, then the 3-plane inverse pass 2.
     //      Returns false when this geometry has no fused kernel (caller falls back to cols + legs_cols).

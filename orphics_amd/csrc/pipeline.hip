@@ -4,6 +4,7 @@
 // rng.hip (the same kernels the fine-grained calls launch), plus an RCCL all-reduce for hosts that do not bring
 // torch.distributed (librccl is dlopen'ed on first use, so the library has no link-time dependency on it).
 #include <dlfcn.h>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 #include "common.hpp"
@@ -34,6 +35,8 @@ struct Pipeline {
     unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
     void* split_legs = nullptr;       // oa_qe_tt_splits / oa_qe_mv: pool of compact leg planes
     int split_cap = 0;                // planes / 3
+    void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
+    std::vector<const void*> mv_fkey; // what the table holds
 };
 
 static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
@@ -53,6 +56,7 @@ void pipeline_release(oa_plan* p) {
     if (q->counts_tmp) (void)hipFree(q->counts_tmp);
     if (q->ticket) (void)hipFree(q->ticket);
     if (q->split_legs) (void)hipFree(q->split_legs);
+    if (q->mv_ftab) (void)hipFree(q->mv_ftab);
     delete q;
     p->pipe = nullptr;
 }
@@ -290,10 +294,42 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
         q->split_cap = cap;
     }
     auto plane = [&](int k) { return (void*)((char*)q->split_legs + (size_t)k * lb); };      // gradient pair g: 2g, 2g + 1; H plane h: 2 ng + h
-    for (int g = 0; g < ng; ++g)
-        if (int rc = qe_legs_subset_w(p, grad[g].src, grad[g].f, plane(2 * g), plane(2 * g + 1), 2, leg_cols, leg_rows, pl, st, my)) return rc;
-    for (int h = 0; h < nh; ++h)
-        if (int rc = qe_legs_subset_w(p, hpl[h].src, hpl[h].f, plane(2 * ng + h), nullptr, 1, leg_cols, leg_rows, pl, st, my)) return rc;
+    // all leg planes in ONE inverse pass-1 launch when the fields come from at most three sources (T, E, B)
+    std::vector<const void*> srcs;
+    unsigned long long srcsel = 0;
+    bool batch = ng + nh <= 32 && !getenv("OA_MV_NO_BATCH");        // (A/B and test switch: one launch per field)
+    for (int f = 0; f < ng + nh && batch; ++f) {
+        const void* sp = f < ng ? grad[f].src : hpl[f - ng].src;
+        size_t k = 0;
+        while (k < srcs.size() && srcs[k] != sp) ++k;
+        if (k == srcs.size()) srcs.push_back(sp);
+        if (srcs.size() > 3) batch = false;
+        srcsel |= (unsigned long long)k << (2 * f);
+    }
+    if (batch) {
+        std::vector<const void*> key;
+        for (int g = 0; g < ng; ++g) key.push_back(grad[g].f);
+        for (int h = 0; h < nh; ++h) key.push_back(hpl[h].f);
+        if (!q->mv_ftab) OA_HIP(hipMalloc((void**)&q->mv_ftab, 32 * sizeof(void*)));
+        if (key != q->mv_fkey) {       // (pageable source: staged before the call returns; ordered on this stream)
+            OA_HIP(hipMemcpyAsync(q->mv_ftab, key.data(), key.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+            q->mv_fkey = key;
+        }
+        const long off1 = srcs.size() > 1 ? (long)(((const char*)srcs[1] - (const char*)srcs[0]) / (long)es) : 0;
+        const long off2 = srcs.size() > 2 ? (long)(((const char*)srcs[2] - (const char*)srcs[0]) / (long)es) : 0;
+        bool aligned = true;
+        for (size_t k = 1; k < srcs.size(); ++k) aligned = aligned && (((const char*)srcs[k] - (const char*)srcs[0]) % (long)es == 0);
+        if (aligned) {
+            if (int rc = qe_legs_batch_w(p, srcs[0], off1, off2, srcsel, (const void* const*)q->mv_ftab, ng, nh, q->split_legs, (long)(lb / es),
+                                         leg_cols, leg_rows, pl, st, my)) return rc;
+        } else batch = false;
+    }
+    if (!batch) {
+        for (int g = 0; g < ng; ++g)
+            if (int rc = qe_legs_subset_w(p, grad[g].src, grad[g].f, plane(2 * g), plane(2 * g + 1), 2, leg_cols, leg_rows, pl, st, my)) return rc;
+        for (int h = 0; h < nh; ++h)
+            if (int rc = qe_legs_subset_w(p, hpl[h].src, hpl[h].f, plane(2 * ng + h), nullptr, 1, leg_cols, leg_rows, pl, st, my)) return rc;
+    }
     if (int rc = qe_legs_pass2_w(p, q->split_legs, nplanes, (long)(lb / es), leg_cols, pl, st, my)) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
     int at = 0;

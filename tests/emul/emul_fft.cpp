@@ -79,7 +79,7 @@ struct EmuLauncher {
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
-            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_legs_body<T, S>(c, a); }, a.split ? (a.zcount ? a.zcount : 3) : 1);
+            run(gx, gy, nt, smem, [&](EmuCtx& c) { col_legs_body<T, S>(c, a); }, a.batch ? a.batch : (a.split ? (a.zcount ? a.zcount : 3) : 1));
         });
     }
     template <typename T> void col_fwdlegs(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a) {

@@ -1,6 +1,8 @@
 """GPU parity of the TT quadratic estimator vs oracle/qe_oracle.py (float64
 NumPy).  Tolerances: f64 kernels 1e-9 on kappa modes, f32 kernels 1e-5 on the
 binned kappa bandpowers (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -353,6 +355,12 @@ def test_mv_one_call_equals_per_estimator_calls(N, res, prune, masks):
         dirty = torch.full_like(one, 3.0)                   # caller-owned plane: zero-filled outside kappa's region
         again = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], out=dirty)
         assert torch.equal(again[:, :e.nxh + 1], one[:, :e.nxh + 1])       # (columns beyond nx/2 are row padding)
+        os.environ["OA_MV_NO_BATCH"] = "1"                  # one leg launch per distinct field instead of one for all
+        try:
+            per_field = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"]).clone()
+        finally:
+            del os.environ["OA_MV_NO_BATCH"]
+        assert torch.equal(per_field, one)
         sub = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], estimators=("TT", "EB")).clone()
         sub_per = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], estimators=("TT", "EB"), fused=False).clone()
         assert float((sub - sub_per).abs().max() / sub_per.abs().max()) < tol
