@@ -94,6 +94,12 @@ int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, c
 // one filtered field (subset 1: H plane into a; 2: gradient pair into a, b), inverse pass 1 only; then pass 2 over a pool of planes
 int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* b, int subset, int width, int rband, long pl,
                      hipStream_t st, int my = 0);
+// divergence of nmaps estimators in one launch: product planes (A_e, B_e adjacent: B_e = A_e + in_moff / 2) in_moff apart, Fn planes
+// fn_moff apart, outputs out_moff apart (offsets in elements of the respective plane type); tmp: 2 nmaps compact planes
+int qe_cols_div_batch_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, void* tmp, int nmaps, long in_moff,
+                        long fn_moff, long out_moff, int width, int rband, long pk, hipStream_t st, int my = 0);
+int sum_region(int dtype, const void* parts, long part_stride, int nparts, void* out, int accumulate, int ny, long kp, int w, int rb,
+               hipStream_t st);
 // all leg planes of several estimators in one inverse pass-1 launch (ColLegsArgs::batch); offsets in complex elements
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
                     int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my = 0);

@@ -101,6 +101,21 @@ __global__ __launch_bounds__(256) void stack_add_region_kernel(const T* __restri
     acc[i] += (double)x[i];
 }
 
+// out (+)= sum of `nparts` planes `stride` elements apart, over the active region of an hc plane (oa_qe_mv: the estimators'
+// weighted kappa planes, summed in estimator order)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_region_kernel(const cx<T>* __restrict__ parts, long stride, int nparts, cx<T>* __restrict__ out,
+                                                         int accumulate, int ny, long kp, int w, int rb) {
+    int y = blockIdx.y;
+    if (rb > 0 && y >= rb) y += ny - (2 * rb - 1);
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    const long at = (long)y * kp + x;
+    cx<T> acc = accumulate ? out[at] : mk<T>((T)0, (T)0);
+    for (int e = 0; e < nparts; ++e) acc = acc + parts[at + e * stride];
+    out[at] = acc;
+}
+
 // ---------------------------------------------------------------- split-based 4-point combination
 // SplitLensing.cross_estimator (lensing.py:980-1003) per Fourier mode from the N^2 pairwise reconstructions
 // K[i*N+j] = QE(X leg from split i, Y leg from split j).  The QE is bilinear, so with s = mean of the splits
@@ -323,6 +338,18 @@ __global__ __launch_bounds__(256) void lens_gather_kernel(const T* __restrict__ 
 }  // namespace oa
 
 namespace oa {
+int sum_region(int dtype, const void* parts, long part_stride, int nparts, void* out, int accumulate, int ny, long kp, int w, int rb,
+               hipStream_t st) {
+    if (w <= 0 || w > kp) w = (int)kp;
+    if (!(rb > 0 && 2L * rb - 1 < ny)) rb = 0;
+    dim3 grid((w + 255) / 256, rb ? 2 * rb - 1 : ny);
+    if (dtype == OA_F32)
+        hipLaunchKernelGGL(sum_region_kernel<float>, grid, dim3(256), 0, st, (const cx<float>*)parts, part_stride, nparts, (cx<float>*)out, accumulate, ny, kp, w, rb);
+    else
+        hipLaunchKernelGGL(sum_region_kernel<double>, grid, dim3(256), 0, st, (const cx<double>*)parts, part_stride, nparts, (cx<double>*)out, accumulate, ny, kp, w, rb);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
 // mean-field stack of the one-call Monte-Carlo driver (pipeline.hip)
 int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st) {
     if (w <= 0 || w > kp) w = (int)kp;

@@ -377,6 +377,19 @@ static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void*
     return q.rc;
 }
 
+// oa_qe_mv: the divergence of `nmaps` estimators in one launch (grid z = estimator): product planes in_moff apart, Fn planes
+// fn_moff apart, each estimator's kappa into its own plane (out_moff apart); tmp: 2 nmaps compact planes for the two-pass path
+template <typename T>
+static int cols_div_batch_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, void* tmp, int nmaps, long in_moff,
+                               long fn_moff, long out_moff, int width, int rband, hipStream_t st, long pin, int my) {
+    HipLauncher q{st};
+    cx<T>* tA = (cx<T>*)tmp;
+    cx<T>* tB = tA + (in_moff >> 1);
+    coarse_view<T>(p, my).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)out, tA,
+                                   tB, 0, width, rband, pin, nmaps, in_moff, in_moff, out_moff, fn_moff);
+    return q.rc;
+}
+
 // ---- TWO real maps -> two kappa_hat planes with every coarse-grid stage launched once for both (pipeline.hip,
 //      oa_qe_tt_moments2).  The small launches behind the row R2C are latency-bound and far from filling the chip: doing
 //      two realisations' worth of work per launch costs little more than one.  Returns -1 when this geometry lacks one
@@ -468,6 +481,11 @@ int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* 
                      hipStream_t st, int my) {
     return p->dtype == OA_F32 ? legs_subset_impl<float>(p, src, F, a, b, subset, width, rband, st, pl, my)
                               : legs_subset_impl<double>(p, src, F, a, b, subset, width, rband, st, pl, my);
+}
+int qe_cols_div_batch_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, void* tmp, int nmaps, long in_moff,
+                        long fn_moff, long out_moff, int width, int rband, long pk, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? cols_div_batch_impl<float>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my)
+                              : cols_div_batch_impl<double>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my);
 }
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
                     int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my) {

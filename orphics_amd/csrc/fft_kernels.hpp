@@ -1365,7 +1365,8 @@ struct ColDivArgs {
     int accumulate;
     int rband, ny;   // rband > 0: Fn vanishes on output rows rband <= y <= ny - rband, which are not written
     int yshift;      // COLUMN GRID: output row y of this My-row transform is row y + (y >= ny/2 ? yshift : 0) of Fn, ly, out
-    long in_moff, out_moff;   // two maps per launch (grid z = map): offsets of the second map's A / B planes and of its `out`
+    long in_moff, out_moff;   // several maps per launch (grid z = map): map z's A / B planes and its `out` sit z * {in,out}_moff behind
+    long fn_moff;             // ... and its Fn plane z * fn_moff behind (0: one Fn for all -- two Monte-Carlo maps; oa_qe_mv: one per estimator)
 };
 
 // LOGC: log2 of the tile width.  The default (32 columns) is the two-pass layout; with a WHOLE column in the tile (SEQ = the
@@ -1397,7 +1398,8 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     cx<T>* twl = s + (1 << (logL + logC));
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
     ctx.sync();
-    const long imo = ctx.bid_z() ? a.in_moff : 0, omo = ctx.bid_z() ? a.out_moff : 0;
+    const long zmap = ctx.bid_z();
+    const long imo = zmap * a.in_moff, omo = zmap * a.out_moff;
     const ColLoad<T> la{a.A + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     const ColLoad<T> lb{a.B + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     if constexpr (n == 2) {
@@ -1420,7 +1422,7 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
         col_pipeline_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL, lb);
     }
     const long oorg = g * a.out_gs * a.opitch + c0;
-    const T* Fnb = a.Fn + oorg;
+    const T* Fnb = a.Fn + zmap * a.fn_moff + oorg;
     cx<T>* outb = a.out + omo + oorg;
     const unsigned ostr = (unsigned)(a.out_ks * a.opitch);
 #pragma unroll

@@ -296,7 +296,7 @@ struct Fft2dPlan {
     template <class Launcher>
     void cols_div(Launcher& q, const cx<T>* pa, const cx<T>* pb, const T* Fn, const T* lxd, const T* lyd, cx<T>* out,
                   cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0, int nmaps = 1,
-                  long in_moff = 0, long tmp_moff = 0, long out_moff = 0) const {
+                  long in_moff = 0, long tmp_moff = 0, long out_moff = 0, long fn_moff = 0) const {
         const long pi = pin > 0 ? pin : kp;     // pitch of pa, pb AND of the two scratch planes
         if (single_pass_div() && (logNy == 10 || logNy == 11) && sizeof(T) == 4) {
             // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column tile in LDS, the product planes
@@ -306,9 +306,9 @@ struct Fft2dPlan {
             a.A = pa; a.B = pb; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = clampw(wmax);
             a.logC = lc; a.NT = 1024; a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = 1; a.out_gs = 1; a.out_ks = 1;
             a.accumulate = accumulate; a.rband = clampr(rband); a.ny = ny; a.yshift = yshift();
-            a.in_moff = in_moff; a.out_moff = out_moff;
+            a.in_moff = in_moff; a.out_moff = out_moff; a.fn_moff = fn_moff;
             const int tl = (a.width + Cs - 1) / Cs;
-            if (q.col_div_sp(tl, ((size_t)(1 << 14) + tw_lds_size(logNy)) * sizeof(cx<T>), logNy, a, nmaps > 1 ? 2 : 1)) return;
+            if (q.col_div_sp(tl, ((size_t)(1 << 14) + tw_lds_size(logNy)) * sizeof(cx<T>), logNy, a, nmaps)) return;
         }
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
@@ -323,8 +323,8 @@ struct Fft2dPlan {
         a.logC = COLC; a.NT = (int)((N2 * C) / EPT); if (a.NT < 1) a.NT = 1;
         a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = N1; a.out_gs = 1; a.out_ks = N1; a.accumulate = accumulate;
         a.rband = clampr(rband); a.ny = ny; a.yshift = yshift();
-        a.in_moff = tmp_moff; a.out_moff = out_moff;
-        q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a, nmaps > 1 ? 2 : 1);
+        a.in_moff = tmp_moff; a.out_moff = out_moff; a.fn_moff = fn_moff;
+        q.col_div(tiles, (int)N1, a.NT, ((size_t)N2 * C + tw_lds_size(logN2) + N2) * sizeof(cx<T>), logN2, a, nmaps);
     }
 
     // real (ny,nx) -> half-complex (ny, kp); tmp: one hc plane

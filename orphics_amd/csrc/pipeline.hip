@@ -34,7 +34,7 @@ struct Pipeline {
     int64_t* counts_tmp = nullptr;
     unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
     void* split_legs = nullptr;       // oa_qe_tt_splits / oa_qe_mv: pool of compact leg planes
-    int split_cap = 0;                // planes / 3
+    size_t split_bytes = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
 };
@@ -72,6 +72,15 @@ static int ensure_work(oa_plan* p, Pipeline* q) {
     q->kT = b + 5 * pb;
     q->kk = b + 6 * pb;
     return plan_ensure_scratch(p, 2 * pb);          // never reallocated inside a stream-ordered call afterwards
+}
+
+// pool of compact planes of the multi-map entries (grown on demand; growing synchronises the device once)
+static int ensure_pool(Pipeline* q, size_t bytes) {
+    if (q->split_bytes >= bytes) return 0;
+    if (q->split_legs) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->split_legs); q->split_legs = nullptr; q->split_bytes = 0; }
+    OA_HIP(hipMalloc(&q->split_legs, bytes));
+    q->split_bytes = bytes;
+    return 0;
 }
 
 // zero the part of a caller-supplied output plane that the pruned divergence kernel never writes: every 16-byte unit of
@@ -287,12 +296,11 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     const int ng = (int)grad.size(), nh = (int)hpl.size(), nplanes = 2 * ng + nh;
     const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8);
     const size_t lb = (size_t)pl * p->ny * es;                      // one compact leg plane
-    if (3 * q->split_cap < nplanes) {
-        if (q->split_legs) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->split_legs); q->split_legs = nullptr; q->split_cap = 0; }
-        const int cap = (nplanes + 2) / 3;
-        OA_HIP(hipMalloc(&q->split_legs, 3 * lb * cap));
-        q->split_cap = cap;
-    }
+    // pool: leg planes | 2 product planes per estimator | 2 pass-1 planes per estimator (two-pass divergence)
+    const size_t lbk = (size_t)pk * p->ny * es;                     // one compact product plane
+    if (int rc = ensure_pool(q, nplanes * lb + 4 * (size_t)nest * lbk)) return rc;
+    char* const prod = (char*)q->split_legs + nplanes * lb;
+    char* const tmp = prod + 2 * (size_t)nest * lbk;
     auto plane = [&](int k) { return (void*)((char*)q->split_legs + (size_t)k * lb); };      // gradient pair g: 2g, 2g + 1; H plane h: 2 ng + h
     // all leg planes in ONE inverse pass-1 launch when the fields come from at most three sources (T, E, B)
     std::vector<const void*> srcs;
@@ -332,14 +340,34 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     }
     if (int rc = qe_legs_pass2_w(p, q->split_legs, nplanes, (long)(lb / es), leg_cols, pl, st, my)) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
+    // divergence of all estimators in ONE launch when their Fnorm planes are evenly spaced (one stacked allocation): each
+    // estimator's weighted kappa goes to its own plan-owned plane (c[0..2], g[0..1], kT are contiguous and unused here),
+    // then one pass sums them in estimator order
+    const size_t rs = es / 2, pb = plane_bytes(p);
+    long fn_moff = 0;
+    bool dbatch = nest >= 2 && nest <= 6 && !getenv("OA_MV_NO_BATCH");
+    if (dbatch) {
+        const long d = (long)((const char*)host_Fnorm[1] - (const char*)host_Fnorm[0]);
+        dbatch = d > 0 && d % (long)rs == 0;
+        for (int e = 2; e < nest && dbatch; ++e) dbatch = ((const char*)host_Fnorm[e] - (const char*)host_Fnorm[0]) == e * d;
+        fn_moff = d / (long)rs;
+    }
     int at = 0;
     for (int e = 0; e < nest; ++e) {
+        void* g0 = dbatch ? (void*)(prod + 2 * (size_t)e * lbk) : q->g[0];
+        void* g1 = dbatch ? (void*)(prod + (2 * (size_t)e + 1) * lbk) : q->g[1];
         for (int i = 0; i < host_npieces[e]; ++i, ++at) {
-            int rc = qe_rows_w(p, plane(2 * gslot[at]), plane(2 * gslot[at] + 1), plane(2 * ng + hslot[at]), q->g[0], q->g[1],
+            int rc = qe_rows_w(p, plane(2 * gslot[at]), plane(2 * gslot[at] + 1), plane(2 * ng + hslot[at]), g0, g1,
                                host_signs[at] * s * s * sy, i > 0, leg_cols, kappa_cols, mrow, pl, pk, st, my);
             if (rc) return rc;
         }
-        if (int rc = qe_cols_div_w(p, q->g[0], q->g[1], host_Fnorm[e], out, (accumulate || e > 0) ? 1 : 0, kappa_cols, kappa_rows, pk, st, my)) return rc;
+        if (!dbatch)
+            if (int rc = qe_cols_div_w(p, g0, g1, host_Fnorm[e], out, (accumulate || e > 0) ? 1 : 0, kappa_cols, kappa_rows, pk, st, my)) return rc;
+    }
+    if (dbatch) {
+        if (int rc = qe_cols_div_batch_w(p, prod, prod + lbk, host_Fnorm[0], q->c[0], tmp, nest, (long)(2 * lbk / es), fn_moff, (long)(pb / es),
+                                         kappa_cols, kappa_rows, pk, st, my)) return rc;
+        return sum_region(p->dtype, q->c[0], (long)(pb / es), nest, out, accumulate ? 1 : 0, p->ny, p->kp, kappa_cols, kappa_rows, st);
     }
     return 0;
 }
@@ -351,11 +379,20 @@ int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void
     hipStream_t st = (hipStream_t)stream;
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     const size_t lb = (size_t)pl * p->ny * 2 * (p->dtype == OA_F32 ? 4 : 8);      // one compact leg plane
-    if (q->split_cap < nsplits) {
-        if (q->split_legs) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->split_legs); q->split_legs = nullptr; q->split_cap = 0; }
-        OA_HIP(hipMalloc(&q->split_legs, 3 * lb * nsplits));
-        q->split_cap = nsplits;
+    const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), lbk = (size_t)pk * p->ny * es;
+    const int npairs = nsplits * nsplits;
+    // evenly spaced output planes (one (n, n, Ny, kp) block): the divergence of all pairs runs as ONE launch
+    bool dbatch = npairs >= 2 && !getenv("OA_MV_NO_BATCH");
+    long out_moff = 0;
+    if (dbatch) {
+        const long d = (long)((char*)host_out[1] - (char*)host_out[0]);
+        dbatch = d > 0 && d % (long)es == 0;
+        for (int k = 2; k < npairs && dbatch; ++k) dbatch = host_out[k] && ((char*)host_out[k] - (char*)host_out[0]) == k * d;
+        out_moff = d / (long)es;
     }
+    // pool: 3 leg planes per split | 2 product planes per pair | 2 pass-1 planes per pair (two-pass divergence)
+    if (int rc = ensure_pool(q, 3 * lb * nsplits + (dbatch ? 4 * (size_t)npairs * lbk : 0))) return rc;
+    char* const prod = (char*)q->split_legs + 3 * lb * nsplits;
     const int my = q->my;
     auto leg = [&](int i, int c) { return (void*)((char*)q->split_legs + (3 * (size_t)i + c) * lb); };
     for (int i = 0; i < nsplits; ++i) {
@@ -365,13 +402,19 @@ int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
     for (int i = 0; i < nsplits; ++i)
         for (int j = 0; j < nsplits; ++j) {
-            void* out = host_out[i * nsplits + j];
+            const int k = i * nsplits + j;
+            void* out = host_out[k];
             OA_REQUIRE(out, "oa_qe_tt_splits: NULL output plane");
             int rc;
             if (zero_outside && (rc = zero_complement(p, out, q->wk, q->rk, st))) return rc;
-            if ((rc = qe_rows_w(p, leg(i, 0), leg(i, 1), leg(j, 2), q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my))) return rc;
-            if ((rc = qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st, my))) return rc;
+            void* g0 = dbatch ? (void*)(prod + 2 * (size_t)k * lbk) : q->g[0];
+            void* g1 = dbatch ? (void*)(prod + (2 * (size_t)k + 1) * lbk) : q->g[1];
+            if ((rc = qe_rows_w(p, leg(i, 0), leg(i, 1), leg(j, 2), g0, g1, s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my))) return rc;
+            if (!dbatch && (rc = qe_cols_div_w(p, g0, g1, q->Fn, out, 0, q->wk, q->rk, pk, st, my))) return rc;
         }
+    if (dbatch)
+        return qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, host_out[0], prod + 2 * (size_t)npairs * lbk, npairs, (long)(2 * lbk / es), 0,
+                                   out_moff, q->wk, q->rk, pk, st, my);
     return 0;
 }
 

@@ -753,9 +753,11 @@ class Estimator(object):
             w = self.mv_weights(estimators)
             L = self.modl_h
             planes = {}
-            for XY in estimators:
+            stack = e.hcreal(len(estimators))          # ONE allocation: evenly spaced planes let oa_qe_mv run every estimator's
+            for i, XY in enumerate(estimators):        # divergence in one launch
                 AL = self.AL[XY]
-                planes[XY] = self._hcreal(e, -(L * (L + 1.) / 2.) * AL * self.mask_K * w[XY])
+                stack[i].copy_(self._hcreal(e, -(L * (L + 1.) / 2.) * AL * self.mask_K * w[XY]))
+                planes[XY] = stack[i]
             self._mv = (key, planes)
         f = {"T": kT, "E": kE, "B": kB}
         if not e.pow2 or not fused:

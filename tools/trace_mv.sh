@@ -15,9 +15,13 @@ for f in glob.glob(O + '/p_mv/**/*kernel_trace.csv', recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 # one MV reconstruction ends with its 5th divergence launch; take the last complete run of kernels between zero fills
-div = [i for i, r in enumerate(rows) if 'col_div' in r['Kernel_Name']]
-last = div[-1]
-start = div[-6] + 1
+# one MV reconstruction ends with the sum of the estimators' planes (oa_qe_mv) -- or, per estimator, with its divergence
+end = [i for i, r in enumerate(rows) if 'sum_region' in r['Kernel_Name']]
+if len(end) >= 2:
+    last, start = end[-1], end[-2] + 1
+else:
+    div = [i for i, r in enumerate(rows) if 'col_div' in r['Kernel_Name']]
+    last, start = div[-1], div[-6] + 1
 seg = rows[start:last + 1]
 out = []
 prev_end = int(rows[start - 1]['End_Timestamp'])
