@@ -208,6 +208,18 @@ struct CoarseHolder {
     }
 };
 
+template <typename T>
+static int do_cols_div_batch(int ny_full, int my, int nx, const void* prod, const T* Fn, const T* lxd, const T* lyd, void* out, int nmaps,
+                             int width, int rband) {
+    CoarseHolder<T> hd(ny_full, my, nx);
+    const long plane = (long)my * hd.p.kp;
+    std::vector<cx<T>> tmp((size_t)plane * 2 * nmaps);
+    EmuLauncher q;
+    hd.p.cols_div(q, (const cx<T>*)prod, (const cx<T>*)prod + plane, Fn, lxd, lyd, (cx<T>*)out, tmp.data(), tmp.data() + plane, 0, width, rband, 0,
+                  nmaps, 2 * plane, 2 * plane, (long)ny_full * hd.p.kp, (long)ny_full * hd.p.kp);
+    return 0;
+}
+
 extern "C" {
 // one-wave-per-row R2C pass (fft_r2c_w64.hpp): nx must be 8192; out has pitch nx/2+16
 int emu_r2c_rows_w64_f32(int ny, int nx, const float* in, void* out, double scale, int width, int nwg) {
@@ -270,6 +282,27 @@ int emu_cols_div_cg_f32(int ny_full, int my, int nx, const void* pa, const void*
     EmuLauncher q;
     hd.p.cols_div(q, (const cx<float>*)pa, (const cx<float>*)pb, Fn, lxd, lyd, (cx<float>*)out, tA.data(), tB.data(), 0, width, rband);
     return 0;
+}
+// oa_qe_mv's batched launches: ngrad gradient fields + nh H fields of up to three sources in ONE inverse pass-1 launch and
+// one pass-2 launch over the pool; the divergence of nmaps estimators in one launch
+int emu_legs_batch_cg_f64(int ny_full, int my, int nx, const void* src0, long off1, long off2, unsigned long long srcsel,
+                          const double* const* ftab, int ngrad, int nh, const double* lxd, const double* lyd, void* pool, long ostride,
+                          int width, int rband) {
+    CoarseHolder<double> hd(ny_full, my, nx);
+    EmuLauncher q;
+    hd.p.legs_cols_batch(q, (const cx<double>*)src0, off1, off2, srcsel, ftab, ngrad, nh, lxd, lyd, (cx<double>*)pool, ostride, width, rband,
+                         0, 0);
+    hd.p.cols(q, (const cx<double>*)pool, hd.p.kp, (cx<double>*)pool, hd.p.kp, hd.p.clampw(width), true, 1.0, 2, 1, nullptr, nullptr, 0, false,
+              -1, 2 * ngrad + nh, ostride, ostride);
+    return 0;
+}
+int emu_cols_div_batch_cg_f64(int ny_full, int my, int nx, const void* prod, const double* Fn, const double* lxd, const double* lyd, void* out,
+                              int nmaps, int width, int rband) {
+    return do_cols_div_batch<double>(ny_full, my, nx, prod, Fn, lxd, lyd, out, nmaps, width, rband);
+}
+int emu_cols_div_batch_cg_f32(int ny_full, int my, int nx, const void* prod, const float* Fn, const float* lxd, const float* lyd, void* out,
+                              int nmaps, int width, int rband) {
+    return do_cols_div_batch<float>(ny_full, my, nx, prod, Fn, lxd, lyd, out, nmaps, width, rband);
 }
 int emu_map_legs_cols_f64(int ny, int nx, const double* map, const double* FG, const double* FH, const double* lxd,
                           const double* lyd, void* gx, void* gy, void* h, int width, int rband) {

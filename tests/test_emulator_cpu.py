@@ -301,6 +301,62 @@ def test_column_grid_views(emu, ny_full, my, w, rb):
         assert np.all(out[:, wv:W] == 3.0)
 
 
+@pytest.mark.parametrize("ny_full,my,w,rb", [(256, 64, 21, 9), (256, 128, 0, 33)])
+def test_batched_leg_and_divergence_launches(emu, ny_full, my, w, rb):
+    """oa_qe_mv's launches (include/orphics_amd.h): every distinct filtered field of several estimators in ONE col_legs launch
+    (grid z = leg plane, source by a 2-bit field, filter planes through a pointer table) + one pass-2 launch over the pool;
+    the divergence of several estimators in one launch (grid z, per-estimator Fn / product / output offsets).  Same results
+    as the one-field / one-estimator launches."""
+    nx = 64
+    rng = np.random.default_rng(ny_full + my)
+    W = nx // 2 + 1
+    wv = w if w else W
+    kp = emu.emu_kpitch(nx)
+    ly = 2 * np.pi * np.fft.fftfreq(ny_full) * 100
+    lx = 2 * np.pi * np.fft.fftfreq(nx) * 100
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[ny_full // 2] = 0
+    lxd[nx // 2] = 0
+    band = np.r_[0:rb, ny_full - rb + 1:ny_full]
+    src = np.full((3, ny_full, kp), 1e30 + 0j)                       # three sources (T, E, B) in one block
+    src[:, band, :wv] = rng.standard_normal((3, band.size, wv)) + 1j * rng.standard_normal((3, band.size, wv))
+    ngrad, nh = 3, 2
+    filt = np.zeros((ngrad + nh, ny_full, kp))
+    filt[:, band, :wv] = rng.uniform(0.5, 1.5, (ngrad + nh, band.size, wv))
+    which = [0, 2, 1, 1, 0]                                          # source of each field (gradient fields first)
+    srcsel = sum(k << (2 * f) for f, k in enumerate(which))
+    ftab = (ctypes.c_void_p * (ngrad + nh))(*[filt[f].ctypes.data for f in range(ngrad + nh)])
+    nplanes = 2 * ngrad + nh
+    pool = np.full((nplanes, my, kp), 3.0 + 0j)
+    plane = ny_full * kp
+    assert emu.emu_legs_batch_cg_f64(ny_full, my, nx, _p(src), ctypes.c_long(plane), ctypes.c_long(2 * plane), ctypes.c_ulonglong(srcsel),
+                                     ftab, ngrad, nh, _p(lxd), _p(lyd), _p(pool), ctypes.c_long(my * kp), w, rb) == 0
+    for f in range(ngrad + nh):
+        ref = [_hc(emu, my, nx, fill=3.0) for _ in range(3)]
+        k = np.ascontiguousarray(src[which[f]]); F = np.ascontiguousarray(filt[f])
+        assert emu.emu_legs_cols_cg_f64(ny_full, my, nx, _p(k), _p(k), _p(F), _p(F), _p(lxd), _p(lyd), _p(ref[0]), _p(ref[1]), _p(ref[2]), w, rb) == 0
+        if f < ngrad:
+            assert np.array_equal(pool[2 * f], ref[0]) and np.array_equal(pool[2 * f + 1], ref[1])
+        else:
+            assert np.array_equal(pool[ngrad + f], ref[2])
+    # divergence of three estimators in one launch
+    ne = 3
+    for dt, cdt, fn in ((np.float64, np.complex128, emu.emu_cols_div_batch_cg_f64), (np.float32, np.complex64, emu.emu_cols_div_batch_cg_f32)):
+        prod = np.zeros((ne, 2, my, kp), dtype=cdt)
+        prod[..., :W] = rng.standard_normal((ne, 2, my, W)) + 1j * rng.standard_normal((ne, 2, my, W))
+        Fn = np.zeros((ne, ny_full, kp), dtype=dt)
+        Fn[:, band, :wv] = rng.uniform(0.5, 1.5, (ne, band.size, wv))
+        out = np.full((ne, ny_full, kp), 3.0 + 0j, dtype=cdt)
+        lxd_t, lyd_t = lxd.astype(dt), lyd.astype(dt)
+        assert fn(ny_full, my, nx, _p(prod), _p(Fn), _p(lxd_t), _p(lyd_t), _p(out), ne, w, rb) == 0
+        one = emu.emu_cols_div_cg_f64 if dt == np.float64 else emu.emu_cols_div_cg_f32
+        for e_ in range(ne):
+            ref = np.full((ny_full, kp), 3.0 + 0j, dtype=cdt)
+            A = np.ascontiguousarray(prod[e_, 0]); B = np.ascontiguousarray(prod[e_, 1]); F = np.ascontiguousarray(Fn[e_])
+            assert one(ny_full, my, nx, _p(A), _p(B), _p(F), _p(lxd_t), _p(lyd_t), _p(ref), w, rb) == 0
+            assert np.array_equal(out[e_], ref)
+
+
 def test_one_wave_per_row_r2c(emu):
     """row_r2c_w64_body (fft_r2c_w64.hpp): 8192-point real rows, one 64-lane wave per row, two radix-64 stages around
     one LDS transpose, pruned second stage -> the first `width` columns of numpy.fft.rfft."""
