@@ -598,6 +598,12 @@ def main():
                         "frac": d["hbm_frac"], "traffic": traffic, "bytes_per_launch": d["hbm_min_GB"] * 1e9,
                         "note": "achieved = bytes the kernel must move once (inputs + outputs on its active columns/rows) / live HIP-event duration"}
         assert roofline["frac"] <= 1.0, "roofline fraction %g > 1: byte/flop model is wrong" % roofline["frac"]
+        if dom.startswith("row_fft_kernel<R2C>"):
+            # the stage name above is bench.py's; the launch behind it, as rocprofv3 lists it (fft.hip HipLauncher::row_w64)
+            wl_ = G["wl"] or W
+            w64 = os.environ.get("OA_R2C_W64", "1") != "0" and args.prec == "f32"
+            roofline["kernel_symbol"] = ("row_r2c_w64_kernel" if (w64 and N == 8192 and wl_ <= 512) else
+                                         "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel")
         roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
         roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
                                 "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}

@@ -179,7 +179,10 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
  * weight x normalisation of estimator e), pieces flattened in estimator order (host_npieces[e] each; host_kX/kY/Fnorm per
  * estimator).  Every distinct filtered field -- identified by its (source plane, filter plane) POINTERS -- is transformed
  * once, all in one inverse pass-2 launch: 17 leg planes instead of 30 for TT+TE+EE+EB+TB when the caller shares its filter
- * plane objects.  Same arithmetic per piece as oa_qe_pol, same results. */
+ * plane objects.  Same arithmetic per piece as oa_qe_pol, same results.  When the Fnorm planes are evenly spaced in memory
+ * (one stacked allocation) the divergence of all estimators is one launch, each into a plan-owned plane, and one pass sums
+ * them in estimator order.  oa_qe_mv and oa_qe_tt_splits keep their leg / product planes in a plan-owned pool that is
+ * allocated on first use and grown on demand: THAT call synchronises the device once; later calls are stream-ordered. */
 int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_signs, const void* const* host_FG,
              const void* const* host_FH, const int* host_swap, const void* const* host_kX, const void* const* host_kY,
              const void* const* host_Fnorm, void* out, int accumulate, int leg_cols, int kappa_cols, int leg_rows, int kappa_rows,

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Golden vectors for the PURE-NumPy host helpers of the reference's maps.py (run in the build container only).
 
-`import orphics.maps` fails here (pixell is absent), but `gauss_beam`, `cosine_window` and the body of
-`FourierCalc.f2power` do not touch pixell: their function definitions are taken out of /root/reference/orphics/maps.py
+`import orphics.maps` fails here (pixell is absent), but `gauss_beam`, `cosine_window`, `kspace_coadd`, the body of
+`FourierCalc.f2power`, the multi-component branch of `FourierCalc.power2d` and `lensing.fkappa_to_fphi` do not touch pixell: their function definitions are taken out of /root/reference/orphics/maps.py
 with `ast` and executed as they stand (no stand-in for any missing module is written), on seeded inputs; inputs + outputs are stored in
 maps_host_reference.npz next to this script.  The fixture is data; no reference source travels.
 
@@ -62,6 +62,19 @@ def main():
     fake_self = types.SimpleNamespace(normfact=0.37)
     out["f2_out"] = f2power(fake_self, k1, k2)
     out["f2_out_pixel_units"] = f2power(fake_self, k1, k2, pixel_units=True)
+    # FourierCalc.power2d (maps.py:1639-1677) with both transforms supplied (kmap, kmap2): the (ncomp, ncomp, Ny, Nx) assembly
+    # -- autos on the diagonal, upper-triangle crosses mirrored, skip_cross, pixel_units -- touches no pixell function
+    class WithWcs(np.ndarray):
+        wcs = None
+    power2d = reference_method("FourierCalc", "power2d")
+    fake_self.f2power = types.MethodType(f2power, fake_self)
+    ka = (rng.standard_normal((3, 32, 36)) + 1j * rng.standard_normal((3, 32, 36)))
+    kb = (rng.standard_normal((3, 32, 36)) + 1j * rng.standard_normal((3, 32, 36)))
+    out["p2d_k1"], out["p2d_k2"] = ka, kb
+    out["p2d_cross"] = power2d(fake_self, kmap=ka.copy().view(WithWcs), kmap2=kb.copy().view(WithWcs))[0]
+    out["p2d_auto"] = power2d(fake_self, kmap=ka.copy().view(WithWcs))[0]
+    out["p2d_skip_cross_pixel_units"] = power2d(fake_self, kmap=ka.copy().view(WithWcs), kmap2=kb.copy().view(WithWcs), skip_cross=True,
+                                                pixel_units=True)[0]
     # kspace_coadd (maps.py:1098-1114), with zero-noise and zero-beam modes to exercise the non-finite handling
     km = rng.standard_normal((3, 32, 36)) + 1j * rng.standard_normal((3, 32, 36))
     kb = rng.uniform(0.2, 1.0, (3, 32, 36))

@@ -350,6 +350,14 @@ def test_coadd_and_kappa_to_phi_match_the_reference_functions():
     want = gd["coadd_out"]
     assert np.array_equal(got == 0, want == 0)            # the non-finite -> 0 modes are the same modes
     assert rel(got, want) < 1e-13
+    # FourierCalc.power2d's (ncomp, ncomp, Ny, Nx) assembly from supplied transforms (maps.py:1661-1670)
+    ka, kb = gd["p2d_k1"], gd["p2d_k2"]
+    fc = maps.FourierCalc(ka.shape, geom(ka.shape[-2:]))
+    fc.normfact = float(gd["f2_norm"])
+    for kw, key in ((dict(kmap2=kb), "p2d_cross"), (dict(), "p2d_auto"), (dict(kmap2=kb, skip_cross=True, pixel_units=True), "p2d_skip_cross_pixel_units")):
+        got = np.asarray(fc.power2d(kmap=ka, **kw)[0])
+        assert got.shape == gd[key].shape and rel(got, gd[key]) < 1e-13
+        assert np.array_equal(got == 0, gd[key] == 0)      # skip_cross leaves the off-diagonal blocks zero
     # kappa -> phi on a real map: the reference function applied to the oracle's DFT of kappa, inverted on the host
     shape = (64, 128)
     g = geom(shape)

@@ -313,6 +313,11 @@ def test_maps_host_helpers_match_the_reference_functions():
     fc.normfact = norm
     assert np.array_equal(fc.f2power(k1, k2), g["f2_out"])
     assert np.array_equal(fc.f2power(k1, k2, pixel_units=True), g["f2_out_pixel_units"])
+    # power2d's multi-component assembly (maps.py:1661-1670): autos, mirrored upper-triangle crosses, skip_cross, pixel_units
+    ka, kb = g["p2d_k1"], g["p2d_k2"]
+    assert np.array_equal(fc.power2d(kmap=ka, kmap2=kb)[0], g["p2d_cross"])
+    assert np.array_equal(fc.power2d(kmap=ka)[0], g["p2d_auto"])
+    assert np.array_equal(fc.power2d(kmap=ka, kmap2=kb, skip_cross=True, pixel_units=True)[0], g["p2d_skip_cross_pixel_units"])
     # kspace_coadd (maps.py:1098-1114) with zero-noise / zero-beam modes, and lensing.fkappa_to_fphi (lensing.py:662-665)
     from oracle import qe_oracle as qo
     assert np.array_equal(mo.kspace_coadd(g["coadd_kmaps"], g["coadd_kbeams"], g["coadd_kncovs"], fkbeam=0.8), g["coadd_out"])

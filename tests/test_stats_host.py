@@ -124,3 +124,26 @@ def test_lensforecast_knoxcov_formula():
     sn, errs = LF.sn(edges, 0.4, "kk")
     assert abs(sn - np.sqrt(s1.sum())) < 1e-12 and np.allclose(errs, np.sqrt(var))
     assert np.allclose(cosmology.knox_cov(3.0, 50), 2 * 9. / 50)
+
+
+def test_lensforecast_matches_the_reference_methods():
+    """LensForecast.KnoxCov / sn / sigmaClSquared vs outputs of the REFERENCE's own method definitions
+    (cosmology.py:976-1094, executed by tests/golden/make_golden_forecast.py): autos, crosses, mixed pairs, ntot."""
+    import os
+    from orphics_amd import cosmology
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "forecast_reference.npz"))
+    ells = g["ells"]
+    LF = cosmology.LensForecast()
+    LF.loadKK(ells, g["kk"], ells, g["n_kk"])
+    LF.loadGenericCls("gg", ells, g["gg"], ells, g["n_gg"])
+    LF.loadGenericCls("kg", ells, g["kg"])
+    edges, fsky = g["edges"], float(g["fsky"])
+    for xy, wz in (("kk", "kk"), ("kg", "kg"), ("kk", "kg"), ("gg", "kk")):
+        for ntot in (False, True):
+            tag = "%s_%s_%d" % (xy, wz, int(ntot))
+            cov, s1, s2 = LF.KnoxCov(xy, wz, edges, fsky, ntot=ntot)
+            for got, key in ((cov, "cov_"), (s1, "s1_"), (s2, "s2_")):
+                assert np.allclose(got, g[key + tag], rtol=1e-13, atol=0), (tag, key)
+    sn, errs = LF.sn(edges, fsky, "kg")
+    assert abs(sn / float(g["sn_kg"]) - 1) < 1e-13 and np.allclose(errs, g["errs_kg"], rtol=1e-13, atol=0)
+    assert np.allclose(LF.sigmaClSquared("kk", edges, fsky), g["sigma2_kk"], rtol=1e-13, atol=0)

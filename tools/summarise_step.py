@@ -108,7 +108,7 @@ def bench_keys(table):
     r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_w64x2_kernel")
     c0 = first("col_fft_kernel")
     q = first("row_qe_pair_kernel", "row_qe_kernel")
-    d = first("col_div_kernel")
+    d = first("col_div_kernel", "col_div_sp_kernel")
     if r0 is not None:
         keys["row_fft_kernel<R2C>"] = [r0]
     if c0 is not None:
