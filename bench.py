@@ -2,7 +2,11 @@
 """Benchmark of the hot path: full TT quadratic-estimator kappa reconstructions
 per second on N^2 0.5' maps (BASELINE.json metric; default N = 8192).
 
-One "step" = one reconstruction from a real-space map resident in HBM:
+One "step" = one pass of the hot path over one BATCH of --batch (default 64) independent real-space maps resident in HBM
+(the shard of realisations a GPU is handed in the Monte-Carlo job); value = reconstructions/s =
+K x batch x ranks / elapsed.  (The driver times K = 20 steps: 20 single reconstructions would be a 2.6 ms timed region,
+a fifth of which is the clock / pipeline ramp after the synchronising barrier -- 7.6 k/s measured against 9.1 k/s
+sustained.)  Each reconstruction of the batch:
   row R2C -> forward column pass 1 -> [forward column pass 2 + leg filters + inverse column pass 1] -> inverse
   column pass 2 (3 planes, one launch) -> [fused row stage: 3 C2R, 2 products, 2 R2C in LDS] -> forward column
   pass 1 (2 planes, one launch) -> [forward column pass 2 + divergence * A_L] -> [|kappa_hat|^2 + radial
@@ -17,7 +21,7 @@ With N > 1 and no torchrun environment the script starts N ranks itself (a child
 under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE and checks them against --gpus.
 
 Prints one JSON line (rank 0):
-  value / ms_per_step : whole-job reconstructions/s over the K timed steps (max over ranks)
+  value / ms_per_step : whole-job reconstructions/s over the K timed steps = K batches (max over ranks); ms per batch
   roofline            : the dominant kernel against the roof that binds it -- "valu" (f32 vector peak, on the
                         arithmetic it executes) for the fused row stage, "hbm" (on the bytes it moves) otherwise;
                         `frac` <= 1 by construction.  `hbm` holds the memory side: the dense pipeline against
@@ -179,7 +183,7 @@ class Runner(object):
         """map -> kappa_hat -> 19 bandpowers -> moments: ONE C-ABI call (oa_qe_tt_moments) on this step's stream"""
         j = i % self.ns
         with self.torch.cuda.stream(self.streams[j]):
-            self.qs[j].tt_moments(self.tmaps[i & 1], self.mom_n[j], self.mom_S[j], self.mom_C[j])
+            self.qs[j].tt_moments(self.tmaps[i % len(self.tmaps)], self.mom_n[j], self.mom_S[j], self.mom_C[j])
 
     def run(self, first, count):
         """`count` reconstructions starting at step index `first`: in pair mode two steps (maps 0 and 1) per call."""
@@ -187,10 +191,12 @@ class Runner(object):
             for i in range(first, first + count):
                 self.step(i)
             return
+        M = len(self.tmaps)
         for c in range(count // 2):
-            j = (first // 2 + c) % self.ns
+            k = first // 2 + c
+            j = k % self.ns
             with self.torch.cuda.stream(self.streams[j]):
-                self.qs[j].tt_moments2(self.tmaps[0], self.tmaps[1], self.mom_n[j], self.mom_S[j], self.mom_C[j])
+                self.qs[j].tt_moments2(self.tmaps[(2 * k) % M], self.tmaps[(2 * k + 1) % M], self.mom_n[j], self.mom_S[j], self.mom_C[j])
         if count & 1:
             self.step(first + count - 1)
 
@@ -216,13 +222,18 @@ class Runner(object):
         return nsteps / (time.perf_counter() - t0)
 
 
+def side_count(args):
+    """reconstructions per side measurement: the headline's K x B, bounded (the dense leg runs at 1.7 ms each)"""
+    return int(min(max(args.steps * max(1, args.batch), 40), 400))
+
+
 def side_leg(torch, args, name, ref_p1d, seed, **kw):
     """One side measurement: its own estimator + runner on the same synthetic job; bandpowers compared with `ref_p1d`
     (same maps: the GRF draw depends only on (seed, index))."""
     P = build_pipeline(args.n, args.res, kw.pop("prec", args.prec), torch, **kw)
     tm = make_maps(P, torch, seed)
     R = Runner(P, torch, tm, args.streams)
-    rate = R.rate(args.steps)
+    rate = R.rate(side_count(args))
     p1d = R.bandpowers(0)
     out = {"reconstructions_per_s": rate, "streams_per_gpu": R.ns}
     if ref_p1d is not None:
@@ -250,10 +261,11 @@ def bandlimited_leg(P, args, torch, tmaps, ref_p1d):
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    nrec = side_count(args)
+    for i in range(nrec):
         step(i)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / nrec
     step(0)
     torch.cuda.synchronize()
     p1d = res["sums"][1:-1] / counts[1:-1]
@@ -468,8 +480,10 @@ def cpu_baseline(N_gpu, res_arcmin, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; ONE STEP = one batch of --batch independent maps through the whole path")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps (batches) before the timed region")
+    ap.add_argument("--batch", type=int, default=64, help="maps per step: a shard of independent realisations resident in HBM, each one "
+                    "map -> kappa_hat -> bandpowers -> moments (SURVEY 8e: the unit a GPU is handed in the Monte-Carlo job)")
     ap.add_argument("--n", type=int, default=8192, help="map side (default 8192, the metric's size)")
     ap.add_argument("--res", type=float, default=0.5)
     ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
@@ -514,7 +528,11 @@ def main():
     P = build_pipeline(N, args.res, args.prec, torch, prune=not args.no_prune, tlmax=args.tlmax, row_grid=args.row_grid)
     q, eng = P["q"], P["eng"]
     seed = 1234 + rank                                    # distinct realisations per rank
-    tmaps = make_maps(P, torch, seed)
+    B = max(1, args.batch)
+    # the batch is resident in HBM before the timed region: B distinct maps (fewer, cycled, if B of them would not leave
+    # room: 16384^2 maps are 1.07 GB each)
+    nmaps = max(2, min(B, int(32e9 // (4.0 * N * N))))
+    tmaps = make_maps(P, torch, seed, nmaps)
     R = Runner(P, torch, tmaps, args.streams, pair=not args.no_pair)
     ns = R.ns
 
@@ -524,7 +542,7 @@ def main():
     while time.perf_counter() - t_pre < args.preroll:
         R.run(0, 8)
         torch.cuda.synchronize()
-    R.run(0, args.warmup)
+    R.run(0, args.warmup * B)
     torch.cuda.synchronize()
     # rehearse the end-of-job reduction once (first use of a torch op / of the RCCL communicator loads code
     # objects and opens connections: tens of ms that belong to start-up, not to the K timed steps)
@@ -540,13 +558,13 @@ def main():
     t0 = time.perf_counter()
     evs = []
     if args.trace_steps:
-        for i in range(args.steps):
+        for i in range(args.steps * B):
             R.step(i)
             ev = torch.cuda.Event(enable_timing=True)
             ev.record(R.streams[i % ns])
             evs.append(ev)
     else:
-        R.run(0, args.steps)          # exactly K reconstructions (pair mode: K // 2 two-map calls + one single if K is odd)
+        R.run(0, args.steps * B)      # exactly K batches of B reconstructions (pair mode: two maps per C-ABI call)
     t_issue = time.perf_counter() - t0          # host time to enqueue the K steps (diagnostic: must stay < elapsed)
     torch.cuda.synchronize()
     if args.trace_steps and rank == 0:
@@ -569,7 +587,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total = int(mom_n.item())
-    assert total == args.steps * max(world, 1), "moment counter %d != steps x ranks" % total
+    assert total == args.steps * B * max(world, 1), "moment counter %d != steps x batch x ranks" % total
 
     if rank == 0:
         per, G = per_kernel_table(torch, P, R, args)
@@ -632,6 +650,7 @@ def main():
                                    "incl. R2C of the input map and 19-bin kappa auto-bandpowers; T filter ell in (300,%d), "
                                    "kappa mask (20,3500), 1.5' beam, 1 uK' noise" % (N, N, args.res, int(args.tlmax)),
                        "map_side": N, "res_arcmin": args.res, "estimator": "TT", "nbins": R.d,
+                       "maps_per_step": B, "distinct_resident_maps": len(tmaps),
                        "streams_per_gpu": ns, "realisations_per_call": 2 if R.pair else 1,
                        "parallelism": "independent realisations per GPU + 1 all-reduce of bandpower moments"},
             "roofline": roofline,

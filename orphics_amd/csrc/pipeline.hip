@@ -367,7 +367,9 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     if (dbatch) {
         if (int rc = qe_cols_div_batch_w(p, prod, prod + lbk, host_Fnorm[0], q->c[0], tmp, nest, (long)(2 * lbk / es), fn_moff, (long)(pb / es),
                                          kappa_cols, kappa_rows, pk, st, my)) return rc;
-        return sum_region(p->dtype, q->c[0], (long)(pb / es), nest, out, accumulate ? 1 : 0, p->ny, p->kp, kappa_cols, kappa_rows, st);
+        // (the divergence writes columns <= nx/2 only: the planes' row padding beyond holds whatever the work planes held)
+        const int wsum = (kappa_cols > 0 && kappa_cols <= p->nx / 2 + 1) ? kappa_cols : p->nx / 2 + 1;
+        return sum_region(p->dtype, q->c[0], (long)(pb / es), nest, out, accumulate ? 1 : 0, p->ny, p->kp, wsum, kappa_rows, st);
     }
     return 0;
 }
