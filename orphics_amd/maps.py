@@ -696,32 +696,30 @@ def _hp_like(t, like):
 
 
 def split_calc(isplits, jsplits, icoadd, jcoadd, fourier_calc=None, alt=True, wcs=None):
-    """maps.py:2296-2333: (total, crosses, noise) power from Fourier transforms of splits.
-    ``isplits``/``jsplits``: (nsplits,Ny,Nx) complex arrays or lists of HalfPlane."""
-    i_list = [isplits[i] for i in range(len(isplits))]
-    j_list = [jsplits[i] for i in range(len(jsplits))]
-    fc = fourier_calc if fourier_calc is not None else FourierCalc(tuple(np.shape(icoadd))[-2:] if not isinstance(icoadd, HalfPlane) else icoadd.shape[-2:], wcs)
+    """maps.py:2296-2333: (total, mean cross-split, noise) 2-D power from the Fourier transforms of n splits of two maps
+    and their coadds.  ``isplits`` / ``jsplits``: (nsplits, Ny, Nx) complex arrays or lists of HalfPlane.
+
+    ``alt``: noise = sum_i P(i_i - icoadd, j_i - jcoadd) / ((1 - 1/n) n^2), crosses = total - noise.
+    otherwise: crosses = mean over i != j of P(i_i, j_j), noise = total - crosses.  P is bilinear, so the sum over ALL
+    ordered pairs is the power of the summed splits: sum_{i != j} P(i_i, j_j) = P(sum_i i_i, sum_j j_j) - sum_i P(i_i, j_i)
+    -- n + 1 power evaluations instead of the reference's n (n - 1)."""
+    first = icoadd if not isinstance(icoadd, HalfPlane) else None
+    fc = fourier_calc if fourier_calc is not None else FourierCalc(tuple(np.shape(first))[-2:] if first is not None else icoadd.shape[-2:], wcs)
+    I = [isplits[k] for k in range(len(isplits))]
+    J = [jsplits[k] for k in range(len(jsplits))]
+    ni, nj = len(I), len(J)
     total = fc.f2power(icoadd, jcoadd)
-    insplits, jnsplits = len(i_list), len(j_list)
+    power = lambda a, b: _hp_val(fc.f2power(_hp_like(a, icoadd), _hp_like(b, jcoadd)))      # noqa: E731
     if alt:
-        assert insplits == jnsplits
-        noise = 0.
-        for i in range(insplits):
-            diff1 = _hp_like(_hp_val(i_list[i]) - _hp_val(icoadd), icoadd)
-            diff2 = _hp_like(_hp_val(j_list[i]) - _hp_val(jcoadd), jcoadd)
-            noise = noise + _hp_val(fc.f2power(diff1, diff2))
-        noise = noise / ((1. - 1. / insplits) * insplits ** 2)
+        assert ni == nj
+        spread = sum(power(_hp_val(a) - _hp_val(icoadd), _hp_val(b) - _hp_val(jcoadd)) for a, b in zip(I, J))
+        noise = spread / ((1. - 1. / ni) * ni ** 2)
         crosses = _hp_val(total) - noise
     else:
-        ncrosses = 0.
-        totcross = 0.
-        for i in range(insplits):
-            for j in range(jnsplits):
-                if i == j:
-                    continue
-                totcross = totcross + _hp_val(fc.f2power(i_list[i], j_list[j]))
-                ncrosses += 1.
-        crosses = totcross / ncrosses
+        same = min(ni, nj)
+        all_pairs = power(sum(_hp_val(a) for a in I), sum(_hp_val(b) for b in J))
+        diagonal = sum(power(_hp_val(I[k]), _hp_val(J[k])) for k in range(same))
+        crosses = (all_pairs - diagonal) / float(ni * nj - same)
         noise = _hp_val(total) - crosses
     return total, _hp_like(crosses, total), _hp_like(noise, total)
 
