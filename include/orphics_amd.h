@@ -204,6 +204,12 @@ int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, 
 int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void* const* host_out, int zero_outside, void* stream);
 int oa_split_cross_power(int dtype, int nsplits, const void* const* host_kappa, void* out_hcreal, double norm, int ny, long kpitch,
                          int active_cols, int active_rows, void* stream);
+/* oa_mc_run: realisations sim_lo .. sim_hi-1 (Philox stream = realisation index): GRF draw -> TT estimator -> bandpowers ->
+ * moments [-> mean-field stack], no host work per realisation.  Up to 6 realisations (environment OA_MC_BATCH, 1 = one by
+ * one) share every launch in front of the binning (grid z: draw, leg planes, inverse pass 2, row stage, divergence): at
+ * 4096^2 a realisation is launch latency, not bytes.  Same kernels on the same operands in the same order per realisation:
+ * the moments and the stack do not depend on the batch size.  The first call allocates the batch's planes (one device
+ * synchronisation). */
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S,
               double* C, double* meanfield_acc, void* stream);
 /* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py roofline; the

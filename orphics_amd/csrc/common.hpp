@@ -102,7 +102,12 @@ int sum_region(int dtype, const void* parts, long part_stride, int nparts, void*
                hipStream_t st);
 // all leg planes of several estimators in one inverse pass-1 launch (ColLegsArgs::batch); offsets in complex elements
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
-                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my = 0);
+                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my = 0, int selbits = 2);
+// row stage of nmaps maps in one launch; -1: this geometry's row stage is not the two-rows-per-transform kernel
+int qe_rows_batch_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout, int mrow,
+                    long pl, long pk, hipStream_t st, int my, int nmaps, long in_moff, long h_moff, long out_moff);
+int grf_hc_band_batch(oa_plan* p, uint64_t seed, uint64_t stream_id, int nreal, const void* covsqrt_hc, void* hc_out, long zstride,
+                      int width, int rband, hipStream_t stream);
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my = 0);
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
               int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0);

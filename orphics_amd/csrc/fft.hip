@@ -462,10 +462,10 @@ static int legs_subset_impl(oa_plan* p, const void* src, const void* F, void* a,
 }
 template <typename T>
 static int legs_batch_impl(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
-                           int ngrad, int nh, void* pool, long ostride, int width, int rband, hipStream_t st, long pout, int my) {
+                           int ngrad, int nh, void* pool, long ostride, int width, int rband, hipStream_t st, long pout, int my, int selbits) {
     HipLauncher q{st};
     coarse_view<T>(p, my).legs_cols_batch(q, (const cx<T>*)src0, off1, off2, srcsel, (const T* const*)ftab, ngrad, nh, (const T*)p->lxd,
-                                          (const T*)p->lyd, (cx<T>*)pool, ostride, width, rband, 0, pout);
+                                          (const T*)p->lyd, (cx<T>*)pool, ostride, width, rband, 0, pout, selbits);
     return q.rc;
 }
 template <typename T>
@@ -488,9 +488,27 @@ int qe_cols_div_batch_w(oa_plan* p, const void* pa, const void* pb, const void* 
                               : cols_div_batch_impl<double>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my);
 }
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
-                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my) {
-    return p->dtype == OA_F32 ? legs_batch_impl<float>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my)
-                              : legs_batch_impl<double>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my);
+                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my, int selbits) {
+    return p->dtype == OA_F32 ? legs_batch_impl<float>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my, selbits)
+                              : legs_batch_impl<double>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my, selbits);
+}
+// the row stage of `nmaps` maps in one launch (two-rows-per-transform kernel only): -1 when this geometry runs another kernel
+template <typename T>
+static int qe_rows_batch_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout,
+                              int mrow, hipStream_t st, long pin, long pout, int my, int nmaps, long in_moff, long h_moff, long out_moff) {
+    HipLauncher q{st};
+    auto f = coarse_view<T>(p, my);
+    const int wi = f.clampw(win), wo = f.clampw(wout);
+    if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo); if (2L * wi + wo > mrow) mrow = 0; }
+    if (!f.rows_qe_is_pair(wi, wo, mrow)) return -1;
+    f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, 0, wi, wo, mrow, pin, pout, nmaps, in_moff,
+              out_moff, h_moff);
+    return q.rc;
+}
+int qe_rows_batch_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout, int mrow,
+                    long pl, long pk, hipStream_t st, int my, int nmaps, long in_moff, long h_moff, long out_moff) {
+    return p->dtype == OA_F32 ? qe_rows_batch_impl<float>(p, gx, gy, h, px, py, scale, win, wout, mrow, st, pl, pk, my, nmaps, in_moff, h_moff, out_moff)
+                              : qe_rows_batch_impl<double>(p, gx, gy, h, px, py, scale, win, wout, mrow, st, pl, pk, my, nmaps, in_moff, h_moff, out_moff);
 }
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my) {
     return p->dtype == OA_F32 ? legs_pass2_impl<float>(p, pool, nplanes, stride, width, st, pl, my)

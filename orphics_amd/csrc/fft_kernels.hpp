@@ -509,9 +509,10 @@ struct RowQeArgs {
     T scale;      // product scale: (1/Npix)^2 for two normalised inverse transforms
     int accumulate;  // != 0: add the (scaled) result to the existing contents of px, py
     int win, wout;   // leg columns >= win are zero (not read); only product columns < wout are written
-    // TWO MAPS PER LAUNCH (pair row stage only): workgroups >= npairs work on the second map, whose planes sit in_moff /
-    // out_moff elements behind the first one's.  npairs = 0: one map.
-    int npairs; long in_moff, out_moff;
+    // SEVERAL MAPS PER LAUNCH (pair row stage only): workgroups [m npairs, (m + 1) npairs) work on map m, whose gx / gy planes
+    // sit m in_moff, whose h plane m h_moff and whose product planes m out_moff elements behind the first map's.
+    // npairs = 0: one map.
+    int npairs; long in_moff, out_moff, h_moff;
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -741,15 +742,15 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     constexpr int M = 1 << logM;
     const int RS = a.rowStride;
     long wg = ctx.bid_x();
-    long imo = 0, omo = 0;
-    if (a.npairs && wg >= a.npairs) { wg -= a.npairs; imo = a.in_moff; omo = a.out_moff; }
+    long imo = 0, omo = 0, hmo = 0;
+    while (a.npairs && wg >= a.npairs) { wg -= a.npairs; imo += a.in_moff; omo += a.out_moff; hmo += a.h_moff; }
     const long r0 = wg * 2;
     constexpr int R0 = SEQ::get(0);
     cx<T> hreg[EPT], v[EPT];
     cx<T>* twl = work + RS;
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
-    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, a.h + imo + r0 * a.pitch, a.h + imo + (r0 + 1) * a.pitch, a.win);
+    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, a.h + hmo + r0 * a.pitch, a.h + hmo + (r0 + 1) * a.pitch, a.win);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * a.scale;
@@ -1029,6 +1030,8 @@ struct ColLegsArgs {
     // h + z * ostride.  (Offsets and bit fields, not by-value pointer tables: see ColArgs; the filter pointers sit in a small
     // DEVICE table, read with a uniform index.)
     int batch, ngrad;
+    int selbits;     // 2: source of field f = {0, src_off1, src_off2}[(srcsel >> 2f) & 3]; 4: source (srcsel >> 4f) & 15 of an evenly
+                     // spaced family, src_off1 apart (oa_mc_run: one realisation each)
     unsigned long long srcsel;
     long src_off1, src_off2, ostride;
     const T* const* ftab;
@@ -1065,8 +1068,11 @@ OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
         const int z = ctx.bid_z();
         const bool grad = z < 2 * a.ngrad;
         const int f = grad ? (z >> 1) : z - a.ngrad;
-        const unsigned sel = (unsigned)(a.srcsel >> (2 * f)) & 3u;
-        kXb += (long)(sel == 1u) * a.src_off1 + (long)(sel == 2u) * a.src_off2;
+        if (a.selbits == 4) kXb += (long)((unsigned)(a.srcsel >> (4 * f)) & 15u) * a.src_off1;
+        else {
+            const unsigned sel = (unsigned)(a.srcsel >> (2 * f)) & 3u;
+            kXb += (long)(sel == 1u) * a.src_off1 + (long)(sel == 2u) * a.src_off2;
+        }
         kYb = kXb;
         FGb = a.ftab[f] + forg;
         FHb = FGb;

@@ -101,7 +101,7 @@ struct Fft2dPlan {
     template <class Launcher>
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
                  int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0, long pin = 0,
-                 long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0) const {
+                 long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0, long h_moff = -1) const {
         RowQeArgs<T> a{};
         // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
         // transforms with no assumption beyond win / wout
@@ -115,8 +115,8 @@ struct Fft2dPlan {
             // alias-free row grid: two rows per complex transform of length M (row_qe_pair_body)
             const int M = 1 << logM;
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
-            if (nmaps > 1) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; }
-            q.row_qe_pair(ny / 2 * (nmaps > 1 ? 2 : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
+            if (nmaps > 1) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
+            q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
             return;
         }
         a.logL = logM - 1;
@@ -212,7 +212,7 @@ struct Fft2dPlan {
     //      stored at pool + z * ostride.  The caller runs the inverse pass 2 over the pool.
     template <class Launcher>
     void legs_cols_batch(Launcher& q, const cx<T>* src0, long off1, long off2, unsigned long long srcsel, const T* const* ftab, int ngrad, int nh, const T* lxd, const T* lyd, cx<T>* pool, long ostride, int wmax,
-                         int rband, long pin, long pout) const {
+                         int rband, long pin, long pout, int selbits = 2) const {
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
@@ -225,7 +225,7 @@ struct Fft2dPlan {
         a.width = width; a.logC = COLC; a.NT = (int)((N1 * C) / EPT); a.tw = tw_y; a.logTw = logNy;
         a.in_gs = 1; a.in_ns = N2; a.out_gs = N1; a.out_ks = 1; a.twiddle = 1;
         a.rband = clampr(rband); a.ny = ny; a.yshift = yshift(); a.xfull = 1;
-        a.split = 1; a.batch = 2 * ngrad + nh; a.ngrad = ngrad; a.srcsel = srcsel; a.src_off1 = off1; a.src_off2 = off2;
+        a.split = 1; a.batch = 2 * ngrad + nh; a.ngrad = ngrad; a.selbits = selbits; a.srcsel = srcsel; a.src_off1 = off1; a.src_off2 = off2;
         a.ostride = ostride;
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
     }

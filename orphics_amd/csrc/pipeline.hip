@@ -35,6 +35,8 @@ struct Pipeline {
     unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
     void* split_legs = nullptr;       // oa_qe_tt_splits / oa_qe_mv: pool of compact leg planes
     size_t split_bytes = 0;
+    void* mc_src = nullptr;           // oa_mc_run: hc planes of a batch of realisations
+    int mc_cap = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
 };
@@ -57,6 +59,7 @@ void pipeline_release(oa_plan* p) {
     if (q->ticket) (void)hipFree(q->ticket);
     if (q->split_legs) (void)hipFree(q->split_legs);
     if (q->mv_ftab) (void)hipFree(q->mv_ftab);
+    if (q->mc_src) (void)hipFree(q->mc_src);
     delete q;
     p->pipe = nullptr;
 }
@@ -474,7 +477,60 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_mc_run: call oa_plan_set_filters and oa_plan_set_bins first");
     OA_REQUIRE(covsqrt_hc && n && S && C && sim_hi >= sim_lo, "oa_mc_run: bad argument");
     Pipeline* q = (Pipeline*)p->pipe;
-    for (long i = sim_lo; i < sim_hi; ++i) {
+    hipStream_t st = (hipStream_t)stream;
+    long i = sim_lo;
+    // BATCHES of realisations: at 4096^2 a realisation is ~60 MB of traffic behind ~10 launches, i.e. launch latency; with B
+    // realisations per launch (grid z) the column and row stages fill the chip.  Same kernels on the same operands in the same
+    // order per realisation as the one-by-one loop below: identical moments.
+    const char* be = getenv("OA_MC_BATCH");                 // (per call: tests compare batch sizes in one process)
+    const int BMAX = be ? std::max(1, std::min(6, atoi(be))) : 6;     // 1 / 2 / 4 / 6 per launch at 4096^2: 16.5 / 26.0 / 37.6 / 40.3 k realisations/s
+    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
+    const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p);
+    const size_t lb = (size_t)pl * p->ny * es, lbk = (size_t)pk * p->ny * es;
+    const int my = q->my;
+    bool batched = BMAX >= 2 && p->pow2 && sim_hi - sim_lo >= 2;
+    while (batched && sim_hi - i >= 2) {
+        const int B = (int)std::min<long>(BMAX, sim_hi - i);
+        if (q->mc_cap < B) {
+            if (q->mc_src) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->mc_src); q->mc_src = nullptr; q->mc_cap = 0; }
+            OA_HIP(hipMalloc(&q->mc_src, (size_t)6 * pb));
+            q->mc_cap = 6;
+        }
+        // pool: 3 B leg planes (gx_b, gy_b at 2b, 2b + 1; h_b at 2B + b) | 2 B product planes | 2 B pass-1 planes
+        if (int rc = ensure_pool(q, 3 * (size_t)B * lb + 4 * (size_t)B * lbk)) return rc;
+        char* const legs = (char*)q->split_legs;
+        char* const prod = legs + 3 * (size_t)B * lb;
+        char* const tmp = prod + 2 * (size_t)B * lbk;
+        int rc = grf_hc_band_batch(p, base_seed, (uint64_t)i, B, covsqrt_hc, q->mc_src, (long)(pb / es), q->wl, q->rl, st);
+        if (rc) return rc;
+        std::vector<const void*> key;
+        for (int b = 0; b < B; ++b) key.push_back(q->FG);
+        for (int b = 0; b < B; ++b) key.push_back(q->FH);
+        if (!q->mv_ftab) OA_HIP(hipMalloc((void**)&q->mv_ftab, 32 * sizeof(void*)));
+        if (key != q->mv_fkey) {
+            OA_HIP(hipMemcpyAsync(q->mv_ftab, key.data(), key.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+            q->mv_fkey = key;
+        }
+        unsigned long long sel = 0;                       // field f (gradient fields 0..B-1, H fields B..2B-1) reads realisation f mod B
+        for (int f = 0; f < 2 * B; ++f) sel |= (unsigned long long)(f % B) << (4 * f);
+        if ((rc = qe_legs_batch_w(p, q->mc_src, (long)(pb / es), 0, sel, (const void* const*)q->mv_ftab, B, B, legs, (long)(lb / es), q->wl, q->rl,
+                                  pl, st, my, 4))) return rc;
+        if ((rc = qe_legs_pass2_w(p, legs, 3 * B, (long)(lb / es), q->wl, pl, st, my))) return rc;
+        const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
+        rc = qe_rows_batch_w(p, legs, legs + lb, legs + 2 * (size_t)B * lb, prod, prod + lbk, s * s * sy, q->wl, q->wk, q->mrow, pl, pk, st, my, B,
+                             (long)(2 * lb / es), (long)(lb / es), (long)(2 * lbk / es));
+        if (rc < 0) { batched = false; break; }          // this geometry's row stage takes one map per launch: one-by-one loop
+        if (rc) return rc;
+        if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my)))
+            return rc;
+        for (int b = 0; b < B; ++b) {
+            const void* kap = (const char*)q->c[0] + (size_t)b * pb;
+            if ((rc = bandpower_moments(p, q, n, S, C, stream, kap))) return rc;
+            if (meanfield_acc && (rc = stack_add_region(p->dtype, kap, meanfield_acc, p->ny, p->kp, q->wk, q->rk, st))) return rc;
+        }
+        i += B;
+    }
+    for (; i < sim_hi; ++i) {
         // only the leg band of the realisation is ever read (col_legs: columns < wl, rows |ky index| < rl)
         int rc = oa_grf_hc_band(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, q->wl, q->rl, stream);
         if (rc) return rc;

@@ -48,7 +48,11 @@ OA_D void normals4(uint64_t seed, uint64_t sid, uint64_t idx, float* n) {
 // One Philox call serves 2 modes: (row y', column pair p) -> columns 2p, 2p+1.
 template <typename T>
 __global__ __launch_bounds__(256) void grf_hc_kernel(uint64_t seed, uint64_t sid, const T* __restrict__ cs,
-                                                     cx<T>* __restrict__ out, int ny, int nx, long kp, int wpairs, int rband) {
+                                                     cx<T>* __restrict__ out, int ny, int nx, long kp, int wpairs, int rband,
+                                                     long zstride) {
+    // grid z = realisation: stream id sid + z into the plane z * zstride elements behind `out` (oa_mc_run's batches)
+    sid += blockIdx.z;
+    out += (long)blockIdx.z * zstride;
     const int nxh = nx / 2;
     const int npair = nxh / 2 + 1;  // pairs cover columns 0..nxh(+1)
     const int pr = blockIdx.x * blockDim.x + threadIdx.x;
@@ -128,23 +132,33 @@ extern "C" {
 
 int oa_grf_hc_band(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, int width, int rband,
                    void* stream) {
-    OA_REQUIRE(p && hc_out, "oa_grf_hc: NULL argument");
+    return oa::grf_hc_band_batch(p, seed, stream_id, 1, covsqrt_hc, hc_out, 0, width, rband, (hipStream_t)stream);
+}
+}  // extern "C"
+
+namespace oa {
+int grf_hc_band_batch(oa_plan* p, uint64_t seed, uint64_t stream_id, int nreal, const void* covsqrt_hc, void* hc_out, long zstride,
+                      int width, int rband, hipStream_t stream) {
+    OA_REQUIRE(p && hc_out && nreal >= 1, "oa_grf_hc: NULL argument");
     const int npair = p->nx / 4 + 1;
     int wpairs = (width > 0 && width < p->nx / 2 + 1) ? (width + 1) / 2 : 0;          // column pairs drawn (0 = all)
     if (wpairs >= npair) wpairs = 0;
     const int rb = (rband > 0 && 2L * rband - 1 < p->ny) ? rband : 0;
     const int np = wpairs ? wpairs : npair;
     const int bs = np >= 256 ? 256 : 64;
-    dim3 grid((np + bs - 1) / bs, rb ? 2 * rb - 1 : p->ny);
+    dim3 grid((np + bs - 1) / bs, rb ? 2 * rb - 1 : p->ny, nreal);
     if (p->dtype == OA_F32)
-        hipLaunchKernelGGL(grf_hc_kernel<float>, grid, dim3(bs), 0, (hipStream_t)stream, seed, stream_id,
-                           (const float*)covsqrt_hc, (cx<float>*)hc_out, p->ny, p->nx, p->kp, wpairs, rb);
+        hipLaunchKernelGGL(grf_hc_kernel<float>, grid, dim3(bs), 0, stream, seed, stream_id,
+                           (const float*)covsqrt_hc, (cx<float>*)hc_out, p->ny, p->nx, p->kp, wpairs, rb, zstride);
     else
-        hipLaunchKernelGGL(grf_hc_kernel<double>, grid, dim3(bs), 0, (hipStream_t)stream, seed, stream_id,
-                           (const double*)covsqrt_hc, (cx<double>*)hc_out, p->ny, p->nx, p->kp, wpairs, rb);
+        hipLaunchKernelGGL(grf_hc_kernel<double>, grid, dim3(bs), 0, stream, seed, stream_id,
+                           (const double*)covsqrt_hc, (cx<double>*)hc_out, p->ny, p->nx, p->kp, wpairs, rb, zstride);
     OA_LAUNCH_CHECK();
     return 0;
 }
+}  // namespace oa
+
+extern "C" {
 
 int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream) {
     return oa_grf_hc_band(p, seed, stream_id, covsqrt_hc, hc_out, 0, 0, stream);

@@ -214,3 +214,40 @@ def test_two_maps_per_call_equals_two_calls(N, res, prec):
     assert float(a[1].abs().min()) > 0
     np.testing.assert_allclose(b[1].cpu().numpy(), a[1].cpu().numpy(), rtol=1e-13)
     np.testing.assert_allclose(b[2].cpu().numpy(), a[2].cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (2048, 1.0, "f64"), (512, 2.0, "f32")])
+def test_mc_run_in_batches_equals_one_by_one(N, res, prec):
+    """oa_mc_run hands OA_MC_BATCH realisations to every launch (grid z: GRF draw, leg planes, inverse pass 2, row stage,
+    divergence); the moments and the mean-field stack are those of the one-realisation-per-launch loop (same kernels on the
+    same operands, accumulated in the same order).  512^2: geometry without the batched row stage -> falls back."""
+    import os
+    from orphics_amd import cosmology, lensing, maps, mc
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=maps.mask_kspace(shape, g, lmin=300, lmax=2000),
+                     kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=3500), unlensed_equals_lensed=True, dtype=prec)
+    tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(20, 3500, 20)
+    res_ = {}
+    for batch in ("1", "4", "3", "6"):
+        os.environ["OA_MC_BATCH"] = batch
+        try:
+            drv = mc.GaussianN0MonteCarlo(q, tot, edges, comm=None, base_seed=21, mean_field=True)
+            st = drv.run(11)                                       # 11 = 4 + 4 + 3 (batch 4), 6 + 5, 3 + 3 + 3 + 2, ...
+            res_[batch] = (st.count("n0"), np.array(st.mean("n0")), np.array(st.cov("n0")), st.stack_sum("mf").copy())
+        finally:
+            del os.environ["OA_MC_BATCH"]
+    n1, m1, c1, s1 = res_["1"]
+    assert n1 == 11 and np.all(m1 > 0)
+    for batch in ("4", "3", "6"):
+        nb, mb, cb, sb = res_[batch]
+        assert nb == 11
+        np.testing.assert_allclose(mb, m1, rtol=1e-13)
+        np.testing.assert_allclose(cb, c1, rtol=1e-9, atol=1e-13 * np.abs(c1).max())
+        assert np.array_equal(sb, s1)

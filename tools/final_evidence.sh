@@ -5,7 +5,7 @@ cat gpurun_out/r02z/summary/r02z_step.txt
 bash tools/pmc_step.sh r02z > /dev/null 2>&1
 # bench.py reads profiles/traffic_r02*.json (PROFILE_TAG): give it the tables just measured
 for suf in "" _fullrows _dense; do cp gpurun_out/r02z/summary/traffic_r02z$suf.json profiles/traffic_r02$suf.json; done
-timeout -k 10 500 python bench.py > gpurun_out/r02z/bench.json 2> gpurun_out/r02z/bench.err; echo "bench rc=$?"
+timeout -k 10 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r02z/bench.json 2> gpurun_out/r02z/bench.err; echo "bench rc=$?"
 python - <<'PY'
 import json
 d=json.load(open('gpurun_out/r02z/bench.json'))
