@@ -64,7 +64,7 @@ def mcn0(N=4096, res=0.5, nsims=600):
     nxh = N // 2
     tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :nxh + 1]
     edges = np.linspace(20, 3500, 20)
-    for mf, ns in ((False, 1), (True, 1), (False, 3), (True, 3)):
+    for mf, ns in (((False, 1),) if "mc1" in sys.argv else ((False, 1), (True, 1), (False, 3), (True, 3))):
         drv = mc.GaussianN0MonteCarlo(q, tot, edges, mean_field=mf, streams=ns)
         drv.run_local(range(24))
         torch.cuda.synchronize()
@@ -104,7 +104,7 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("mv", "all"):
         mv()
-    if what in ("mc", "all"):
+    if what in ("mc", "mc1", "all"):          # mc1: one stream without the mean-field stack only (tools/trace_mc.sh)
         mcn0()
     if what in ("splits", "all"):
         splits()
