@@ -106,6 +106,10 @@ int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned
 // row stage of nmaps maps in one launch; -1: this geometry's row stage is not the two-rows-per-transform kernel
 int qe_rows_batch_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout, int mrow,
                     long pl, long pk, hipStream_t st, int my, int nmaps, long in_moff, long h_moff, long out_moff);
+int qe_rows_table_w(oa_plan* p, int n, const void* const* gx, const void* const* gy, const void* const* h, void* const* px, void* const* py,
+                    const double* scales, void* dev_tab, int upload, int accumulate, int win, int wout, int mrow, long pl, long pk, hipStream_t st,
+                    int my);
+size_t qe_rows_table_entry_bytes(const oa_plan* p);
 int grf_hc_band_batch(oa_plan* p, uint64_t seed, uint64_t stream_id, int nreal, const void* covsqrt_hc, void* hc_out, long zstride,
                       int width, int rband, hipStream_t stream);
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my = 0);

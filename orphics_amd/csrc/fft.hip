@@ -1,4 +1,5 @@
 // HIP launchers for the LDS-staged 2-D FFT passes (K1) + oa_fft_* entry points.
+#include <vector>
 #include "fft_launch.hpp"
 #include "fft_r2c_w64.hpp"
 
@@ -505,6 +506,35 @@ static int qe_rows_batch_impl(oa_plan* p, const void* gx, const void* gy, const 
               out_moff, h_moff);
     return q.rc;
 }
+// row stage of n maps with per-map planes and scales (device table `dev_tab`, n entries of RowQeMap<T>, rewritten from the host
+// arrays when `upload`); -1 when this geometry's row stage is not the two-rows-per-transform kernel
+template <typename T>
+static int qe_rows_table_impl(oa_plan* p, int n, const void* const* gx, const void* const* gy, const void* const* h, void* const* px,
+                              void* const* py, const double* scales, void* dev_tab, int upload, int accumulate, int win, int wout, int mrow,
+                              hipStream_t st, long pin, long pout, int my) {
+    HipLauncher q{st};
+    auto f = coarse_view<T>(p, my);
+    const int wi = f.clampw(win), wo = f.clampw(wout);
+    if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo); if (2L * wi + wo > mrow) mrow = 0; }
+    if (!f.rows_qe_is_pair(wi, wo, mrow)) return -1;
+    if (upload) {
+        std::vector<RowQeMap<T>> tab(n);
+        const double fac = f.row_grid_scale(mrow);
+        for (int i = 0; i < n; ++i)
+            tab[i] = RowQeMap<T>{(const cx<T>*)gx[i], (const cx<T>*)gy[i], (const cx<T>*)h[i], (cx<T>*)px[i], (cx<T>*)py[i], (T)(scales[i] * fac)};
+        OA_HIP(hipMemcpyAsync(dev_tab, tab.data(), n * sizeof(RowQeMap<T>), hipMemcpyHostToDevice, st));     // pageable: staged before return
+    }
+    f.rows_qe(q, (const cx<T>*)gx[0], (const cx<T>*)gy[0], (const cx<T>*)h[0], (cx<T>*)px[0], (cx<T>*)py[0], (T)scales[0], accumulate, wi, wo, mrow,
+              pin, pout, n, 0, 0, 0, (const RowQeMap<T>*)dev_tab);
+    return q.rc;
+}
+int qe_rows_table_w(oa_plan* p, int n, const void* const* gx, const void* const* gy, const void* const* h, void* const* px, void* const* py,
+                    const double* scales, void* dev_tab, int upload, int accumulate, int win, int wout, int mrow, long pl, long pk, hipStream_t st,
+                    int my) {
+    return p->dtype == OA_F32 ? qe_rows_table_impl<float>(p, n, gx, gy, h, px, py, scales, dev_tab, upload, accumulate, win, wout, mrow, st, pl, pk, my)
+                              : qe_rows_table_impl<double>(p, n, gx, gy, h, px, py, scales, dev_tab, upload, accumulate, win, wout, mrow, st, pl, pk, my);
+}
+size_t qe_rows_table_entry_bytes(const oa_plan* p) { return p->dtype == OA_F32 ? sizeof(RowQeMap<float>) : sizeof(RowQeMap<double>); }
 int qe_rows_batch_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout, int mrow,
                     long pl, long pk, hipStream_t st, int my, int nmaps, long in_moff, long h_moff, long out_moff) {
     return p->dtype == OA_F32 ? qe_rows_batch_impl<float>(p, gx, gy, h, px, py, scale, win, wout, mrow, st, pl, pk, my, nmaps, in_moff, h_moff, out_moff)

@@ -497,6 +497,15 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
 // 3 half-complex planes in, 2 out; the real-space planes never touch HBM.
 // LDS: one padded work row set + one unpadded real row set (h).
 // ===========================================================================
+// per-map operands of a multi-map row-stage launch whose planes are not evenly spaced (oa_qe_mv: the k-th separable piece of
+// every estimator in one launch; the leg planes of a piece are shared, arbitrary slots of the pool) -- a DEVICE array
+template <typename T>
+struct RowQeMap {
+    const cx<T>* gx; const cx<T>* gy; const cx<T>* h;
+    cx<T>* px; cx<T>* py;
+    T scale;
+};
+
 template <typename T>
 struct RowQeArgs {
     const cx<T>* gx; const cx<T>* gy; const cx<T>* h;
@@ -513,6 +522,7 @@ struct RowQeArgs {
     // sit m in_moff, whose h plane m h_moff and whose product planes m out_moff elements behind the first map's.
     // npairs = 0: one map.
     int npairs; long in_moff, out_moff, h_moff;
+    const RowQeMap<T>* tab;   // != nullptr: map m takes its planes and its scale from tab[m] instead
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -743,21 +753,29 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     const int RS = a.rowStride;
     long wg = ctx.bid_x();
     long imo = 0, omo = 0, hmo = 0;
-    while (a.npairs && wg >= a.npairs) { wg -= a.npairs; imo += a.in_moff; omo += a.out_moff; hmo += a.h_moff; }
+    int m = 0;
+    while (a.npairs && wg >= a.npairs) { wg -= a.npairs; imo += a.in_moff; omo += a.out_moff; hmo += a.h_moff; ++m; }
+    const cx<T>* gxp = a.gx + imo; const cx<T>* gyp = a.gy + imo; const cx<T>* hp = a.h + hmo;
+    cx<T>* pxp = a.px + omo; cx<T>* pyp = a.py + omo;
+    T scale = a.scale;
+    if (a.tab) {                       // uniform index: scalar loads
+        const RowQeMap<T> e = a.tab[m];
+        gxp = e.gx; gyp = e.gy; hp = e.h; pxp = e.px; pyp = e.py; scale = e.scale;
+    }
     const long r0 = wg * 2;
     constexpr int R0 = SEQ::get(0);
     cx<T> hreg[EPT], v[EPT];
     cx<T>* twl = work + RS;
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
-    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, a.h + hmo + r0 * a.pitch, a.h + hmo + (r0 + 1) * a.pitch, a.win);
+    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
-    for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * a.scale;
+    for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * scale;
     ctx.sync();
     for (int leg = 0; leg < 2; ++leg) {
-        const cx<T>* src = (leg ? a.gy : a.gx) + imo;
-        cx<T>* dst = (leg ? a.py : a.px) + omo;
+        const cx<T>* src = leg ? gyp : gxp;
+        cx<T>* dst = leg ? pyp : pxp;
         pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
         // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
 #pragma unroll

@@ -81,6 +81,8 @@ struct Fft2dPlan {
     // have products band-limited to 2 (win - 1), so the row stage evaluated on ANY grid of mrow >= 2 win + wout
     // points yields the same product columns k < wout (no aliasing reaches them) times mrow / nx -- folded into the
     // scale here.  The real-space planes exist only in LDS, so the sampling grid is not observable.
+    // factor rows_qe puts on the caller's scale when the products are formed on an mrow-point grid
+    double row_grid_scale(int mrow) const { return (mrow > 0 && mrow < nx) ? (double)nx / (double)mrow : 1.0; }
     // does rows_qe run the two-rows-per-transform kernel (the only row stage that takes two maps per launch)?
     bool rows_qe_is_pair(int win, int wout, int mrow) const {
         const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
@@ -101,7 +103,9 @@ struct Fft2dPlan {
     template <class Launcher>
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
                  int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0, long pin = 0,
-                 long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0, long h_moff = -1) const {
+                 long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0, long h_moff = -1,
+                 const RowQeMap<T>* tab = nullptr) const {
+        // tab (device array of nmaps entries, pair kernel only): per-map planes and FINAL scales (see row_grid_scale)
         RowQeArgs<T> a{};
         // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
         // transforms with no assumption beyond win / wout
@@ -115,7 +119,8 @@ struct Fft2dPlan {
             // alias-free row grid: two rows per complex transform of length M (row_qe_pair_body)
             const int M = 1 << logM;
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
-            if (nmaps > 1) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
+            if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
+            a.tab = tab;
             q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
             return;
         }

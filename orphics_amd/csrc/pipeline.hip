@@ -35,6 +35,8 @@ struct Pipeline {
     unsigned* ticket = nullptr;       // last-workgroup ticket of the fused bin + moments launch (bin.hip, BinTail)
     void* split_legs = nullptr;       // oa_qe_tt_splits / oa_qe_mv: pool of compact leg planes
     size_t split_bytes = 0;
+    void* mv_rtab = nullptr;          // oa_qe_mv: device table of per-piece row-stage operands (RowQeMap), 64 entries
+    std::vector<unsigned long long> mv_rkey;
     void* mc_src = nullptr;           // oa_mc_run: hc planes of a batch of realisations
     int mc_cap = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
@@ -60,6 +62,7 @@ void pipeline_release(oa_plan* p) {
     if (q->split_legs) (void)hipFree(q->split_legs);
     if (q->mv_ftab) (void)hipFree(q->mv_ftab);
     if (q->mc_src) (void)hipFree(q->mc_src);
+    if (q->mv_rtab) (void)hipFree(q->mv_rtab);
     delete q;
     p->pipe = nullptr;
 }
@@ -355,8 +358,51 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
         for (int e = 2; e < nest && dbatch; ++e) dbatch = ((const char*)host_Fnorm[e] - (const char*)host_Fnorm[0]) == e * d;
         fn_moff = d / (long)rs;
     }
+    // ROW STAGE: the k-th separable piece of every estimator in ONE launch (they write different product planes; a launch
+    // of one piece is 1024 workgroups of two waves and leaves most of the chip's wave slots empty), per-piece planes and
+    // scales through a device table; pieces k > 0 accumulate.  Same arithmetic per piece, same order per estimator.
+    bool rbatch = dbatch && total <= 64 && !getenv("OA_MV_NO_ROWBATCH");
+    if (rbatch) {
+        int maxp = 0;
+        for (int e = 0; e < nest; ++e) maxp = std::max(maxp, host_npieces[e]);
+        std::vector<const void*> tgx, tgy, th;
+        std::vector<void*> tpx, tpy;
+        std::vector<double> tsc;
+        std::vector<int> count(maxp, 0);
+        for (int k = 0; k < maxp; ++k) {
+            int base = 0;
+            for (int e = 0; e < nest; base += host_npieces[e], ++e) {
+                if (host_npieces[e] <= k) continue;
+                const int idx = base + k;
+                tgx.push_back(plane(2 * gslot[idx])); tgy.push_back(plane(2 * gslot[idx] + 1)); th.push_back(plane(2 * ng + hslot[idx]));
+                tpx.push_back(prod + 2 * (size_t)e * lbk); tpy.push_back(prod + (2 * (size_t)e + 1) * lbk);
+                tsc.push_back(host_signs[idx] * s * s * sy);
+                ++count[k];
+            }
+        }
+        std::vector<unsigned long long> key;
+        for (size_t i = 0; i < tgx.size(); ++i) {
+            unsigned long long bits;
+            memcpy(&bits, &tsc[i], sizeof bits);
+            key.insert(key.end(), {(unsigned long long)(uintptr_t)tgx[i], (unsigned long long)(uintptr_t)tgy[i], (unsigned long long)(uintptr_t)th[i],
+                                   (unsigned long long)(uintptr_t)tpx[i], (unsigned long long)(uintptr_t)tpy[i], bits});
+        }
+        key.push_back((unsigned long long)my); key.push_back((unsigned long long)(unsigned)mrow); key.push_back((unsigned long long)p->dtype);
+        const size_t eb = qe_rows_table_entry_bytes(p);
+        if (!q->mv_rtab) OA_HIP(hipMalloc(&q->mv_rtab, 64 * 64));
+        const int upload = key != q->mv_rkey;
+        size_t off = 0;
+        for (int k = 0; k < maxp && rbatch; ++k) {
+            int rc = qe_rows_table_w(p, count[k], tgx.data() + off, tgy.data() + off, th.data() + off, tpx.data() + off, tpy.data() + off,
+                                     tsc.data() + off, (char*)q->mv_rtab + off * eb, upload, k > 0, leg_cols, kappa_cols, mrow, pl, pk, st, my);
+            if (rc < 0) { rbatch = false; break; }      // (only possible at k = 0: nothing launched yet)
+            if (rc) return rc;
+            off += count[k];
+        }
+        if (rbatch) q->mv_rkey = key;
+    }
     int at = 0;
-    for (int e = 0; e < nest; ++e) {
+    for (int e = 0; e < nest && !rbatch; ++e) {
         void* g0 = dbatch ? (void*)(prod + 2 * (size_t)e * lbk) : q->g[0];
         void* g1 = dbatch ? (void*)(prod + (2 * (size_t)e + 1) * lbk) : q->g[1];
         for (int i = 0; i < host_npieces[e]; ++i, ++at) {

@@ -361,6 +361,12 @@ def test_mv_one_call_equals_per_estimator_calls(N, res, prune, masks):
         finally:
             del os.environ["OA_MV_NO_BATCH"]
         assert torch.equal(per_field, one)
+        os.environ["OA_MV_NO_ROWBATCH"] = "1"               # one row-stage launch per piece instead of one per piece rank
+        try:
+            per_piece = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"]).clone()
+        finally:
+            del os.environ["OA_MV_NO_ROWBATCH"]
+        assert torch.equal(per_piece, one)
         sub = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], estimators=("TT", "EB")).clone()
         sub_per = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], estimators=("TT", "EB"), fused=False).clone()
         assert float((sub - sub_per).abs().max() / sub_per.abs().max()) < tol

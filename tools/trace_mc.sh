@@ -9,7 +9,7 @@ mkdir -p $O
 for B in 1 6; do
   export OA_MC_BATCH=$B
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_mc$B -- python3 tools/config_bench.py mc1 > $O/mc_run$B.txt 2> $O/mc$B.err
-  python3 - $O/p_mc$B $B <<'PY' | tee $O/mc_stats_b$2.txt
+  python3 - $O/p_mc$B $B <<'PY' | tee $O/mc_stats_b$B.txt
 import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + '/**/*kernel_stats.csv', recursive=True):
