@@ -206,7 +206,7 @@ int oa_split_cross_power(int dtype, int nsplits, const void* const* host_kappa, 
                          int active_cols, int active_rows, void* stream);
 /* oa_mc_run: realisations sim_lo .. sim_hi-1 (Philox stream = realisation index): GRF draw -> TT estimator -> bandpowers ->
  * moments [-> mean-field stack], no host work per realisation.  Up to 6 realisations (environment OA_MC_BATCH, 1 = one by
- * one) share every launch in front of the binning (grid z: draw, leg planes, inverse pass 2, row stage, divergence): at
+ * one) share every launch (grid z / y: draw, leg planes, inverse pass 2, row stage, divergence, binned power, moment tail, stack): at
  * 4096^2 a realisation is launch latency, not bytes.  Same kernels on the same operands in the same order per realisation:
  * the moments and the stack do not depend on the batch size.  The first call allocates the batch's planes (one device
  * synchronisation). */

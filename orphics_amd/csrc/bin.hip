@@ -148,7 +148,10 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
                                                         const T* __restrict__ w, const double* __restrict__ aux, long n,
                                                         int nids, int mode, int skip_nan, unsigned hp, int nxh, unsigned wq,
                                                         unsigned rb, double* __restrict__ part_sum, double* __restrict__ part_w,
-                                                        unsigned long long* __restrict__ part_cnt) {
+                                                        unsigned long long* __restrict__ part_cnt, long dstride, long pstride) {
+    // grid y = plane of a batch (oa_mc_run): data planes dstride elements apart, partial arrays pstride apart
+    data += (long)blockIdx.y * dstride; data2 += (long)blockIdx.y * dstride;
+    part_sum += (long)blockIdx.y * pstride; part_w += (long)blockIdx.y * pstride; part_cnt += (long)blockIdx.y * pstride;
     extern __shared__ __attribute__((aligned(16))) char sm_raw[];
     double* s_sum = reinterpret_cast<double*>(sm_raw);                        // [WAVES][nids]
     double* s_w = s_sum + BIN_WAVES * nids;                                   // [WAVES][nids] (weighted)
@@ -290,7 +293,14 @@ __global__ __launch_bounds__(BIN_BLOCK) void bin_kernel(const T* __restrict__ da
 __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict__ part_sum, const double* __restrict__ part_w,
                                                         const unsigned long long* __restrict__ part_cnt, int nblocks,
                                                         int nids, int weighted, double* __restrict__ sums,
-                                                        int64_t* __restrict__ counts, double* __restrict__ wsums, BinTail tail) {
+                                                        int64_t* __restrict__ counts, double* __restrict__ wsums, BinTail tail,
+                                                        long pstride) {
+    // grid y = plane of a batch: partial arrays pstride apart, sums / counts nids apart; the LAST workgroup of the whole grid
+    // adds the planes' bandpower vectors to the moments one after the other, in plane order
+    double* const sums0 = sums;
+    part_sum += (long)blockIdx.y * pstride; part_w += (long)blockIdx.y * pstride; part_cnt += (long)blockIdx.y * pstride;
+    sums += (long)blockIdx.y * nids;
+    if (counts) counts += (long)blockIdx.y * nids;
     __shared__ double sh_s[256];
     __shared__ double sh_q[256];
     __shared__ unsigned long long sh_c[256];
@@ -318,31 +328,35 @@ __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict
     if (!tail.ticket) return;
     if (t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through store of sums[i] has been acknowledged
-        s_last = (__hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
+        s_last = (__hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
     // moments of the bandpower vector b[a] = sums[1 + a] / mcounts[1 + a], a < d = nids - 2 (stats.bin2D [1:-1])
     const int d = nids - 2;
-    for (int a0 = 0; a0 < d; a0 += 256) {              // S, and b staged through LDS in chunks of 256
-        const int a = a0 + t;
-        double bv = 0.0;
-        if (a < d) {
-            bv = __hip_atomic_load(sums + 1 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)tail.mcounts[1 + a];
-            tail.S[a] += bv;
+    for (int zb = 0; zb < (int)gridDim.y; ++zb) {
+        const double* sm = sums0 + (long)zb * nids;
+        for (int a0 = 0; a0 < d; a0 += 256) {              // S, and b staged through LDS in chunks of 256
+            const int a = a0 + t;
+            double bv = 0.0;
+            if (a < d) {
+                bv = __hip_atomic_load(sm + 1 + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)tail.mcounts[1 + a];
+                tail.S[a] += bv;
+            }
+            __syncthreads();
+            sh_s[t] = bv;
+            __syncthreads();
+            // C rows a0 .. a0+255 need every b: column values are re-read from global (write-through, agent scope)
+            for (long e = t; e < (long)((d - a0 < 256) ? d - a0 : 256) * d; e += 256) {
+                const int ra = (int)(e / d), cb = (int)(e - (long)ra * d);
+                const double bb = __hip_atomic_load(sm + 1 + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)tail.mcounts[1 + cb];
+                tail.C[(long)(a0 + ra) * d + cb] += sh_s[ra] * bb;
+            }
         }
         __syncthreads();
-        sh_s[t] = bv;
-        __syncthreads();
-        // C rows a0 .. a0+255 need every b: column values are re-read from global (write-through, agent scope)
-        for (long e = t; e < (long)((d - a0 < 256) ? d - a0 : 256) * d; e += 256) {
-            const int ra = (int)(e / d), cb = (int)(e - (long)ra * d);
-            const double bb = __hip_atomic_load(sums + 1 + cb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (double)tail.mcounts[1 + cb];
-            tail.C[(long)(a0 + ra) * d + cb] += sh_s[ra] * bb;
-        }
     }
     if (t == 0) {
-        tail.n[0] += 1;
+        tail.n[0] += (int64_t)gridDim.y;
         __hip_atomic_store(tail.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
     }
 }
@@ -351,7 +365,10 @@ template <typename T>
 static int bin_impl(const void* data, const void* data2, double pnorm, bool power, const int32_t* ids, const void* weights,
                     const double* aux, long n, int nids, int mode,
                     int skip_nan, long hp, int nxh, double* sums, int64_t* counts, double* wsums, void* scratch,
-                    hipStream_t st, int active_cols = 0, int active_rows = 0, const BinTail* fused = nullptr) {
+                    hipStream_t st, int active_cols = 0, int active_rows = 0, const BinTail* fused = nullptr, int nbatch = 1,
+                    long dstride = 0) {
+    // nbatch > 1 (bin_power_moments): planes dstride elements of T apart; scratch, sums and counts hold nbatch sets
+    const long pstride = (long)2 * BIN_GMAX * nids;
     unsigned wq = 0;                                  // 4-element chunks visited per row (0 = whole rows)
     if (active_cols > 0 && nxh >= 0 && hp > 0 && (long)active_cols < hp && n % hp == 0) wq = (unsigned)((active_cols + 3) / 4);
     const unsigned rb = (wq && active_rows > 0 && 2L * active_rows - 1 < n / hp) ? (unsigned)active_rows : 0u;
@@ -374,9 +391,9 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
         if (smem > 48 * 1024)                                                                                        \
             OA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)smem));                                                                  \
-        hipLaunchKernelGGL(k, dim3(G), dim3(BIN_BLOCK), smem, st, (const T*)data, (const T*)data2, pnorm, ids,       \
+        hipLaunchKernelGGL(k, dim3(G, nbatch), dim3(BIN_BLOCK), smem, st, (const T*)data, (const T*)data2, pnorm, ids, \
                            (const T*)weights, aux, n, nids, mode, skip_nan, (unsigned)(hp > 0 ? hp : 4), nxh, wq, rb, \
-                           part_sum, part_w, part_cnt);                                                              \
+                           part_sum, part_w, part_cnt, dstride, pstride);                                            \
     }
     if (weighted && power) OA_BIN_LAUNCH(true, true)
     else if (weighted) OA_BIN_LAUNCH(true, false)
@@ -384,8 +401,8 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
     else OA_BIN_LAUNCH(false, false)
 #undef OA_BIN_LAUNCH
     OA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bin_final_kernel, dim3(nids), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
-                       weighted ? 1 : 0, sums, counts, wsums, tail);
+    hipLaunchKernelGGL(bin_final_kernel, dim3(nids, nbatch), dim3(256), 0, st, part_sum, part_w, part_cnt, G, nids,
+                       weighted ? 1 : 0, sums, counts, wsums, tail, pstride);
     OA_LAUNCH_CHECK();
     return 0;
 }
@@ -393,13 +410,15 @@ static int bin_impl(const void* data, const void* data2, double pnorm, bool powe
 // kappa_hat -> binned auto-power -> moment accumulation in ONE launch (pipeline.hip)
 int bin_power_moments(int dtype, const void* k, double norm, const int32_t* ids, long n, int nids, long hp, int nxh, double* sums,
                       int64_t* counts, void* scratch, int active_cols, int active_rows, unsigned* ticket,
-                      const int64_t* mcounts, int64_t* mn, double* S, double* C, hipStream_t st) {
+                      const int64_t* mcounts, int64_t* mn, double* S, double* C, hipStream_t st, int nbatch, long kstride) {
+    // nbatch planes kstride complex elements apart (scratch / sums / counts sized for nbatch sets): their bandpower vectors
+    // are added to (n, S, C) in plane order by the last workgroup
     BinTail t{ticket, mcounts, mn, S, C};
     if (dtype == OA_F32)
         return bin_impl<float>(k, k, norm, true, ids, nullptr, nullptr, n, nids, 0, 0, hp, nxh, sums, counts, nullptr, scratch, st,
-                               active_cols, active_rows, &t);
+                               active_cols, active_rows, &t, nbatch, 2 * kstride);
     return bin_impl<double>(k, k, norm, true, ids, nullptr, nullptr, n, nids, 0, 0, hp, nxh, sums, counts, nullptr, scratch, st,
-                            active_cols, active_rows, &t);
+                            active_cols, active_rows, &t, nbatch, 2 * kstride);
 }
 
 }  // namespace oa

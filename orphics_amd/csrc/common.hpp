@@ -83,8 +83,8 @@ void pipeline_release(oa_plan* p);
 long work_pitch(const oa_plan* p, int w);
 int bin_power_moments(int dtype, const void* k, double norm, const int32_t* ids, long n, int nids, long hp, int nxh, double* sums,
                       int64_t* counts, void* scratch, int active_cols, int active_rows, unsigned* ticket,
-                      const int64_t* mcounts, int64_t* mn, double* S, double* C, hipStream_t st);
-int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st);
+                      const int64_t* mcounts, int64_t* mn, double* S, double* C, hipStream_t st, int nbatch = 1, long kstride = 0);
+int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st, int nbatch = 1, long xstride = 0);
 // my > 0: COLUMN GRID -- legs, row stage and divergence run on my < ny rows (plan_ensure_col_grid(p, my) first)
 int plan_ensure_col_grid(oa_plan* p, int my);
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,

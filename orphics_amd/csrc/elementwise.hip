@@ -92,13 +92,15 @@ __global__ __launch_bounds__(256) void stack_add_kernel(const T* __restrict__ x,
 // the same over the active region of an hc plane only (columns < w, band rows): kappa_hat is exactly zero elsewhere
 template <typename T>
 __global__ __launch_bounds__(256) void stack_add_region_kernel(const T* __restrict__ x, double* __restrict__ acc, int ny, long kp,
-                                                               int w, int rb) {
+                                                               int w, int rb, int nbatch, long xstride) {
     int y = blockIdx.y;
     if (rb > 0 && y >= rb) y += ny - (2 * rb - 1);
     const int c = blockIdx.x * blockDim.x + threadIdx.x;      // real-valued element within the row (2 per complex column)
     if (c >= 2 * w) return;
     const long i = 2 * (long)y * kp + c;
-    acc[i] += (double)x[i];
+    double a = acc[i];
+    for (int b = 0; b < nbatch; ++b) a += (double)x[i + b * xstride];      // planes of a batch, added in plane order
+    acc[i] = a;
 }
 
 // out (+)= sum of `nparts` planes `stride` elements apart, over the active region of an hc plane (oa_qe_mv: the estimators'
@@ -351,12 +353,13 @@ int sum_region(int dtype, const void* parts, long part_stride, int nparts, void*
     return 0;
 }
 // mean-field stack of the one-call Monte-Carlo driver (pipeline.hip)
-int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st) {
+int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st, int nbatch, long xstride) {
+    // xstride: real elements between the planes of a batch
     if (w <= 0 || w > kp) w = (int)kp;
     if (!(rb > 0 && 2L * rb - 1 < ny)) rb = 0;
     dim3 grid((2 * w + 255) / 256, rb ? 2 * rb - 1 : ny);
-    if (dtype == OA_F32) hipLaunchKernelGGL(stack_add_region_kernel<float>, grid, dim3(256), 0, st, (const float*)x, acc, ny, kp, w, rb);
-    else hipLaunchKernelGGL(stack_add_region_kernel<double>, grid, dim3(256), 0, st, (const double*)x, acc, ny, kp, w, rb);
+    if (dtype == OA_F32) hipLaunchKernelGGL(stack_add_region_kernel<float>, grid, dim3(256), 0, st, (const float*)x, acc, ny, kp, w, rb, nbatch, xstride);
+    else hipLaunchKernelGGL(stack_add_region_kernel<double>, grid, dim3(256), 0, st, (const double*)x, acc, ny, kp, w, rb, nbatch, xstride);
     OA_LAUNCH_CHECK();
     return 0;
 }

@@ -12,6 +12,8 @@
 
 namespace oa {
 
+constexpr int MC_BATCH_MAX = 6;      // realisations per launch in oa_mc_run (kappa planes: the six plan-owned work planes in front of kk)
+
 struct Pipeline {
     // filters (caller-owned device planes) + active region of the TT estimator
     const void* FG = nullptr; const void* FH = nullptr; const void* Fn = nullptr;
@@ -174,10 +176,11 @@ int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, v
         if (q->bin_scratch) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->bin_scratch); (void)hipFree(q->sums); (void)hipFree(q->counts_full); (void)hipFree(q->counts_tmp); }
         const long sb = oa_bin_scratch_bytes(nids);
         OA_REQUIRE(sb > 0, "oa_plan_set_bins: bad nids");
-        OA_HIP(hipMalloc(&q->bin_scratch, (size_t)sb));
-        OA_HIP(hipMalloc((void**)&q->sums, nids * sizeof(double)));
+        // (x MC_BATCH_MAX: oa_mc_run bins a batch of realisations per launch)
+        OA_HIP(hipMalloc(&q->bin_scratch, (size_t)sb * MC_BATCH_MAX));
+        OA_HIP(hipMalloc((void**)&q->sums, MC_BATCH_MAX * nids * sizeof(double)));
         OA_HIP(hipMalloc((void**)&q->counts_full, nids * sizeof(int64_t)));
-        OA_HIP(hipMalloc((void**)&q->counts_tmp, nids * sizeof(int64_t)));
+        OA_HIP(hipMalloc((void**)&q->counts_tmp, MC_BATCH_MAX * nids * sizeof(int64_t)));
     }
     if (!q->ticket) {
         OA_HIP(hipMalloc((void**)&q->ticket, sizeof(unsigned)));
@@ -529,7 +532,7 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     // realisations per launch (grid z) the column and row stages fill the chip.  Same kernels on the same operands in the same
     // order per realisation as the one-by-one loop below: identical moments.
     const char* be = getenv("OA_MC_BATCH");                 // (per call: tests compare batch sizes in one process)
-    const int BMAX = be ? std::max(1, std::min(6, atoi(be))) : 6;     // 1 / 2 / 4 / 6 per launch at 4096^2: 16.5 / 26.0 / 37.6 / 40.3 k realisations/s
+    const int BMAX = be ? std::max(1, std::min(MC_BATCH_MAX, atoi(be))) : MC_BATCH_MAX;     // 1 / 2 / 4 / 6 per launch at 4096^2: 16.5 / 26.0 / 37.6 / 40.3 k realisations/s
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p);
     const size_t lb = (size_t)pl * p->ny * es, lbk = (size_t)pk * p->ny * es;
@@ -539,8 +542,8 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
         const int B = (int)std::min<long>(BMAX, sim_hi - i);
         if (q->mc_cap < B) {
             if (q->mc_src) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->mc_src); q->mc_src = nullptr; q->mc_cap = 0; }
-            OA_HIP(hipMalloc(&q->mc_src, (size_t)6 * pb));
-            q->mc_cap = 6;
+            OA_HIP(hipMalloc(&q->mc_src, (size_t)MC_BATCH_MAX * pb));
+            q->mc_cap = MC_BATCH_MAX;
         }
         // pool: 3 B leg planes (gx_b, gy_b at 2b, 2b + 1; h_b at 2B + b) | 2 B product planes | 2 B pass-1 planes
         if (int rc = ensure_pool(q, 3 * (size_t)B * lb + 4 * (size_t)B * lbk)) return rc;
@@ -569,11 +572,10 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
         if (rc) return rc;
         if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my)))
             return rc;
-        for (int b = 0; b < B; ++b) {
-            const void* kap = (const char*)q->c[0] + (size_t)b * pb;
-            if ((rc = bandpower_moments(p, q, n, S, C, stream, kap))) return rc;
-            if (meanfield_acc && (rc = stack_add_region(p->dtype, kap, meanfield_acc, p->ny, p->kp, q->wk, q->rk, st))) return rc;
-        }
+        // binned power of the B kappa planes + their moment updates in realisation order: two launches; the mean-field stack: one
+        if ((rc = bin_power_moments(p->dtype, q->c[0], q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
+                                    q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, st, B, (long)(pb / es)))) return rc;
+        if (meanfield_acc && (rc = stack_add_region(p->dtype, q->c[0], meanfield_acc, p->ny, p->kp, q->wk, q->rk, st, B, (long)(2 * pb / es)))) return rc;
         i += B;
     }
     for (; i < sim_hi; ++i) {
