@@ -488,8 +488,12 @@ int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, 
         if ((rc = oa_qe_tt_moments(p, real_map0, n, S, C, stream))) return rc;
         return oa_qe_tt_moments(p, real_map1, n, S, C, stream);
     }
-    if ((rc = bandpower_moments(p, q, n, S, C, stream, q->kk))) return rc;
-    return bandpower_moments(p, q, n, S, C, stream, q->kT);
+    // both kappa planes binned in one launch pair (grid y = map; kT sits one plane IN FRONT of kk: stride -1 plane), the moment
+    // tail adds the two bandpower vectors in map order
+    const long es = 2 * (p->dtype == OA_F32 ? 4 : 8);
+    const long back = ((const char*)q->kT - (const char*)q->kk) / es;
+    return bin_power_moments(p->dtype, q->kk, q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
+                             q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, (hipStream_t)stream, 2, back);
 }
 
 /* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py):
