@@ -339,6 +339,29 @@ int emu_qe_rows_wm_f64(int ny, int nx, const void* gx, const void* gy, const voi
 int emu_qe_rows_wm_f32(int ny, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout, int mrow) {
     return do_qe_rows<float>(ny, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s, win, wout, mrow);
 }
+// several maps in one row-stage launch (two-rows-per-transform kernel): planes[m] = {gx, gy, h, px, py} of map m, scales[m];
+// table != 0: per-map operands through a RowQeMap table, else evenly spaced planes (the maps' planes must then be evenly
+// spaced in memory: gx / gy / px / py by the same offsets the caller passes).  Returns 0, or 1 if this geometry is another kernel.
+int emu_qe_rows_multi_f64(int ny, int nx, int nmaps, const void* const* gx, const void* const* gy, const void* const* h, void* const* px,
+                          void* const* py, const double* scales, int accumulate, int win, int wout, int mrow, int table) {
+    Holder<double> hd(ny, nx);
+    EmuLauncher q;
+    const int wi = hd.p.clampw(win), wo = hd.p.clampw(wout);
+    if (!hd.p.rows_qe_is_pair(wi, wo, mrow)) return 1;
+    typedef cx<double> C;
+    if (table) {
+        std::vector<RowQeMap<double>> tab(nmaps);
+        for (int m = 0; m < nmaps; ++m)
+            tab[m] = RowQeMap<double>{(const C*)gx[m], (const C*)gy[m], (const C*)h[m], (C*)px[m], (C*)py[m], scales[m] * hd.p.row_grid_scale(mrow)};
+        hd.p.rows_qe(q, (const C*)gx[0], (const C*)gy[0], (const C*)h[0], (C*)px[0], (C*)py[0], scales[0], accumulate, wi, wo, mrow, 0, 0, nmaps, 0, 0, 0,
+                     tab.data());
+    } else {
+        const long io = nmaps > 1 ? (const C*)gx[1] - (const C*)gx[0] : 0, ho = nmaps > 1 ? (const C*)h[1] - (const C*)h[0] : 0;
+        const long oo = nmaps > 1 ? (C*)px[1] - (C*)px[0] : 0;
+        hd.p.rows_qe(q, (const C*)gx[0], (const C*)gy[0], (const C*)h[0], (C*)px[0], (C*)py[0], scales[0], accumulate, wi, wo, mrow, 0, 0, nmaps, io, oo, ho);
+    }
+    return 0;
+}
 int emu_legs_cols_w_f64(int ny, int nx, const void* kX, const void* kY, const double* FG, const double* FH, const double* lxd,
                         const double* lyd, void* gx, void* gy, void* h, int width, int rband) {
     return do_legs_cols<double>(ny, nx, (const cx<double>*)kX, (const cx<double>*)kY, FG, FH, lxd, lyd, (cx<double>*)gx,

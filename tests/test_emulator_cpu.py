@@ -170,6 +170,49 @@ def test_fused_row_stage_on_alias_free_row_grid(emu, ny, nx, win, wout, mrow, ex
         assert np.all(got[:, wout:W] == 5.0)
 
 
+def test_row_stage_of_several_maps_per_launch(emu):
+    """row_qe_pair_body with workgroup ranges = maps: evenly spaced planes (oa_mc_run, oa_qe_tt_moments2; the h planes may
+    have their own spacing) and a table of per-map planes and scales (oa_qe_mv) give, map by map, bit for bit what one
+    launch per map gives -- also when accumulating."""
+    ny, nx, win, wout, mrow = 8, 4096, 100, 150, 1024
+    rng = np.random.default_rng(77)
+    kp = emu.emu_kpitch(nx)
+    nm = 3
+    G = np.full((2 * nm, ny, kp), 1e30 + 0j)           # gx_m, gy_m interleaved: even spacing 2 planes
+    H = np.full((nm, ny, kp), 1e30 + 0j)               # h_m: spacing 1 plane
+    for a in (G, H):
+        a[..., :win] = rng.standard_normal(a.shape[:-1] + (win,)) + 1j * rng.standard_normal(a.shape[:-1] + (win,))
+        a[..., 0] = a[..., 0].real
+    scales = np.array([1.0, -0.5, 2.0])
+    arr = lambda xs: (ctypes.c_void_p * len(xs))(*[x.ctypes.data for x in xs])      # noqa: E731
+    one = np.zeros((2 * nm, ny, kp), dtype=np.complex128)
+    for m in range(nm):                                  # reference: one launch per map, twice (the second accumulates)
+        for acc in (0, 1):
+            sc = (ctypes.c_double * 1)(scales[m])
+            assert emu.emu_qe_rows_multi_f64(ny, nx, 1, arr([G[2 * m]]), arr([G[2 * m + 1]]), arr([H[m]]), arr([one[2 * m]]), arr([one[2 * m + 1]]),
+                                             sc, acc, win, wout, mrow, 0) == 0
+    assert np.abs(one[:, :, :wout]).min() > 0
+    # evenly spaced: one scale for all maps
+    even = np.zeros_like(one)
+    ref_even = np.zeros_like(one)
+    sc1 = (ctypes.c_double * 1)(0.75)
+    for m in range(nm):
+        assert emu.emu_qe_rows_multi_f64(ny, nx, 1, arr([G[2 * m]]), arr([G[2 * m + 1]]), arr([H[m]]), arr([ref_even[2 * m]]), arr([ref_even[2 * m + 1]]),
+                                         sc1, 0, win, wout, mrow, 0) == 0
+    sc3 = (ctypes.c_double * nm)(0.75, 0.75, 0.75)
+    assert emu.emu_qe_rows_multi_f64(ny, nx, nm, arr([G[2 * m] for m in range(nm)]), arr([G[2 * m + 1] for m in range(nm)]), arr([H[m] for m in range(nm)]),
+                                     arr([even[2 * m] for m in range(nm)]), arr([even[2 * m + 1] for m in range(nm)]), sc3, 0, win, wout, mrow, 0) == 0
+    assert np.array_equal(even, ref_even)
+    # table: arbitrary plane order (maps reversed), per-map scales, two launches (the second accumulates)
+    tab = np.zeros_like(one)
+    order = [2, 0, 1]
+    scs = (ctypes.c_double * nm)(*[scales[m] for m in order])
+    for acc in (0, 1):
+        assert emu.emu_qe_rows_multi_f64(ny, nx, nm, arr([G[2 * m] for m in order]), arr([G[2 * m + 1] for m in order]), arr([H[m] for m in order]),
+                                         arr([tab[2 * m] for m in order]), arr([tab[2 * m + 1] for m in order]), scs, acc, win, wout, mrow, 1) == 0
+    assert np.array_equal(tab, one)
+
+
 @pytest.mark.parametrize("ny,nx,w,rb", [(64, 64, 0, 0), (64, 128, 21, 0), (128, 64, 32, 9), (256, 64, 7, 40), (64, 64, 0, 5)])
 def test_fused_column_stages(emu, ny, nx, w, rb):
     """col_legs (+ pass 2) = inverse column transforms of (i lx FG kX, i ly FG kX, FH kY);
