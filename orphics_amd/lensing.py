@@ -696,8 +696,12 @@ class Estimator(object):
         Fn = G["Fnorm"] if norm is None else norm
         e._ordered()
         check(e.lib.oa_plan_set_col_grid(e.plan, int(self.mcol)))       # plans are shared per geometry: policy per call
-        check(e.lib.oa_qe_pol(e.plan, n, signs, fgs, fhs, swaps, _ptr(kX), _ptr(kY), _ptr(Fn), _ptr(out), 1 if accumulate else 0,
-                              int(wl), int(wk), int(rl), int(rk), int(self.mrow), zero, _stream()))
+        # one estimator through oa_qe_mv (nest = 1): the same pieces as oa_qe_pol, with all distinct leg planes of the estimator
+        # in ONE inverse pass-1 launch and one pass-2 launch (a piece pair shares its cos / sin filtered fields)
+        one = ctypes.c_void_p * 1
+        check(e.lib.oa_qe_mv(e.plan, 1, (ctypes.c_int * 1)(n), signs, fgs, fhs, swaps, one(kX.data_ptr()), one(kY.data_ptr()),
+                             one(Fn.data_ptr()), _ptr(out), 1 if accumulate else 0, int(wl), int(wk), int(rl), int(rk), int(self.mrow), zero,
+                             _stream()))
         mark_dirty(out)
         if wk or rk:
             set_clean_region(out, (wk, rk))

@@ -151,7 +151,8 @@ def test_one_call_entries_from_raw_pointers():
 
 
 def test_one_call_pol_estimator_matches_fine_grained():
-    """oa_qe_pol (through Estimator.reconstruct_hc) == the chain of fine-grained calls it replaces."""
+    """One polarised estimator in one call -- oa_qe_mv with one estimator (Estimator.reconstruct_hc) and oa_qe_pol (called
+    directly) -- == the chain of fine-grained calls they replace."""
     from orphics_amd import cosmology, lensing, maps
     from orphics_amd.geometry import FlatGeometry
     N = 128
@@ -180,6 +181,13 @@ def test_one_call_pol_estimator_matches_fine_grained():
         want = e.qe_cols_div(ax, ay, G["Fnorm"], width=G["wk"], rband=G["rk"]).cpu().numpy()
         w = N // 2 + 1
         assert np.abs(got[:, :w] - want[:, :w]).max() <= 1e-14 * np.abs(want).max()
+        from orphics_amd._lib import check
+        from orphics_amd.engine import _ptr, _stream
+        n, signs, fgs, fhs, swaps = G["c_args"]
+        pol = e.hc()
+        check(e.lib.oa_qe_pol(e.plan, n, signs, fgs, fhs, swaps, _ptr(kE), _ptr(kB), _ptr(G["Fnorm"]), _ptr(pol), 0, int(G["wl"]), int(G["wk"]),
+                              int(G["rl"]), int(G["rk"]), int(q.mrow), 0, _stream()))
+        assert np.array_equal(pol.cpu().numpy()[:, :w], got[:, :w])           # same kernels on the same operands
 
 
 @pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (4096, 0.5, "f64"), (1024, 1.0, "f32")])
