@@ -41,6 +41,9 @@ typedef struct oa_plan oa_plan;
 
 /* ---- library ----------------------------------------------------------- */
 const char* oa_last_error(void);
+/* ABI version = 100 x the build round that last changed a signature in this header; bindings must refuse a library
+ * that reports less than the version they were written against (OA_ABI_VERSION) */
+#define OA_ABI_VERSION 300
 int oa_version(void);
 /* number of HIP devices visible; <0 on error (no compute) */
 int oa_device_count(void);

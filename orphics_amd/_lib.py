@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("ORPHICS_AMD_LIB", os.path.join(_HERE, "liborphics_amd
 
 OA_F32 = 0
 OA_F64 = 1
+ABI_VERSION = 300     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -118,6 +119,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.oa_version()
+    if got != ABI_VERSION:
+        raise OrphicsAmdError("orphics_amd: %s reports C-ABI version %d, this binding was written against %d "
+                              "(stale build? run __graft_entry__.build())" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

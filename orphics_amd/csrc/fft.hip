@@ -66,8 +66,9 @@ __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void
 }
 
 // single-pass forward column transform + divergence on short (coarse-grid) columns: 1024 threads hold a whole column tile
+// (f64: half the tile width -- the same 128 KB of LDS -- and 512 threads with the 256-register budget)
 template <typename T, class SEQ, int LOGC>
-__global__ __launch_bounds__(1024, 4) void col_div_sp_kernel(ColDivArgs<T> a) {
+__global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 : 4)) void col_div_sp_kernel(ColDivArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     col_div_body<T, SEQ, GpuCtx, LOGC>(c, a);
 }
@@ -103,8 +104,8 @@ struct HipLauncher {
         w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
         w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = ny;
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (int)(LDS_MAX / W64_LDS_BYTES); }();
-        w.nwg = cus * per_cu;                              // resident waves: one per SIMD (LDS-limited)
+        static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+        w.nwg = cus * per_cu;                              // resident waves: one per SIMD (launch bound; 16.6 KB of LDS each)
         if (two) w.nwg = cus * (int)(LDS_MAX / W64X2_LDS_BYTES);
         if (w.nwg > ny) w.nwg = ny;
         if (two) {
@@ -195,13 +196,17 @@ struct HipLauncher {
         });
         if (!ok && !rc) rc = fail("fft: unsupported column length");
     }
-    // single pass: logL = whole column length (10 or 11), tile of 2^(14 - logL) columns, 1024 threads
+    // single pass: logL = whole column length (10 or 11), tile of 2^(14 - logL) columns, 1024 threads (f32) / 2^(13 - logL)
+    // columns, 512 threads (f64): 128 KB of LDS either way
     template <typename T>
     bool col_div_sp(int gx, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
+        if (rc) return true;
         if constexpr (sizeof(T) == 4) {
-            if (rc) return true;
             if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, 3>, dim3(gx, 1, gz), 1024, smem, a); return true; }
             if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, 4>, dim3(gx, 1, gz), 1024, smem, a); return true; }
+        } else {
+            if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, 2>, dim3(gx, 1, gz), 512, smem, a); return true; }
+            if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, 3>, dim3(gx, 1, gz), 512, smem, a); return true; }
         }
         return false;
     }

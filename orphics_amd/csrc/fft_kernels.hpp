@@ -1407,8 +1407,8 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     constexpr int NT = ((1 << (seq_total_log<SEQ>() + LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + LOGC)) / EPT) : 1;
     const int tid = ctx.tid();
     int tile = ctx.bid_x();
-    if (LOGC < 4) {
-        // 8-column tiles read 64-byte row segments: two adjacent tiles share every 128-byte line.  Workgroups are dealt
+    if ((sizeof(cx<T>) << LOGC) < 128) {
+        // 8-column f32 / 4-column f64 tiles read 64-byte row segments: two adjacent tiles share every 128-byte line.  Workgroups are dealt
         // round-robin over the 8 XCDs, so give tiles 2m and 2m+1 to workgroups b and b + 8 of a group of 16: the same XCD,
         // dispatched together -- the second tile's lines are L2 hits instead of a second trip over the fabric.
         const int nt = ctx.grid_x(), base = tile & ~15, r = tile & 15;

@@ -303,17 +303,18 @@ struct Fft2dPlan {
                   cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0, int nmaps = 1,
                   long in_moff = 0, long tmp_moff = 0, long out_moff = 0, long fn_moff = 0) const {
         const long pi = pin > 0 ? pin : kp;     // pitch of pa, pb AND of the two scratch planes
-        if (single_pass_div() && (logNy == 10 || logNy == 11) && sizeof(T) == 4) {
-            // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column tile in LDS, the product planes
-            // are read once and nothing is written back but kappa's band rows
-            const int lc = 14 - logNy, Cs = 1 << lc;
+        if (single_pass_div() && (logNy == 10 || logNy == 11)) {
+            // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column (f64: 4- / 8-column) tile in LDS --
+            // 128 KB --, the product planes are read once and nothing is written back but kappa's band rows
+            const int lt = sizeof(T) == 4 ? 14 : 13;
+            const int lc = lt - logNy, Cs = 1 << lc;
             ColDivArgs<T> a{};
             a.A = pa; a.B = pb; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = clampw(wmax);
-            a.logC = lc; a.NT = 1024; a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = 1; a.out_gs = 1; a.out_ks = 1;
+            a.logC = lc; a.NT = (1 << lt) / EPT; a.tw = tw_y; a.logTw = logNy; a.in_gs = 1; a.in_ns = 1; a.out_gs = 1; a.out_ks = 1;
             a.accumulate = accumulate; a.rband = clampr(rband); a.ny = ny; a.yshift = yshift();
             a.in_moff = in_moff; a.out_moff = out_moff; a.fn_moff = fn_moff;
             const int tl = (a.width + Cs - 1) / Cs;
-            if (q.col_div_sp(tl, ((size_t)(1 << 14) + tw_lds_size(logNy)) * sizeof(cx<T>), logNy, a, nmaps)) return;
+            if (q.col_div_sp(tl, ((size_t)(1 << lt) + tw_lds_size(logNy)) * sizeof(cx<T>), logNy, a, nmaps)) return;
         }
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;

@@ -83,18 +83,26 @@ struct RowW64Args {
     int ny, nwg;
 };
 
-// LDS: the 64 x 64 transpose, rows of 65 complex elements (the b64 writes of consecutive lanes and the row-strided
-// reads are both conflict-free).  33 KB per wave = one wave per SIMD, which therefore owns the whole register file
-// (512): a variant that halves the LDS (transpose in two halves) to fit two waves per SIMD needs v and u live together
-// within 256 registers and spills (176 us at 8192^2).  Prefetching the next row -- all of it into 128 more registers,
-// or into the first stage's registers once they are dead -- measured slower than not prefetching (68.6 / 68.9 us vs
-// 61.1; the four waves of a CU cover each other's load phases), so each row simply loads, transforms, stores.
+// LDS: the 64 x 64 transpose goes through ONE 64 x 65 plane of 4-byte words, twice (real parts, then imaginary parts:
+// the b32 writes of consecutive lanes and the row-strided reads are both conflict-free, and two b32 passes cost the LDS
+// the same cycles as one b64 pass).  16.6 KB per wave instead of 33: the four persistent waves of a CU (one per SIMD,
+// each owning the whole register file: 512) hold 66 KB, so the coarse-grid kernels of ANOTHER reconstruction (32-column
+// tiles: 34 KB; row stage 18 KB) find LDS on every CU while this kernel streams the map -- with the 33 KB layout the
+// four waves held 132 of the 160 KB for the whole launch and every launch of the other streams waited for its last
+// row (tools/overlap_trace.sh: col_fft 10.6 -> 42 us, col_div 19.7 -> 62 us under an R2C; profiles/r03b_overlap.txt).
+// The real-transform untangle partners use the first 4 KB of the same buffer.
+// Tried before: halving the LDS by transposing in two halves of 32 rows needs v and u live together within 256
+// registers and spills (176 us at 8192^2).  Prefetching the next row -- all of it into 128 more registers, or into the
+// first stage's registers once they are dead -- measured slower than not prefetching (68.6 / 68.9 us vs 61.1; the four
+// waves of a CU cover each other's load phases), so each row simply loads, transforms, stores.
 constexpr int W64_LDS_STRIDE = 65;
-constexpr size_t W64_LDS_BYTES = (size_t)64 * W64_LDS_STRIDE * sizeof(cx<float>);
+constexpr size_t W64_LDS_BYTES = (size_t)64 * W64_LDS_STRIDE * sizeof(float);
+constexpr size_t W64_LDS_BYTES_CX = (size_t)64 * W64_LDS_STRIDE * sizeof(cx<float>);   // two-waves-per-row kernel below
 
 template <class Ctx>
 OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
-    cx<float>* s = reinterpret_cast<cx<float>*>(ctx.smem());
+    float* sf = reinterpret_cast<float*>(ctx.smem());
+    cx<float>* s = reinterpret_cast<cx<float>*>(ctx.smem());   // untangle exchange (first 4 KB)
     const int j = ctx.tid();                       // lane = point residue (stage 1) = bin residue k1 (stage 2)
     const int sh = a.logTw - 12;                   // W4096^e = tw[e << sh]
     const int jm = (64 - j) & 63;
@@ -118,15 +126,27 @@ OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int k1 = aa + 8 * b;
-                cx<float> x = v[8 * aa + b];
-                if (k1) x = x * ((aa && b) ? P[aa] * Q[b] : (aa ? P[aa] : Q[b]));
-                s[k1 * W64_LDS_STRIDE + j] = x;
+                if (k1) v[8 * aa + b] = v[8 * aa + b] * ((aa && b) ? P[aa] * Q[b] : (aa ? P[aa] : Q[b]));
             }
         }
+        // transpose, real parts: lane j writes word [k1][j], lane k1 = j reads [j][t]
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].x;
+        ctx.sync();
+        float re[64];
+#pragma unroll
+        for (int t = 0; t < 64; ++t) re[t] = sf[j * W64_LDS_STRIDE + t];
+        ctx.sync();                                // every read of the plane precedes the writes below
+#pragma unroll
+        for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].y;
         ctx.sync();
 #pragma unroll
-        for (int t = 0; t < 64; ++t) v[t] = s[j * W64_LDS_STRIDE + t];
-        ctx.sync();                                // every read of the transpose precedes the writes below
+        for (int t = 0; t < 64; ++t) v[t] = mk<float>(re[t], sf[j * W64_LDS_STRIDE + t]);
+        ctx.sync();
         dft64<true>(v);                            // lane k1 = j: Z[k1 + 64 m] in v[8 m], Z[k1 + 64 (56 + m)] in v[8 m + 7]
 #pragma unroll
         for (int m = 0; m < 8; ++m) s[m * 64 + j] = v[8 * m + 7];
@@ -157,7 +177,7 @@ OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
 // in front of the untangle  X[k] = E + W16384^k O  finishes the row.  Columns k < 768 only (bins k2 <= 11 and their
 // mirror images k2 >= 52 of each half transform).  One workgroup barrier per exchange (two waves).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr size_t W64X2_LDS_BYTES = 2 * W64_LDS_BYTES;
+constexpr size_t W64X2_LDS_BYTES = 2 * W64_LDS_BYTES_CX;
 constexpr int W64X2_KEEP = 12;     // kept bins k2 per side of each half transform
 
 template <class Ctx>

@@ -253,18 +253,39 @@ class Estimator(object):
         other.eng.set_laxes(*self.geom.laxes())
         rdt = other.eng.rdt
         other._F = {k: tuple(t.to(rdt) for t in v) for k, v in self._F.items()}
+        # the tag -> device filter plane cache is PER PRECISION: converted once, and the converted pieces are looked up in
+        # it by plane identity so that estimators sharing a filtered field keep sharing ONE plane object (oa_qe_mv
+        # deduplicates leg transforms by pointer); estimators set up later on either handle fill their own cache
+        fdev = getattr(self, "_fdev", None)
+        conv = {}
+        if fdev is not None:
+            other._fdev = {}
+            for tag, t in fdev.items():
+                other._fdev[tag] = conv[id(t)] = t.to(rdt)
+
+        def plane(t):
+            if id(t) not in conv:
+                conv[id(t)] = t.to(rdt)
+            return conv[id(t)]
         if getattr(self, "_gen", None) is not None:
             other._gen = {}
             for XY, G in self._gen.items():
                 G2 = {k: v for k, v in G.items() if k != "c_args"}
-                G2["pieces"] = [(sg, fg.to(rdt), fh.to(rdt), sw) for (sg, fg, fh, sw) in G["pieces"]]
+                G2["pieces"] = [(sg, plane(fg), plane(fh), sw) for (sg, fg, fh, sw) in G["pieces"]]
                 G2["Fnorm"] = G["Fnorm"].to(rdt)
                 other._gen[XY] = G2
         if getattr(self, "_mv", None) is not None:
-            other._mv = (self._mv[0], {k: v.to(rdt) for k, v in self._mv[1].items()})
+            # one stacked allocation again: evenly spaced planes let oa_qe_mv run every estimator's divergence in one launch
+            keys = list(self._mv[1])
+            stack = other.eng.hcreal(len(keys))
+            for i, k in enumerate(keys):
+                stack[i].copy_(self._mv[1][k])
+            other._mv = (self._mv[0], {k: stack[i] for i, k in enumerate(keys)})
         other.AL, other.Nlkk = dict(self.AL), dict(self.Nlkk)
         other._work = None
         other._rwork = None
+        other._racc = None
+        other._acc = None
         other._bins = None
         return other
 
@@ -317,6 +338,9 @@ class Estimator(object):
     def bind_bins(self, ids_hc, nids, norm):
         """Radial bins of the one-call Monte-Carlo entries (``tt_moments``, ``mc.GaussianN0MonteCarlo``): int32 ids
         on the hc grid (``Engine.modl_digitize(edges, half=True)``), ``nids = len(edges) + 1``, ``norm = area/Npix^2``."""
+        cur = getattr(self, "_bins", None)
+        if cur is not None and cur[0] is ids_hc and cur[1] == int(nids) and cur[2] == float(norm):
+            return self                   # unchanged: the plan keeps its (whole-plane) mode counts
         self._bins = (ids_hc, int(nids), float(norm))
         self.eng._bins_owner = None
         return self

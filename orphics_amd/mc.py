@@ -69,6 +69,9 @@ class GaussianN0MonteCarlo(object):
         if not sims:
             return self
         q = self.q
+        # (re)bind THIS driver's bins: another driver -- or a direct bind_bins call -- may have given the shared estimator
+        # other edges since __init__, and the accumulators below are sized for self.d
+        q.bind_bins(self.ids, self.nids, self.norm)
         e = q._bind_bins()
         n, S, C = self.acc.device_moments("n0", self.d)
         mf = self.acc.device_stack("mf", (e.ny, e.kp, 2)) if self.mean_field else None
@@ -123,6 +126,7 @@ class GaussianN0MonteCarlo(object):
                 stream = st
                 stream.wait_stream(cur)
             with torch.cuda.stream(stream):
+                qj.bind_bins(self.ids, self.nids, self.norm)
                 ej = qj._bind_bins()
                 lo = prev = mine[0]
                 for i in mine[1:] + [None]:

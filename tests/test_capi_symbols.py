@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "missing export " + s
     assert sorted(_lib.SIGNATURES.keys()) == syms  # ctypes table mirrors the header 1:1
-    assert lib.oa_version() >= 100
+    assert lib.oa_version() == _lib.ABI_VERSION
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -465,35 +465,38 @@ def test_fused_forward_pass2_legs_on_the_column_grid(emu, ny, my, w, rb):
             assert np.all(a[:, wv:W] == 3.0)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("ny_full,my,w,rb,nx", [(4096, 1024, 20, 150, 64), (8192, 2048, 0, 300, 64), (8192, 2048, 200, 300, 512)])
-def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb, nx):
-    """col_div_body with a whole 1024- / 2048-point column in the tile (16 / 8 columns, 1024 threads): forward column
-    transform + divergence in ONE pass (f32), with the column-grid row mapping of Fn, ly and the output; the 512-column
-    case has more than 16 tiles, i.e. exercises the XCD-pairing tile order."""
+def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb, nx, prec):
+    """col_div_body with a whole 1024- / 2048-point column in the tile (f32: 16 / 8 columns, 1024 threads; f64: 8 / 4
+    columns, 512 threads -- 128 KB of LDS either way): forward column transform + divergence in ONE pass, with the
+    column-grid row mapping of Fn, ly and the output; the 512-column case has more than 16 tiles, i.e. exercises the
+    XCD-pairing tile order of the 64-byte-segment tiles."""
+    rdt, cdt = (np.float32, np.complex64) if prec == "f32" else (np.float64, np.complex128)
+    fn = emu.emu_cols_div_cg_f32 if prec == "f32" else emu.emu_cols_div_cg_f64
     rng = np.random.default_rng(my + w)
     W = nx // 2 + 1
     wv = w if w else W
     kp = emu.emu_kpitch(nx)
-    ly = (2 * np.pi * np.fft.fftfreq(ny_full) * 100).astype(np.float32)
-    lx = (2 * np.pi * np.fft.fftfreq(nx) * 100).astype(np.float32)
+    ly = (2 * np.pi * np.fft.fftfreq(ny_full) * 100).astype(rdt)
+    lx = (2 * np.pi * np.fft.fftfreq(nx) * 100).astype(rdt)
     lyd, lxd = ly.copy(), lx.copy()
     lyd[ny_full // 2] = 0
     lxd[nx // 2] = 0
     rows = np.r_[0:my // 2, ny_full - my // 2:ny_full]
     band = np.r_[0:rb, ny_full - rb + 1:ny_full]
-    Fn = np.zeros((ny_full, kp), dtype=np.float32)
-    Fn[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv)).astype(np.float32)
-    A = np.zeros((my, kp), dtype=np.complex64); B = np.zeros((my, kp), dtype=np.complex64)
-    A[:, :W] = (rng.standard_normal((my, W)) + 1j * rng.standard_normal((my, W))).astype(np.complex64)
-    B[:, :W] = (rng.standard_normal((my, W)) + 1j * rng.standard_normal((my, W))).astype(np.complex64)
-    out = np.full((ny_full, kp), 3.0 + 0j, dtype=np.complex64)
-    assert emu.emu_cols_div_cg_f32(ny_full, my, nx, _p(A), _p(B), _p(Fn), _p(lxd), _p(lyd), _p(out), w, rb) == 0
+    Fn = np.zeros((ny_full, kp), dtype=rdt)
+    Fn[band, :wv] = rng.uniform(0.5, 1.5, (band.size, wv)).astype(rdt)
+    A = np.zeros((my, kp), dtype=cdt); B = np.zeros((my, kp), dtype=cdt)
+    A[:, :W] = (rng.standard_normal((my, W)) + 1j * rng.standard_normal((my, W))).astype(cdt)
+    B[:, :W] = (rng.standard_normal((my, W)) + 1j * rng.standard_normal((my, W))).astype(cdt)
+    out = np.full((ny_full, kp), 3.0 + 0j, dtype=cdt)
+    assert fn(ny_full, my, nx, _p(A), _p(B), _p(Fn), _p(lxd), _p(lyd), _p(out), w, rb) == 0
     lx2, ly2 = lxd[None, :W].astype(np.float64), lyd[rows][:, None].astype(np.float64)
     want = Fn[rows][:, :W] * (1j * lx2 * np.fft.fft(A[:, :W].astype(np.complex128), axis=0) + 1j * ly2 * np.fft.fft(B[:, :W].astype(np.complex128), axis=0))
     cb = np.r_[0:rb, my - rb + 1:my]
-    assert np.abs(out[rows[cb]][:, :wv] - want[cb][:, :wv]).max() < 2e-5 * np.abs(want).max()
+    assert np.abs(out[rows[cb]][:, :wv] - want[cb][:, :wv]).max() < (2e-5 if prec == "f32" else 1e-12) * np.abs(want).max()
     untouched = np.setdiff1d(np.arange(ny_full), rows[cb])
     assert np.all(out[untouched] == 3.0)
     if w:
         assert np.all(out[:, wv:W] == 3.0)
-

@@ -185,7 +185,30 @@ def test_tt_bandpowers_match_numpy_oracle_at_full_size(N):
         p1d = (sums[1:-1] / counts[1:-1].double()).cpu().numpy()
         err = np.max(np.abs(p1d / p1r - 1))
         assert err < tol, "%s: bandpowers differ from the oracle by %.3g" % (prec, err)
-        del q
+        # THE BENCHMARKED CALL (bench.py Runner.run): bins bound to the plan, two real maps per C-ABI call
+        # (oa_qe_tt_moments2: row R2C -> col_fwdlegs_cg -> row_qe_pair -> col_div -> binned power -> moment tail), against the
+        # same oracle bandpowers.  Second map = 0.5 x the first, rolled: kappa_hat is bilinear and translation-covariant, so
+        # its oracle bandpowers are b / 16 exactly; the two maps occupy different slots of every shared launch.
+        d = len(edges) - 1
+        x1 = (0.5 * torch.roll(x, shifts=(17, 5), dims=(0, 1))).contiguous()
+        n = torch.zeros(1, dtype=torch.int64, device=e.device)
+        S = torch.zeros(d, dtype=torch.float64, device=e.device)
+        C = torch.zeros(d, d, dtype=torch.float64, device=e.device)
+        q.bind_bins(ids, len(edges) + 1, g.area / float(N * N) ** 2)
+        assert np.array_equal(q.bin_counts().cpu().numpy(), counts.cpu().numpy())      # plan-side mode counts: bit-exact
+        q.tt_moments2(x, x1, n, S, C)
+        torch.cuda.synchronize()
+        assert int(n.item()) == 2
+        errS = np.max(np.abs(S.cpu().numpy() / (p1r * (1 + 1 / 16.)) - 1))
+        errC = np.max(np.abs(C.cpu().numpy() / (np.outer(p1r, p1r) * (1 + 1 / 256.)) - 1))
+        assert errS < tol and errC < 2 * tol, "%s: moments of the two-map call differ from the oracle: %.3g %.3g" % (prec, errS, errC)
+        # ... and one map per call (oa_qe_tt_moments) on the second map alone
+        n.zero_(); S.zero_(); C.zero_()
+        q.tt_moments(x1, n, S, C)
+        torch.cuda.synchronize()
+        err1 = np.max(np.abs(S.cpu().numpy() * 16. / p1r - 1))
+        assert int(n.item()) == 1 and err1 < tol, "%s: one-map call: %.3g" % (prec, err1)
+        del q, x1
     assert t_oracle > 0
 
 

@@ -335,6 +335,84 @@ def test_mv_combination_matches_oracle():
         assert np.all(nmv[sel] <= q.N_kappa("TT")[sel] * (1 + 1e-9))   # MV is never noisier than TT
 
 
+def test_pol_and_mv_match_oracle_with_row_and_column_grids_engaged():
+    """TE / EE / EB / TB / TT through the batched general path (``reconstruct_hc`` -> oa_qe_mv with one estimator) and the
+    five-estimator MV combination (``reconstruct_mv_hc`` -> one oa_qe_mv call), at 2048^2 1' where the band limits put the
+    row stage on a 1024-point row grid and the column stages on a 1024-row column grid -- against oracle.QEOracle on the
+    same Gaussian T, E, B: kappa bandpowers within 1e-5 (f32 kernels) / 1e-8 (f64 kernels)."""
+    from orphics_amd import lensing
+    N, res = 2048, 1.0
+    shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup(N, res, seed=14)
+    mo.set_workers(16)
+    qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)
+    ests = ("TT", "TE", "EE", "EB", "TB")
+    edges = np.linspace(40, 2900, 16)
+    bo = so.bin2D(ml, edges)
+    fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+    pref = {}
+    for XY in ests:
+        qr.setup(XY)
+        kr = qr.kappa_ft(XY, k[XY[0]], k[XY[1]])
+        pref[XY] = bo.bin(fo.f2power(kr, kr))[1]
+    kr = qr.kappa_mv_ft(k, ests)
+    pref["MV"] = bo.bin(fo.f2power(kr, kr))[1]
+    mo.set_workers(1)
+    kw = dict(noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask, pol=True, unlensed_equals_lensed=True)
+    q64 = lensing.qest(shape, g, th, dtype="f64", **kw)
+    for prec, tol in (("f64", 1e-8), ("f32", 1e-5)):
+        q = q64 if prec == "f64" else q64.astype("f32")
+        e = q.eng
+        hk = {X: e.full_to_hc(e.to_complex(k[X])) for X in "TEB"}
+        ids = e.modl_digitize(torch.as_tensor(edges, device=e.device), half=True)
+        _, counts = e.bin_power(hk["T"], hk["T"], 1.0, ids, len(edges) + 1, herm=True)
+        assert np.array_equal(counts[1:-1].cpu().numpy(), np.bincount(bo.digitized, minlength=len(edges) + 1)[1:len(edges)])
+
+        def bandpowers(kk):
+            sums, _ = e.bin_power(kk, kk, g.area / float(N * N) ** 2, ids, len(edges) + 1, herm=True)
+            return (sums[1:-1] / counts[1:-1].double()).cpu().numpy()
+        for XY in ests:
+            kk = q.reconstruct_hc(XY, hk[XY[0]], hk[XY[1]])
+            G = q._gen[XY]
+            # both grids engaged: a 1024-point row grid and a 1024-row column grid hold the band-limited products exactly
+            assert 0 < 2 * G["wl"] + G["wk"] <= 1024 and 0 < max(2 * G["rl"] + G["rk"], 2 * G["rk"]) <= 1024, (XY, G["wl"], G["wk"], G["rl"], G["rk"])
+            err = np.max(np.abs(bandpowers(kk) / pref[XY] - 1))
+            assert err < tol, "%s %s: bandpowers differ from the oracle by %.3g" % (XY, prec, err)
+        kk = q.reconstruct_mv_hc(hk["T"], hk["E"], hk["B"], ests)
+        err = np.max(np.abs(bandpowers(kk) / pref["MV"] - 1))
+        assert err < tol, "MV %s: bandpowers differ from the oracle by %.3g" % (prec, err)
+        # ADVICE r2: an estimator set up on the converted handle AFTER astype must not pick up planes of the other precision
+        if prec == "f32":
+            fresh = lensing.qest(shape, g, th, dtype="f32", **kw)
+            for a_, b_ in zip(q._gen["EB"]["pieces"], fresh._setup_general("EB")["pieces"]):
+                assert a_[1].dtype == torch.float32 and a_[2].dtype == torch.float32
+                assert torch.equal(a_[1], b_[1]) and torch.equal(a_[2], b_[2])
+
+
+def test_estimator_set_up_after_astype_uses_its_own_precision():
+    """q64 set up for EE, then q64.astype('f32') set up for EB (which shares the W^EE filtered fields with EE): the f32
+    handle must build / convert f32 planes (its own tag cache), and the f64 handle's cache must stay f64."""
+    from orphics_amd import lensing
+    N, res = 256, 2.0
+    shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup(N, res, seed=3)
+    kw = dict(noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask, pol=True, unlensed_equals_lensed=True)
+    q64 = lensing.qest(shape, g, th, dtype="f64", **kw)
+    q64._setup_general("EE")
+    q32 = q64.astype("f32")
+    e = q32.eng
+    hk = {X: e.full_to_hc(e.to_complex(k[X].astype(np.complex64))) for X in "EB"}
+    got = q32.reconstruct_hc("EB", hk["E"], hk["B"])
+    fresh = lensing.qest(shape, g, th, dtype="f32", **kw)
+    ref = fresh.reconstruct_hc("EB", hk["E"], hk["B"])
+    assert all(t.dtype == torch.float32 for t in q32._fdev.values())
+    assert all(t.dtype == torch.float64 for t in q64._fdev.values())
+    assert (got - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    # and the f64 handle still reconstructs EB with f64 planes afterwards
+    e64 = q64.eng
+    hk64 = {X: e64.full_to_hc(e64.to_complex(k[X])) for X in "EB"}
+    got64 = q64.reconstruct_hc("EB", hk64["E"], hk64["B"])
+    assert (got64.to(torch.complex64) - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("N,res,prune,masks", [(128, 2.0, True, "same"), (512, 1.0, True, "differ"), (256, 2.0, False, "same"), (1024, 1.0, True, "same")])
 def test_mv_one_call_equals_per_estimator_calls(N, res, prune, masks):
     """oa_qe_mv (every distinct filtered field transformed once, one inverse pass-2 launch over all leg planes) vs one
