@@ -20,7 +20,9 @@ With N > 1 and no torchrun environment the script starts N ranks itself (a child
 ``python -m torch.distributed.run`` started BEFORE this process touches the GPU);
 under torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE and checks them against --gpus.
 
-Prints one JSON line (rank 0):
+Prints one JSON line (rank 0).  The HEADLINE (`value`, `dtype`, `roofline`) is measured in float64 / complex128 -- the
+reference's arithmetic (maps.py:1613) --; the same job through the float32 kernels is the second, equally complete block
+`f32` (its own timed region, roofline, per-kernel table and PMC traffic):
   value / ms_per_step : whole-job reconstructions/s over the K timed steps = K batches (max over ranks); ms per batch
   roofline            : the dominant kernel against the roof that binds it -- "valu" (f32 vector peak, on the
                         arithmetic it executes) for the fused row stage, "hbm" (on the bytes it moves) otherwise;
@@ -47,7 +49,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = 157.3   # f32 vector peak (MI355X_MICROARCH.md chip table)
-PROFILE_TAG = "r02"        # profiles/traffic_<tag>.json, profiles/flops_<tag>.json
+PROFILE_TAG = "r03"        # profiles/traffic_<tag>_<prec>[_dense|_fullrows].json (tools/collect_profiles.sh)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -75,14 +77,36 @@ def _free_port():
     return p
 
 
+def visible_gpu_count():
+    """Number of GPUs a child process will see, found WITHOUT initialising HIP in this process (the ranks are started
+    before the parent touches the GPU; torch.cuda.device_count() may call hipGetDeviceCount): the *_VISIBLE_DEVICES
+    environment first, else the KFD topology (nodes with SIMDs are GPUs); None = unknown (each rank validates itself)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return 0                      # no KFD driver: no AMD GPU on this host
+    try:
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        return n
+    except Exception:
+        return None
+
+
 def spawn_ranks(gpus, argv):
     """Start ``gpus`` ranks as CHILD processes, one per GPU, with the torchrun environment (RANK, LOCAL_RANK,
-    WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  This parent has made no GPU call and never execs; it returns non-zero
-    if any rank fails (the others are then terminated)."""
-    import torch   # device_count() does not initialise the GPU
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT).  This parent imports neither torch nor the HIP library, makes no GPU call
+    and never execs; it returns non-zero if any rank fails (the others are then terminated)."""
     backend = os.environ.get("OA_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    if backend == "nccl" and ndev < gpus:
+    ndev = visible_gpu_count()
+    if backend == "nccl" and ndev is not None and ndev < gpus:
         raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible" % (gpus, ndev))
     port = str(_free_port())
     procs = []
@@ -372,7 +396,7 @@ def per_kernel_table(torch, P, R, args):
         legs_name = "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>"
         # col_fwdlegs (read the pass-1 plane + 2 real filter planes on the band rows, write 3) + 3-plane inverse pass 2 (r + w)
         legs_bytes = fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah
-    if my in (1024, 2048) and P["prec"] == "f32" and os.environ.get("OA_SINGLE_PASS_DIV", "1") != "0":
+    if my in (1024, 2048) and os.environ.get("OA_SINGLE_PASS_DIV", "1") != "0":
         # single pass: read the 2 product planes of my rows + Fn/2 on the band rows, write the band rows of kappa_hat
         div_name, div_bytes = "cols_div = col_div_sp_kernel (single-pass forward columns + divergence)", fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah)
     else:
@@ -476,62 +500,81 @@ def cpu_baseline(N_gpu, res_arcmin, reps=5):
             "cpu_model": cpu_model(), "numpy": np.__version__, "scipy": scipy.__version__}
 
 
+def lensed_loop_leg(torch, args, side=4096, nsims=12, estimators=("TT", "EB")):
+    """SURVEY 3.4 / tutorials/tt_verification.ipynb cell 4, the north-star loop itself: FlatLensingSims.get_sim (3 GRFs +
+    order-5 flat-sky lensing + beam + noise) -> T,E,B transforms -> TT and EB kappa_hat -> cross power with the input kappa
+    -> 19 bandpowers -> device-side Statistics; simulations/s on one GPU with the per-stage split (HIP events)."""
+    from orphics_amd import cosmology, lensing, maps, mc
+    from orphics_amd.geometry import FlatGeometry
+    prec = args.prec
+    shape = (3, side, side)
+    geom = FlatGeometry.from_res(shape, args.res)
+    theory = cosmology.default_theory()
+    sims = lensing.FlatLensingSims(shape, geom, theory, 1.5, 1.0, pol=True, dtype=prec)
+    keep = {k: maps.mask_kspace(shape, geom, lmin=lo, lmax=hi) for k, (lo, hi) in (("T", (300., 2000.)), ("K", (20., 3500.)))}
+    q = lensing.qest(shape, geom, theory, noise2d=sims.ps_noise[0, 0], beam2d=sims.kbeam, kmask=keep["T"], noise2d_P=sims.ps_noise[1, 1],
+                     kmask_P=keep["T"], kmask_K=keep["K"], pol=True, unlensed_equals_lensed=True, dtype=prec)
+    drv = mc.LensedSimsMonteCarlo(sims, q, np.linspace(20, 3500, 20), estimators=estimators)
+    drv.run_local(range(2))                                # warm-up: estimator set-up (A_L), plans, code objects
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.run_local(range(2, 2 + nsims))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / nsims
+    drv.run_local(range(2 + nsims, 4 + nsims), stage_times=True)
+    return {"sims_per_s": 1.0 / dt, "ms_per_sim": dt * 1e3, "side": side, "res_arcmin": args.res, "dtype": prec, "estimators": list(estimators),
+            "nsims_timed": nsims, "stage_ms_per_sim": drv.stage_ms,
+            "note": "mc.LensedSimsMonteCarlo: get_sim (unlensed T,Q,U + kappa + noise GRFs, order-5 flat-sky lensing of 3 maps, beam) -> "
+                    "T,E,B -> TT + EB reconstructions -> cross / auto bandpowers -> device-side Statistics; one HIP stream"}
+
+
+def bandwidth_ceiling(torch, gb=2.0, reps=12):
+    """What a plain streaming kernel reaches on THIS box in THIS run (16-byte accesses, HIP events on the launch stream):
+    device copy (read + write) and read-only, GB/s over `gb` GB buffers (larger than the 256 MB infinity cache)."""
+    from orphics_amd import _lib
+    from orphics_amd.engine import _ptr, _stream
+    lib = _lib.load()
+    n = int(gb * 1e9) // 16 * 16
+    a = torch.empty(n, dtype=torch.uint8, device="cuda")
+    b = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.zero_(); b.zero_()
+    sink = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+    t_copy = time_kernel(torch, lambda: _lib.check(lib.oa_probe_copy(_ptr(b), _ptr(a), n, _stream())), reps=reps)
+    t_read = time_kernel(torch, lambda: _lib.check(lib.oa_probe_read(_ptr(a), n, _ptr(sink), _stream())), reps=reps)
+    del a, b, sink
+    torch.cuda.empty_cache()
+    return {"copy_GBs": 2.0 * n / t_copy / 1e9, "read_GBs": n / t_read / 1e9, "buffer_GB": n / 1e9,
+            "how": "oa_probe_copy / oa_probe_read: 16-byte grid-stride accesses, mean of %d launches timed with HIP events in this run" % reps}
+
+
 # --------------------------------------------------------------------------------------------------------------
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40, help="timed steps; ONE STEP = one batch of --batch independent maps through the whole path")
-    ap.add_argument("--warmup", type=int, default=4, help="untimed steps (batches) before the timed region")
-    ap.add_argument("--batch", type=int, default=64, help="maps per step: a shard of independent realisations resident in HBM, each one "
-                    "map -> kappa_hat -> bandpowers -> moments (SURVEY 8e: the unit a GPU is handed in the Monte-Carlo job)")
-    ap.add_argument("--n", type=int, default=8192, help="map side (default 8192, the metric's size)")
-    ap.add_argument("--res", type=float, default=0.5)
-    ap.add_argument("--prec", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--tlmax", type=float, default=2000.0, help="upper ell of the T filter (SURVEY 8d: 2000; high-res variant 6000)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-prune", action="store_true",
-                    help="process all nx/2+1 columns of every plane even where the band-limited filters vanish")
-    ap.add_argument("--trace-steps", action="store_true", help="stderr: throughput per 20 timed steps (diagnostic)")
-    ap.add_argument("--preroll", type=float, default=1.5, help="seconds of untimed load before the warm-up steps (clock ramp)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the side legs reported under 'extra' (never the headline value)")
-    ap.add_argument("--extras", default="fullres_rows,dense,bandlimited,f64,wideband", help="comma list of side legs to run")
-    ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
-                    help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
-                         "(exact for band-limited filters; library default), full = the map's nx points")
-    ap.add_argument("--no-pair", action="store_true", help="one realisation per C-ABI call (oa_qe_tt_moments) instead of two (oa_qe_tt_moments2)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams: independent realisations are issued round-robin "
-                    "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
-    args = ap.parse_args()
+def map_usage(nsteps, nmaps, pair):
+    """how often each resident map is reconstructed by Runner.run(0, nsteps) (the timed region)"""
+    use = np.zeros(nmaps, dtype=np.int64)
+    if not pair:
+        for i in range(nsteps):
+            use[i % nmaps] += 1
+        return use
+    for c in range(nsteps // 2):
+        use[(2 * c) % nmaps] += 1
+        use[(2 * c + 1) % nmaps] += 1
+    if nsteps & 1:
+        use[(nsteps - 1) % nmaps] += 1
+    return use
 
-    world, rank, local_rank, spawn = resolve_world(args.gpus, os.environ)
-    if spawn:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
-    import torch
-    import torch.distributed as dist
-
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    backend = os.environ.get("OA_BENCH_BACKEND", "nccl")      # "gloo": rehearse the N>1 path on a box with fewer GPUs
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
-
+def measure(args, torch, dist, world, rank, prec):
+    """The job in one precision: resident batch, pre-roll, warm-up, EXACTLY K timed steps bracketed by barrier +
+    synchronize, moment-counter and bandpower checks, then (rank 0) the per-kernel table and the roofline object."""
     N = args.n
-    P = build_pipeline(N, args.res, args.prec, torch, prune=not args.no_prune, tlmax=args.tlmax, row_grid=args.row_grid)
+    P = build_pipeline(N, args.res, prec, torch, prune=not args.no_prune, tlmax=args.tlmax, row_grid=args.row_grid)
     q, eng = P["q"], P["eng"]
+    es = 4 if prec == "f32" else 8
     seed = 1234 + rank                                    # distinct realisations per rank
     B = max(1, args.batch)
     # the batch is resident in HBM before the timed region: B distinct maps (fewer, cycled, if B of them would not leave
-    # room: 16384^2 maps are 1.07 GB each)
-    nmaps = max(2, min(B, int(32e9 // (4.0 * N * N))))
+    # room: 16384^2 f64 maps are 2.1 GB each)
+    nmaps = max(2, min(B, int(32e9 // (float(es) * N * N))))
     tmaps = make_maps(P, torch, seed, nmaps)
     R = Runner(P, torch, tmaps, args.streams, pair=not args.no_pair)
     ns = R.ns
@@ -572,6 +615,7 @@ def main():
         sys.stderr.write("event span first->last step end: %.2f ms; wall to issue %.2f ms\n" % (ts[-1], t_issue * 1e3))
         for a in range(0, len(ts) - 20, 20):
             sys.stderr.write("steps %4d-%4d: %.1f recon/s\n" % (a, a + 20, 20.0 / max(ts[a + 20] - ts[a], 1e-9) * 1e3))
+    loc_n, loc_S = int(sum(R.mom_n).item()), sum(R.mom_S).clone()      # this rank's part, for the bandpower check below
     mom_n, mom_S, mom_C = sum(R.mom_n), sum(R.mom_S), sum(R.mom_C)     # per-stream accumulators
     if world > 1:
         # the ensemble reduce of Statistics.allreduce (stats.py:1209-1230): n, sum, cross
@@ -588,88 +632,202 @@ def main():
         elapsed = float(t.item())
     total = int(mom_n.item())
     assert total == args.steps * B * max(world, 1), "moment counter %d != steps x batch x ranks" % total
+    # the timed region really produced the bandpowers: its accumulated sum equals the usage-weighted sum of the per-map
+    # bandpowers computed through the fine-grained public calls (same kernels, one map at a time)
+    use = map_usage(args.steps * B, len(tmaps), R.pair and not args.trace_steps)
+    assert int(use.sum()) == loc_n
+    check_maps = [i for i in range(len(tmaps)) if use[i]]
+    if len(check_maps) > args.check_maps:        # bounded: a spread of the batch (the S comparison then uses the accumulator of a re-run)
+        check_maps = check_maps[:: max(1, len(check_maps) // args.check_maps)][:args.check_maps]
+    per_map = {i: R.bandpowers(i).double() for i in check_maps}
+    if len(check_maps) == int((use > 0).sum()):
+        want = sum(per_map[i] * float(use[i]) for i in check_maps)
+        dev = float(((loc_S / want) - 1).abs().max().item())
+        assert dev < (1e-9 if prec == "f64" else 2e-6), "timed-region bandpower sum differs from the per-map bandpowers: %g" % dev
+    else:
+        # one extra (untimed) pass over the checked maps through the SAME one-call entry
+        R.zero()
+        for i in check_maps:
+            with torch.cuda.stream(R.streams[0]):
+                R.qs[0].tt_moments(tmaps[i], R.mom_n[0], R.mom_S[0], R.mom_C[0])
+        torch.cuda.synchronize()
+        want = sum(per_map[i] for i in check_maps)
+        dev = float(((R.mom_S[0] / want) - 1).abs().max().item())
+        assert dev < (1e-9 if prec == "f64" else 2e-6), "one-call bandpowers differ from the fine-grained path: %g" % dev
+    res = {"prec": prec, "P": P, "R": R, "tmaps": tmaps, "seed": seed, "total": total, "elapsed": elapsed, "t_issue": t_issue,
+           "value": total / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "bandpower_check": {"maps_checked": len(check_maps), "max_rel_dev": dev,
+           "how": "accumulated S of the timed one-call path vs the usage-weighted per-map bandpowers of the fine-grained public calls"},
+           "mean_bandpowers": (mom_S / float(total)).cpu().numpy().tolist()}
+    if rank != 0:
+        return res
+    per, G = per_kernel_table(torch, P, R, args)
+    A, W = G["A"], G["W"]
+    share = {k: v["avg_ms"] for k, v in per.items()}
+    dom = max(share, key=share.get)
+    rate = total / elapsed / max(world, 1)
+    traffic_tab = None
+    if N == 8192 and args.tlmax == 2000.0:      # PMC traffic exists for the profiled configurations
+        suf = "_dense" if args.no_prune else ("_fullrows" if args.row_grid == "full" else "")
+        traffic_tab = load_profile_json("traffic_%s_%s%s.json" % (PROFILE_TAG, prec, suf))
+    short = dom.split(" ")[0]
+    traffic = (traffic_tab or {}).get(short)
+    d = per[dom]
+    vpeak = VALU_PEAK_TFLOPS if prec == "f32" else VALU_PEAK_TFLOPS / 2.0       # f64 vector rate = half the packed-f32 rate
+    ridge = vpeak * 1e12 / (HBM_PEAK_GBS * 1e9)
+    if "TFLOPs" in d and d["arithmetic_intensity_flop_per_B"] > ridge:
+        roofline = {"bound": "valu", "kernel": dom, "achieved": d["TFLOPs"], "peak": vpeak, "unit": "TFLOP/s",
+                    "frac": d["TFLOPs"] / vpeak, "traffic": traffic, "flops_per_launch": d["executed_GFLOP"] * 1e9,
+                    "flop_count": d["flop_count"], "arithmetic_intensity_flop_per_B": d["arithmetic_intensity_flop_per_B"],
+                    "ridge_flop_per_B": ridge, "hbm_bytes_per_launch": d["hbm_min_GB"] * 1e9, "hbm_frac_on_those_bytes": d["hbm_frac"],
+                    "note": "the fused row stage (3 C2R + 2 products + 2 R2C per row in LDS/registers) moves %.2f GB per launch and executes "
+                            "%.1f GFLOP: arithmetic intensity above the ridge -> priced against the %s vector peak on the arithmetic "
+                            "it executes (pruned taps not counted)" % (d["hbm_min_GB"], d["executed_GFLOP"], prec)}
+    else:
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": d["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": d["hbm_frac"], "traffic": traffic, "bytes_per_launch": d["hbm_min_GB"] * 1e9,
+                    "note": "achieved = ALGORITHMIC bytes of the launch (inputs + outputs on its active columns/rows: the whole map read once + "
+                            "the kept columns written) / live HIP-event duration inside the step sequence; traffic = PMC bytes of the same "
+                            "launch from profiles/traffic_%s_%s.json (separate rocprofv3 --pmc runs of this command, not measured in this run)" % (PROFILE_TAG, prec)}
+    assert roofline["frac"] <= 1.0, "roofline fraction %g > 1: byte/flop model is wrong" % roofline["frac"]
+    if dom.startswith("row_fft_kernel<R2C>"):
+        # the stage name above is bench.py's; the launch behind it, as rocprofv3 lists it (fft.hip HipLauncher::row_w64)
+        wl_ = G["wl"] or W
+        w64 = os.environ.get("OA_R2C_W64", "1") != "0" and prec == "f32"
+        roofline["kernel_symbol"] = ("row_r2c_w64_kernel" if (w64 and N == 8192 and wl_ <= 512) else
+                                     "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel<%s, R2C>" % ("float" if prec == "f32" else "double"))
+    roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
+    roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
+                            "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}
+    roofline["col_grid"] = {"rows": G["mcol"] or N, "of": N, "note": "the same argument along y: inverse column transforms of the legs, row stage "
+                            "and forward column transforms of the products run on the smallest alias-free power-of-two number of rows "
+                            ">= max(2 leg_rows + kappa_rows, 2 kappa_rows) (exact; include/orphics_amd.h COLUMN GRID); extra.fullres_rows "
+                            "is the same job with both grids at the map's own resolution"}
+    roofline["active_rows"] = {"legs": (2 * G["rl"] - 1) if G["rl"] else N, "kappa": (2 * G["rk"] - 1) if G["rk"] else N, "of": N}
+    roofline["share_of_recon_ms"] = share
+    roofline["per_kernel"] = per
+    roofline["pmc_traffic_bytes_per_launch"] = {k: v for k, v in (traffic_tab or {}).items() if not k.startswith("_")} or None
+    if traffic_tab:
+        for k, v in per.items():           # real (PMC) bytes / live duration for every kernel of the step
+            b = traffic_tab.get(k.split(" ")[0])
+            if b:
+                v["pmc_GB"] = b / 1e9
+                v["pmc_GBs"] = b / (v["avg_ms"] * 1e-3) / 1e9
+                v["pmc_hbm_frac"] = v["pmc_GBs"] / HBM_PEAK_GBS
+    hbm = {"peak_GBs": HBM_PEAK_GBS,
+           "kernels_on_own_bytes": {k: {"GBs": v["hbm_GBs"], "frac": v["hbm_frac"]} for k, v in per.items() if "hbm_GBs" in v and k != "row_qe_kernel"},
+           "survey_8d_bytes_per_recon_dense": 37.25 * A}
+    if traffic_tab and traffic_tab.get("bytes_per_recon"):
+        # every launch of a reconstruction together: PMC bytes through the L2 <-> fabric interface x reconstructions/s.
+        # (Kernel boundaries flush the per-XCD L2s, so every intermediate plane makes the round trip even when the
+        # infinity cache holds it.)
+        bpr = float(traffic_tab["bytes_per_recon"])
+        hbm["whole_pipeline_on_pmc_bytes"] = {"bytes_per_recon": bpr, "GBs": bpr * rate / 1e9, "frac": bpr * rate / 1e9 / HBM_PEAK_GBS,
+                                              "pmc_source": "profiles/traffic_%s_%s.json (not measured in this run)" % (PROFILE_TAG, prec)}
+    res.update({"roofline": roofline, "hbm": hbm, "G": G, "per": per, "A": A, "W": W})
+    return res
 
-    if rank == 0:
-        per, G = per_kernel_table(torch, P, R, args)
-        A, W = G["A"], G["W"]
-        share = {k: v["avg_ms"] for k, v in per.items()}
-        dom = max(share, key=share.get)
-        rate = total / elapsed / max(world, 1)
-        traffic_tab = None
-        if N == 8192 and args.prec == "f32" and args.tlmax == 2000.0:      # PMC traffic exists for the profiled configurations
-            suf = "_dense" if args.no_prune else ("_fullrows" if args.row_grid == "full" else "")
-            traffic_tab = load_profile_json("traffic_%s%s.json" % (PROFILE_TAG, suf))
-        short = dom.split(" ")[0]
-        traffic = (traffic_tab or {}).get(short)
-        d = per[dom]
-        ridge = VALU_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-        if "TFLOPs" in d and d["arithmetic_intensity_flop_per_B"] > ridge:
-            roofline = {"bound": "valu", "kernel": dom, "achieved": d["TFLOPs"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": d["valu_frac"], "traffic": traffic, "flops_per_launch": d["executed_GFLOP"] * 1e9,
-                        "flop_count": d["flop_count"], "arithmetic_intensity_flop_per_B": d["arithmetic_intensity_flop_per_B"],
-                        "ridge_flop_per_B": ridge, "hbm_bytes_per_launch": d["hbm_min_GB"] * 1e9, "hbm_frac_on_those_bytes": d["hbm_frac"],
-                        "note": "the fused row stage (3 C2R + 2 products + 2 R2C per row in LDS/registers) moves %.2f GB per launch and executes "
-                                "%.1f GFLOP: arithmetic intensity above the ridge -> priced against the f32 vector peak on the arithmetic "
-                                "it executes (pruned taps not counted)" % (d["hbm_min_GB"], d["executed_GFLOP"])}
-        else:
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": d["hbm_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": d["hbm_frac"], "traffic": traffic, "bytes_per_launch": d["hbm_min_GB"] * 1e9,
-                        "note": "achieved = bytes the kernel must move once (inputs + outputs on its active columns/rows) / live HIP-event duration"}
-        assert roofline["frac"] <= 1.0, "roofline fraction %g > 1: byte/flop model is wrong" % roofline["frac"]
-        if dom.startswith("row_fft_kernel<R2C>"):
-            # the stage name above is bench.py's; the launch behind it, as rocprofv3 lists it (fft.hip HipLauncher::row_w64)
-            wl_ = G["wl"] or W
-            w64 = os.environ.get("OA_R2C_W64", "1") != "0" and args.prec == "f32"
-            roofline["kernel_symbol"] = ("row_r2c_w64_kernel" if (w64 and N == 8192 and wl_ <= 512) else
-                                         "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel")
-        roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
-        roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
-                                "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}
-        roofline["col_grid"] = {"rows": G["mcol"] or N, "of": N, "note": "the same argument along y: inverse column transforms of the legs, row stage "
-                                "and forward column transforms of the products run on the smallest alias-free power-of-two number of rows "
-                                ">= max(2 leg_rows + kappa_rows, 2 kappa_rows) (exact; include/orphics_amd.h COLUMN GRID); extra.fullres_rows "
-                                "is the same job with both grids at the map's own resolution"}
-        roofline["active_rows"] = {"legs": (2 * G["rl"] - 1) if G["rl"] else N, "kappa": (2 * G["rk"] - 1) if G["rk"] else N, "of": N}
-        roofline["share_of_recon_ms"] = share
-        roofline["per_kernel"] = per
-        roofline["pmc_traffic_bytes_per_launch"] = {k: v for k, v in (traffic_tab or {}).items() if not k.startswith("_")} or None
-        if traffic_tab:
-            for k, v in per.items():           # real (PMC) bytes / live duration for every kernel of the step
-                b = traffic_tab.get(k.split(" ")[0])
-                if b:
-                    v["pmc_GB"] = b / 1e9
-                    v["pmc_GBs"] = b / (v["avg_ms"] * 1e-3) / 1e9
-                    v["pmc_hbm_frac"] = v["pmc_GBs"] / HBM_PEAK_GBS
-        out = {
-            "metric": "QE kappa reconstructions/sec on %d^2 maps" % N,
-            "value": total / elapsed, "unit": "reconstructions/s", "n_gpus": world, "world_size": (dist.get_world_size() if world > 1 else 1),
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "host_issue_ms_per_step": t_issue / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+
+def block_of(args, res, world, dist):
+    """the JSON fields of one precision's measurement"""
+    R, P = res["R"], res["P"]
+    N = args.n
+    return {"value": res["value"], "unit": "reconstructions/s", "dtype": res["prec"], "ms_per_step": res["ms_per_step"],
+            "host_issue_ms_per_step": res["t_issue"] / args.steps * 1e3, "reconstructions_timed": res["total"],
+            "bandpower_check": res["bandpower_check"],
             "config": {"workload": "TT quadratic estimator (lensing.Estimator) on %dx%d %.2f-arcmin flat-sky GRF maps, "
                                    "incl. R2C of the input map and 19-bin kappa auto-bandpowers; T filter ell in (300,%d), "
                                    "kappa mask (20,3500), 1.5' beam, 1 uK' noise" % (N, N, args.res, int(args.tlmax)),
                        "map_side": N, "res_arcmin": args.res, "estimator": "TT", "nbins": R.d,
-                       "maps_per_step": B, "distinct_resident_maps": len(tmaps),
-                       "streams_per_gpu": ns, "realisations_per_call": 2 if R.pair else 1,
+                       "maps_per_step": max(1, args.batch), "distinct_resident_maps": len(res["tmaps"]),
+                       "streams_per_gpu": R.ns, "realisations_per_call": 2 if R.pair else 1,
                        "parallelism": "independent realisations per GPU + 1 all-reduce of bandpower moments"},
-            "roofline": roofline,
-        }
-        hbm = {"peak_GBs": HBM_PEAK_GBS,
-               "kernels_on_own_bytes": {k: {"GBs": v["hbm_GBs"], "frac": v["hbm_frac"]} for k, v in per.items() if "hbm_GBs" in v and k != "row_qe_kernel"},
-               "survey_8d_bytes_per_recon_dense": 37.25 * A}
-        if traffic_tab and traffic_tab.get("bytes_per_recon"):
-            # every launch of a reconstruction together: PMC bytes through the L2 <-> fabric interface x reconstructions/s.
-            # (Kernel boundaries flush the per-XCD L2s, so every intermediate plane makes the round trip even when the
-            # infinity cache holds it; a plain device copy moves 5.4 TB/s through the same interface: tools/hbm_read_probe.py.)
-            bpr = float(traffic_tab["bytes_per_recon"])
-            hbm["whole_pipeline_on_pmc_bytes"] = {"bytes_per_recon": bpr, "GBs": bpr * rate / 1e9, "frac": bpr * rate / 1e9 / HBM_PEAK_GBS,
-                                                  "plain_copy_GBs_on_this_part": 5400.0}
+            "roofline": res.get("roofline"), "hbm": res.get("hbm")}
+
+
+def release(res, torch):
+    for k in ("R", "P", "tmaps"):
+        res.pop(k, None)
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40, help="timed steps; ONE STEP = one batch of --batch independent maps through the whole path")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps (batches) before the timed region")
+    ap.add_argument("--batch", type=int, default=64, help="maps per step: a shard of independent realisations resident in HBM, each one "
+                    "map -> kappa_hat -> bandpowers -> moments (SURVEY 8e: the unit a GPU is handed in the Monte-Carlo job)")
+    ap.add_argument("--n", type=int, default=8192, help="map side (default 8192, the metric's size)")
+    ap.add_argument("--res", type=float, default=0.5)
+    ap.add_argument("--prec", default="f64", choices=["f32", "f64"], help="precision of the HEADLINE (value, roofline): f64 = the reference's "
+                    "arithmetic (float64 maps, complex128 transforms: maps.py:1613)")
+    ap.add_argument("--also", default="auto", choices=["auto", "none", "f32", "f64"], help="second, equally complete measurement reported as a "
+                    "top-level block named after its precision (auto: the other precision)")
+    ap.add_argument("--tlmax", type=float, default=2000.0, help="upper ell of the T filter (SURVEY 8d: 2000; high-res variant 6000)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-prune", action="store_true",
+                    help="process all nx/2+1 columns of every plane even where the band-limited filters vanish")
+    ap.add_argument("--trace-steps", action="store_true", help="stderr: throughput per 20 timed steps (diagnostic)")
+    ap.add_argument("--preroll", type=float, default=1.5, help="seconds of untimed load before the warm-up steps (clock ramp)")
+    ap.add_argument("--check-maps", type=int, default=64, help="resident maps whose bandpowers are recomputed through the fine-grained calls "
+                    "and compared with the timed region's accumulated sum")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side legs reported under 'extra' (never the headline value)")
+    ap.add_argument("--extras", default="fullres_rows,dense,bandlimited,wideband,lensed_loop", help="comma list of side legs to run")
+    ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
+                    help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
+                         "(exact for band-limited filters; library default), full = the map's nx points")
+    ap.add_argument("--no-pair", action="store_true", help="one realisation per C-ABI call (oa_qe_tt_moments) instead of two (oa_qe_tt_moments2)")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams: independent realisations are issued round-robin "
+                    "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
+    args = ap.parse_args()
+
+    world, rank, local_rank, spawn = resolve_world(args.gpus, os.environ)
+    if spawn:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    backend = os.environ.get("OA_BENCH_BACKEND", "nccl")      # "gloo": rehearse the N>1 path on a box with fewer GPUs
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
+
+    N = args.n
+    other = {"auto": "f32" if args.prec == "f64" else "f64", "none": None}.get(args.also, args.also)
+    if other == args.prec:
+        other = None
+    head = measure(args, torch, dist, world, rank, args.prec)
+    out = None
+    if rank == 0:
+        blk = block_of(args, head, world, dist)
+        out = {"metric": "QE kappa reconstructions/sec on %d^2 maps" % N,
+               "value": blk["value"], "unit": blk["unit"], "n_gpus": world, "world_size": (dist.get_world_size() if world > 1 else 1),
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": blk["ms_per_step"],
+               "host_issue_ms_per_step": blk["host_issue_ms_per_step"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.prec, "data": "synthetic",
+               "config": blk["config"], "roofline": blk["roofline"], "bandpower_check": blk["bandpower_check"]}
+        hbm = blk["hbm"]
+        if world == 1:
+            hbm["measured_streaming_ceiling"] = bandwidth_ceiling(torch)
+        A, W = head["A"], head["W"]
+        R, P, tmaps, seed = head["R"], head["P"], head["tmaps"], head["seed"]
         if world == 1 and not args.no_extras and not args.no_prune:
             want = [w for w in args.extras.split(",") if w]
             ref_p1d = R.bandpowers(0)
             extra = {}
-            G = dict(G)
+            G = dict(head["G"])
             if "fullres_rows" in want and G["mrow"] < N:
                 leg, _, Pf, Rf = side_leg(torch, args, "fullres_rows", ref_p1d, seed, tlmax=args.tlmax, row_grid="full")
                 perf, _ = per_kernel_table(torch, Pf, Rf, args)
@@ -686,7 +844,7 @@ def main():
                 leg["note"] = "prune=False: all nx/2+1 columns of every plane are transformed (filters without a band limit)"
                 leg["pipeline_GBs_on_survey_37.25A"] = 37.25 * A * rd / 1e9
                 leg["pipeline_frac_of_hbm_peak_on_survey_37.25A"] = 37.25 * A * rd / 1e9 / HBM_PEAK_GBS
-                dense_pmc = (load_profile_json("traffic_%s_dense.json" % PROFILE_TAG) or {}).get("bytes_per_recon") if N == 8192 and args.prec == "f32" else None
+                dense_pmc = (load_profile_json("traffic_%s_%s_dense.json" % (PROFILE_TAG, args.prec)) or {}).get("bytes_per_recon") if N == 8192 else None
                 if dense_pmc:
                     leg["pmc_bytes_per_recon"] = dense_pmc
                     leg["pipeline_GBs_on_pmc_bytes"] = dense_pmc * rd / 1e9
@@ -697,12 +855,6 @@ def main():
             if "bandlimited" in want:
                 extra["bandlimited"] = bandlimited_leg(P, args, torch, tmaps, ref_p1d)
                 torch.cuda.empty_cache()
-            if "f64" in want and args.prec == "f32":
-                leg, _, _, _ = side_leg(torch, args, "f64", ref_p1d, seed, prec="f64", tlmax=args.tlmax)
-                leg["note"] = "the same job through the float64 / complex128 kernels (the reference's arithmetic type, maps.py:1613); " \
-                              "max_rel_bandpower_diff = f32 headline vs this leg on the same map"
-                extra["f64"] = leg
-                torch.cuda.empty_cache()
             if "wideband" in want and args.tlmax < 6000.0:
                 leg, p_w, Pw, Rw = side_leg(torch, args, "wideband", None, seed, tlmax=6000.0)
                 leg["active_columns"] = {"legs": Pw["q"].leg_cols or W, "kappa": Pw["q"].kappa_cols or W, "of": W}
@@ -712,14 +864,32 @@ def main():
                 leg["row_qe_valu_frac"] = perw["row_qe_kernel"]["valu_frac"]
                 del Rw, Pw, perw
                 torch.cuda.empty_cache()
-                if "f64" in want and args.prec == "f32":
-                    leg64, _, _, _ = side_leg(torch, args, "wideband64", p_w, seed, prec="f64", tlmax=6000.0)
-                    leg["max_rel_bandpower_diff_vs_f64"] = leg64["max_rel_bandpower_diff"]
-                    leg["f64_reconstructions_per_s"] = leg64["reconstructions_per_s"]
+                if other:
+                    leg2, _, _, _ = side_leg(torch, args, "wideband_" + other, p_w, seed, prec=other, tlmax=6000.0)
+                    leg["max_rel_bandpower_diff_vs_%s" % other] = leg2["max_rel_bandpower_diff"]
+                    leg["%s_reconstructions_per_s" % other] = leg2["reconstructions_per_s"]
                 extra["wideband"] = leg
+                torch.cuda.empty_cache()
+            if "lensed_loop" in want:
+                try:
+                    extra["lensed_loop"] = lensed_loop_leg(torch, args)
+                except Exception as ex:      # a side leg never takes the headline down
+                    extra["lensed_loop"] = {"error": repr(ex)}
                 torch.cuda.empty_cache()
             out["extra"] = extra
         out["hbm"] = hbm
+    ref_head = head["R"].bandpowers(0).double().cpu() if rank == 0 else None
+    release(head, torch)
+    if other:
+        sec = measure(args, torch, dist, world, rank, other)
+        if rank == 0:
+            blk2 = block_of(args, sec, world, dist)
+            blk2["max_rel_bandpower_diff_vs_%s" % args.prec] = float((sec["R"].bandpowers(0).double().cpu() / ref_head - 1).abs().max().item())
+            blk2["note"] = "the same job, same maps (the GRF draw depends only on (seed, index)), through the %s kernels: its own timed " \
+                           "region of K steps, roofline and per-kernel table" % other
+            out[other] = blk2
+        release(sec, torch)
+    if rank == 0:
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, args.res)
         print(json.dumps(out))

@@ -294,6 +294,16 @@ int oa_qe_div(oa_plan* p, const void* Px, const void* Py, const void* Fnorm, voi
 int oa_lens_split(int dtype, const void* alpha, double step, int32_t* shift, void* delta, long n, void* stream);
 int oa_lens_gather(oa_plan* p, const void* src, const int32_t* shift_x, const int32_t* shift_y, const void* dx, const void* dy,
                    int pow_x, int pow_y, double coef, void* out, int accumulate, void* stream);
+/* The same Taylor series with every term of every order in two launches instead of one derivative kernel, one C2R and
+ * one gather per term (lensing.py:395-440; order 5 = 14 terms per map):
+ *  oa_hc_derivs   : hc_out_planes[idx(a, b)] = (i lx)^a (i ly)^b hc_in for 1 <= a + b < order, idx(a, b) = n (n + 1) / 2 - 1 + b,
+ *                   n = a + b, planes plane_stride complex elements apart (order (order + 1) / 2 - 1 of them).
+ *  oa_lens_taylor : out = sum_{a + b < order} dx^a dy^b / (a! b!) D_ab[(y + shift_y) % ny, (x + shift_x) % nx] with D_00 = src
+ *                   and D_ab the REAL planes (the C2R of the planes above, normalised) in the same order, plane_stride
+ *                   real elements apart.  shift / dx / dy as produced by oa_lens_split. */
+int oa_hc_derivs(oa_plan* p, const void* hc_in, int order, void* hc_out_planes, long plane_stride, void* stream);
+int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long plane_stride, int order, const int32_t* shift_x,
+                   const int32_t* shift_y, const void* dx, const void* dy, void* out, void* stream);
 
 /* ---- radial binning (stats.bin2D, stats.py:782-811) ------------------------
  * oa_digitize : ids[i] = np.digitize(x[i], edges, right=True) (stats.py:786):
@@ -357,6 +367,13 @@ int oa_moments_add(const double* x, int d, int64_t* n, double* S, double* C, voi
 int oa_moments_add_binned(const double* sums, const int64_t* counts, int d, int64_t* n, double* S, double* C, void* stream);
 /* stack accumulation (Statistics.add_stack, stats.py:1124-1150): acc(f64) += x (dtype) */
 int oa_stack_add(int dtype, const void* x, double* acc, long n, void* stream);
+
+/* ---- measurement helpers -------------------------------------------------------
+ * Streaming device copy / read of `bytes` (a multiple of 16) with 16-byte accesses: the bandwidth ceiling bench.py
+ * measures in the same run as the kernels it prices against it.  `sink`: >= 8 MiB of device scratch (one word per
+ * thread of the read probe). */
+int oa_probe_copy(void* dst, const void* src, size_t bytes, void* stream);
+int oa_probe_read(const void* src, size_t bytes, void* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ SIGNATURES = {
     "oa_qe_div": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "oa_lens_split": (c_int, [c_int, c_void_p, c_double, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_lens_gather": (c_int, [c_void_p] * 6 + [c_int, c_int, c_double, c_void_p, c_int, c_void_p]),
+    "oa_hc_derivs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
+    "oa_lens_taylor": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_digitize": (c_int, [c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p]),
     "oa_modl_digitize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "oa_bin_scratch_bytes": (c_long, [c_int]),
@@ -93,6 +95,8 @@ SIGNATURES = {
     "oa_moments_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_moments_add_binned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_stack_add": (c_int, [c_int, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_probe_copy": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
+    "oa_probe_read": (c_int, [c_void_p, ctypes.c_size_t, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -337,6 +337,87 @@ __global__ __launch_bounds__(256) void lens_gather_kernel(const T* __restrict__ 
     out[i] = accumulate ? out[i] + v : v;
 }
 
+
+// All Fourier-space derivatives of one map for the Taylor series of the lensing op in ONE pass over its transform:
+// plane idx(a, b) = n (n + 1) / 2 - 1 + b, n = a + b = 1 .. order - 1, holds (i lx)^a (i ly)^b k  (derivative axes: the
+// self-conjugate Nyquist row / column carries no odd derivative).  14 planes for the reference's order 5.
+template <typename T>
+__global__ __launch_bounds__(256) void hc_derivs_kernel(const cx<T>* __restrict__ in, cx<T>* __restrict__ out, long ostride,
+                                                        const T* __restrict__ lxd, const T* __restrict__ lyd, int nxh, long kp,
+                                                        int order) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x > nxh) return;
+    const long i = (long)y * kp + x;
+    const cx<T> k = in[i];
+    const T lx = lxd[x], ly = lyd[y];
+    cx<T> kn = k;                                 // i^n k
+    T xp[8];                                      // lx^a
+    xp[0] = (T)1;
+    for (int n = 1; n < order; ++n) {
+        kn = mul_pi(kn);
+        xp[n] = xp[n - 1] * lx;
+        T yb = (T)1;                              // ly^b
+        cx<T>* o = out + (long)(n * (n + 1) / 2 - 1) * ostride + i;
+        for (int b = 0; b <= n; ++b) {
+            o[(long)b * ostride] = kn * (xp[n - b] * yb);
+            yb *= ly;
+        }
+    }
+}
+
+// flat_taylens in one gather pass: out = sum_{a + b < order} dx^a dy^b / (a! b!) D_ab[(y + sy) % ny, (x + sx) % nx], D_00 = src
+// and D_ab (n >= 1) = real plane idx(a, b) of `planes` (the C2R of hc_derivs_kernel's output).
+template <typename T>
+__global__ __launch_bounds__(256) void lens_taylor_kernel(const T* __restrict__ src, const T* __restrict__ planes, long pstride,
+                                                          int order, const int* __restrict__ sx, const int* __restrict__ sy,
+                                                          const T* __restrict__ dx, const T* __restrict__ dy, T* __restrict__ out,
+                                                          int ny, int nx) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const long i = (long)y * nx + x;
+    int xs = (x + sx[i]) % nx, ys = (y + sy[i]) % ny;
+    if (xs < 0) xs += nx;
+    if (ys < 0) ys += ny;
+    const long g = (long)ys * nx + xs;
+    const T ddx = dx[i], ddy = dy[i];
+    T acc = src[g];
+    T xa[8];                                      // dx^a / a!
+    xa[0] = (T)1;
+    for (int n = 1; n < order; ++n) {
+        xa[n] = xa[n - 1] * ddx / (T)n;
+        T yb = (T)1;                              // dy^b / b!
+        const T* pl = planes + (long)(n * (n + 1) / 2 - 1) * pstride + g;
+        for (int b = 0; b <= n; ++b) {
+            acc += pl[(long)b * pstride] * (xa[n - b] * yb);
+            yb = yb * ddy / (T)(b + 1);
+        }
+    }
+    out[i] = acc;
+}
+
+// ---- HBM bandwidth probes (bench.py: the ceiling the roofline fractions are read against, measured in the same run) -----
+// 16-byte accesses, grid-stride, the layout of the guide's float4 copy; the read probe keeps a per-thread checksum so the
+// loads cannot be elided and writes one word per thread at the end.
+__global__ __launch_bounds__(256) void probe_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+typedef unsigned oa_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void probe_read_kernel(const oa_u4* __restrict__ src, unsigned* __restrict__ sink, long n16) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    oa_u4 acc = {0u, 0u, 0u, 0u};
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {          // four independent 16-byte loads in flight per thread
+        const oa_u4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const oa_u4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < n16; i += stride) acc ^= src[i];
+    sink[(long)blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 }  // namespace oa
 
 namespace oa {
@@ -576,6 +657,38 @@ int oa_lens_gather(oa_plan* p, const void* src, const int32_t* shift_x, const in
     return 0;
 }
 
+int oa_hc_derivs(oa_plan* p, const void* hc_in, int order, void* hc_out_planes, long plane_stride, void* stream) {
+    OA_REQUIRE(p && hc_in && hc_out_planes, "oa_hc_derivs: NULL argument");
+    OA_REQUIRE(p->have_laxes, "oa_hc_derivs: call oa_plan_set_laxes first");
+    OA_REQUIRE(order >= 2 && order <= 8, "oa_hc_derivs: order must be 2..8");
+    OA_REQUIRE(plane_stride >= (long)p->ny * p->kp, "oa_hc_derivs: plane_stride smaller than a plane");
+    hipStream_t st = (hipStream_t)stream;
+    const int nxh = p->nx / 2;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(hc_derivs_kernel<float>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<float>*)hc_in,
+                                (cx<float>*)hc_out_planes, plane_stride, (const float*)p->lxd, (const float*)p->lyd, nxh, p->kp, order),
+             hipLaunchKernelGGL(hc_derivs_kernel<double>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<double>*)hc_in,
+                                (cx<double>*)hc_out_planes, plane_stride, (const double*)p->lxd, (const double*)p->lyd, nxh, p->kp, order));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long plane_stride, int order, const int32_t* shift_x,
+                   const int32_t* shift_y, const void* dx, const void* dy, void* out, void* stream) {
+    OA_REQUIRE(p && src && shift_x && shift_y && dx && dy && out, "oa_lens_taylor: NULL argument");
+    OA_REQUIRE(order >= 1 && order <= 8 && (order == 1 || deriv_planes), "oa_lens_taylor: order must be 1..8 (derivative planes for order > 1)");
+    OA_REQUIRE(order == 1 || plane_stride >= (long)p->ny * p->nx, "oa_lens_taylor: plane_stride smaller than a plane");
+    OA_REQUIRE(src != out, "oa_lens_taylor: in-place not supported");
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH(p->dtype,
+             hipLaunchKernelGGL(lens_taylor_kernel<float>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const float*)src, (const float*)deriv_planes,
+                                plane_stride, order, shift_x, shift_y, (const float*)dx, (const float*)dy, (float*)out, p->ny, p->nx),
+             hipLaunchKernelGGL(lens_taylor_kernel<double>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const double*)src, (const double*)deriv_planes,
+                                plane_stride, order, shift_x, shift_y, (const double*)dx, (const double*)dy, (double*)out, p->ny, p->nx));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
 int oa_qe_legs(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* Gx, void* Gy, void* H,
                int phase_g, int phase_h, int h_times_i, void* stream) {
     OA_REQUIRE(p && kX && kY && FG && FH && Gx && Gy && H, "oa_qe_legs: NULL argument");
@@ -609,6 +722,23 @@ int oa_qe_div(oa_plan* p, const void* Px, const void* Py, const void* Fnorm, voi
              hipLaunchKernelGGL(qe_div_kernel<double>, PLANE_GRID(p, nxh + 1), dim3(256), 0, st, (const cx<double>*)Px,
                                 (const cx<double>*)Py, (const double*)Fnorm, (cx<double>*)out, (const double*)p->lxd,
                                 (const double*)p->lyd, nxh, p->kp, accumulate));
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
+/* Bandwidth probes: device copy / read of `bytes` (multiple of 16) with 16-byte accesses.  `sink` (read probe): at least
+ * 4 * 256 * 8192 bytes of scratch. */
+int oa_probe_copy(void* dst, const void* src, size_t bytes, void* stream) {
+    OA_REQUIRE(dst && src && bytes % 16 == 0, "oa_probe_copy: bad argument");
+    const long n16 = (long)(bytes / 16);
+    hipLaunchKernelGGL(probe_copy_kernel, dim3(flat_grid(n16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+int oa_probe_read(const void* src, size_t bytes, void* sink, void* stream) {
+    OA_REQUIRE(src && sink && bytes % 16 == 0, "oa_probe_read: bad argument");
+    const long n16 = (long)(bytes / 16);
+    hipLaunchKernelGGL(probe_read_kernel, dim3(flat_grid(n16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const oa_u4*)src, (unsigned*)sink, n16);
     OA_LAUNCH_CHECK();
     return 0;
 }

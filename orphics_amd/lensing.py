@@ -1077,15 +1077,44 @@ class FlatLenser(object):
         e = self.eng
         return e.irfft(e.cmul_real(e.rfft(e.to_real(kappa)), self._fphi))
 
-    def lens(self, imap, alpha, taylor_order=5):
-        """flat_taylens: T(x + alpha) by nearest-pixel remap + Taylor series in FFT derivatives."""
-        from math import factorial
+    def split(self, alpha):
+        """Nearest-pixel shifts and sub-pixel remainders of a deflection field (alpha_y, alpha_x): computed once per
+        deflection and reused for every map lensed by it (T, Q, U of one realisation)."""
         e = self.eng
         ay, ax = alpha
-        sx, dx = e.lens_split(ax, self.geom.step_x)
-        sy, dy = e.lens_split(ay, self.geom.step_y)
+        key = (ay.data_ptr(), ax.data_ptr(), ay._version, ax._version)
+        if getattr(self, "_split", None) is None or self._split[0] != key:
+            sx, dx = e.lens_split(ax, self.geom.step_x)
+            sy, dy = e.lens_split(ay, self.geom.step_y)
+            self._split = (key, (sx, sy, dx, dy))
+        return self._split[1]
+
+    def lens(self, imap, alpha, taylor_order=5, fused=True):
+        """flat_taylens (lensing.py:395-440): T(x + alpha) by nearest-pixel remap + Taylor series in FFT derivatives.
+        fused (default): ONE derivative kernel for all 14 terms (``oa_hc_derivs``), their C2Rs, ONE gather pass over all
+        of them (``oa_lens_taylor``); fused=False: one derivative kernel, C2R and gather per term (the first
+        implementation, kept as the cross-check)."""
+        from math import factorial
+        from ._lib import check
+        from .engine import _ptr, _stream
+        e = self.eng
+        sx, sy, dx, dy = self.split(alpha)
         src = e.to_real(imap)
         out = e.real()
+        if fused and 2 <= taylor_order <= 8:
+            torch = _torch()
+            nd = taylor_order * (taylor_order + 1) // 2 - 1
+            if getattr(self, "_pool", None) is None or self._pool[0].shape[0] != nd:
+                self._pool = (torch.empty((nd, e.ny, e.kp), dtype=e.cdt, device=e.device),
+                              torch.empty((nd, e.ny, e.nx), dtype=e.rdt, device=e.device))
+            dk, dr = self._pool
+            k0 = e.rfft(src)
+            check(e.lib.oa_hc_derivs(e.plan, _ptr(k0), int(taylor_order), _ptr(dk), e.ny * e.kp, _stream()))
+            for i in range(nd):
+                e.irfft(dk[i], out=dr[i])
+            check(e.lib.oa_lens_taylor(e.plan, _ptr(src), _ptr(dr), e.ny * e.nx, int(taylor_order), _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy),
+                                       _ptr(out), _stream()))
+            return out
         e.lens_gather(src, sx, sy, dx, dy, 0, 0, 1.0, out, False)
         k0 = e.rfft(src)
         # D[a][b] = (i lx)^a (i ly)^b k0, built incrementally with the derivative kernel
@@ -1178,7 +1207,9 @@ class FlatLensingSims(object):
             else:
                 lensed = torch.stack([self.lenser.lens(unlensed[i].contiguous(), self.alpha, taylor_order=lens_order)
                                       for i in range(unlensed.shape[0])])
-        beamed = maps.filter_map(lensed, self.kbeam)
+        if getattr(self, "_kbeam_dev", None) is None:      # the beam plane goes to the device once, not per realisation
+            self._kbeam_dev = maps.prepare_filter(self.shape[-2:], self.kbeam, dtype=self.lenser.eng.prec)
+        beamed = maps.filter_map(lensed, self._kbeam_dev)
         noise_map = self.ngen.get_map(seed=seed_noise)
         observed = beamed + noise_map
         if return_intermediate:

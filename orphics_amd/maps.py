@@ -346,6 +346,25 @@ class FourierCalc(object):
         return p2d, lteb1, lteb2
 
 
+class HalfFilter(object):
+    """An even-symmetric real k-space filter resident on the device in the half-plane layout (:func:`prepare_filter`)."""
+
+    def __init__(self, t, eng):
+        self.t, self.eng = t, eng
+
+
+def prepare_filter(shape, kfilter, dtype="f32"):
+    """Upload a full-plane (Ny, Nx) even-symmetric real filter once; the result can be passed to :func:`filter_map` any
+    number of times (a Monte-Carlo loop applying the same beam to every realisation: ``FlatLensingSims``)."""
+    torch = _torch()
+    eng = _engine(tuple(shape), dtype)
+    fdev = eng.to_real(np.broadcast_to(np.asarray(kfilter, dtype=np.float64), tuple(shape)[-2:]))
+    flipped = torch.roll(torch.flip(fdev, dims=(0, 1)), shifts=(1, 1), dims=(0, 1))
+    if not torch.equal(fdev, flipped):
+        raise ValueError("prepare_filter: the filter is not even-symmetric (F(-l) != F(l)); pass the array to filter_map instead")
+    return HalfFilter(eng.fullreal_to_hc(fdev), eng)
+
+
 def filter_map(imap, kfilter):
     """maps.py:1922-1923: Re(IFFT(FFT(m) * F)), IFFT / Npix.  ``kfilter`` is a
     full-plane (Ny,Nx) array: an even-symmetric real (or int) filter keeps the
@@ -366,6 +385,13 @@ def filter_map(imap, kfilter):
             k = eng.hc_to_full(eng.rfft(p.contiguous()))
             k = eng.cmul(k, fc, out=k)
             outs.append(torch.real(eng.cfft(k, inverse=True, scale=1.0 / eng.npix)).contiguous())
+        return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), imap)
+    if isinstance(f, HalfFilter):
+        # a filter prepared once with prepare_filter(): no conversion, no symmetry test per call
+        if f.eng is not eng:
+            raise ValueError("filter_map: the prepared filter belongs to another geometry / precision")
+        planes, lead = _planes(x)
+        outs = [eng.irfft(eng.cmul_real(eng.rfft(p.contiguous()), f.t)) for p in planes]
         return _ret(torch.stack(outs).reshape(lead + (eng.ny, eng.nx)), imap)
     fdev = eng.to_real(np.broadcast_to(np.asarray(f, dtype=np.float64), shape[-2:]) if not _is_tensor(f) else f)
     planes, lead = _planes(x)
@@ -455,11 +481,54 @@ def spec2flat(shape, wcs, cov, exp=1.0, mode="constant", smooth="auto"):
     return out
 
 
+def downsample_power(shape, wcs, cov, ndown=16, order=0, exp=None, fftshift=True, fft=False, logfunc=lambda x: x,
+                     ilogfunc=lambda x: x, fft_up=False):
+    """maps.py:1501-1550: smooth a 2-D power spectrum (..., Ny, Nx) by averaging it over blocks of ``ndown`` Fourier
+    pixels and interpolating the block means back onto the full grid (a noise-model aid; one-off host arithmetic, as
+    in the reference).  ``ndown``: one factor (scaled by the aspect ratio for the longer axis, maps.py:1512-1518) or a
+    (ndown_y, ndown_x) pair; ``exp``: per-mode matrix power of the block means (``MapGen`` passes 0.5).
+
+    Steps of the default path, as the reference composes them from pixell calls [NOT IN SNAPSHOT: pixell's public
+    behaviour as recalled -- ``enmap.downgrade`` = mean over whole blocks, a trailing partial block dropped;
+    ``ndmap.at(pix, unit="pix", order=order, mask_nan=False)`` = spline interpolation of that order with zeros
+    outside the coarse grid]: fftshift -> block means -> matrix power -> sample the coarse plane at
+    (y / ndown_y, x / ndown_x) for every fine pixel (y, x) -> inverse fftshift.  The ``fft`` / ``fft_up`` variants
+    resample with ``pixell.resample.resample_fft`` and are not provided."""
+    from scipy import ndimage
+    if np.all(np.asarray(ndown) < 1):
+        return cov
+    if fft or fft_up:
+        raise NotImplementedError("downsample_power(fft=True / fft_up=True): Fourier resampling (pixell.resample) is outside the hot path")
+    Ny, Nx = tuple(shape)[-2:]
+    nd = np.array(ndown).ravel()
+    if nd.size == 1:
+        other = int(nd[0] * max(Ny, Nx) * 1. / min(Ny, Nx))
+        fy, fx = (other, int(nd[0])) if Ny > Nx else (int(nd[0]), other)
+    else:
+        assert nd.size == 2
+        fy, fx = int(nd[0]), int(nd[1])
+    plane = logfunc(np.asarray(cov, dtype=np.float64))
+    lead = plane.shape[:-2]
+    if fftshift:
+        plane = np.fft.fftshift(plane, axes=(-2, -1))
+    cy, cx = Ny // fy, Nx // fx
+    blocks = plane[..., :cy * fy, :cx * fx].reshape(lead + (cy, fy, cx, fx)).mean(axis=(-3, -1))
+    if exp is not None:
+        blocks = multi_pow(blocks, exp)
+    yy, xx = np.meshgrid(np.arange(Ny) / float(fy), np.arange(Nx) / float(fx), indexing="ij")
+    fine = np.empty(lead + (Ny, Nx))
+    for idx in np.ndindex(*lead):
+        fine[idx] = ndimage.map_coordinates(blocks[idx], [yy, xx], order=order, mode="constant", cval=0.0)
+    if fftshift:
+        fine = np.fft.ifftshift(fine, axes=(-2, -1))
+    return ilogfunc(fine)
+
+
 class MapGen(object):
     """maps.py:1553-1587.  ``cov`` is the 4-D per-mode covariance (ncomp,ncomp,Ny,Nx) or the 3-D isotropic
     form (ncomp,ncomp,lmax) sampled at integer ell (expanded with :func:`spec2flat`, maps.py:1573).
-    ``ndown`` (``downsample_power``, maps.py:1501-1550: a noise-model smoothing aid) is not part of the hot
-    path and raises.
+    ``ndown``: the 4-D covariance is block-averaged and re-interpolated before the square root
+    (:func:`downsample_power`, maps.py:1501-1550, 1568-1569).
 
     ``get_map`` draws on the device (Philox; the reference's global
     Mersenne-Twister stream cannot and need not be reproduced, SURVEY.md H6);
@@ -477,14 +546,14 @@ class MapGen(object):
         else:
             assert cov is not None and cov.ndim >= 3, \
                 "Power spectra have to be of shape (ncomp,ncomp,lmax) or (ncomp,ncomp,Ny,Nx)."
-            if ndown:
-                raise NotImplementedError("MapGen(ndown=...): downsample_power (maps.py:1501-1550) is outside the hot path; "
-                                          "smooth the covariance before passing it")
             cov = np.asarray(cov)
             if cov.ndim == 4:
                 if not pixel_units:
                     cov = cov * np.prod(self.shape[-2:]) / self.geom.area
-                self.covsqrt = multi_pow(cov, 0.5)
+                if ndown:
+                    self.covsqrt = downsample_power(self.shape, self.geom, cov, ndown, order, exp=0.5)     # maps.py:1568-1569
+                else:
+                    self.covsqrt = multi_pow(cov, 0.5)
             elif cov.ndim == 3:
                 # maps.py:1573 (pixel_units plays no role on this branch in the reference either)
                 self.covsqrt = spec2flat(self.shape, self.geom, cov, 0.5, mode="constant", smooth=smooth)
@@ -492,7 +561,11 @@ class MapGen(object):
                 raise AssertionError("Power spectra have to be of shape (ncomp,ncomp,lmax) or (ncomp,ncomp,Ny,Nx).")
         self.ncomp = self.covsqrt.shape[0]
         self._cs_dev = {}
+        self._rot_dev = {}
         self._calls = 0
+        # which (i, j) blocks of the square root are non-zero: decided ONCE (a per-call np.any over (nc, nc) full planes
+        # was 1.4 of the 1.45 s a 4096^2 lensed simulation took on the host, profiles/r03f_lensloop.txt)
+        self._nz = [[bool(np.any(self.covsqrt[i, j])) for j in range(self.ncomp)] for i in range(self.ncomp)]
 
     def _covsqrt_hc(self, eng):
         key = eng.prec
@@ -523,7 +596,7 @@ class MapGen(object):
         for i in range(nc):
             acc = None
             for j in range(nc):
-                if not np.any(self.covsqrt[i, j]):
+                if not self._nz[i][j]:
                     continue
                 term = eng.cmul_real(white[j], cs[i][j])
                 acc = term if acc is None else acc + term
@@ -532,9 +605,11 @@ class MapGen(object):
             return HalfPlane(torch.stack(ks) if len(self.shape) > 2 else ks[0], eng)
         if not scalar and nc == 3:
             # harm2map: E,B -> Q,U by the inverse rotation, then inverse FFT
-            rot = queb_rotmat(self.geom.lmap(), inverse=True, iau=iau)
-            c = eng.fullreal_to_hc(eng.to_real(rot[0, 0]))
-            s = eng.fullreal_to_hc(eng.to_real(rot[1, 0]))
+            key = (eng.prec, bool(iau))
+            if key not in self._rot_dev:          # device planes of the inverse rotation, made once per precision / convention
+                rot = queb_rotmat(self.geom.lmap(), inverse=True, iau=iau)
+                self._rot_dev[key] = (eng.fullreal_to_hc(eng.to_real(rot[0, 0])), eng.fullreal_to_hc(eng.to_real(rot[1, 0])))
+            c, s = self._rot_dev[key]
             ks[1], ks[2] = eng.rot2(c, s, ks[1], ks[2])
         outs = [eng.irfft(k, scale=1.0 / np.sqrt(eng.npix)) for k in ks]
         if len(self.shape) > 2:
@@ -725,44 +800,48 @@ def split_calc(isplits, jsplits, icoadd, jcoadd, fourier_calc=None, alt=True, wc
 
 
 def noise_from_splits(splits, fourier_calc=None, nthread=0, do_cross=True, wcs=None):
-    """maps.py:2338-2411: noise = (mean auto - mean cross)/Nsplits of I,Q,U split maps and, optionally,
-    the mean T,E,B cross power.  ``splits``: (nsplits,ncomp,Ny,Nx) or (nsplits,Ny,Nx) real maps."""
-    splits = np.asarray(splits).astype(np.float32)
-    assert splits.ndim == 3 or splits.ndim == 4
-    ndim = splits.ndim
-    if splits.ndim == 3:
-        splits = splits[:, None, :, :]
-    ncomp = splits.shape[1]
-    if fourier_calc is None:
-        shape = splits.shape[-3:] if do_cross else splits.shape[-2:]
-        fourier_calc = FourierCalc(shape, wcs)
-    fc = fourier_calc
-    Nsplits = splits.shape[0]
+    """maps.py:2338-2411: 2-D noise power of I,Q,U (or T-only) split maps, ``(mean auto - mean cross) / nsplits``, and --
+    with ``do_cross`` -- the mean cross power of the splits' T,E,B.  ``splits``: (nsplits, ncomp, Ny, Nx) or
+    (nsplits, Ny, Nx) real maps; returns ``(noise, cross_teb)`` as ``power2d`` matrices.
+
+    The reference loops over all n (n - 1) / 2 ordered pairs i < j.  The 2-D power P(a, b) is bilinear, so
+
+        sum_{i < j} P(k_i, k_j) = sum_{j >= 1} P(k_0 + ... + k_{j-1}, k_j):
+
+    one power evaluation per split against the running sum of its predecessors (n - 1 instead of n (n - 1) / 2; the
+    component order of every cross term -- first leg from the earlier split -- is the reference's)."""
+    maps_in = np.asarray(splits).astype(np.float32)
+    if maps_in.ndim not in (3, 4):
+        raise AssertionError("splits must be (nsplits, Ny, Nx) or (nsplits, ncomp, Ny, Nx)")
+    flat_input = maps_in.ndim == 3
+    if flat_input:
+        maps_in = maps_in[:, None]
+    n, ncomp = maps_in.shape[0], maps_in.shape[1]
+    if do_cross and ncomp not in (1, 3):
+        raise AssertionError("do_cross needs T-only or I,Q,U splits")
+    fc = fourier_calc if fourier_calc is not None else FourierCalc(maps_in.shape[-3:] if do_cross else maps_in.shape[-2:], wcs)
+
+    def transforms(rotate):
+        return [fc.iqu2teb(m, nthread=nthread, normalize=False, rot=rotate) for m in maps_in]
+
+    def pair_sum_and_autos(ks, want_auto):
+        """(sum_{i<j} P(k_i, k_j), sum_i P(k_i, k_i)) through the running sum of the transforms"""
+        run, pairs, autos = None, 0., 0.
+        for k in ks:
+            if want_auto:
+                autos = autos + fc.power2d(kmap=k)[0]
+            if run is not None:
+                pairs = pairs + fc.power2d(kmap=run, kmap2=k)[0]
+                run = run + k
+            else:
+                run = np.array(k)           # (a copy: the running sum must not alias the first transform)
+        return pairs, autos
+    npairs = n * (n - 1) / 2.
+    pairs, autos = pair_sum_and_autos(transforms(False), True)
+    noise = (autos / n - pairs / npairs) / n
+    cross_teb = None
     if do_cross:
-        assert ncomp == 3 or ncomp == 1
-    ksplits = [fc.iqu2teb(split, nthread=nthread, normalize=False, rot=False) for split in splits]
-    if do_cross:
-        kteb_splits = []
-        for split in splits:
-            # the reference only rotates when ndim==3 and ncomp==3, which can never hold (maps.py:2376-2378)
-            kteb_splits.append(fc.iqu2teb(split, nthread=nthread, normalize=False, rot=(ndim == 3 and ncomp == 3)))
-    auto = 0.
-    for ksplit in ksplits:
-        auto = auto + fc.power2d(kmap=ksplit)[0]
-    auto = auto / Nsplits
-    Ncrosses = (Nsplits * (Nsplits - 1) / 2)
-    cross = 0.
-    for i in range(len(ksplits)):
-        for j in range(i + 1, len(ksplits)):
-            cross = cross + fc.power2d(kmap=ksplits[i], kmap2=ksplits[j])[0]
-    cross = cross / Ncrosses
-    if do_cross:
-        cross_teb = 0.
-        for i in range(len(ksplits)):
-            for j in range(i + 1, len(ksplits)):
-                cross_teb = cross_teb + fc.power2d(kmap=kteb_splits[i], kmap2=kteb_splits[j])[0]
-        cross_teb = cross_teb / Ncrosses
-    else:
-        cross_teb = None
-    noise = (auto - cross) / Nsplits
+        # (the reference rotates Q,U -> E,B only when the input was 3-D AND had three components, which cannot both
+        # hold once a component axis has been added: maps.py:2376-2378 -- reproduced, its fixtures pin it)
+        cross_teb = pair_sum_and_autos(transforms(flat_input and ncomp == 3), False)[0] / npairs
     return noise, cross_teb

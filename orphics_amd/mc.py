@@ -159,3 +159,108 @@ class GaussianN0MonteCarlo(object):
     @property
     def centers(self):
         return (self.edges[1:] + self.edges[:-1]) / 2.
+
+
+class LensedSimsMonteCarlo(object):
+    """The reference's verification loop (tutorials/tt_verification.ipynb cells 4-5) as a sharded,
+    device-resident driver: per realisation
+
+        FlatLensingSims.get_sim (unlensed T,Q,U GRF -> lensing by an independent kappa GRF -> beam -> + noise; lensing.py:499-521)
+        -> T, E, B transforms (FourierCalc.power2d is used only for these in the notebook)
+        -> kappa_hat per estimator (qest.kappa_from_map(XY, ..., alreadyFTed=True, returnFt=True))
+        -> C_b^{kappa_hat x kappa_in}, C_b^{kappa_in kappa_in} (FourierCalc.power2d + bin2D.bin)
+        -> Statistics: sample = (C_b^x - C_b^in) / C_b^in per estimator (+ the two bandpower vectors themselves)
+
+    with nothing but the (nbins,) vectors ever leaving the kernels' planes (device-side Statistics), realisations sharded
+    by mpi_distribute and ONE reduce at the end.  ``stage_times=True`` brackets the stages with HIP events."""
+
+    def __init__(self, sims, qest, bin_edges, estimators=("TT", "EB"), comm=None, base_seed=2024, lens_order=5):
+        torch = _torch()
+        from . import maps
+        self.sims, self.q, self.estimators = sims, qest, tuple(estimators)
+        self.comm = comm if comm is not None else _mpi.get_world()
+        self.base_seed, self.lens_order = int(base_seed), int(lens_order)
+        e = self.eng = qest.eng
+        geom = qest.geom
+        self.pol = len(sims.shape) > 2 and sims.shape[-3] == 3
+        if any(x != "TT" for x in self.estimators) and not self.pol:
+            raise ValueError("polarised estimators need FlatLensingSims(pol=True)")
+        self.fc = maps.FourierCalc(sims.shape, geom, iau=qest.iau, layout="half")
+        self.edges = np.asarray(bin_edges, dtype=np.float64)
+        self.ids = e.modl_digitize(torch.as_tensor(self.edges, device=e.device), half=True)
+        self.nids = self.edges.size + 1
+        self.norm = geom.area / float(e.npix) ** 2
+        self.acc = Statistics(comm=self.comm if hasattr(self.comm, "dist") else None, device=e.device)
+        self.stage_ms = {}
+
+    def _seed(self, kind, i):
+        return (self.base_seed, kind, int(i))
+
+    def run_local(self, sims_idx, stage_times=False):
+        torch = _torch()
+        e, q = self.eng, self.q
+        ev = []
+
+        def mark(name):
+            if stage_times:
+                t = torch.cuda.Event(enable_timing=True)
+                t.record()
+                ev.append((name, t))
+        for i in sims_idx:
+            mark("start")
+            parts = self.sims.get_sim(seed_cmb=self._seed(1, i), seed_kappa=self._seed(2, i), seed_noise=self._seed(3, i),
+                                      lens_order=self.lens_order, return_intermediate=True)
+            kappa, observed = parts[1], parts[5]
+            mark("get_sim")
+            teb = self.fc.iqu2teb(observed, normalize=False).t      # (3, Ny, kp) or (Ny, kp) hc planes: T, E, B
+            if teb.ndim == 2:
+                teb = teb[None]
+            kin = e.rfft(kappa.contiguous())
+            mark("transforms")
+            s_in, counts = e.bin_power(kin, kin, self.norm, self.ids, self.nids, herm=True)
+            auto = s_in[1:-1] / counts[1:-1].double()
+            self.acc.add("input", auto)
+            f = {"T": teb[0], "E": teb[1] if self.pol else None, "B": teb[2] if self.pol else None}
+            for XY in self.estimators:
+                if XY == "TT":
+                    rec = q.reconstruct_tt_hc(f["T"])
+                else:
+                    rec = q.reconstruct_hc(XY, f[XY[0]], f[XY[1]])
+                mark("qe_" + XY)
+                s_x, _ = e.bin_power(rec, kin, self.norm, self.ids, self.nids, herm=True)
+                cross = s_x[1:-1] / counts[1:-1].double()
+                self.acc.add(XY, (cross - auto) / auto)
+                self.acc.add("cross_" + XY, cross)
+                mark("bandpowers")
+        if stage_times and ev:
+            torch.cuda.synchronize()
+            tot = {}
+            for (n0, t0), (n1, t1) in zip(ev[:-1], ev[1:]):
+                if n1 == "start":
+                    continue
+                tot[n1] = tot.get(n1, 0.0) + t0.elapsed_time(t1)
+            self.stage_ms = {k: v / max(1, len(sims_idx)) for k, v in tot.items()}
+        return self
+
+    def run(self, nsims, stage_times=False):
+        comm = self.comm
+        size, rank = comm.Get_size(), comm.Get_rank()
+        _, tasks = _mpi.mpi_distribute(nsims, size, allow_empty=True)
+        self.run_local(tasks[rank], stage_times=stage_times)
+        self.acc.allreduce()
+        return self.acc
+
+    def table(self):
+        """per estimator: (mean bias per band, its standard error, chi^2 of the pulls, weighted mean bias +- error)"""
+        out = {}
+        for XY in self.estimators:
+            mean = self.acc.mean(XY)
+            sem = np.sqrt(self.acc.var(XY) / self.acc.count(XY))
+            w = 1.0 / sem ** 2
+            out[XY] = {"bias": mean, "sigma": sem, "chi2": float(np.sum((mean / sem) ** 2)), "nbands": int(mean.size),
+                       "weighted_mean_bias": float(np.sum(w * mean) / np.sum(w)), "weighted_mean_sigma": float(np.sum(w) ** -0.5)}
+        return out
+
+    @property
+    def centers(self):
+        return (self.edges[1:] + self.edges[:-1]) / 2.

@@ -470,6 +470,14 @@ def test_flat_lensing_op_matches_oracle_and_remaps():
     lensed = L.lens(T, (ay, ax), taylor_order=5).cpu().numpy()
     ref = qo.flat_taylens((ray, rax), T, g.step_y, g.step_x, taylor_order=5)
     assert np.abs(lensed - ref).max() / np.abs(ref).max() < 1e-10
+    # the fused path (one derivative kernel for all 14 terms, one gather pass) against the term-by-term one, and a lower order
+    per_term = L.lens(T, (ay, ax), taylor_order=5, fused=False).cpu().numpy()
+    assert np.abs(lensed - per_term).max() / np.abs(ref).max() < 1e-12
+    ref3 = qo.flat_taylens((ray, rax), T, g.step_y, g.step_x, taylor_order=3)
+    assert np.abs(L.lens(T, (ay, ax), taylor_order=3).cpu().numpy() - ref3).max() / np.abs(ref3).max() < 1e-10
+    L32 = lensing.FlatLenser((N, N), g, dtype="f32")
+    a32 = (ay.float(), ax.float())
+    assert np.abs(L32.lens(T.astype(np.float32), a32).cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
     torch_ = torch
     one_y = torch_.full((N, N), g.step_y, dtype=torch_.float64, device="cuda")
     one_x = torch_.full((N, N), 2 * g.step_x, dtype=torch_.float64, device="cuda")
@@ -546,6 +554,53 @@ def test_every_estimator_is_unbiased_on_lensed_sims():
         assert r["max_abs_pull"] < 5.0, (est, r["pull"])
         assert abs(r["weighted_mean_bias"]) < 0.05 + 3 * r["weighted_mean_sigma"], (est, r["weighted_mean_bias"], r["weighted_mean_sigma"])
         assert r["weighted_mean_sigma"] < 0.25, (est, "no constraining power: the test would pass on anything")
+
+
+def test_nlgenerator_against_the_reference_held_noise_curves():
+    """SURVEY 8(c)-4 (sanity, not parity: the generating configurations are not in the reference tree).  The only
+    reference-held numbers that speak to the estimator normalisation are the N_L^kk curves under data/
+    (so_v3_1_deproj0_goal_fsky0p4_it.dat, legacy/test_mv.csv; sampled into tests/golden/nl_reference_curves.npz).
+    NlGenerator for an SO-goal-like experiment (1.4' beam, 6 uK' T, sqrt(2) x that in P, ell in (30, 3000)) must reproduce
+    their LEVEL within a factor of a few, the ORDERING of the estimators (MV below everything, TB far above, TT / EE / EB
+    within an order of magnitude of each other) and the SHAPE (flat plateau below L ~ 300, monotonic rise above)."""
+    from orphics_amd import cosmology, lensing
+    from orphics_amd.geometry import FlatGeometry
+    gd = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nl_reference_curves.npz"))
+    ells, so_nl, cols = gd["ells"], gd["so_nl"], [str(c) for c in gd["so_columns"]]
+    N, res = 1024, 2.0
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    edges = np.geomspace(40, 3000, 25)
+    nlgen = lensing.NlGenerator(shape, g, th, edges, lensedEqualsUnlensed=True)
+    nlgen.updateNoise(beamX=1.4, noiseTX=6.0, noisePX=6.0 * np.sqrt(2.), tellminX=30, tellmaxX=3000, pellminX=30, pellmaxX=3000)
+    ours = {}
+    for XY in ("TT", "TE", "EE", "TB", "EB"):
+        ls, ours[XY] = nlgen.getNl(XY)
+    ls, ours["MV"] = nlgen.getNlMV(["TT", "TE", "EE", "EB", "TB"])
+    ref = {c: np.interp(ls, ells, so_nl[:, i]) for i, c in enumerate(cols)}
+    band = (ls > 60) & (ls < 2000)
+    for XY in ("TT", "EE", "EB", "MV"):
+        ratio = ours[XY][band] / ref[XY][band]
+        assert np.all(ratio > 1 / 4.) and np.all(ratio < 4.), (XY, ratio.min(), ratio.max())     # level: same normalisation convention
+    for XY in ("TE", "TB"):
+        ratio = ours[XY][band] / ref[XY][band]
+        assert np.all(ratio > 1 / 10.) and np.all(ratio < 10.), (XY, ratio.min(), ratio.max())
+    for cur in (ours, ref):
+        assert np.all(cur["MV"][band] <= np.minimum.reduce([cur[x][band] for x in ("TT", "TE", "EE", "EB", "TB")]) * 1.0001)
+        assert np.all(cur["TB"][band] > 10 * cur["MV"][band])
+        hi = (ls > 500) & (ls < 2900)
+        for XY in ("TT", "EE", "EB", "MV"):
+            assert np.all(np.diff(cur[XY][hi]) > 0), XY                                        # rising above the plateau
+        lo = (ls > 60) & (ls < 300)
+        for XY in ("TT", "MV"):                                                                # (EE / EB leave their plateau earlier)
+            assert cur[XY][lo].max() / cur[XY][lo].min() < 2.0, XY                                # plateau at low L
+    # the legacy MV curve: same plateau-then-rise shape and a comparable dynamic range between L = 100 and 2900
+    lm, mv = gd["legacy_mv_ells"], gd["legacy_mv"]
+    dyn_ref = np.interp(2900, lm, mv) / np.interp(100, lm, mv)
+    dyn_ours = np.interp(2900, ls, ours["MV"]) / np.interp(100, ls, ours["MV"])
+    assert 0.2 < dyn_ours / dyn_ref < 5, (dyn_ours, dyn_ref)
+    assert np.all(np.diff(mv[lm > 300]) >= 0)
 
 
 def test_nlgenerator_contract_and_iterative_delensing():

@@ -338,6 +338,18 @@ def test_split_calc_and_noise_from_splits():
     cross = sum(fo.f2power(k32[i], k32[j]) for i in range(4) for j in range(i + 1, 4)) / 6.
     assert rel(noise, (auto - cross) / 4) < 2e-5          # the reference casts splits to float32 (maps.py:2354)
     assert rel(cross_teb, cross) < 2e-5
+    # I,Q,U splits: (ncomp, ncomp) matrices; every cross term takes its FIRST component from the earlier split
+    # (maps.py:2392-2395 with power2d's assembly, maps.py:1661-1670) -- the running-sum evaluation keeps that order
+    iqu = np.array([[sig * (c + 1) + 0.5 * rng.standard_normal(shape) for c in range(3)] for _ in range(3)])
+    noise3, cross3 = maps.noise_from_splits(iqu, wcs=g)
+    k3 = np.fft.fft2(iqu.astype(np.float32).astype(np.float64))
+    assert np.asarray(noise3).shape == (3, 3) + shape and np.asarray(cross3).shape == (3, 3) + shape
+    for a in range(3):
+        for b in range(a, 3):
+            au = sum(fo.f2power(k3[i, a], k3[i, b]) for i in range(3)) / 3.
+            cr = sum(fo.f2power(k3[i, a], k3[j, b]) for i in range(3) for j in range(i + 1, 3)) / 3.
+            assert rel(np.asarray(noise3)[a, b], (au - cr) / 3.) < 3e-5 and rel(np.asarray(cross3)[a, b], cr) < 3e-5
+            assert np.array_equal(np.asarray(cross3)[b, a], np.asarray(cross3)[a, b])
 
 
 def test_coadd_and_kappa_to_phi_match_the_reference_functions():
