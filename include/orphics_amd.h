@@ -215,6 +215,12 @@ int oa_split_cross_power(int dtype, int nsplits, const void* const* host_kappa, 
  * synchronisation). */
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S,
               double* C, double* meanfield_acc, void* stream);
+/* The same shard with a real-space window applied to every realisation before its transform (the reference's analysis
+ * flow: maps.py:1873-1878 get_taper, maps.py:1350-1361): full-plane draw (same Philox counters as oa_mc_run) -> C2R / Npix
+ * -> x window_real (ny x nx reals of the plan's dtype) -> TT estimator -> bandpower moments (+ mean-field stack).  With
+ * window == 1 the moments equal oa_mc_run's up to rounding; with a taper the stack holds the window's mean field. */
+int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, const void* window_real,
+                       int64_t* n, double* S, double* C, double* meanfield_acc, void* stream);
 /* One stage of oa_qe_tt_moments on the plan's own work planes, for per-kernel timing (bench.py roofline; the
  * one-call path keeps its intermediates on COMPACT planes -- pitch = active columns rounded up to a 32-column tile
  * -- so its kernels are not the same launches as the fine-grained calls on caller planes of pitch kpitch):

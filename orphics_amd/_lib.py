@@ -56,6 +56,7 @@ SIGNATURES = {
     "oa_split_cross_power": (c_int, [c_int, c_int, c_void_p, c_void_p, c_double, c_int, c_long, c_int, c_int, c_void_p]),
     "oa_qe_tt_stage": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "oa_mc_run": (c_int, [c_void_p, c_u64, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oa_mc_run_windowed": (c_int, [c_void_p, c_u64, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_malloc": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_size_t]),
     "oa_free": (c_int, [c_void_p]),
     "oa_memcpy": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_void_p]),

@@ -594,6 +594,34 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     return 0;
 }
 
+/* Monte-Carlo shard with a REAL-SPACE WINDOW (the reference's analysis flow multiplies every map by its apodisation taper
+ * before any transform: maps.py:1873-1878 get_taper, maps.py:1350-1361 binned_power(imap * mask) / mean(mask^2)): per
+ * realisation a FULL-plane Philox draw (key = (base_seed, sim), the same counters as oa_mc_run's band draw) -> C2R / Npix ->
+ * x window -> TT estimator from the real map (row R2C on the active columns ...) -> bandpower moments (+ mean-field stack:
+ * with a window the ensemble mean of kappa_hat no longer vanishes -- that is the mean field Statistics.add_stack exists
+ * for, stats.py:1123-1150).  The real map lives in the plan's first leg plane, which the estimator overwrites only after its
+ * row pass has consumed the map. */
+int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, const void* window_real,
+                       int64_t* n, double* S, double* C, double* meanfield_acc, void* stream) {
+    OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_mc_run_windowed: call oa_plan_set_filters and oa_plan_set_bins first");
+    OA_REQUIRE(covsqrt_hc && window_real && n && S && C && sim_hi >= sim_lo, "oa_mc_run_windowed: bad argument");
+    OA_NEED_POW2(p, "oa_mc_run_windowed");
+    Pipeline* q = (Pipeline*)p->pipe;
+    void* tmap = q->c[0];
+    const double inv = 1.0 / ((double)p->ny * p->nx);
+    const long npix = (long)p->ny * p->nx;
+    for (long i = sim_lo; i < sim_hi; ++i) {
+        int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
+        if (rc) return rc;
+        if ((rc = oa_fft_c2r(p, q->kT, tmap, inv, 0, stream))) return rc;
+        if ((rc = oa_mul_real(p->dtype, tmap, window_real, tmap, npix, stream))) return rc;
+        if ((rc = oa_qe_tt(p, tmap, nullptr, nullptr, nullptr, 0, stream))) return rc;
+        if ((rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
+        if (meanfield_acc && (rc = stack_add_region(p->dtype, q->kk, meanfield_acc, p->ny, p->kp, q->wk, q->rk, (hipStream_t)stream))) return rc;
+    }
+    return 0;
+}
+
 // ---- device memory for hosts that bring no GPU array library (the reference is NumPy) -----------------------------
 int oa_malloc(void** out, size_t bytes) {
     OA_REQUIRE(out, "oa_malloc: NULL");

@@ -336,10 +336,45 @@ class _Moments(object):
 
 
 class _Stack(object):
-    __slots__ = ("shape", "count", "total")
+    __slots__ = ("shape", "count", "total", "support")
 
     def __init__(self, shape, total):
         self.shape, self.count, self.total = tuple(int(v) for v in shape), 0, total
+        self.support = None     # (rows, cols): the stack is zero outside rows y < rows or y > ny - rows, columns < cols
+
+
+def _pack_support(t, support):
+    """the possibly non-zero part of a (ny, kp, ...) device stack as one contiguous tensor"""
+    import torch
+    rb, w = support
+    ny = t.shape[0]
+    if rb <= 0 or 2 * rb - 1 >= ny:
+        return t[:, :w].contiguous()
+    return torch.cat((t[:rb, :w], t[ny - rb + 1:, :w])).contiguous()
+
+
+def _unpack_support(sub, shape, support):
+    import torch
+    rb, w = support
+    ny = shape[0]
+    out = torch.zeros(shape, dtype=sub.dtype, device=sub.device)
+    if rb <= 0 or 2 * rb - 1 >= ny:
+        out[:, :w] = sub
+    else:
+        out[:rb, :w] = sub[:rb]
+        out[ny - rb + 1:, :w] = sub[rb:]
+    return out
+
+
+class _RegionSum(object):
+    """Reduced stack known to vanish outside its support: only the support travelled through the all-reduce; the full
+    plane is materialised when somebody asks for it."""
+
+    def __init__(self, sub, shape, support):
+        self.sub, self.shape, self.support = sub, tuple(shape), support
+
+    def full(self):
+        return _unpack_support(self.sub, self.shape, self.support)
 
 
 class Statistics(object):
@@ -460,12 +495,20 @@ class Statistics(object):
     def note_samples(self, label, k):
         self._vec[label].count += int(k)
 
-    def device_stack(self, label, shape):
+    def device_stack(self, label, shape, support=None):
         """float64 device accumulator of a stack label (``oa_stack_add`` / ``oa_mc_run`` mean field); report the
-        number of arrays added with :meth:`note_stacked`."""
+        number of arrays added with :meth:`note_stacked`.  ``support = (rows, cols)``: the caller only ever adds to the
+        rows y < rows or y > ny - rows, columns < cols of the (ny, kp, ...) plane (kappa_hat's active region): the
+        all-reduce then moves that region only (14 MB instead of a 135 MB plane and its copy at 4096^2)."""
         if self.device is None:
             raise RuntimeError("device_stack() needs Statistics(device=...)")
-        return self._slot_pile(label, shape).total
+        p = self._slot_pile(label, shape)
+        if support is not None:
+            support = (int(support[0]), int(support[1]))
+            if p.support not in (None, support):
+                raise ValueError("label %r already stacks with support %s" % (label, p.support))
+            p.support = support
+        return p.total
 
     def note_stacked(self, label, k):
         self._pile[label].count += int(k)
@@ -515,7 +558,8 @@ class Statistics(object):
 
     # -- reduction ----------------------------------------------------------------------------------------------
     def _schema(self):
-        return {"vec": {lab: m.dim for lab, m in self._vec.items()}, "pile": {lab: p.shape for lab, p in self._pile.items()}}
+        return {"vec": {lab: m.dim for lab, m in self._vec.items()}, "pile": {lab: p.shape for lab, p in self._pile.items()},
+                "support": {lab: p.support for lab, p in self._pile.items() if p.support is not None}}
 
     def _agree_on_schema(self):
         """Union of the labels of all ranks (a label may be missing on some: it contributes zeros there,
@@ -533,6 +577,11 @@ class Statistics(object):
         both = set(vec) & set(pile)
         if both:
             raise ValueError("label(s) %s collect vectors on one rank and stacked arrays on another" % sorted(both))
+        self._supports = {}
+        for sch in everyone:
+            for lab, sup in sch.get("support", {}).items():
+                if self._supports.setdefault(lab, tuple(sup)) != tuple(sup):
+                    raise ValueError("label %r stacks with support %s on one rank and %s on another" % (lab, self._supports[lab], tuple(sup)))
         return vec, pile
 
     def _sum_over_ranks(self, buf):
@@ -588,7 +637,11 @@ class Statistics(object):
                 at += n
         for kind, l, field, arr in items:
             if (kind, l, field) not in reduced:
-                reduced[(kind, l, field)] = self._sum_over_ranks(arr.clone())
+                sup = getattr(self, "_supports", {}).get(l) if kind == "pile" else None
+                if sup is not None:      # only the region that can be non-zero travels; no copy of the full plane
+                    reduced[(kind, l, field)] = _RegionSum(self._sum_over_ranks(_pack_support(arr, sup)), tuple(arr.shape), sup)
+                else:
+                    reduced[(kind, l, field)] = self._sum_over_ranks(arr.clone())
         gv, gp = {}, {}
         for i, l in enumerate(order_v):
             g = _Moments(vec[l], reduced[("vec", l, "first")], reduced[("vec", l, "second")])
@@ -624,6 +677,8 @@ class Statistics(object):
     def stack_sum(self, label, on_device=False):
         """Reduced sum of a stack label (NumPy; ``on_device=True`` returns the GPU tensor of a device-resident stack)."""
         t = self._reduced("pile", label).total
+        if isinstance(t, _RegionSum):
+            t = t.full()
         if hasattr(t, "detach"):
             return t if on_device else t.detach().cpu().numpy()
         return t

@@ -86,6 +86,24 @@ def _worker(rank, world, port, q):
         S = torch.tensor([float(sum(mine)), 1.0], dtype=torch.float64)
         mc.allreduce_tensors([n, S], comm)
         out["mc_n"], out["mc_S"] = int(n.item()), S.numpy().copy()
+        # --- mean-field stack with a declared support: only the active region goes through the all-reduce; a rank that
+        #     stacked nothing still takes part with the same buffer; the local accumulator is left untouched
+        reg = stats.Statistics(comm=comm, device=torch.device("cpu"))
+        reg.PACK_LIMIT = 100                                  # (so that this small plane takes the large-stack path)
+        ny, kp, rb, w = 16, 12, 3, 5
+        if rank == 1:
+            plane = reg.device_stack("mf", (ny, kp, 2), support=(rb, w))
+            plane[:rb, :w] += 2.0
+            plane[ny - rb + 1:, :w] += 3.0
+            reg.note_stacked("mf", 4)
+            keep = plane.clone()
+        reg.add("b", np.array([1.0 + rank, 2.0]))
+        reg.allreduce()
+        full = reg.stack_sum("mf")
+        want = np.zeros((ny, kp, 2)); want[:rb, :w] = 2.0; want[ny - rb + 1:, :w] = 3.0
+        out["region_ok"] = bool(np.array_equal(full, want)) and reg.stack_count("mf") == 4 and reg.count("b") == 2
+        if rank == 1:
+            out["region_ok"] = out["region_ok"] and bool(torch.equal(plane, keep))
         comm.Barrier()
         dist.destroy_process_group()
         q.put((rank, out))
@@ -125,6 +143,7 @@ def test_world_size_two_gloo():
         np.testing.assert_allclose(o["var"], o["covdiag"], rtol=0, atol=1e-12)
         assert o["mismatch"] is True
         assert o["mc_n"] == 7 and np.allclose(o["mc_S"], [21.0, 2.0])
+        assert o["region_ok"] is True
     assert res[0]["tasks"] == [0, 1, 2] and res[1]["tasks"] == [3, 4, 5, 6]   # remainder on the LAST rank
     assert res[0]["legacy_n"] == 5
     np.testing.assert_allclose(res[0]["legacy_mean"], np.mean([[0, 0], [1, 2], [1, 0], [2, 2], [3, 4]], axis=0))
