@@ -87,6 +87,10 @@ int oa_plan_set_laxes(oa_plan* p, const double* host_ly, const double* host_lx);
  * on oa_qe_legs_cols: input rows outside the band are not read (the filters vanish there).  0 = all rows. */
 int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, int rband, void* stream);
 int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream);
+/* oa_fft_c2r with a real-space window multiplied into the result at the last pass's store: real_out = window_real *
+ * scale * IDFT(hc_in) (window_real: ny x nx reals of the plan's dtype; power-of-two sides).  The apodisation step of the
+ * reference's analysis flow (maps.py:1350-1361 binned_power(imap * mask)) without another pass over the map. */
+int oa_fft_c2r_windowed(oa_plan* p, const void* hc_in, void* real_out, double scale, const void* window_real, void* stream);
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream);
 /* One constituent pass of the transforms above, for per-kernel timing (bench.py roofline):
  * pass_id 0 = R2C row pass (real in -> hc out), 1 = column pass 1 (hc -> hc, out != in),

@@ -32,6 +32,7 @@ SIGNATURES = {
     "oa_plan_set_laxes": (c_int, [c_void_p, c_void_p, c_void_p]),
     "oa_fft_r2c": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_void_p]),
     "oa_fft_c2r": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
+    "oa_fft_c2r_windowed": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     "oa_fft_c2c": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_fft_pass": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "oa_fft_cols": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_int, c_void_p]),

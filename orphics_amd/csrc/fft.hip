@@ -266,10 +266,10 @@ static int r2c_impl(oa_plan* p, const void* in, void* out, double scale, int wid
     return q.rc;
 }
 template <typename T>
-static int c2r_impl(oa_plan* p, const void* in, void* out, double scale, int width, hipStream_t st) {
+static int c2r_impl(oa_plan* p, const void* in, void* out, double scale, int width, hipStream_t st, const void* mul = nullptr) {
     if (int rc = plan_ensure_scratch(p, (size_t)p->ny * p->kp * sizeof(cx<T>))) return rc;
     HipLauncher q{st};
-    view<T>(p).c2r(q, (const cx<T>*)in, (T*)out, (cx<T>*)p->scratch, (T)scale, width);
+    view<T>(p).c2r(q, (const cx<T>*)in, (T*)out, (cx<T>*)p->scratch, (T)scale, width, (const T*)mul);
     return q.rc;
 }
 template <typename T>
@@ -632,6 +632,14 @@ int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int 
     if (!p->pow2) return czt_c2r(p, hc_in, real_out, scale, (hipStream_t)stream);
     return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, width, (hipStream_t)stream)
                               : c2r_impl<double>(p, hc_in, real_out, scale, width, (hipStream_t)stream);
+}
+
+int oa_fft_c2r_windowed(oa_plan* p, const void* hc_in, void* real_out, double scale, const void* window_real, void* stream) {
+    OA_REQUIRE(p && hc_in && real_out && window_real, "oa_fft_c2r_windowed: NULL argument");
+    OA_REQUIRE(hc_in != real_out && window_real != real_out, "oa_fft_c2r_windowed: in-place not supported");
+    OA_NEED_POW2(p, "oa_fft_c2r_windowed");
+    return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, 0, (hipStream_t)stream, window_real)
+                              : c2r_impl<double>(p, hc_in, real_out, scale, 0, (hipStream_t)stream, window_real);
 }
 
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream) {

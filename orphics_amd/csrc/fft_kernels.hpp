@@ -316,6 +316,8 @@ struct RowArgs {
     T scale;
     int mode;
     int wcols;                 // R2C: columns produced; C2R: columns read (the rest are zero).  >= L+1: all
+    const void* mul;           // C2R only, may be NULL: real plane (layout and pitch of `out`) multiplied into the result at the
+                               // store -- a real-space window applied without another pass over the map (oa_mc_run_windowed)
 };
 
 template <typename T, bool SWAP>
@@ -349,9 +351,12 @@ struct RowStore {
     cx<T>* out;        // pre-offset to the first row of this workgroup
     unsigned pitch;
     T scale;
+    const cx<T>* mul = nullptr;   // optional: per-element real factors (two packed reals per complex slot), same offsets as out
     template <typename U> OA_HD void put(int n, int c, cx<U> v) const {
         if (SWAP) v = swp(v);
-        out[(unsigned)c * pitch + (unsigned)n] = v * scale;
+        cx<U> r = v * scale;
+        if (mul) { const cx<U> m = mul[(unsigned)c * pitch + (unsigned)n]; r = mk<U>(r.x * m.x, r.y * m.y); }
+        out[(unsigned)c * pitch + (unsigned)n] = r;
     }
 };
 
@@ -487,7 +492,8 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
         c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.wcols);
         ctx.sync();
         fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{},
-                                                RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
+                                                RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale,
+                                                                  a.mul ? reinterpret_cast<const cx<T>*>(a.mul) + r0 * a.out_pitch : nullptr});
     }
 }
 

@@ -55,8 +55,9 @@ struct Fft2dPlan {
     // ---- row passes -------------------------------------------------------
     template <class Launcher>
     void rows(Launcher& q, int mode, const void* in, long in_pitch, void* out, long out_pitch, T scale,
-              int wcols = 0x7fffffff) const {
+              int wcols = 0x7fffffff, const void* mul = nullptr) const {
         RowArgs<T> a{};
+        a.mul = mul;
         const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R);
         a.logL = real_mode ? logNx - 1 : logNx;
         const int L = 1 << a.logL;
@@ -344,10 +345,11 @@ struct Fft2dPlan {
     // half-complex -> real; input preserved; tmp: two hc planes (tmp, tmp2)
     template <class Launcher>
     // columns >= wmax of `in` are taken as zero (never read) when wmax is given
-    void c2r(Launcher& q, const cx<T>* in, T* out, cx<T>* tmp, T scale, int wmax = 0x7fffffff) const {
+    // mul != nullptr: real (ny, nx) plane multiplied into the result at the row pass's store (a real-space window)
+    void c2r(Launcher& q, const cx<T>* in, T* out, cx<T>* tmp, T scale, int wmax = 0x7fffffff, const T* mul = nullptr) const {
         const int w = clampw(wmax);
         cols(q, in, kp, tmp, kp, w, true, (T)1);
-        rows(q, ROW_C2R, tmp, kp, out, nx / 2, scale, w);
+        rows(q, ROW_C2R, tmp, kp, out, nx / 2, scale, w, mul);
     }
     // full complex (ny,nx) contiguous; tmp: one full plane; out != in
     template <class Launcher>

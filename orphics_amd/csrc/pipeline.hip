@@ -609,12 +609,10 @@ int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi,
     Pipeline* q = (Pipeline*)p->pipe;
     void* tmap = q->c[0];
     const double inv = 1.0 / ((double)p->ny * p->nx);
-    const long npix = (long)p->ny * p->nx;
     for (long i = sim_lo; i < sim_hi; ++i) {
         int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
         if (rc) return rc;
-        if ((rc = oa_fft_c2r(p, q->kT, tmap, inv, 0, stream))) return rc;
-        if ((rc = oa_mul_real(p->dtype, tmap, window_real, tmap, npix, stream))) return rc;
+        if ((rc = oa_fft_c2r_windowed(p, q->kT, tmap, inv, window_real, stream))) return rc;     // the window rides on the row pass's store
         if ((rc = oa_qe_tt(p, tmap, nullptr, nullptr, nullptr, 0, stream))) return rc;
         if ((rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
         if (meanfield_acc && (rc = stack_add_region(p->dtype, q->kk, meanfield_acc, p->ny, p->kp, q->wk, q->rk, (hipStream_t)stream))) return rc;

@@ -272,14 +272,19 @@ class Engine(object):
         check(self.lib.oa_fft_r2c(self.plan, _ptr(x), _ptr(out), float(scale), int(width), int(rband), _stream()))
         return out
 
-    def irfft(self, k, scale=None, out=None, width=0):
+    def irfft(self, k, scale=None, out=None, width=0, window=None):
         """hc -> real; default scale 1/Npix (pixell fft.ifft normalize=True, maps.py:1633).
-        ``width`` > 0 asserts that columns >= width of ``k`` are zero (they are not read)."""
+        ``width`` > 0 asserts that columns >= width of ``k`` are zero (they are not read).
+        ``window``: real (ny, nx) device plane multiplied into the result inside the last pass (``oa_fft_c2r_windowed``)."""
         self._ordered()
         self._chk(k, "hc")
         out = self.real() if out is None else _dirty(self._chk(out, "real"))
         if scale is None:
             scale = 1.0 / self.npix
+        if window is not None:
+            self._chk(window, "real")
+            check(self.lib.oa_fft_c2r_windowed(self.plan, _ptr(k), _ptr(out), float(scale), _ptr(window), _stream()))
+            return out
         check(self.lib.oa_fft_c2r(self.plan, _ptr(k), _ptr(out), float(scale), int(width), _stream()))
         return out
 

@@ -37,6 +37,11 @@ def test_rfft_irfft(ny, nx, prec):
     assert rel(y, x) < TOL[prec]
     # input preserved by c2r
     assert np.array_equal(k.cpu().numpy()[:, :nx // 2 + 1], got)
+    # windowed C2R (power-of-two sides): the window rides on the last pass's store
+    if e.pow2:
+        w = rng.uniform(0.0, 1.0, (ny, nx))
+        yw = e.irfft(k, window=e.to_real(w)).cpu().numpy()
+        assert rel(yw, x * w) < TOL[prec]
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])

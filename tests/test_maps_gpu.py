@@ -205,8 +205,17 @@ def test_mapgen_1d_spectra_and_real_space_draw():
     for (i, j), amp in (((0, 0), 1.0), ((1, 1), 0.1), ((0, 1), 0.2), ((2, 2), 0.01)):
         _, p1d = b.bin(acc[i, j])
         assert np.abs(p1d / (amp * np.interp(cents, ell, cl)) - 1).max() < (0.12 if i != j else 0.06)
-    with pytest.raises(NotImplementedError):
-        maps.MapGen(shape, g, cl[None, None], ndown=4)
+    # ndown (maps.py:1568-1569): the 4-D covariance is block-averaged / re-interpolated before the square root; the draws
+    # follow the smoothed spectrum (a smooth C_l is nearly a fixed point of the smoothing)
+    cov4 = np.interp(g.modlmap(), ell, cl)[None, None]
+    mgd = maps.MapGen(shape, g, cov4, ndown=2, order=1)
+    np.testing.assert_allclose(mgd.covsqrt, maps.downsample_power(shape, g, cov4 * np.prod(shape) / g.area, 2, 1, exp=0.5), rtol=1e-13)
+    accd = 0
+    for sd in range(12):
+        accd = accd + fo.power2d(mgd.get_map(seed=80 + sd).cpu().numpy().astype(np.float64))[0]
+    _, pd1 = b.bin(accd / 12)
+    mid = (cents > 0.15 * cents.max()) & (cents < 0.7 * cents.max())
+    assert np.abs(pd1 / np.interp(cents, ell, cl) - 1)[mid].max() < 0.15
 
 
 def test_bin2d_against_reference_golden(golden_dir):
