@@ -1181,6 +1181,21 @@ class FlatLensingSims(object):
     def get_unlensed(self, seed=None):
         return self.mgen.get_map(seed=seed)
 
+    def lens_maps(self, unlensed, alpha, lens_order=5):
+        """every component of ``unlensed`` displaced by the deflection ``alpha`` = (alpha_y, alpha_x).  The reference calls
+        pixell.lensing.displace_map(order=lens_order) (lensing.py:512); here the FFT-only Taylens of lensing.py:395-440 is
+        used (same Taylor order)."""
+        torch = _torch()
+        if unlensed.ndim == 2:
+            return self.lenser.lens(unlensed, alpha, taylor_order=lens_order)
+        return torch.stack([self.lenser.lens(unlensed[i].contiguous(), alpha, taylor_order=lens_order) for i in range(unlensed.shape[0])])
+
+    def beam_maps(self, lensed):
+        """filter_map(lensed, kbeam) (lensing.py:513) with the beam plane resident on the device"""
+        if getattr(self, "_kbeam_dev", None) is None:      # the beam plane goes to the device once, not per realisation
+            self._kbeam_dev = maps.prepare_filter(self.shape[-2:], self.kbeam, dtype=self.lenser.eng.prec)
+        return maps.filter_map(lensed, self._kbeam_dev)
+
     def get_kappa(self, seed=None):
         return self.kgen.get_map(seed=seed, scalar=True)
 
@@ -1200,16 +1215,8 @@ class FlatLensingSims(object):
             else:
                 kappa = None
                 assert seed_kappa is None
-            # the reference calls pixell.lensing.displace_map(order=lens_order) (lensing.py:512); here the
-            # FFT-only Taylens of lensing.py:395-440 is used (same Taylor order)
-            if unlensed.ndim == 2:
-                lensed = self.lenser.lens(unlensed, self.alpha, taylor_order=lens_order)
-            else:
-                lensed = torch.stack([self.lenser.lens(unlensed[i].contiguous(), self.alpha, taylor_order=lens_order)
-                                      for i in range(unlensed.shape[0])])
-        if getattr(self, "_kbeam_dev", None) is None:      # the beam plane goes to the device once, not per realisation
-            self._kbeam_dev = maps.prepare_filter(self.shape[-2:], self.kbeam, dtype=self.lenser.eng.prec)
-        beamed = maps.filter_map(lensed, self._kbeam_dev)
+            lensed = self.lens_maps(unlensed, self.alpha, lens_order)
+        beamed = self.beam_maps(lensed)
         noise_map = self.ngen.get_map(seed=seed_noise)
         observed = beamed + noise_map
         if return_intermediate:

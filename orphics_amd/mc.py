@@ -197,8 +197,16 @@ class LensedSimsMonteCarlo(object):
     with nothing but the (nbins,) vectors ever leaving the kernels' planes (device-side Statistics), realisations sharded
     by mpi_distribute and ONE reduce at the end.  ``stage_times=True`` brackets the stages with HIP events."""
 
-    def __init__(self, sims, qest, bin_edges, estimators=("TT", "EB"), comm=None, base_seed=2024, lens_order=5):
+    def __init__(self, sims, qest, bin_edges, estimators=("TT", "EB"), comm=None, base_seed=2024, lens_order=5, paired=False,
+                 kappa_scale=1.0):
+        """paired: every realisation is lensed TWICE, by +kappa and by -kappa, with the SAME unlensed CMB and the SAME noise;
+        the estimator's odd part (kappa_hat[+] - kappa_hat[-]) / 2 keeps the terms of odd order in kappa -- the linear
+        response plus O(kappa^3) -- while the Gaussian reconstruction noise (the N0 scatter that dominates the unpaired
+        samples) and every even-order term cancel exactly: the normalisation is tested at the 1e-3 level with tens of
+        simulations.  kappa_scale: amplitude factor on the input kappa; the O(kappa^3) part of the paired bias scales as
+        kappa_scale^2, a normalisation error does not scale at all -- two values attribute a residual."""
         torch = _torch()
+        self.paired, self.kappa_scale = bool(paired), float(kappa_scale)
         from . import maps
         self.sims, self.q, self.estimators = sims, qest, tuple(estimators)
         self.comm = comm if comm is not None else _mpi.get_world()
@@ -231,6 +239,9 @@ class LensedSimsMonteCarlo(object):
                 ev.append((name, t))
         for i in sims_idx:
             mark("start")
+            if self.paired:
+                self._paired_sample(i)
+                continue
             parts = self.sims.get_sim(seed_cmb=self._seed(1, i), seed_kappa=self._seed(2, i), seed_noise=self._seed(3, i),
                                       lens_order=self.lens_order, return_intermediate=True)
             kappa, observed = parts[1], parts[5]
@@ -264,6 +275,34 @@ class LensedSimsMonteCarlo(object):
                 tot[n1] = tot.get(n1, 0.0) + t0.elapsed_time(t1)
             self.stage_ms = {k: v / max(1, len(sims_idx)) for k, v in tot.items()}
         return self
+
+    def _paired_sample(self, i):
+        e, q, sims = self.eng, self.q, self.sims
+        unl = sims.get_unlensed(self._seed(1, i))
+        kappa = sims.get_kappa(self._seed(2, i)) * self.kappa_scale
+        ay, ax = sims.lenser.alpha_from_kappa(kappa)
+        noise = sims.ngen.get_map(seed=self._seed(3, i))
+        kin = e.rfft(kappa.contiguous())
+        s_in, counts = e.bin_power(kin, kin, self.norm, self.ids, self.nids, herm=True)
+        auto = s_in[1:-1] / counts[1:-1].double()
+        self.acc.add("input", auto)
+        recs = {XY: [] for XY in self.estimators}
+        for sgn in (1.0, -1.0):
+            alpha = (ay, ax) if sgn > 0 else (-ay, -ax)
+            observed = sims.beam_maps(sims.lens_maps(unl, alpha, self.lens_order)) + noise
+            teb = self.fc.iqu2teb(observed, normalize=False).t
+            if teb.ndim == 2:
+                teb = teb[None]
+            f = {"T": teb[0], "E": teb[1] if self.pol else None, "B": teb[2] if self.pol else None}
+            for XY in self.estimators:
+                rec = q.reconstruct_tt_hc(f["T"]) if XY == "TT" else q.reconstruct_hc(XY, f[XY[0]], f[XY[1]])
+                recs[XY].append(rec)
+        for XY in self.estimators:
+            odd = (recs[XY][0] - recs[XY][1]) * 0.5
+            s_x, _ = e.bin_power(odd, kin, self.norm, self.ids, self.nids, herm=True)
+            cross = s_x[1:-1] / counts[1:-1].double()
+            self.acc.add(XY, (cross - auto) / auto)
+            self.acc.add("cross_" + XY, cross)
 
     def run(self, nsims, stage_times=False):
         comm = self.comm
