@@ -600,6 +600,32 @@ def test_every_estimator_is_unbiased_on_lensed_sims():
         assert r["weighted_mean_sigma"] < 0.25, (est, "no constraining power: the test would pass on anything")
 
 
+def test_linear_response_normalisation_of_every_estimator():
+    """The normalisation of EVERY estimator at the few-per-mille level, independent of the oracle's tables: paired
+    simulations (the same CMB and noise lensed by +kappa and -kappa; the odd part of kappa_hat has no N0 scatter) with the
+    UNLENSED spectra in the gradient leg (the exact first-order response) at two lensing amplitudes s = 1 and s = 1/4.
+    The bias b(s) = b0 + b2 s^2: the O(kappa^3) part must scale as s^2 and the extrapolated linear-response error
+    b0 = (16 b(1/4) - b(1)) / 15 must vanish: |b0| < 0.4 % + 3 sigma (profiles/r03_unbiasedness_attribution.txt has the
+    4096^2 / 200-pair version: every |b0| <= 0.2 %).  A 1 % normalisation slip fails this gate."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("qe_unbiasedness", os.path.join(root, "examples", "qe_unbiasedness.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ests = ("TT", "TE", "EE", "EB", "TB")
+    kw = dict(nsims=32, side=2048, res=0.5, estimators=ests, nbins=12, lrange=(20., 3000.), paired=True, gradient="unlensed")
+    full = mod.run(kappa_scale=1.0, **kw)["estimators"]
+    quarter = mod.run(kappa_scale=0.25, **kw)["estimators"]
+    for est in ests:
+        b1, s1 = full[est]["weighted_mean_bias"], full[est]["weighted_mean_sigma"]
+        bq, sq = quarter[est]["weighted_mean_bias"], quarter[est]["weighted_mean_sigma"]
+        b0 = (16. * bq - b1) / 15.
+        s0 = np.hypot(16. * sq, s1) / 15.
+        assert s0 < 0.01, (est, s0, "no constraining power")
+        assert abs(b0) < 0.004 + 3 * s0, (est, b0, s0)
+        assert b1 < -0.01 and abs(bq) < abs(b1) / 4., (est, b1, bq)      # the full-amplitude bias is higher-order lensing: it shrinks with s^2
+
+
 def test_nlgenerator_against_the_reference_held_noise_curves():
     """SURVEY 8(c)-4 (sanity, not parity: the generating configurations are not in the reference tree).  The only
     reference-held numbers that speak to the estimator normalisation are the N_L^kk curves under data/
