@@ -174,6 +174,11 @@ int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* 
  * with the row bands of each call (mrow == 0 switches it off there too). */
 int oa_plan_set_col_grid(oa_plan* p, int mcol);
 int oa_plan_col_grid(const oa_plan* p);
+/* R of the R-SPLIT from-map path this plan's one-call TT entries run (0 = not this geometry): the row R2C carries the first
+ * radix-R butterfly of the column transform (R = ny / column grid) and ONE single-pass column kernel goes from its output to
+ * the three leg planes -- instead of forward pass 1, [forward pass 2 + filters + inverse pass 1] and inverse pass 2.
+ * Same arithmetic up to the order of the column butterflies; results agree with the multi-pass path to rounding. */
+int oa_plan_rsplit(const oa_plan* p);
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);
 void* oa_plan_kappa(oa_plan* p);
 const int64_t* oa_plan_bin_counts(oa_plan* p);

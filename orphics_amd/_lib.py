@@ -43,6 +43,7 @@ SIGNATURES = {
     "oa_plan_set_filters": (c_int, [c_void_p] * 4 + [c_int] * 5),
     "oa_plan_set_col_grid": (c_int, [c_void_p, c_int]),
     "oa_plan_col_grid": (c_int, [c_void_p]),
+    "oa_plan_rsplit": (c_int, [c_void_p]),
     "oa_plan_set_bins": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_plan_kappa": (c_void_p, [c_void_p]),
     "oa_plan_bin_counts": (c_void_p, [c_void_p]),

@@ -87,8 +87,11 @@ int bin_power_moments(int dtype, const void* k, double norm, const int32_t* ids,
 int stack_add_region(int dtype, const void* x, double* acc, int ny, long kp, int w, int rb, hipStream_t st, int nbatch = 1, long xstride = 0);
 // my > 0: COLUMN GRID -- legs, row stage and divergence run on my < ny rows (plan_ensure_col_grid(p, my) first)
 int plan_ensure_col_grid(oa_plan* p, int my);
+// lr > 0 (qe_rsplit_lr): R-SPLIT path -- row R2C with the first radix-R column butterfly, then one single-pass column kernel;
+// the leg planes are then in the R-LAYOUT and qe_rows_w must be told so (same lr)
+int qe_rsplit_lr(const oa_plan* p, int my, int width, int wout, int mrow);
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
-                       int rband, long pl, hipStream_t st, int stages = 7, int my = 0);
+                       int rband, long pl, hipStream_t st, int stages = 7, int my = 0, int lr = 0);
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my = 0);
 // one filtered field (subset 1: H plane into a; 2: gradient pair into a, b), inverse pass 1 only; then pass 2 over a pool of planes
@@ -114,7 +117,7 @@ int grf_hc_band_batch(oa_plan* p, uint64_t seed, uint64_t stream_id, int nreal, 
                       int width, int rband, hipStream_t stream);
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my = 0);
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
-              int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0);
+              int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0, int lr = 0);
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
                   long pk, hipStream_t st, int my = 0);
 // two maps at once (fft.hip); -1 = not available for this geometry

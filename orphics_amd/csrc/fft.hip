@@ -17,6 +17,26 @@ __global__ __launch_bounds__(64, 1) void row_r2c_w64_kernel(RowW64Args a) {
     row_r2c_w64_body(c, a);
 }
 
+template <int LR>
+__global__ __launch_bounds__(64, 1) void row_r2c_w64r_kernel(RowW64Args a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_w64_body_t<LR>(c, a);
+}
+
+// (the accumulators live across the row loop: the f32 build spills 27-93 VGPRs at 4 waves/SIMD, none at 3)
+template <typename T, class SEQ, int LR>
+__global__ __launch_bounds__(row_maxnt<SEQ>(), (sizeof(T) == 8 ? 2 : 3)) void row_r2c_rsplit_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_rsplit_body<T, SEQ, LR>(c, a);
+}
+
+// single-pass column stage of the R-split path: [My][C] tile, all threads forward, R groups inverse (fft_fband.hpp)
+template <typename T, class SEQF, int LR, int LOGC>
+__global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 : 4)) void col_fband_kernel(ColFBandArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_fband_body<T, SEQF, LR, LOGC>(c, a);
+}
+
 // 16384-point rows: two waves per row (even / odd packed samples), one workgroup of 128 threads per row in flight
 __global__ __launch_bounds__(128, 1) void row_r2c_w64x2_kernel(RowW64Args a) {
     GpuCtx c{oa_dyn_smem};
@@ -53,10 +73,10 @@ template <typename T, class SEQ> constexpr int pair_waves_per_eu() {
     return sizeof(T) == 8 ? 1 : (seq_logl<SEQ>() == 12 ? 3 : 2);
 }
 #endif
-template <typename T, class SEQ, int NZ>
+template <typename T, class SEQ, int NZ, int LR = 0>
 __global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ>())) void row_qe_pair_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
-    row_qe_pair_body<T, SEQ, NZ>(c, a);
+    row_qe_pair_body<T, SEQ, NZ, LR>(c, a);
 }
 
 template <typename T, class SEQ>
@@ -134,6 +154,44 @@ struct HipLauncher {
         });
         if (!ok && !rc) rc = fail("fft: unsupported row length");
     }
+    void fail_rlayout() { if (!rc) rc = fail("fft: the R-layout needs the two-rows-per-transform row stage"); }
+    // R-split row R2C: the one-wave-per-row kernel for f32 rows of 8192 points (<= 512 columns), else the general pass
+    bool row_w64r(const RowArgs<float>& a) {
+        if (!r2c_w64_mode() || rc || !(a.logL == 12 && a.wcols <= 512 && a.lr == 2)) return false;
+        RowW64Args w{};
+        w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
+        w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = a.my << a.lr; w.kplane = a.kplane; w.twy = a.twy;
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+        w.nwg = cus * per_cu;
+        if (w.nwg > a.my) w.nwg = a.my;
+        hipLaunchKernelGGL(row_r2c_w64r_kernel<2>, dim3(w.nwg), dim3(64), W64_LDS_BYTES, st, w);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+        return true;
+    }
+    bool row_w64r(const RowArgs<double>&) { return false; }
+    template <typename T>
+    void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (row_w64r(a)) return;
+        bool ok = false;
+        if (a.lr == 2) {
+            if (a.logL == 10) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 4>, 2>, dim3(grid), nt, smem, a); ok = true; }
+            else if (a.logL == 11) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 8>, 2>, dim3(grid), nt, smem, a); ok = true; }
+            else if (a.logL == 12) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 16>, 2>, dim3(grid), nt, smem, a); ok = true; }
+            else if (a.logL == 13) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 16, 2>, 2>, dim3(grid), nt, smem, a); ok = true; }
+        }
+        if (!ok && !rc) rc = fail("fft: unsupported R-split row pass");
+    }
+    template <typename T>
+    void col_fband(int gx, int gy, int gz, size_t smem, int logMy, const ColFBandArgs<T>& a) {
+        if (rc) return;
+        constexpr int nt = sizeof(T) == 4 ? 1024 : 512;
+        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
+        if (gy == 4 && logMy == 11) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11>, dim3(gx, gy, gz), nt, smem, a);
+        else if (gy == 4 && logMy == 10) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10>, dim3(gx, gy, gz), nt, smem, a);
+        else rc = fail("fft: unsupported R-split column stage");
+    }
     template <typename T>
     void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         // rows of 16384 / 32768 points: put the short radix FIRST so that the reversed (inverse) sequence starts with
@@ -164,7 +222,9 @@ struct HipLauncher {
             if constexpr (seq_logl<S>() >= 10 && seq_logl<S>() <= 13) {
                 if (nt != pair_nt<S>()) { if (!rc) rc = fail("fft: pair row stage launched with the wrong workgroup size"); return; }
                 dispatch_pair_nz<S>(pair_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
-                    go(row_qe_pair_kernel<T, S, decltype(nzc)::value>, dim3(grid), nt, smem, a);
+                    if (a.lr == 2) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 2>, dim3(grid), nt, smem, a);
+                    else if (a.lr == 0) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 0>, dim3(grid), nt, smem, a);
+                    else if (!rc) rc = fail("fft: unsupported R-layout of the pair row stage");
                 });
             } else if (!rc) rc = fail("fft: unsupported row grid for the pair row stage");
         });
@@ -304,7 +364,7 @@ static int cols_impl(oa_plan* p, const void* in, void* out, int inverse, double 
 }
 template <typename T>
 static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
-                        int accumulate, int win, int wout, int mrow, hipStream_t st, long pin = 0, long pout = 0, int my = 0) {
+                        int accumulate, int win, int wout, int mrow, hipStream_t st, long pin = 0, long pout = 0, int my = 0, int lr = 0) {
     HipLauncher q{st};
     auto f = coarse_view<T>(p, my);
     const int wi = f.clampw(win), wo = f.clampw(wout);
@@ -316,9 +376,22 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
         if (!is_pow2(mrow) || mrow < 64) return fail("oa_qe_rows: mrow must be a power of two >= 64");
         if (2L * wi + wo > mrow) return fail("oa_qe_rows: mrow < 2*win + wout would alias the leg products into the kept columns");
     }
+    if (lr && !f.rows_qe_is_pair(wi, wo, mrow)) return fail("oa_qe_rows: leg planes in the R-layout need the two-rows-per-transform row stage");
     f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate, wi, wo, mrow,
-              pin, pout);
+              pin, pout, 1, 0, 0, -1, nullptr, lr);
     return q.rc;
+}
+// does the from-map path of this geometry run the R-split row pass + single-pass column stage (leg planes in the R-LAYOUT)?
+template <typename T>
+static int rsplit_lr(const oa_plan* p, int my, int width, int wout, int mrow) {
+    auto f = view<T>(p);
+    const int w = f.clampw(width), wo = f.clampw(wout);
+    if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !Fft2dPlan<T>::has_rsplit(p->logNy, p->logNx, my, w)) return 0;
+    if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, w, wo); if (2L * w + wo > mrow) mrow = 0; }
+    return coarse_view<T>(p, my).rows_qe_is_pair(w, wo, mrow) ? p->logNy - ilog2(my) : 0;
+}
+int qe_rsplit_lr(const oa_plan* p, int my, int width, int wout, int mrow) {
+    return p->dtype == OA_F32 ? rsplit_lr<float>(p, my, width, wout, mrow) : rsplit_lr<double>(p, my, width, wout, mrow);
 }
 
 template <typename T>
@@ -332,7 +405,7 @@ static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void
 // real map -> the three column-transformed leg planes (both legs from this one map)
 template <typename T>
 static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7, int my = 0) {
+                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7, int my = 0, int lr = 0) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
@@ -342,6 +415,15 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
     const int w = f.clampw(width);
     const long pw = pwork > 0 ? pwork : p->kp;          // pitch of the two scratch planes
     // stages (per-kernel timing, oa_qe_tt_stage): 1 = row R2C, 2 = forward column pass 1, 4 = fused legs + inverse pass 2
+    if (lr > 0) {
+        // R-SPLIT: the row pass carries the first radix-R butterfly of the column transform; ONE column kernel to the leg planes
+        const auto cv = coarse_view<T>(p, my);
+        const long kplane = (long)my * pw;
+        if (stages & 1) f.rows_rsplit(q, map, tA, pw, kplane, w, my);
+        if (stages & 4) f.legs_fband(q, cv, tA, kplane, pw, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
+                                     (cx<T>*)h, width, rband, pout > 0 ? pout : p->kp);
+        return q.rc;
+    }
     if (stages & 1) f.rows(q, ROW_R2C, map, p->nx / 2, tA, pw, (T)1, w);
     if (my > 0 && my < p->ny) {
         // COLUMN GRID: the map's transform is needed on the leg band only (forward pass 2 stores just those rows, at
@@ -406,7 +488,8 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
                            void* c1, void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow,
                            int my, long pl, long pk, hipStream_t st) {
     auto f = view<T>(p);
-    if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my)) return -1;
+    const int lr = rsplit_lr<T>(p, my, wl, wk, mrow);
+    if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !(lr || Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my))) return -1;
     const auto cv = coarse_view<T>(p, my);
     const int wi = f.clampw(wl), wo = f.clampw(wk);
     if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo); if (2L * wi + wo > mrow) mrow = 0; }
@@ -418,6 +501,20 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
     HipLauncher q{st};
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = (double)p->ny / my;
+    if (lr) {
+        // R-SPLIT: two row passes, then ONE column launch, ONE row-stage launch and ONE divergence launch for both maps
+        const long kplane = (long)my * pl;
+        f.rows_rsplit(q, map0, tA, pl, kplane, wi, my);
+        f.rows_rsplit(q, map1, tA + ms, pl, kplane, wi, my);
+        f.legs_fband(q, cv, tA, kplane, pl, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)c0, (cx<T>*)c1, (cx<T>*)c2, wl, rl,
+                     pl, 2, ms, cms);
+        cv.rows_qe(q, (const cx<T>*)c0, (const cx<T>*)c1, (const cx<T>*)c2, (cx<T>*)g0, (cx<T>*)g1, (T)(s * s * sy), 0, wi, wo, mrow, pl, pk, 2, cms, gms,
+                   -1, nullptr, lr);
+        cv.cols_div(q, (const cx<T>*)g0, (const cx<T>*)g1, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)out0, tA, tB, 0, wk, rk, pk, 2,
+                    gms, gms, (long)((cx<T>*)out1 - (cx<T>*)out0));
+        return q.rc;
+    }
     f.rows(q, ROW_R2C, map0, p->nx / 2, tA, pl, (T)1, wi);
     f.rows(q, ROW_R2C, map1, p->nx / 2, tA + ms, pl, (T)1, wi);
     const cx<T>* ins[2] = {tA, tA + ms};
@@ -426,7 +523,6 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
     if (!f.legs_cols_from_pass1_cg(q, cv, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)c0, (cx<T>*)c1,
                                    (cx<T>*)c2, wl, pl, pl, 2, ms, cms))
         return -1;
-    const double s = 1.0 / ((double)p->ny * p->nx), sy = (double)p->ny / my;
     cv.rows_qe(q, (const cx<T>*)c0, (const cx<T>*)c1, (const cx<T>*)c2, (cx<T>*)g0, (cx<T>*)g1, (T)(s * s * sy), 0, wi, wo, mrow, pl, pk, 2, cms, gms);
     cv.cols_div(q, (const cx<T>*)g0, (const cx<T>*)g1, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)out0, tA, tB, 0, wk, rk, pk, 2,
                 gms, gms, (long)((cx<T>*)out1 - (cx<T>*)out0));
@@ -445,9 +541,9 @@ long work_pitch(const oa_plan* p, int w) {
     return p->dtype == OA_F32 ? view<float>(p).work_pitch(w) : view<double>(p).work_pitch(w);
 }
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
-                       int rband, long pl, hipStream_t st, int stages, int my) {
-    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my)
-                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my);
+                       int rband, long pl, hipStream_t st, int stages, int my, int lr) {
+    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr)
+                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr);
 }
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my) {
@@ -550,9 +646,9 @@ int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width,
                               : legs_pass2_impl<double>(p, pool, nplanes, stride, width, st, pl, my);
 }
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
-              int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my) {
-    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my)
-                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my);
+              int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my, int lr) {
+    return p->dtype == OA_F32 ? qe_rows_impl<float>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my, lr)
+                              : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my, lr);
 }
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
                   long pk, hipStream_t st, int my) {

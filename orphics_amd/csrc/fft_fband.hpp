@@ -1,0 +1,115 @@
+// Single-pass column stage between the R-split row R2C (row_r2c_rsplit_body / row_r2c_w64r_body) and the fused row stage:
+// ONE kernel takes the row pass's output to the three leg planes the row stage reads.
+//
+// The column transform of length ny = R My (My = the alias-free column grid, include/orphics_amd.h COLUMN GRID) is split
+// y = g + My n, k = k1 + R k2.  The row pass already did the radix-R butterfly over n and the twiddle W_ny^(g k1): its
+// output plane k1 holds Y[k1][g], g < My, and
+//     X[k1 + R k2] = sum_g Y[k1][g] W_My^(g k2)                     (forward, My points, THIS kernel, one k1 per workgroup)
+// Only the band |ky| < leg_rows survives the filters; on the My-row grid it sits at k' = k1 + R k2' with
+//     k2' = k2 (k2 < Mq / 2),   k2' = k2 - (My - Mq) (k2 >= My - Mq / 2),   Mq = My / R.
+// The last forward radix is 2 R, so a thread's butterfly u holds bins j + t Mq / 2 (t < 2 R): exactly one low-band bin
+// (t = 0 -> k2' = j) and one high-band bin (t = 2 R - 1 -> k2' = j + Mq / 2) -- every k2' of the coarse spectrum exactly once,
+// no zero-fill.  The inverse on the My-row grid splits y' = y_lo + Mq y_hi:
+//     x[y_lo + Mq y_hi] = sum_k1 W_R^(-k1 y_hi) { W_My^(-k1 y_lo) sum_k2' X'[k1 + R k2'] W_Mq^(-k2' y_lo) }
+// The braces -- an Mq-point inverse transform over k2' and a twiddle, for the three filtered legs -- are computed here
+// (B[k1][y_lo], stored at row y_lo R + k1: the R-LAYOUT); the radix-R butterfly over k1 is taken by the row stage at its
+// loads (pair_rows_at).  What used to be forward pass 1, [forward pass 2 + filters + 16-point inverse pass 1] and inverse
+// pass 2 x 3 -- three launches, two round trips of the row pass's output and one of the leg planes -- is one launch that
+// reads the row pass's output once and writes the leg planes once.
+// LDS: the [My][C] forward tile (128 KB: C = 8 f32 / 4 f64 columns at My = 2048) is reused as R buffers of [Mq][C]: three
+// legs + idle groups that only keep the barriers company.
+#pragma once
+#include "fft_kernels.hpp"
+
+namespace oa {
+
+template <typename T>
+struct ColFBandArgs {
+    const cx<T>* in;            // R planes Y[k1] (kplane elements apart) of My rows, row pitch `pitch`
+    long kplane, pitch;
+    const T* FG; const T* FH;   // full-resolution filter planes (row pitch fpitch)
+    long fpitch;
+    const T* lxd; const T* lyd;
+    cx<T>* gx; cx<T>* gy; cx<T>* h;   // My-row leg planes in the R-LAYOUT, row pitch opitch
+    long opitch;
+    int width;
+    const cx<T>* tw;            // W_My^k
+    int ny_full, rband;         // rband > 0: the filters vanish on rows rband <= y <= ny_full - rband (not read)
+    long in_moff, out_moff;     // several maps per launch (grid z = map)
+};
+
+template <typename T, class SEQF, int LR, int LOGC, class Ctx>
+OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    constexpr int logL = seq_total_log<SEQF>();
+    constexpr int L = 1 << logL, R = 1 << LR, logMq = logL - LR, Mq = 1 << logMq;
+    constexpr int RL = SEQF::get(SEQF::n - 1), NB = EPT / RL, Ns = L / RL;
+    static_assert(RL == 2 * R, "col_fband: the last forward radix must be 2 R (one low and one high band bin per butterfly)");
+    static_assert(Ns == Mq / 2, "col_fband: band layout");
+    constexpr int C = 1 << LOGC;
+    constexpr int NT = (1 << (logL + LOGC)) / EPT;          // forward: all threads
+    constexpr int NTQ = NT / R;                              // inverse: threads per leg buffer
+    static_assert(NTQ * EPT == Mq * C, "col_fband: inverse thread groups");
+    const int tid = ctx.tid();
+    int tile = ctx.bid_x();
+    if ((sizeof(cx<T>) << LOGC) < 128) {
+        // 64-byte row segments: tiles 2m and 2m+1 share every 128-byte line -> give them to workgroups b and b + 8 of a group
+        // of 16 (same XCD under the round-robin dispatch; see col_div_body)
+        const int nt = ctx.grid_x(), base = tile & ~15, r = tile & 15;
+        if (base + 16 <= nt) tile = base + 2 * (r & 7) + (r >> 3);
+    }
+    const int c0 = tile << LOGC;
+    const int k1 = ctx.bid_y();
+    int ncols = a.width - c0;
+    if (ncols > C) ncols = C;
+    cx<T> gv[EPT];
+    cx<T>* twl = s + (1 << (logL + LOGC));                   // forward stage twiddles (W_My)
+    cx<T>* twq = twl + tw_lds_size(logL);                    // inverse stage twiddles (W_Mq)
+    cx<T>* ti = twq + tw_lds_size(logMq);                    // W_My^(k1 y_lo), y_lo < Mq
+    tw_lds_fill<T>(ctx, twl, a.tw, logL, logL, NT);
+    tw_lds_fill<T>(ctx, twq, a.tw, logL, logMq, NT);
+    for (int i = tid; i < Mq; i += NT) ti[i] = a.tw[((unsigned)k1 * (unsigned)i) & (unsigned)(L - 1)];
+    ctx.sync();
+    const long zmap = ctx.bid_z();
+    const ColLoad<T> ld{a.in + zmap * a.in_moff + (long)k1 * a.kplane + c0, (unsigned)a.pitch, ncols, false};
+    col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, LOGC, twl, logL, ld);
+    ctx.sync();                                              // every LDS read of the forward precedes the leg buffers' writes
+    cx<T>* bh = s;
+    cx<T>* bx = s + (Mq << LOGC);
+    cx<T>* by = s + 2 * (Mq << LOGC);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b & (C - 1), j = b >> LOGC;            // j < Ns = Mq / 2
+        const bool ok = c < ncols;
+        const T lx = ok ? a.lxd[c0 + c] : (T)0;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const cx<T> x = side ? gv[u * RL + RL - 1] : gv[u * RL];
+            const int k2 = side ? j + (RL - 1) * Ns : j;     // bin of the My-point forward transform
+            const int k2p = side ? j + Ns : j;               // its place in the Mq-point coarse spectrum of this k1
+            const int yf = k1 + R * k2;                      // row of the full-resolution grid
+            bool live = ok;
+            if (a.rband) live = ok && !(yf >= a.rband && yf <= a.ny_full - a.rband);
+            T fg = 0, fh = 0, ly = 0;
+            if (live) {
+                const long fi = (long)yf * a.fpitch + (c0 + c);
+                fg = a.FG[fi]; fh = a.FH[fi]; ly = a.lyd[yf];
+            }
+            const cx<T> g = mul_pi(x * fg);
+            const int at = (k2p << LOGC) + c;
+            bh[at] = swp(x * fh);                            // inverse transform = forward transform of the swapped data
+            bx[at] = swp(g * lx);
+            by[at] = swp(g * ly);
+        }
+    }
+    ctx.sync();
+    const int grp = tid / NTQ, tq = tid - grp * NTQ;         // groups 0..2: H, Gx, Gy; the others idle along
+    cx<T>* outp = grp == 0 ? a.h : (grp == 1 ? a.gx : a.gy);
+    const ColStore<T> st{outp + zmap * a.out_moff + (long)k1 * a.opitch + c0, (unsigned)(R * a.opitch), grp < 3 ? ncols : 0, true, ti, 0u, (T)1,
+                         0, 0, 0, 0};
+    using SI = typename SeqOf<logMq>::type;
+    fft_pipeline<T, false, false, true, SI>(ctx, s + grp * (Mq << LOGC), tq, NTQ, logMq, LOGC, 0, twq, logMq, NoLoad{}, st);
+}
+
+}  // namespace oa

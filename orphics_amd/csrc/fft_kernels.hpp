@@ -287,6 +287,17 @@ inline bool dispatch_seq(int logL, F&& f) {
     }
 }
 
+// the same table at compile time
+template <int LOGL> struct SeqOf;
+template <> struct SeqOf<4> { using type = Seq<16>; };
+template <> struct SeqOf<5> { using type = Seq<16, 2>; };
+template <> struct SeqOf<6> { using type = Seq<16, 4>; };
+template <> struct SeqOf<7> { using type = Seq<16, 8>; };
+template <> struct SeqOf<8> { using type = Seq<16, 16>; };
+template <> struct SeqOf<9> { using type = Seq<16, 16, 2>; };
+template <> struct SeqOf<10> { using type = Seq<16, 16, 4>; };
+template <> struct SeqOf<11> { using type = Seq<16, 16, 8>; };
+
 // radix sequences of the fused row stage: as dispatch_seq, except that 4-stage lengths lead with the short radix
 // (3-stage lengths with a short radix -- 1024..4096-point rows -- were measured faster in the greedy order: their
 // active-column variants spill)
@@ -318,6 +329,13 @@ struct RowArgs {
     int wcols;                 // R2C: columns produced; C2R: columns read (the rest are zero).  >= L+1: all
     const void* mul;           // C2R only, may be NULL: real plane (layout and pitch of `out`) multiplied into the result at the
                                // store -- a real-space window applied without another pass over the map (oa_mc_run_windowed)
+    // R-SPLIT R2C (row_r2c_rsplit_body): the first radix-R butterfly of the COLUMN transform rides on the row pass.  The
+    // workgroup transforms the R rows g + my n (n < R = 2^lr) of its group g one after the other and keeps, per kept
+    // column, Y[k1][g] = W_ny^(g k1) sum_n X_n W_R^(n k1) in registers: output plane k1 (kplane elements apart) row g.
+    // The column transform is then X[k1 + R k2] = DFT_my over g of Y[k1][g] -- one single-pass kernel (col_fband_body).
+    int lr, my;
+    long kplane;
+    const cx<T>* twy;          // W_ny^k, ny = my << lr
 };
 
 template <typename T, bool SWAP>
@@ -497,6 +515,74 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// R2C row pass with the first radix-R butterfly of the column transform on top (see RowArgs::lr).  Only kept columns
+// k < wcols <= L / 2 are produced; a thread owns the columns k0 + i * (threads per row), i < RS_MAXS, of one row slot.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RS_MAXS = 2;     // (4 slots spill the f32 build at 4 waves/SIMD; 2 cover every band-limited geometry: wcols <= L / 8)
+template <typename T, class SEQ, int LR, class Ctx>
+OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    const int tid = ctx.tid(), NT = a.NT;
+    constexpr int logL = seq_total_log<SEQ>();
+    constexpr int L = 1 << logL, R = 1 << LR;
+    const int C = 1 << a.logC, RS = a.rowStride;
+    const long r0 = (long)ctx.bid_x() * C;                 // first group of this workgroup
+    const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
+    cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
+    cx<T>* twl = s + C * RS;
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    ctx.sync();
+    const int tpr = (NT >> a.logC) > 0 ? (NT >> a.logC) : 1;
+    const int c = tid / tpr, k0 = tid - c * tpr;
+    const int sh = a.logTw - (logL + 1);
+    cx<T> acc[R][RS_MAXS];
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1)
+#pragma unroll
+        for (int i = 0; i < RS_MAXS; ++i) acc[k1][i] = mk<T>((T)0, (T)0);
+#pragma unroll 1
+    for (int n = 0; n < R; ++n) {
+        const cx<T>* inb = in + (r0 + (long)n * a.my) * a.in_pitch;
+        fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, RowLoadOnce<T>{inb, (unsigned)a.in_pitch}, NoStore{});
+        if (c < C) {
+            const cx<T>* sr = s + c * RS;
+#pragma unroll
+            for (int i = 0; i < RS_MAXS; ++i) {
+                const int kk = k0 + i * tpr;
+                if (kk < a.wcols) {
+                    const int km = (L - kk) & (L - 1);
+                    const cx<T> Zk = sr[kk + (kk >> 4)];
+                    const cx<T> Zm = sr[km + (km >> 4)];
+                    const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
+                    const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
+                    const cx<T> X = (E + a.tw[kk << sh] * O) * a.scale;
+#pragma unroll
+                    for (int k1 = 0; k1 < R; ++k1) {
+                        const cx<T> w = a.tw[(unsigned)((n * k1) & (R - 1)) << (a.logTw - LR)];      // W_R^(n k1): uniform
+                        acc[k1][i] = acc[k1][i] + X * w;
+                    }
+                }
+            }
+        }
+        ctx.sync();                                        // these LDS reads precede the next row's first-stage writes
+    }
+    if (c < C) {
+        const long g = r0 + c;
+        const unsigned nym = ((unsigned)a.my << LR) - 1u;
+#pragma unroll
+        for (int k1 = 0; k1 < R; ++k1) {
+            const cx<T> w = a.twy[((unsigned)g * (unsigned)k1) & nym];                               // W_ny^(g k1)
+            cx<T>* row = out + (long)k1 * a.kplane + g * a.out_pitch;
+#pragma unroll
+            for (int i = 0; i < RS_MAXS; ++i) {
+                const int kk = k0 + i * tpr;
+                if (kk < a.wcols) row[kk] = acc[k1][i] * w;
+            }
+        }
+    }
+}
+
 // ===========================================================================
 // Fused QE row stage (TT and every other estimator term): for each row
 //   h = C2R(H),  for leg in (Gx, Gy):  P_leg = R2C( C2R(leg) * h )
@@ -529,6 +615,7 @@ struct RowQeArgs {
     // npairs = 0: one map.
     int npairs; long in_moff, out_moff, h_moff;
     const RowQeMap<T>* tab;   // != nullptr: map m takes its planes and its scale from tab[m] instead
+    int lr, nrows;            // pair row stage: lr = 2 -> the leg planes are in the R-LAYOUT of col_fband_body (nrows = rows of the grid)
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -688,9 +775,24 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
 // dead taps are literal zeros), the unpacking one LDS pass over the wout kept columns -- no twiddles, no tangle.
 // One workgroup of M/16 threads per row pair; h0 + i h1 stays in 16 registers per thread as in row_qe_body.
 // ===========================================================================
-template <typename T, class SEQ, int NZ, class Ctx>
+// the two rows of a pair at column idx.  LR = 0: two adjacent rows of a natural-order plane.  LR = 2 (R-LAYOUT, the output
+// of col_fband_body): the plane holds B[k1][y_lo] at row y_lo R + k1 and row y_lo + Mq y_hi of the field is
+// sum_k1 W_R^(-k1 y_hi) B[k1][y_lo] -- the last radix-R butterfly of the inverse column transform, taken here at the load;
+// the pair (y_hi = 2 p, 2 p + 1) of group y_lo: with s02 = B0 + B2, d02 = B0 - B2, s13 = B1 + B3, d13 = B1 - B3 and
+// sg = +1 (p = 0) / -1 (p = 1):  a0 = s02 + sg s13,  a1 = d02 + sg i d13.
+template <typename T, int LAY>
+OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, int idx, cx<T>& a0, cx<T>& a1) {
+    static_assert(LAY == 0 || LAY == 2, "pair_rows_at: natural layout or R = 4");
+    if (LAY == 0) { a0 = row0[idx]; a1 = row1[idx]; return; }
+    const cx<T> b0 = row0[idx], b1 = row0[pitch + idx], b2 = row0[2 * pitch + idx], b3 = row0[3 * pitch + idx];
+    const cx<T> s02 = b0 + b2, d02 = b0 - b2, s13 = (b1 + b3) * sg, d13 = (b1 - b3) * sg;
+    a0 = s02 + s13;
+    a1 = add_pi(d02, d13);
+}
+
+template <typename T, class SEQ, int NZ, int LAY = 0, class Ctx>
 OA_HD void pair_inverse_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int RS, const cx<T>* tw,
-                                const cx<T>* row0, const cx<T>* row1, int win) {
+                                const cx<T>* row0, const cx<T>* row1, int win, long pitch = 0, T sg = (T)1) {
     constexpr int n = SEQ::n;
     constexpr int logM = seq_total_log<SEQ>();
     constexpr int R = SEQ::rget(0), LR = Log2c<R>::v, NB = EPT / R;
@@ -707,14 +809,16 @@ OA_HD void pair_inverse_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, i
                 if (t < NZ) {                       // low side: Z[n] = X0[n] + i X1[n], n < win
                     const bool ok = nn < win;
                     const int idx = ok ? nn : 0;    // unconditional loads from a valid address, masked afterwards
-                    const cx<T> a0 = row0[idx], a1 = row1[idx];
+                    cx<T> a0, a1;
+                    pair_rows_at<T, LAY>(row0, row1, pitch, sg, idx, a0, a1);
                     const cx<T> z = add_pi(a0, a1);
                     w[u * R + t] = ok ? swp(z) : mk<T>((T)0, (T)0);
                 } else if (t >= R - NZ) {            // high side: Z[n] = conj X0[M-n] + i conj X1[M-n], M - n < win
                     const int m = M - nn;
                     const bool ok = m < win;
                     const int idx = ok ? m : 0;
-                    const cx<T> a0 = row0[idx], a1 = row1[idx];
+                    cx<T> a0, a1;
+                    pair_rows_at<T, LAY>(row0, row1, pitch, sg, idx, a0, a1);
                     const cx<T> z = mk<T>(a0.x + a1.y, a1.x - a0.y);
                     w[u * R + t] = ok ? swp(z) : mk<T>((T)0, (T)0);
                 } else {
@@ -750,7 +854,7 @@ inline void dispatch_pair_nz(int nz, F&& f) {
     }
 }
 
-template <typename T, class SEQ, int NZ, class Ctx>
+template <typename T, class SEQ, int NZ, int LAY = 0, class Ctx>
 OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
@@ -768,13 +872,24 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
         const RowQeMap<T> e = a.tab[m];
         gxp = e.gx; gyp = e.gy; hp = e.h; pxp = e.px; pyp = e.py; scale = e.scale;
     }
-    const long r0 = wg * 2;
+    // natural layout: the pair is rows 2 wg, 2 wg + 1 of the leg planes and of the product planes.  R-LAYOUT (LR = 2: leg planes
+    // from col_fband_body): workgroup wg = 2 y_lo + p reads the four rows 4 y_lo .. 4 y_lo + 3 (B[k1][y_lo]) and its pair is
+    // rows y_lo + Mq (2 p), y_lo + Mq (2 p + 1) of the field, Mq = rows / 4, which is where its products go.
+    long r0 = wg * 2, ra = wg * 2, rb = wg * 2 + 1;
+    T sg = (T)1;
+    if (LAY > 0) {
+        const long ylo = wg >> 1, mq = a.nrows >> LAY;
+        sg = (wg & 1) ? (T)-1 : (T)1;
+        r0 = ylo << LAY;
+        ra = ylo + mq * (2 * (wg & 1));
+        rb = ra + mq;
+    }
     constexpr int R0 = SEQ::get(0);
     cx<T> hreg[EPT], v[EPT];
     cx<T>* twl = work + RS;
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
-    pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, hreg, tid, NT, RS, twl, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win);
+    pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, hreg, tid, NT, RS, twl, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * scale;
@@ -782,7 +897,7 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? gyp : gxp;
         cx<T>* dst = leg ? pyp : pxp;
-        pair_inverse_to_regs<T, SEQ, NZ>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
+        pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg);
         // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
 #pragma unroll
         for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
@@ -793,8 +908,8 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
         ctx.sync();
         forward_tail<T, SEQ>(ctx, work, tid, NT, logM, 0, RS, twl, logM);
         // unpack the kept columns of both rows
-        cx<T>* o0 = dst + r0 * a.opitch;
-        cx<T>* o1 = o0 + a.opitch;
+        cx<T>* o0 = dst + ra * a.opitch;
+        cx<T>* o1 = dst + rb * a.opitch;
         for (int k = tid; k < a.wout; k += NT) {
             const int km = (M - k) & (M - 1);
             const cx<T> Pk = work[k + (k >> 4)];

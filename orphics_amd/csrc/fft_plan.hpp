@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <vector>
 #include "fft_kernels.hpp"
+#include "fft_fband.hpp"
 
 namespace oa {
 
@@ -77,6 +78,47 @@ struct Fft2dPlan {
         q.row(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
 
+    // ---- R-SPLIT: row R2C with the first radix-R butterfly of the column transform on top (RowArgs::lr), then ONE
+    //      single-pass column kernel to the leg planes (fft_fband.hpp).  THIS plan is the full-resolution one; my = the
+    //      column grid.  Available for R = ny / my = 4, my = 1024 or 2048, leg widths up to a quarter of the packed row.
+    static bool has_rsplit(int logNy, int logNx, int my, int wl) {
+        if (my <= 0) return false;
+        static const bool off = getenv("OA_NO_RSPLIT") != nullptr;        // A/B switch
+        const int logMy = ilog2(my), L = 1 << (logNx - 1);
+        return !off && is_pow2(my) && logNy - logMy == 2 && (logMy == 10 || logMy == 11) && logNx >= 11 && logNx <= 14 && wl <= L / 4 &&
+               wl <= RS_MAXS * (L / EPT);
+    }
+    template <class Launcher>
+    void rows_rsplit(Launcher& q, const void* in, void* out, long out_pitch, long kplane, int wcols, int my) const {
+        RowArgs<T> a{};
+        a.logL = logNx - 1;
+        const int L = 1 << a.logL;
+        int C = 4096 / L;
+        if (C < 1) C = 1;
+        if (C > my) C = my;
+        a.logC = ilog2(C);
+        a.NT = (L * C) / EPT;
+        a.rowStride = L + (L >> 4) + 2;
+        a.tw = tw_x; a.logTw = logNx; a.scale = (T)1; a.mode = ROW_R2C; a.wcols = wcols;
+        a.in = in; a.out = out; a.in_pitch = nx / 2; a.out_pitch = out_pitch;
+        a.lr = logNy - ilog2(my); a.my = my; a.kplane = kplane; a.twy = tw_y;
+        q.row_rsplit(my / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
+    }
+    // cv: the coarse view (ny = my rows, tw_y = W_my); Y: the row pass's R planes; leg planes in the R-LAYOUT (row y_lo R + k1)
+    template <class Launcher>
+    void legs_fband(Launcher& q, const Fft2dPlan<T>& cv, const cx<T>* Y, long kplane, long pin, const T* FG, const T* FH, const T* lxd,
+                    const T* lyd, cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax, int rband, long pout, int nmaps = 1, long in_moff = 0,
+                    long out_moff = 0) const {
+        ColFBandArgs<T> a{};
+        a.in = Y; a.kplane = kplane; a.pitch = pin; a.FG = FG; a.FH = FH; a.fpitch = kp; a.lxd = lxd; a.lyd = lyd;
+        a.gx = gx; a.gy = gy; a.h = h; a.opitch = pout; a.width = clampw(wmax); a.tw = cv.tw_y; a.ny_full = ny; a.rband = clampr(rband);
+        a.in_moff = in_moff; a.out_moff = out_moff;
+        const int lt = sizeof(T) == 4 ? 14 : 13, lc = lt - cv.logNy, Cs = 1 << lc;
+        const int logMq = cv.logNy - (logNy - cv.logNy);
+        const size_t smem = ((size_t)(1 << lt) + tw_lds_size(cv.logNy) + tw_lds_size(logMq) + (1 << logMq)) * sizeof(cx<T>);
+        q.col_fband((a.width + Cs - 1) / Cs, 1 << (logNy - cv.logNy), nmaps, smem, cv.logNy, a);
+    }
+
     // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
     // mrow: length of the real row transforms (power of two, <= nx; 0 = nx).  Legs that vanish beyond column `win`
     // have products band-limited to 2 (win - 1), so the row stage evaluated on ANY grid of mrow >= 2 win + wout
@@ -105,7 +147,8 @@ struct Fft2dPlan {
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
                  int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0, long pin = 0,
                  long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0, long h_moff = -1,
-                 const RowQeMap<T>* tab = nullptr) const {
+                 const RowQeMap<T>* tab = nullptr, int lr = 0) const {
+        // lr = 2: the leg planes are in the R-LAYOUT of legs_fband (pair kernel only)
         // tab (device array of nmaps entries, pair kernel only): per-map planes and FINAL scales (see row_grid_scale)
         RowQeArgs<T> a{};
         // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
@@ -122,9 +165,11 @@ struct Fft2dPlan {
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
             if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
             a.tab = tab;
+            a.lr = lr; a.nrows = ny;
             q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
             return;
         }
+        if (lr) { q.fail_rlayout(); return; }                 // (callers check rows_qe_is_pair first)
         a.logL = logM - 1;
         const int L = 1 << a.logL;
         int C = qe_rows_per_wg(L);

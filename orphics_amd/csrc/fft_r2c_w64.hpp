@@ -81,6 +81,9 @@ struct RowW64Args {
     float scale;
     int wcols;                // columns produced (<= 512)
     int ny, nwg;
+    // R-SPLIT (row_r2c_w64_body_t<LR>): output plane k1 sits kplane elements behind plane 0; twy = W_ny^k
+    long kplane;
+    const cx<float>* twy;
 };
 
 // LDS: the 64 x 64 transpose goes through ONE 64 x 65 plane of 4-byte words, twice (real parts, then imaginary parts:
@@ -99,13 +102,70 @@ constexpr int W64_LDS_STRIDE = 65;
 constexpr size_t W64_LDS_BYTES = (size_t)64 * W64_LDS_STRIDE * sizeof(float);
 constexpr size_t W64_LDS_BYTES_CX = (size_t)64 * W64_LDS_STRIDE * sizeof(cx<float>);   // two-waves-per-row kernel below
 
+// one row: 4096 packed samples at src (lane j reads src[64 t]) -> X[m] = untangled output column j + 64 m, m < 8 (times scale)
 template <class Ctx>
-OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
+OA_HD void w64_row(Ctx& ctx, const RowW64Args& a, const cx<float>* src, const cx<float>* P, const cx<float>* Q, const cx<float>* U, cx<float>* X) {
     float* sf = reinterpret_cast<float*>(ctx.smem());
     cx<float>* s = reinterpret_cast<cx<float>*>(ctx.smem());   // untangle exchange (first 4 KB)
+    const int j = ctx.tid();
+    const int jm = (64 - j) & 63;
+    cx<float> v[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) v[t] = ld_once(src + 64 * t);
+    dft64<false>(v);                           // bin k1 = aa + 8 b sits in v[8 aa + b]
+#pragma unroll
+    for (int aa = 0; aa < 8; ++aa) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int k1 = aa + 8 * b;
+            if (k1) v[8 * aa + b] = v[8 * aa + b] * ((aa && b) ? P[aa] * Q[b] : (aa ? P[aa] : Q[b]));
+        }
+    }
+    // transpose, real parts: lane j writes word [k1][j], lane k1 = j reads [j][t]
+#pragma unroll
+    for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].x;
+    ctx.sync();
+    float re[64];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) re[t] = sf[j * W64_LDS_STRIDE + t];
+    ctx.sync();                                // every read of the plane precedes the writes below
+#pragma unroll
+    for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].y;
+    ctx.sync();
+#pragma unroll
+    for (int t = 0; t < 64; ++t) v[t] = mk<float>(re[t], sf[j * W64_LDS_STRIDE + t]);
+    ctx.sync();
+    dft64<true>(v);                            // lane k1 = j: Z[k1 + 64 m] in v[8 m], Z[k1 + 64 (56 + m)] in v[8 m + 7]
+#pragma unroll
+    for (int m = 0; m < 8; ++m) s[m * 64 + j] = v[8 * m + 7];
+    ctx.sync();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const cx<float> Zk = v[8 * m];
+        // partner Z[4096 - k]: lane (64 - j) & 63, high slot 63 - m (j > 0) or 64 - m (j = 0; m = 0: Z[0] itself)
+        const int idx = j ? (7 - m) : (8 - m);
+        cx<float> Zm = Zk;
+        if (m > 0 || j) Zm = s[(idx & 7) * 64 + jm];
+        const cx<float> E = (Zk + conj(Zm)) * 0.5f;
+        const cx<float> O = mul_mi(Zk - conj(Zm)) * 0.5f;
+        X[m] = (E + U[m] * O) * a.scale;
+    }
+    ctx.sync();                                // the partner reads precede the next row's transpose writes
+}
+
+// LR = 0: out row = in row.  LR > 0 (R-SPLIT, RowArgs::lr): this wave transforms the R = 2^LR rows g + my n of its group g one
+// after the other and accumulates the first radix-R butterfly of the column transform per kept column:
+// Y[k1][g] = W_ny^(g k1) sum_n X_n W_R^(n k1) -> plane k1 (kplane elements apart), row g.  32 (R = 4) complex accumulators
+// per lane; the waves stay independent (no cross-wave exchange, no workgroup barrier).
+template <int LR, class Ctx>
+OA_HD void row_r2c_w64_body_t(Ctx& ctx, const RowW64Args& a) {
+    constexpr int R = 1 << LR;
     const int j = ctx.tid();                       // lane = point residue (stage 1) = bin residue k1 (stage 2)
     const int sh = a.logTw - 12;                   // W4096^e = tw[e << sh]
-    const int jm = (64 - j) & 63;
     // per-lane twiddle bases, kept across the rows of this wave: P[a] = W4096^(j a), Q[b] = W4096^(8 j b);
     // untangle factors U[m] = W8192^(j + 64 m)
     cx<float> P[8], Q[8], U[8];
@@ -115,59 +175,47 @@ OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
         Q[i] = a.tw[(unsigned)((8 * j * i) & 4095) << sh];
         U[i] = a.tw[(unsigned)(j + 64 * i) << (sh - 1)];
     }
-    for (long row = ctx.bid_x(); row < a.ny; row += a.nwg) {
-        cx<float> v[64];
-        const cx<float>* src = a.in + row * a.in_pitch + j;
+    if constexpr (LR == 0) {
+        for (long row = ctx.bid_x(); row < a.ny; row += a.nwg) {
+            cx<float> X[8];
+            w64_row(ctx, a, a.in + row * a.in_pitch + j, P, Q, U, X);
+            cx<float>* dst = a.out + row * a.out_pitch + j;
 #pragma unroll
-        for (int t = 0; t < 64; ++t) v[t] = ld_once(src + 64 * t);
-        dft64<false>(v);                           // bin k1 = aa + 8 b sits in v[8 aa + b]
+            for (int m = 0; m < 8; ++m)
+                if (j + 64 * m < a.wcols) dst[64 * m] = X[m];
+        }
+    } else {
+        const long ngroups = a.ny >> LR;
+        for (long g = ctx.bid_x(); g < ngroups; g += a.nwg) {
+            cx<float> acc[R][8];
 #pragma unroll
-        for (int aa = 0; aa < 8; ++aa) {
+            for (int k1 = 0; k1 < R; ++k1)
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int k1 = aa + 8 * b;
-                if (k1) v[8 * aa + b] = v[8 * aa + b] * ((aa && b) ? P[aa] * Q[b] : (aa ? P[aa] : Q[b]));
+                for (int m = 0; m < 8; ++m) acc[k1][m] = mk<float>(0.f, 0.f);
+#pragma unroll 1
+            for (int n = 0; n < R; ++n) {
+                cx<float> X[8];
+                w64_row(ctx, a, a.in + (g + n * ngroups) * a.in_pitch + j, P, Q, U, X);
+#pragma unroll
+                for (int k1 = 0; k1 < R; ++k1) {
+                    const cx<float> w = a.tw[(unsigned)((n * k1) & (R - 1)) << (a.logTw - LR)];      // W_R^(n k1): uniform
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[k1][m] = acc[k1][m] + X[m] * w;
+                }
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < R; ++k1) {
+                const cx<float> w = a.twy[((unsigned)g * (unsigned)k1) & (unsigned)(a.ny - 1)];      // W_ny^(g k1)
+                cx<float>* dst = a.out + (long)k1 * a.kplane + g * a.out_pitch + j;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    if (j + 64 * m < a.wcols) dst[64 * m] = acc[k1][m] * w;
             }
         }
-        // transpose, real parts: lane j writes word [k1][j], lane k1 = j reads [j][t]
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].x;
-        ctx.sync();
-        float re[64];
-#pragma unroll
-        for (int t = 0; t < 64; ++t) re[t] = sf[j * W64_LDS_STRIDE + t];
-        ctx.sync();                                // every read of the plane precedes the writes below
-#pragma unroll
-        for (int aa = 0; aa < 8; ++aa)
-#pragma unroll
-            for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].y;
-        ctx.sync();
-#pragma unroll
-        for (int t = 0; t < 64; ++t) v[t] = mk<float>(re[t], sf[j * W64_LDS_STRIDE + t]);
-        ctx.sync();
-        dft64<true>(v);                            // lane k1 = j: Z[k1 + 64 m] in v[8 m], Z[k1 + 64 (56 + m)] in v[8 m + 7]
-#pragma unroll
-        for (int m = 0; m < 8; ++m) s[m * 64 + j] = v[8 * m + 7];
-        ctx.sync();
-        cx<float>* dst = a.out + row * a.out_pitch + j;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int k = j + 64 * m;
-            const cx<float> Zk = v[8 * m];
-            // partner Z[4096 - k]: lane (64 - j) & 63, high slot 63 - m (j > 0) or 64 - m (j = 0; m = 0: Z[0] itself)
-            const int idx = j ? (7 - m) : (8 - m);
-            cx<float> Zm = Zk;
-            if (m > 0 || j) Zm = s[(idx & 7) * 64 + jm];
-            const cx<float> E = (Zk + conj(Zm)) * 0.5f;
-            const cx<float> O = mul_mi(Zk - conj(Zm)) * 0.5f;
-            const cx<float> X = (E + U[m] * O) * a.scale;
-            if (k < a.wcols) dst[64 * m] = X;
-        }
-        ctx.sync();                                // the partner reads precede the next row's transpose writes
     }
 }
+template <class Ctx>
+OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) { row_r2c_w64_body_t<0>(ctx, a); }
 
 
 // ---------------------------------------------------------------------------------------------------------------

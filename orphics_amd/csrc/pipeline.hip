@@ -154,6 +154,11 @@ int oa_plan_set_col_grid(oa_plan* p, int mcol) {
 }
 
 int oa_plan_col_grid(const oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->my : 0; }
+int oa_plan_rsplit(const oa_plan* p) {
+    if (!p || !p->pipe) return 0;
+    const Pipeline* q = (const Pipeline*)p->pipe;
+    return q->FG ? (1 << qe_rsplit_lr(p, q->my, q->wl, q->wk, q->mrow)) & ~1 : 0;
+}
 
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
                         int leg_rows, int kappa_rows, int mrow) {
@@ -208,11 +213,12 @@ int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, v
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const int my = q->my;
-    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 7, my);
+    const int lr = real_map ? qe_rsplit_lr(p, my, q->wl, q->wk, q->mrow) : 0;     // from a map: R-split row pass + one column kernel
+    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 7, my, lr);
     else rc = qe_legs_cols_w(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, my);
     if (rc) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;   // DFT on my rows = my/ny x the full one
-    if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my))) return rc;
+    if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my, lr))) return rc;
     return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st, my);
 }
 
@@ -507,11 +513,12 @@ int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int my = q->my;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
+    const int lr = qe_rsplit_lr(p, my, q->wl, q->wk, q->mrow);
     switch (stage) {
         case 0: case 1: case 2:
             OA_REQUIRE(real_map, "oa_qe_tt_stage: stages 0-2 need the map");
-            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my);
-        case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my);
+            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my, lr);
+        case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my, lr);
         case 4: return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st, my);
         case 5: {
             OA_REQUIRE(q->ids, "oa_qe_tt_stage: stage 5 needs oa_plan_set_bins");

@@ -72,9 +72,23 @@ struct EmuLauncher {
             using S = decltype(seq);
             if constexpr (seq_total_log<S>() >= 10 && seq_total_log<S>() <= 13)
                 dispatch_pair_nz<S>(pair_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
-                    run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value>(c, a); });
+                    if (a.lr == 2) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 2>(c, a); });
+                    else run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 0>(c, a); });
                 });
         });
+    }
+    void fail_rlayout() {}
+    template <typename T> void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (a.lr != 2) return;
+        if (a.logL == 10) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 4>, 2>(c, a); });
+        else if (a.logL == 11) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 8>, 2>(c, a); });
+        else if (a.logL == 12) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 16>, 2>(c, a); });
+    }
+    template <typename T> void col_fband(int gx, int gy, int gz, size_t smem, int logMy, const ColFBandArgs<T>& a) {
+        constexpr int nt = sizeof(T) == 4 ? 1024 : 512;
+        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
+        if (gy == 4 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 8>, 2, lc11>(c, a); }, gz);
+        else if (gy == 4 && logMy == 10) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 8>, 2, lc10>(c, a); }, gz);
     }
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
@@ -223,7 +237,65 @@ static int do_cols_div_batch(int ny_full, int my, int nx, const void* prod, cons
     return 0;
 }
 
+// R-SPLIT from-map leg path (rows_rsplit -> legs_fband) and the row stage on its R-LAYOUT planes
+template <typename T>
+static int do_rsplit_rows(int ny, int my, int nx, const T* map, cx<T>* Y, long pitch, int width) {
+    Holder<T> hd(ny, nx);
+    EmuLauncher q;
+    if (!Fft2dPlan<T>::has_rsplit(hd.p.logNy, hd.p.logNx, my, hd.p.clampw(width))) return 1;
+    hd.p.rows_rsplit(q, map, Y, pitch, (long)my * pitch, hd.p.clampw(width), my);
+    return 0;
+}
+template <typename T>
+static int do_rsplit_legs(int ny, int my, int nx, const cx<T>* Y, long pitch, const T* FG, const T* FH, const T* lxd, const T* lyd, cx<T>* gx,
+                          cx<T>* gy, cx<T>* h, long opitch, int width, int rband, int nmaps, long in_moff, long out_moff) {
+    Holder<T> hd(ny, nx);
+    CoarseHolder<T> cv(ny, my, nx);
+    EmuLauncher q;
+    hd.p.legs_fband(q, cv.p, Y, (long)my * pitch, pitch, FG, FH, lxd, lyd, gx, gy, h, width, rband, opitch, nmaps, in_moff, out_moff);
+    return 0;
+}
+template <typename T>
+static int do_qe_rows_rlayout(int my, int nx, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, double s, int win, int wout,
+                              int mrow, int lr) {
+    Holder<T> hd(my, nx);
+    EmuLauncher q;
+    if (!hd.p.rows_qe_is_pair(hd.p.clampw(win), hd.p.clampw(wout), mrow)) return 1;
+    hd.p.rows_qe(q, gx, gy, h, px, py, (T)s, 0, hd.p.clampw(win), hd.p.clampw(wout), mrow, 0, 0, 1, 0, 0, -1, nullptr, lr);
+    return 0;
+}
+
 extern "C" {
+int emu_rsplit_rows_f32(int ny, int my, int nx, const float* map, void* Y, long pitch, int width) { return do_rsplit_rows<float>(ny, my, nx, map, (cx<float>*)Y, pitch, width); }
+int emu_rsplit_rows_f64(int ny, int my, int nx, const double* map, void* Y, long pitch, int width) { return do_rsplit_rows<double>(ny, my, nx, map, (cx<double>*)Y, pitch, width); }
+int emu_rsplit_legs_f32(int ny, int my, int nx, const void* Y, long pitch, const float* FG, const float* FH, const float* lxd, const float* lyd, void* gx,
+                        void* gy, void* h, long opitch, int width, int rband, int nmaps, long in_moff, long out_moff) {
+    return do_rsplit_legs<float>(ny, my, nx, (const cx<float>*)Y, pitch, FG, FH, lxd, lyd, (cx<float>*)gx, (cx<float>*)gy, (cx<float>*)h, opitch, width, rband,
+                                 nmaps, in_moff, out_moff);
+}
+int emu_rsplit_legs_f64(int ny, int my, int nx, const void* Y, long pitch, const double* FG, const double* FH, const double* lxd, const double* lyd, void* gx,
+                        void* gy, void* h, long opitch, int width, int rband, int nmaps, long in_moff, long out_moff) {
+    return do_rsplit_legs<double>(ny, my, nx, (const cx<double>*)Y, pitch, FG, FH, lxd, lyd, (cx<double>*)gx, (cx<double>*)gy, (cx<double>*)h, opitch, width,
+                                  rband, nmaps, in_moff, out_moff);
+}
+int emu_qe_rows_rlayout_f64(int my, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout, int mrow, int lr) {
+    return do_qe_rows_rlayout<double>(my, nx, (const cx<double>*)gx, (const cx<double>*)gy, (const cx<double>*)h, (cx<double>*)px, (cx<double>*)py, s, win, wout, mrow, lr);
+}
+int emu_qe_rows_rlayout_f32(int my, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout, int mrow, int lr) {
+    return do_qe_rows_rlayout<float>(my, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s, win, wout, mrow, lr);
+}
+// one-wave-per-row R-split R2C (row_r2c_w64_body_t<2>): nx = 8192, ny = 4 my
+int emu_rsplit_rows_w64_f32(int ny, int nx, const float* in, void* out, long pitch, int width, int nwg) {
+    if (nx != 8192 || width > 512 || (ny & 3)) return 1;
+    auto tw = make_twiddles<float>(nx);
+    auto twy = make_twiddles<float>(ny);
+    RowW64Args a{};
+    a.in = (const cx<float>*)in; a.out = (cx<float>*)out; a.in_pitch = nx / 2; a.out_pitch = pitch;
+    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = 1.0f; a.wcols = width; a.ny = ny; a.nwg = nwg; a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
+    EmuLauncher q;
+    q.run(nwg, 1, 64, W64_LDS_BYTES, [&](EmuCtx& c) { row_r2c_w64_body_t<2>(c, a); });
+    return 0;
+}
 // one-wave-per-row R2C pass (fft_r2c_w64.hpp): nx must be 8192; out has pitch nx/2+16
 int emu_r2c_rows_w64_f32(int ny, int nx, const float* in, void* out, double scale, int width, int nwg) {
     if (nx != 8192 || width > 512) return 1;

@@ -18,7 +18,7 @@ def emu():
     so = os.path.join(EMUL, "libemul_fft.so")
     src = os.path.join(EMUL, "emul_fft.cpp")
     csrc = os.path.join(HERE, "..", "orphics_amd", "csrc")
-    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "cx.hpp")]
+    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_fband.hpp", "cx.hpp")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -500,3 +500,140 @@ def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb, nx,
     assert np.all(out[untouched] == 3.0)
     if w:
         assert np.all(out[:, wv:W] == 3.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# R-SPLIT from-map path: row R2C with the first radix-4 butterfly of the column transform (general pass and the
+# one-wave-per-row kernel), the single-pass column stage (fft_fband.hpp) and the row stage on its R-LAYOUT planes
+# ---------------------------------------------------------------------------------------------------------------
+def _rsplit_reference(x, my, w):
+    """Y[k1][g][k] = W_ny^(g k1) sum_n rfft(x[g + my n])[k] W_4^(n k1), k < w"""
+    ny = x.shape[0]
+    X = np.fft.rfft(x, axis=1)[:, :w]
+    g = np.arange(my)
+    out = np.zeros((4, my, w), dtype=np.complex128)
+    for k1 in range(4):
+        acc = sum(X[n * my:(n + 1) * my] * np.exp(-2j * np.pi * n * k1 / 4.) for n in range(4))
+        out[k1] = acc * np.exp(-2j * np.pi * g * k1 / ny)[:, None]
+    return out
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_rsplit_row_pass(emu, prec):
+    ny, my, nx, w = 4096, 1024, 2048, 37
+    rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((ny, nx)).astype(rdt)
+    pitch = 64
+    Y = np.full((4, my, pitch), 7.0 + 0j, dtype=cdt)
+    fn = emu.emu_rsplit_rows_f64 if prec == "f64" else emu.emu_rsplit_rows_f32
+    assert fn(ny, my, nx, _p(x), _p(Y), ctypes.c_long(pitch), w) == 0
+    ref = _rsplit_reference(x.astype(np.float64), my, w)
+    assert np.abs(Y[:, :, :w] - ref).max() < tol * np.abs(ref).max()
+    assert np.all(Y[:, :, w:] == 7.0)                                     # nothing beyond the kept columns is written
+    # ... and the column transform of plane k1 over g gives the full-resolution modes k1 + 4 k2
+    full = np.fft.fft(np.fft.rfft(x.astype(np.float64), axis=1)[:, :w], axis=0)
+    for k1 in range(4):
+        assert np.abs(np.fft.fft(ref[k1], axis=0) - full[k1::4]).max() < 1e-9 * np.abs(full).max()
+
+
+def test_rsplit_row_pass_one_wave_per_row(emu):
+    """row_r2c_w64_body_t<2>: the persistent wave walks the four rows of its group and keeps the butterfly in registers"""
+    ny, nx, w = 32, 8192, 380
+    my = ny // 4
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((ny, nx)).astype(np.float32)
+    pitch = 384
+    Y = np.full((4, my, pitch), 7.0 + 0j, dtype=np.complex64)
+    assert emu.emu_rsplit_rows_w64_f32(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3) == 0
+    ref = _rsplit_reference(x.astype(np.float64), my, w)
+    assert np.abs(Y[:, :, :w] - ref).max() < 3e-6 * np.abs(ref).max()
+    assert np.all(Y[:, :, w:] == 7.0)
+
+
+def _fband_reference(Y, my, FG, FH, lxd, lyd, w, ny):
+    """leg planes in the R-LAYOUT (row y_lo 4 + k1) from the row pass's planes Y[k1][g][k]"""
+    mq = my // 4
+    full = np.zeros((ny, w), dtype=np.complex128)
+    for k1 in range(4):
+        full[k1::4] = np.fft.fft(Y[k1][:, :w], axis=0)
+    legs = [full * FH[:, :w], 1j * lxd[None, :w] * FG[:, :w] * full, 1j * lyd[:, None] * FG[:, :w] * full]    # H, Gx, Gy
+    outs, fields = [], []
+    for leg in legs:
+        coarse = np.concatenate([leg[:my // 2], leg[ny - my // 2:]])            # the My-row spectrum (band-limited legs)
+        fields.append(np.fft.ifft(coarse, axis=0) * my)
+        plane = np.zeros((my, w), dtype=np.complex128)
+        ylo = np.arange(mq)
+        for k1 in range(4):
+            B = np.fft.ifft(coarse[k1::4], axis=0) * mq * np.exp(2j * np.pi * k1 * ylo / my)[:, None]
+            plane[k1::4] = B                                                     # row y_lo * 4 + k1
+        outs.append(plane)
+    return outs, fields
+
+
+@pytest.mark.parametrize("prec,nmaps", [("f64", 1), ("f32", 2)])
+def test_rsplit_single_pass_column_stage(emu, prec, nmaps):
+    ny, my, nx, w, rb = 4096, 1024, 2048, 21, 150
+    rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 4e-6)
+    rng = np.random.default_rng(9)
+    kp = emu.emu_kpitch(nx)
+    pitch, opitch = 32, 32
+    ly = (2 * np.pi * np.fft.fftfreq(ny) * 100)
+    lx = (2 * np.pi * np.fft.fftfreq(nx) * 100)
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[ny // 2] = 0
+    lxd[nx // 2] = 0
+    band = np.r_[0:rb, ny - rb + 1:ny]
+    FG = np.zeros((ny, kp)); FH = np.zeros((ny, kp))
+    FG[band, :w] = rng.uniform(0.5, 1.5, (band.size, w))
+    FH[band, :w] = rng.uniform(0.5, 1.5, (band.size, w))
+    Y = np.zeros((nmaps, 4, my, pitch), dtype=cdt)
+    Y[..., :w] = (rng.standard_normal((nmaps, 4, my, w)) + 1j * rng.standard_normal((nmaps, 4, my, w))).astype(cdt)
+    outs = [np.full((nmaps, my, opitch), 5.0 + 0j, dtype=cdt) for _ in range(3)]           # gx, gy, h
+    fn = emu.emu_rsplit_legs_f64 if prec == "f64" else emu.emu_rsplit_legs_f32
+    args = [a.astype(rdt) for a in (FG, FH, lxd, lyd)]
+    assert fn(ny, my, nx, _p(Y), ctypes.c_long(pitch), _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(outs[0]), _p(outs[1]), _p(outs[2]),
+              ctypes.c_long(opitch), w, rb, nmaps, ctypes.c_long(4 * my * pitch), ctypes.c_long(my * opitch)) == 0
+    for m in range(nmaps):
+        (rh, rgx, rgy), fields = _fband_reference(Y[m].astype(np.complex128), my, FG, FH, lxd, lyd, w, ny)
+        for got, want in ((outs[2][m], rh), (outs[0][m], rgx), (outs[1][m], rgy)):
+            assert np.abs(got[:, :w] - want).max() < tol * np.abs(want).max()
+            assert np.all(got[:, w:] == 5.0)
+        # the R-layout really encodes the field: x[y_lo + Mq y_hi] = sum_k1 i^(k1 y_hi) B[k1][y_lo]
+        mq = my // 4
+        B = rh.reshape(mq, 4, w)
+        x = np.stack([sum(B[:, k1] * (1j) ** (k1 * yh) for k1 in range(4)) for yh in range(4)]).reshape(my, w)
+        assert np.abs(x - fields[0]).max() < 1e-9 * np.abs(fields[0]).max()
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_row_stage_on_r_layout_planes(emu, prec):
+    """row_qe_pair_body<.., LAY = 2>: the same products from leg planes in the R-LAYOUT as from natural-order planes"""
+    my, nx, win, wout, M = 64, 4096, 20, 30, 1024
+    rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 2e-5)
+    rng = np.random.default_rng(12)
+    kp = emu.emu_kpitch(nx)
+    nat = []
+    for _ in range(3):
+        a = np.zeros((my, kp), dtype=np.complex128)
+        a[:, :win] = rng.standard_normal((my, win)) + 1j * rng.standard_normal((my, win))
+        a[:, 0] = a[:, 0].real                       # (a real row's transform is real at k = 0)
+        nat.append(a)
+    mq = my // 4
+
+    def to_r(a):                                     # B[k1][y_lo] = (1/4) sum_yh x[y_lo + Mq yh] (-i)^(k1 yh), stored at row y_lo 4 + k1
+        x = a.reshape(4, mq, kp)
+        out = np.zeros_like(a)
+        for k1 in range(4):
+            out[k1::4] = sum(x[yh] * (-1j) ** (k1 * yh) for yh in range(4)) / 4.
+        return out
+    fn = emu.emu_qe_rows_rlayout_f64 if prec == "f64" else emu.emu_qe_rows_rlayout_f32
+    res = []
+    for lr, planes in ((0, nat), (2, [to_r(a) for a in nat])):
+        pl = [np.ascontiguousarray(a.astype(cdt)) for a in planes]
+        px = np.full((my, kp), 3.0 + 0j, dtype=cdt); py = np.full((my, kp), 3.0 + 0j, dtype=cdt)
+        assert fn(my, nx, _p(pl[0]), _p(pl[1]), _p(pl[2]), _p(px), _p(py), ctypes.c_double(1.0 / nx ** 2), win, wout, M, lr) == 0
+        res.append((px, py))
+    for a, b in zip(res[0], res[1]):
+        assert np.abs(a[:, :wout] - b[:, :wout]).max() < tol * np.abs(a[:, :wout]).max()
+        assert np.all(b[:, wout:] == 3.0)
