@@ -7,10 +7,10 @@ One "step" = one pass of the hot path over one BATCH of --batch (default 64) ind
 K x batch x ranks / elapsed.  (The driver times K = 20 steps: 20 single reconstructions would be a 2.6 ms timed region,
 a fifth of which is the clock / pipeline ramp after the synchronising barrier -- 7.6 k/s measured against 9.1 k/s
 sustained.)  Each reconstruction of the batch:
-  row R2C -> forward column pass 1 -> [forward column pass 2 + leg filters + inverse column pass 1] -> inverse
-  column pass 2 (3 planes, one launch) -> [fused row stage: 3 C2R, 2 products, 2 R2C in LDS] -> forward column
-  pass 1 (2 planes, one launch) -> [forward column pass 2 + divergence * A_L] -> [|kappa_hat|^2 + radial
-  bandpowers] -> [bin means + moment accumulation]                                ([...] = one fused kernel).
+  [row R2C + first radix-4 butterfly of the column transform] -> [forward columns + leg filters + inverse columns on the
+  column grid: one single-pass kernel] -> [fused row stage: 3 C2R, 2 products, 2 R2C in LDS] -> [single-pass forward
+  columns + divergence * A_L] -> [|kappa_hat|^2 + radial bandpowers] -> [bin means + moment accumulation]
+                                                                                  ([...] = one fused kernel).
 Multi-GPU: independent realisations per rank (weak scaling, no data-path
 collective) + ONE RCCL all-reduce of the bandpower moments at the end.
 
@@ -382,7 +382,13 @@ def per_kernel_table(torch, P, R, args):
     cg = my / float(N) if my else 1.0
     # name -> (stage, bytes it must move once: inputs + outputs on its active columns / rows)
     logn = int(round(np.log2(N)))
-    if my and logn // 2 == 6 and (my >> (logn - 6)) == 16 and not os.environ.get("OA_NO_FWDLEGS_CG"):
+    rsplit = int(lib.oa_plan_rsplit(plan))
+    if rsplit:
+        legs_name = ("legs_cols = col_fband_kernel (single pass: forward %d-point columns of the R-split row output + leg filters + "
+                     "inverse %d-point columns -> 3 leg planes on the %d-row column grid)" % (my, my // rsplit, my))
+        # read the row pass's output once (R planes = ny rows) + 2 real filter planes on the band rows, write 3 planes of my rows
+        legs_bytes = fl * (Ah + gl * Ah + 3 * cg * Ah)
+    elif my and logn // 2 == 6 and (my >> (logn - 6)) == 16 and not os.environ.get("OA_NO_FWDLEGS_CG"):
         legs_name = "fwdlegs_cols = col_fwdlegs_cg_kernel (fwd pass2 + legs + inv pass1) + col_fft_kernel<inv pass2 x3> on the %d-row column grid" % my
         # fused kernel: read the pass-1 plane + 2 real filter planes on the band rows, write 3 planes of my rows; then the
         # 3-plane inverse pass 2 on my rows (r + w)
@@ -410,6 +416,8 @@ def per_kernel_table(torch, P, R, args):
         div_name: (4, div_bytes),
         "bin_kernel<power>": (5, 1.5 * fk * gk * Ah),
     }
+    if rsplit:           # the R-split row pass carries the first column radix: there is no separate forward column pass 1
+        del kern["col_fft_kernel<fwd pass1, leg width>"]
     # Stage durations IN SEQUENCE: whole steps (stages 0..5 back to back on this stream, alternating between the two
     # input maps as the timed loop does) with a HIP event between consecutive stages.  Timing one stage in a tight
     # loop of its own would let its inputs sit in the 256 MB infinity cache / L2 (the 268 MB map re-read 20 times
@@ -438,7 +446,7 @@ def per_kernel_table(torch, P, R, args):
     rq.update({"executed_GFLOP": flops / 1e9, "flop_count": how, "row_grid": mrow, "TFLOPs": flops / (rq["avg_ms"] * 1e-3) / 1e12,
                "valu_frac": flops / (rq["avg_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
                "arithmetic_intensity_flop_per_B": flops / (rq["hbm_min_GB"] * 1e9)})
-    return per, dict(A=A, Ah=Ah, fl=fl, fk=fk, W=W, wl=wl, wk=wk, rl=rl, rk=rk, mrow=mrow, mcol=my)
+    return per, dict(A=A, Ah=Ah, fl=fl, fk=fk, W=W, wl=wl, wk=wk, rl=rl, rk=rk, mrow=mrow, mcol=my, rsplit=rsplit)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -693,8 +701,14 @@ def measure(args, torch, dist, world, rank, prec):
         # the stage name above is bench.py's; the launch behind it, as rocprofv3 lists it (fft.hip HipLauncher::row_w64)
         wl_ = G["wl"] or W
         w64 = os.environ.get("OA_R2C_W64", "1") != "0" and prec == "f32"
-        roofline["kernel_symbol"] = ("row_r2c_w64_kernel" if (w64 and N == 8192 and wl_ <= 512) else
-                                     "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel<%s, R2C>" % ("float" if prec == "f32" else "double"))
+        tn = "float" if prec == "f32" else "double"
+        if G.get("rsplit"):
+            roofline["kernel_symbol"] = "row_r2c_w64r_kernel<2>" if (w64 and N == 8192 and wl_ <= 512) else "row_r2c_rsplit_kernel<%s, ...>" % tn
+            roofline["rsplit"] = {"R": G["rsplit"], "note": "the row pass also takes the first radix-R butterfly of the column transform (rows g + my n, n < R, "
+                                  "per wave / workgroup) and writes R planes Y[k1][g]; one single-pass column kernel follows (include/orphics_amd.h oa_plan_rsplit)"}
+        else:
+            roofline["kernel_symbol"] = ("row_r2c_w64_kernel" if (w64 and N == 8192 and wl_ <= 512) else
+                                         "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel<%s, R2C>" % tn)
     roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
     roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
                             "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}

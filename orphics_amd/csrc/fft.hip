@@ -12,13 +12,16 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_k
 }
 
 // one wave per row, 64 points per lane: a single wave per SIMD (LDS-limited), so the whole register file is its own
-__global__ __launch_bounds__(64, 1) void row_r2c_w64_kernel(RowW64Args a) {
+#ifndef OA_W64_OCC
+#define OA_W64_OCC 1
+#endif
+__global__ __launch_bounds__(64, OA_W64_OCC) void row_r2c_w64_kernel(RowW64Args a) {
     GpuCtx c{oa_dyn_smem};
     row_r2c_w64_body(c, a);
 }
 
 template <int LR>
-__global__ __launch_bounds__(64, 1) void row_r2c_w64r_kernel(RowW64Args a) {
+__global__ __launch_bounds__(64, OA_W64_OCC) void row_r2c_w64r_kernel(RowW64Args a) {
     GpuCtx c{oa_dyn_smem};
     row_r2c_w64_body_t<LR>(c, a);
 }
@@ -165,7 +168,7 @@ struct HipLauncher {
         static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
         w.nwg = cus * per_cu;
         if (w.nwg > a.my) w.nwg = a.my;
-        hipLaunchKernelGGL(row_r2c_w64r_kernel<2>, dim3(w.nwg), dim3(64), W64_LDS_BYTES, st, w);
+        hipLaunchKernelGGL(row_r2c_w64r_kernel<2>, dim3(w.nwg), dim3(64), W64_LDS_BYTES + W64R_ACC_BYTES, st, w);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
         return true;

@@ -536,11 +536,15 @@ OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
     const int tpr = (NT >> a.logC) > 0 ? (NT >> a.logC) : 1;
     const int c = tid / tpr, k0 = tid - c * tpr;
     const int sh = a.logTw - (logL + 1);
-    cx<T> acc[R][RS_MAXS];
+    static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
+    cx<T> acc[R][RS_MAXS], wy[R];
+    const unsigned nym = ((unsigned)a.my << LR) - 1u;
 #pragma unroll
-    for (int k1 = 0; k1 < R; ++k1)
+    for (int k1 = 0; k1 < R; ++k1) {
+        wy[k1] = a.twy[((unsigned)(r0 + (c < C ? c : 0)) * (unsigned)k1) & nym];                     // W_ny^(g k1): loaded before the rows
 #pragma unroll
         for (int i = 0; i < RS_MAXS; ++i) acc[k1][i] = mk<T>((T)0, (T)0);
+    }
 #pragma unroll 1
     for (int n = 0; n < R; ++n) {
         const cx<T>* inb = in + (r0 + (long)n * a.my) * a.in_pitch;
@@ -559,7 +563,8 @@ OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
                     const cx<T> X = (E + a.tw[kk << sh] * O) * a.scale;
 #pragma unroll
                     for (int k1 = 0; k1 < R; ++k1) {
-                        const cx<T> w = a.tw[(unsigned)((n * k1) & (R - 1)) << (a.logTw - LR)];      // W_R^(n k1): uniform
+                        const int e = (n * k1) & 3;                                                  // W_4^(n k1) = (-i)^e, uniform: no table load
+                        const cx<T> w = mk<T>((T)((e == 0) - (e == 2)), (T)((e == 3) - (e == 1)));
                         acc[k1][i] = acc[k1][i] + X * w;
                     }
                 }
@@ -569,10 +574,9 @@ OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
     }
     if (c < C) {
         const long g = r0 + c;
-        const unsigned nym = ((unsigned)a.my << LR) - 1u;
 #pragma unroll
         for (int k1 = 0; k1 < R; ++k1) {
-            const cx<T> w = a.twy[((unsigned)g * (unsigned)k1) & nym];                               // W_ny^(g k1)
+            const cx<T> w = wy[k1];
             cx<T>* row = out + (long)k1 * a.kplane + g * a.out_pitch;
 #pragma unroll
             for (int i = 0; i < RS_MAXS; ++i) {

@@ -101,10 +101,31 @@ struct RowW64Args {
 constexpr int W64_LDS_STRIDE = 65;
 constexpr size_t W64_LDS_BYTES = (size_t)64 * W64_LDS_STRIDE * sizeof(float);
 constexpr size_t W64_LDS_BYTES_CX = (size_t)64 * W64_LDS_STRIDE * sizeof(cx<float>);   // two-waves-per-row kernel below
+constexpr size_t W64R_ACC_BYTES = (size_t)3 * 8 * 64 * sizeof(cx<float>);                 // R-split: [slot][m][lane] partial butterflies
 
 // one row: 4096 packed samples at src (lane j reads src[64 t]) -> X[m] = untangled output column j + 64 m, m < 8 (times scale)
+// W128^m = exp(-2 pi i m / 128): U[m] = W8192^(j + 64 m) = U[0] W128^m
+OA_HD cx<float> w128(int m) {
+    constexpr float c[8] = {1.0f, 0.99879545620517241f, 0.99518472667219693f, 0.98917650996478101f, 0.98078528040323043f, 0.97003125319454397f,
+                            0.95694033573220882f, 0.94154406518302081f};
+    constexpr float sn[8] = {0.0f, 0.049067674327418015f, 0.098017140329560604f, 0.14673047445536175f, 0.19509032201612825f, 0.24298017990326387f,
+                             0.29028467725446233f, 0.33688985339222005f};
+    return mk<float>(c[m & 7], -sn[m & 7]);
+}
+
 template <class Ctx>
-OA_HD void w64_row(Ctx& ctx, const RowW64Args& a, const cx<float>* src, const cx<float>* P, const cx<float>* Q, const cx<float>* U, cx<float>* X) {
+OA_HD void w64_row(Ctx& ctx, const RowW64Args& a, const cx<float>* src, const cx<float>* Pin, const cx<float>* Qin, const cx<float>* Uin, cx<float>* X) {
+#ifdef OA_W64_DERIVE_TW
+    // only the bases P[1], Q[1], U[0] are kept across rows; the rest is rebuilt per row (19 complex products, 3 deep): 42
+    // registers less while the 64 points are live -- what two waves per SIMD need
+    cx<float> P[8], Q[8], U[8];
+    P[0] = Q[0] = mk<float>(1.f, 0.f);
+    P[1] = Pin[1]; Q[1] = Qin[1];
+    P[2] = P[1] * P[1]; P[3] = P[2] * P[1]; P[4] = P[2] * P[2]; P[5] = P[4] * P[1]; P[6] = P[4] * P[2]; P[7] = P[4] * P[3];
+    Q[2] = Q[1] * Q[1]; Q[3] = Q[2] * Q[1]; Q[4] = Q[2] * Q[2]; Q[5] = Q[4] * Q[1]; Q[6] = Q[4] * Q[2]; Q[7] = Q[4] * Q[3];
+#else
+    const cx<float>* P = Pin; const cx<float>* Q = Qin; const cx<float>* U = Uin;
+#endif
     float* sf = reinterpret_cast<float*>(ctx.smem());
     cx<float>* s = reinterpret_cast<cx<float>*>(ctx.smem());   // untangle exchange (first 4 KB)
     const int j = ctx.tid();
@@ -127,9 +148,10 @@ OA_HD void w64_row(Ctx& ctx, const RowW64Args& a, const cx<float>* src, const cx
 #pragma unroll
         for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].x;
     ctx.sync();
-    float re[64];
+    // (the transposed real parts go straight into the .x slots -- dead once written -- while the .y slots still hold the
+    // untransposed imaginary parts of the first stage: no second 64-register array, which the R-split build cannot afford)
 #pragma unroll
-    for (int t = 0; t < 64; ++t) re[t] = sf[j * W64_LDS_STRIDE + t];
+    for (int t = 0; t < 64; ++t) v[t].x = sf[j * W64_LDS_STRIDE + t];
     ctx.sync();                                // every read of the plane precedes the writes below
 #pragma unroll
     for (int aa = 0; aa < 8; ++aa)
@@ -137,12 +159,17 @@ OA_HD void w64_row(Ctx& ctx, const RowW64Args& a, const cx<float>* src, const cx
         for (int b = 0; b < 8; ++b) sf[(aa + 8 * b) * W64_LDS_STRIDE + j] = v[8 * aa + b].y;
     ctx.sync();
 #pragma unroll
-    for (int t = 0; t < 64; ++t) v[t] = mk<float>(re[t], sf[j * W64_LDS_STRIDE + t]);
+    for (int t = 0; t < 64; ++t) v[t].y = sf[j * W64_LDS_STRIDE + t];
     ctx.sync();
     dft64<true>(v);                            // lane k1 = j: Z[k1 + 64 m] in v[8 m], Z[k1 + 64 (56 + m)] in v[8 m + 7]
 #pragma unroll
     for (int m = 0; m < 8; ++m) s[m * 64 + j] = v[8 * m + 7];
     ctx.sync();
+#ifdef OA_W64_DERIVE_TW
+    U[0] = Uin[0];
+#pragma unroll
+    for (int m = 1; m < 8; ++m) U[m] = U[0] * w128(m);
+#endif
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const cx<float> Zk = v[8 * m];
@@ -185,31 +212,54 @@ OA_HD void row_r2c_w64_body_t(Ctx& ctx, const RowW64Args& a) {
                 if (j + 64 * m < a.wcols) dst[64 * m] = X[m];
         }
     } else {
+        // The partial butterflies live in LDS behind the transpose plane ([slot][m][lane], conflict-free), not in registers: with
+        // 32 more complex registers the wave needs > 256 VGPRs, the allocator parks values in AGPRs and the transform stalls on
+        // its own moves (SQ_WAIT_INST_ANY x 3: 84 us instead of 61, profiles/r03n_pmc_r2c.txt).
+        static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
         const long ngroups = a.ny >> LR;
+        cx<float>* accl = reinterpret_cast<cx<float>*>(reinterpret_cast<char*>(ctx.smem()) + W64_LDS_BYTES) + j;
+        const int mkeep = (a.wcols + 63) >> 6;           // kept column groups (<= 8)
         for (long g = ctx.bid_x(); g < ngroups; g += a.nwg) {
-            cx<float> acc[R][8];
+            cx<float> wy[R];
 #pragma unroll
-            for (int k1 = 0; k1 < R; ++k1)
-#pragma unroll
-                for (int m = 0; m < 8; ++m) acc[k1][m] = mk<float>(0.f, 0.f);
+            for (int k1 = 0; k1 < R; ++k1) wy[k1] = a.twy[((unsigned)g * (unsigned)k1) & (unsigned)(a.ny - 1)];   // W_ny^(g k1): in flight during the rows
+            // rows in the order n = 0, 2, 1, 3 -- two radix-2 levels: a = X0 + X2, b = X0 - X2 (after the second row), then
+            // Y0 = a + c, Y2 = a - c, Y1 = b - i d, Y3 = b + i d with c = X1 + X3, d = X1 - X3 (after the fourth): 64 LDS
+            // operations per lane and group instead of the 192 of four running sums
 #pragma unroll 1
-            for (int n = 0; n < R; ++n) {
+            for (int step = 0; step < R; ++step) {
+                const int n = ((step & 1) << 1) | (step >> 1);
                 cx<float> X[8];
+#ifdef OA_W64R_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
+                w64_row(ctx, a, a.in + (g * R + n) * a.in_pitch + j, P, Q, U, X);
+#else
                 w64_row(ctx, a, a.in + (g + n * ngroups) * a.in_pitch + j, P, Q, U, X);
+#endif
+                if (step == 0 || step == 2) {            // X0 -> slot 0;  X1 -> slot 2
 #pragma unroll
-                for (int k1 = 0; k1 < R; ++k1) {
-                    const cx<float> w = a.tw[(unsigned)((n * k1) & (R - 1)) << (a.logTw - LR)];      // W_R^(n k1): uniform
+                    for (int m = 0; m < 8; ++m)
+                        if (m < mkeep) accl[((step ? 2 : 0) * 8 + m) * 64] = X[m];
+                } else if (step == 1) {                  // a -> slot 0, b -> slot 1
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) acc[k1][m] = acc[k1][m] + X[m] * w;
+                    for (int m = 0; m < 8; ++m)
+                        if (m < mkeep) {
+                            const cx<float> x0 = accl[m * 64];
+                            accl[m * 64] = x0 + X[m];
+                            accl[(8 + m) * 64] = x0 - X[m];
+                        }
+                } else {
+                    cx<float>* dst = a.out + g * a.out_pitch + j;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+                        if (j + 64 * m < a.wcols) {
+                            const cx<float> aa = accl[m * 64], bb = accl[(8 + m) * 64], x1 = accl[(16 + m) * 64];
+                            const cx<float> c = x1 + X[m], d = x1 - X[m];
+                            dst[64 * m] = (aa + c) * wy[0];
+                            dst[a.kplane + 64 * m] = add_mi(bb, d) * wy[1];
+                            dst[2 * a.kplane + 64 * m] = (aa - c) * wy[2];
+                            dst[3 * a.kplane + 64 * m] = add_pi(bb, d) * wy[3];
+                        }
                 }
-            }
-#pragma unroll
-            for (int k1 = 0; k1 < R; ++k1) {
-                const cx<float> w = a.twy[((unsigned)g * (unsigned)k1) & (unsigned)(a.ny - 1)];      // W_ny^(g k1)
-                cx<float>* dst = a.out + (long)k1 * a.kplane + g * a.out_pitch + j;
-#pragma unroll
-                for (int m = 0; m < 8; ++m)
-                    if (j + 64 * m < a.wcols) dst[64 * m] = acc[k1][m] * w;
             }
         }
     }

@@ -293,7 +293,7 @@ int emu_rsplit_rows_w64_f32(int ny, int nx, const float* in, void* out, long pit
     a.in = (const cx<float>*)in; a.out = (cx<float>*)out; a.in_pitch = nx / 2; a.out_pitch = pitch;
     a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = 1.0f; a.wcols = width; a.ny = ny; a.nwg = nwg; a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
     EmuLauncher q;
-    q.run(nwg, 1, 64, W64_LDS_BYTES, [&](EmuCtx& c) { row_r2c_w64_body_t<2>(c, a); });
+    q.run(nwg, 1, 64, W64_LDS_BYTES + W64R_ACC_BYTES, [&](EmuCtx& c) { row_r2c_w64_body_t<2>(c, a); });
     return 0;
 }
 // one-wave-per-row R2C pass (fft_r2c_w64.hpp): nx must be 8192; out has pitch nx/2+16

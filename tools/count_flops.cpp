@@ -91,6 +91,7 @@ static std::atomic<unsigned long long> g_flops{0};
 struct CountLauncher {
     int nz_used = -1;
     int rows_per_wg = 1;
+    void fail_rlayout() {}
     template <typename T> void row_qe_pair(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         rows_per_wg = 2;
         dispatch_seq(a.logL, [&](auto seq) {

@@ -8,7 +8,7 @@ rm -rf $O/pmc; mkdir -p $O/pmc
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $O/pmc/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --no-pair --streams 1 --batch 1 --preroll 0.1 "$@" > /dev/null 2> $O/pmc/err$i.txt
+  rocprofv3 --pmc $set --output-format csv -d $O/pmc/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --also none --no-pair --streams 1 --batch 1 --preroll 0.1 "$@" > /dev/null 2> $O/pmc/err$i.txt
 done
 python3 - $O <<'PY'
 import csv, glob, statistics, collections, sys

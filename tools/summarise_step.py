@@ -105,13 +105,17 @@ def bench_keys(table):
                 return i
         return None
     keys = {}
-    r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_w64x2_kernel")
+    r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_w64x2_kernel", "row_r2c_w64r_kernel", "row_r2c_rsplit_kernel")
     c0 = first("col_fft_kernel")
     q = first("row_qe_pair_kernel", "row_qe_kernel")
     d = first("col_div_kernel", "col_div_sp_kernel")
+    fb = first("col_fband_kernel")
     if r0 is not None:
         keys["row_fft_kernel<R2C>"] = [r0]
-    if c0 is not None:
+    if fb is not None and q is not None:                # R-split path: one column kernel between the row pass and the row stage
+        keys["legs_cols"] = list(range(fb, q))
+        c0 = None
+    if c0 is not None and (q is None or c0 < q):
         keys["col_fft_kernel<fwd"] = [c0]
     if c0 is not None and q is not None and q > c0 + 1:
         keys["fwdlegs_cols"] = list(range(c0 + 1, q))

@@ -6,7 +6,7 @@ TAG=${1:-rXX}; shift
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 bench.py --steps 30 --warmup 5 --no-cpu --no-extras --no-pair --streams 1 --batch 1 "$@" > $O/trace_run.json 2> $O/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 bench.py --steps 30 --warmup 5 --no-cpu --no-extras --also none --no-pair --streams 1 --batch 1 "$@" > $O/trace_run.json 2> $O/trace.err
 python3 - $O <<'PY'
 import csv, glob, sys, statistics
 O = sys.argv[1]
