@@ -2,6 +2,7 @@
 #include <vector>
 #include "fft_launch.hpp"
 #include "fft_r2c_w64.hpp"
+#include "fft_r2c_f64.hpp"
 
 namespace oa {
 
@@ -27,6 +28,13 @@ __global__ __launch_bounds__(64, OA_W64_OCC) void row_r2c_w64r_kernel(RowW64Args
 }
 
 // (the accumulators live across the row loop: the f32 build spills 27-93 VGPRs at 4 waves/SIMD, none at 3)
+// float64: two waves per row, 32 complex128 points per lane (fft_r2c_f64.hpp); one wave per SIMD
+template <int LR>
+__global__ __launch_bounds__(128, 1) void row_r2c_f64_kernel(RowF64Args a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_f64_body<LR>(c, a);
+}
+
 template <typename T, class SEQ, int LR>
 __global__ __launch_bounds__(row_maxnt<SEQ>(), (sizeof(T) == 8 ? 2 : 3)) void row_r2c_rsplit_kernel(RowArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -142,7 +150,33 @@ struct HipLauncher {
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
         return true;
     }
-    bool row_w64(int, const RowArgs<double>&) { return false; }
+    static int r2c_f64_mode() {
+        static const int m = [] { const char* e = getenv("OA_R2C_F64"); return e ? atoi(e) : 1; }();
+        return m;
+    }
+    // float64 rows of 8192 points, <= 512 columns kept: two waves per row (fft_r2c_f64.hpp); lr = 2: with the R-split
+    bool row_f64(int nrows, const RowArgs<double>& a, int lr) {
+        if (a.mode != ROW_R2C || !r2c_f64_mode() || rc || !(a.logL == 12 && a.wcols <= 512 && a.logTw >= 13)) return false;
+        RowF64Args w{};
+        w.in = (const cx<double>*)a.in; w.out = (cx<double>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
+        w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = nrows; w.kplane = a.kplane; w.twy = a.twy;
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        static const int per_cu = [] { const char* e = getenv("OA_F64_ROWS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+        const int units = lr ? (nrows >> lr) : nrows;
+        w.nwg = cus * per_cu;
+        if (w.nwg > units) w.nwg = units;
+        const size_t smem = F64_LDS_BYTES + (lr ? F64_ACC_BYTES : 0);
+        if (lr) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(row_r2c_f64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F64_LDS_BYTES + F64_ACC_BYTES));
+            if (attr != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(attr)); return true; }
+            hipLaunchKernelGGL(row_r2c_f64_kernel<2>, dim3(w.nwg), dim3(128), smem, st, w);
+        } else
+            hipLaunchKernelGGL(row_r2c_f64_kernel<0>, dim3(w.nwg), dim3(128), smem, st, w);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+        return true;
+    }
+    bool row_w64(int ny, const RowArgs<double>& a) { return row_f64(ny, a, 0); }
     template <typename T>
     void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (row_w64(grid << a.logC, a)) return;
@@ -173,7 +207,7 @@ struct HipLauncher {
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
         return true;
     }
-    bool row_w64r(const RowArgs<double>&) { return false; }
+    bool row_w64r(const RowArgs<double>& a) { return a.lr == 2 && row_f64(a.my << a.lr, a, 2); }
     template <typename T>
     void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (row_w64r(a)) return;

@@ -882,10 +882,14 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     long r0 = wg * 2, ra = wg * 2, rb = wg * 2 + 1;
     T sg = (T)1;
     if (LAY > 0) {
-        const long ylo = wg >> 1, mq = a.nrows >> LAY;
-        sg = (wg & 1) ? (T)-1 : (T)1;
+        // the two workgroups of a group read the same four rows: they are workgroups b and b + 8 of a block of 16 -- the same
+        // XCD under the round-robin dispatch, a few slots apart -- so the second read is an L2 hit, not a second trip over the fabric
+        const long blk = wg & ~15L;
+        const int r = (int)(wg & 15), p = r >> 3;
+        const long ylo = (blk >> 1) + (r & 7), mq = a.nrows >> LAY;
+        sg = p ? (T)-1 : (T)1;
         r0 = ylo << LAY;
-        ra = ylo + mq * (2 * (wg & 1));
+        ra = ylo + mq * (2 * p);
         rb = ra + mq;
     }
     constexpr int R0 = SEQ::get(0);
