@@ -150,8 +150,12 @@ struct HipLauncher {
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
         return true;
     }
+    // MEASURED AND NOT THE DEFAULT (profiles/r03_f64_r2c_variants.txt): 174 us (R-split) / 199 us (plain) per 8192^2 map against
+    // 132 / 128 us of the general pass.  32 complex128 points per lane take 256 VGPRs + ~200 AGPRs: one wave per SIMD, two rows
+    // per CU in flight, and without packed arithmetic the 1400 f64 operations per row half are all issue time.  The general
+    // pass (16 points per thread, four waves per row, eight waves per CU) hides more of its latency.  OA_R2C_F64=1 selects it.
     static int r2c_f64_mode() {
-        static const int m = [] { const char* e = getenv("OA_R2C_F64"); return e ? atoi(e) : 1; }();
+        static const int m = [] { const char* e = getenv("OA_R2C_F64"); return e ? atoi(e) : 0; }();
         return m;
     }
     // float64 rows of 8192 points, <= 512 columns kept: two waves per row (fft_r2c_f64.hpp); lr = 2: with the R-split
