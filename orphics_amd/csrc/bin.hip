@@ -134,6 +134,9 @@ OA_D bool wave_accum_sorted(bool valid, int key, double v, double cw, int ci, in
 // the XCD's whole L2.  Measured and dropped: the same ticket in bin_kernel itself (~1000 workgroups: 95 us with
 // __threadfence(), 30 us of same-address atomics without) and a one-workgroup tail kernel (30 us: one CU cannot keep
 // enough of the strided partial loads in flight).
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx942__) || defined(__gfx950__))
+#error "BinTail: the ticket hand-over below relies on gfx942 / gfx950 behaviour (agent-scope relaxed atomic stores are sc1 write-through, and stores count in vmcnt); on another target use release / acquire on the ticket or the two-launch moments_add_binned path"
+#endif
 struct BinTail {
     unsigned* ticket;            // zero before the launch; reset to zero by the last workgroup.  nullptr: no tail
     const int64_t* mcounts;      // moments: data-independent mode counts per id (nullptr: no moments)
