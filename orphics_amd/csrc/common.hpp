@@ -113,6 +113,9 @@ int qe_rows_table_w(oa_plan* p, int n, const void* const* gx, const void* const*
                     const double* scales, void* dev_tab, int upload, int accumulate, int win, int wout, int mrow, long pl, long pk, hipStream_t st,
                     int my);
 size_t qe_rows_table_entry_bytes(const oa_plan* p);
+int qe_rows_chain_w(oa_plan* p, int nest, int total, const void* const* gx, const void* const* gy, const void* const* h, void* const* px,
+                    void* const* py, const double* scales, const int* first, const int* count, void* dev_tab, int upload, int win, int wout, int mrow,
+                    long pl, long pk, hipStream_t st, int my);
 int grf_hc_band_batch(oa_plan* p, uint64_t seed, uint64_t stream_id, int nreal, const void* covsqrt_hc, void* hc_out, long zstride,
                       int width, int rband, hipStream_t stream);
 int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width, long pl, hipStream_t st, int my = 0);

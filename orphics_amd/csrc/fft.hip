@@ -89,6 +89,12 @@ __global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ>())) void
     GpuCtx c{oa_dyn_smem};
     row_qe_pair_body<T, SEQ, NZ, LR>(c, a);
 }
+// estimator chains (oa_qe_mv): two more 16-point register sets (the running products of both legs)
+template <typename T, class SEQ, int NZ>
+__global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? 1 : 2)) void row_qe_chain_kernel(RowQeArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_qe_pair_body<T, SEQ, NZ, 0, true>(c, a);
+}
 
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_div_kernel(ColDivArgs<T> a) {
@@ -263,6 +269,10 @@ struct HipLauncher {
             if constexpr (seq_logl<S>() >= 10 && seq_logl<S>() <= 13) {
                 if (nt != pair_nt<S>()) { if (!rc) rc = fail("fft: pair row stage launched with the wrong workgroup size"); return; }
                 dispatch_pair_nz<S>(pair_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
+                    if (a.chain) {
+                        if constexpr (seq_logl<S>() <= 12) { if (a.lr == 0 && a.tab) go(row_qe_chain_kernel<T, S, decltype(nzc)::value>, dim3(grid), nt, smem, a); else if (!rc) rc = fail("fft: estimator chains need natural-order planes and a table"); }
+                        else if (!rc) rc = fail("fft: estimator chains: unsupported row grid");
+                    } else
                     if (a.lr == 2) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 2>, dim3(grid), nt, smem, a);
                     else if (a.lr == 0) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 0>, dim3(grid), nt, smem, a);
                     else if (!rc) rc = fail("fft: unsupported R-layout of the pair row stage");
@@ -677,6 +687,38 @@ int qe_rows_table_w(oa_plan* p, int n, const void* const* gx, const void* const*
                               : qe_rows_table_impl<double>(p, n, gx, gy, h, px, py, scales, dev_tab, upload, accumulate, win, wout, mrow, st, pl, pk, my);
 }
 size_t qe_rows_table_entry_bytes(const oa_plan* p) { return p->dtype == OA_F32 ? sizeof(RowQeMap<float>) : sizeof(RowQeMap<double>); }
+// estimator chains: `total` pieces (planes, scales as in qe_rows_table_w) grouped into nest estimators (first[e], count[e]); the
+// device table holds the pieces followed by the 2 nest chain integers.  -1: this geometry's row stage is another kernel
+template <typename T>
+static int qe_rows_chain_impl(oa_plan* p, int nest, int total, const void* const* gx, const void* const* gy, const void* const* h, void* const* px,
+                              void* const* py, const double* scales, const int* first, const int* count, void* dev_tab, int upload, int win, int wout,
+                              int mrow, hipStream_t st, long pin, long pout, int my) {
+    HipLauncher q{st};
+    auto f = coarse_view<T>(p, my);
+    const int wi = f.clampw(win), wo = f.clampw(wout);
+    if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, wi, wo); if (2L * wi + wo > mrow) mrow = 0; }
+    if (!f.rows_qe_is_pair(wi, wo, mrow) || (mrow > 0 && ilog2(mrow) > 12)) return -1;
+    const size_t tb = ((size_t)total * sizeof(RowQeMap<T>) + 15) / 16 * 16;
+    if (upload) {
+        std::vector<char> buf(tb + 2 * (size_t)nest * sizeof(int));
+        RowQeMap<T>* tab = reinterpret_cast<RowQeMap<T>*>(buf.data());
+        const double fac = f.row_grid_scale(mrow);
+        for (int i = 0; i < total; ++i)
+            tab[i] = RowQeMap<T>{(const cx<T>*)gx[i], (const cx<T>*)gy[i], (const cx<T>*)h[i], (cx<T>*)px[i], (cx<T>*)py[i], (T)(scales[i] * fac)};
+        int* ch = reinterpret_cast<int*>(buf.data() + tb);
+        for (int e = 0; e < nest; ++e) { ch[2 * e] = first[e]; ch[2 * e + 1] = count[e]; }
+        OA_HIP(hipMemcpyAsync(dev_tab, buf.data(), buf.size(), hipMemcpyHostToDevice, st));                 // pageable: staged before return
+    }
+    f.rows_qe(q, (const cx<T>*)gx[0], (const cx<T>*)gy[0], (const cx<T>*)h[0], (cx<T>*)px[0], (cx<T>*)py[0], (T)scales[0], 0, wi, wo, mrow, pin, pout,
+              nest, 0, 0, 0, (const RowQeMap<T>*)dev_tab, 0, reinterpret_cast<const int*>((const char*)dev_tab + tb));
+    return q.rc;
+}
+int qe_rows_chain_w(oa_plan* p, int nest, int total, const void* const* gx, const void* const* gy, const void* const* h, void* const* px,
+                    void* const* py, const double* scales, const int* first, const int* count, void* dev_tab, int upload, int win, int wout, int mrow,
+                    long pl, long pk, hipStream_t st, int my) {
+    return p->dtype == OA_F32 ? qe_rows_chain_impl<float>(p, nest, total, gx, gy, h, px, py, scales, first, count, dev_tab, upload, win, wout, mrow, st, pl, pk, my)
+                              : qe_rows_chain_impl<double>(p, nest, total, gx, gy, h, px, py, scales, first, count, dev_tab, upload, win, wout, mrow, st, pl, pk, my);
+}
 int qe_rows_batch_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout, int mrow,
                     long pl, long pk, hipStream_t st, int my, int nmaps, long in_moff, long h_moff, long out_moff) {
     return p->dtype == OA_F32 ? qe_rows_batch_impl<float>(p, gx, gy, h, px, py, scale, win, wout, mrow, st, pl, pk, my, nmaps, in_moff, h_moff, out_moff)

@@ -620,6 +620,11 @@ struct RowQeArgs {
     int npairs; long in_moff, out_moff, h_moff;
     const RowQeMap<T>* tab;   // != nullptr: map m takes its planes and its scale from tab[m] instead
     int lr, nrows;            // pair row stage: lr = 2 -> the leg planes are in the R-LAYOUT of col_fband_body (nrows = rows of the grid)
+    // CHAINS (row_qe_pair_body<.., CHAIN = true>, oa_qe_mv): map m is an ESTIMATOR whose separable pieces are the table entries
+    // tab[chain[2 m] .. chain[2 m] + chain[2 m + 1]): per piece three inverse transforms and the real-space product, summed
+    // over the pieces in registers, then ONE forward pair per estimator (the forward transform is linear) into the px / py
+    // of the chain's first entry -- 3 n + 2 transforms per row pair instead of 5 n, no read-modify-write of the product planes
+    const int* chain;
 };
 
 // LDS -> LDS stage I of the reversed (inverse) / forward sequence
@@ -858,7 +863,7 @@ inline void dispatch_pair_nz(int nz, F&& f) {
     }
 }
 
-template <typename T, class SEQ, int NZ, int LAY = 0, class Ctx>
+template <typename T, class SEQ, int NZ, int LAY = 0, bool CHAIN = false, class Ctx>
 OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
@@ -897,6 +902,51 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* twl = work + RS;
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
+    if constexpr (CHAIN) {
+        static_assert(LAY == 0, "chains read natural-order leg planes");
+        const int first = a.chain[2 * m], count = a.chain[2 * m + 1];        // uniform: scalar loads
+        cx<T> accx[EPT], accy[EPT];
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) accx[t] = accy[t] = mk<T>((T)0, (T)0);
+#pragma unroll 1
+        for (int i = 0; i < count; ++i) {
+            const RowQeMap<T> e = a.tab[first + i];
+            pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, hreg, tid, NT, RS, twl, e.h + r0 * a.pitch, e.h + (r0 + 1) * a.pitch, a.win);
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * e.scale;
+            ctx.sync();
+            pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, e.gx + r0 * a.pitch, e.gx + (r0 + 1) * a.pitch, a.win);
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) accx[t] = accx[t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+            ctx.sync();
+            pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, e.gy + r0 * a.pitch, e.gy + (r0 + 1) * a.pitch, a.win);
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) accy[t] = accy[t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+            ctx.sync();
+        }
+        const RowQeMap<T> e0 = a.tab[first];
+        for (int leg = 0; leg < 2; ++leg) {
+            cx<T>* dst = leg ? e0.py : e0.px;
+#pragma unroll
+            for (int t = 0; t < EPT; ++t) v[t] = leg ? accy[t] : accx[t];
+#pragma unroll
+            for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
+            stage_out<T, R0, true, false>(work, v, tid, NT, logM, 0, RS, 0, NoStore{});
+            ctx.sync();
+            forward_tail<T, SEQ>(ctx, work, tid, NT, logM, 0, RS, twl, logM);
+            cx<T>* o0 = dst + ra * a.opitch;
+            cx<T>* o1 = dst + rb * a.opitch;
+            for (int k = tid; k < a.wout; k += NT) {
+                const int km = (M - k) & (M - 1);
+                const cx<T> Pk = work[k + (k >> 4)];
+                const cx<T> Pm = conj(work[km + (km >> 4)]);
+                o0[k] = (Pk + Pm) * (T)0.5;
+                o1[k] = mul_mi(Pk - Pm) * (T)0.5;
+            }
+            ctx.sync();
+        }
+        return;
+    }
     pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, hreg, tid, NT, RS, twl, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll

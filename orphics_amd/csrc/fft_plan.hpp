@@ -147,7 +147,8 @@ struct Fft2dPlan {
     void rows_qe(Launcher& q, const cx<T>* gx, const cx<T>* gy, const cx<T>* h, cx<T>* px, cx<T>* py, T scale,
                  int accumulate = 0, int win = 0x7fffffff, int wout = 0x7fffffff, int mrow = 0, long pin = 0,
                  long pout = 0, int nmaps = 1, long in_moff = 0, long out_moff = 0, long h_moff = -1,
-                 const RowQeMap<T>* tab = nullptr, int lr = 0) const {
+                 const RowQeMap<T>* tab = nullptr, int lr = 0, const int* chain = nullptr) const {
+        // chain != nullptr (with tab): map m = estimator with pieces tab[chain[2m] ..+ chain[2m+1]) (RowQeArgs::chain)
         // lr = 2: the leg planes are in the R-LAYOUT of legs_fband (pair kernel only)
         // tab (device array of nmaps entries, pair kernel only): per-map planes and FINAL scales (see row_grid_scale)
         RowQeArgs<T> a{};
@@ -165,7 +166,7 @@ struct Fft2dPlan {
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
             if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
             a.tab = tab;
-            a.lr = lr; a.nrows = ny;
+            a.lr = lr; a.nrows = ny; a.chain = chain;
             q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
             return;
         }

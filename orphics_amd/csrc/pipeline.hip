@@ -398,17 +398,44 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
         }
         key.push_back((unsigned long long)my); key.push_back((unsigned long long)(unsigned)mrow); key.push_back((unsigned long long)p->dtype);
         const size_t eb = qe_rows_table_entry_bytes(p);
-        if (!q->mv_rtab) OA_HIP(hipMalloc(&q->mv_rtab, 64 * 64));
+        if (!q->mv_rtab) OA_HIP(hipMalloc(&q->mv_rtab, 64 * 64 + 1024));
         const int upload = key != q->mv_rkey;
         size_t off = 0;
-        for (int k = 0; k < maxp && rbatch; ++k) {
+        // ESTIMATOR CHAINS: one launch for all estimators, each workgroup loops over its estimator's pieces and keeps the
+        // summed products in registers (3 n + 2 transforms per row pair instead of 5 n; no read-modify-write of the product
+        // planes).  OA_MV_NO_CHAIN: the piece-by-piece launches below (A/B and test switch)
+        bool chained = false;
+        if (!getenv("OA_MV_NO_CHAIN")) {
+            std::vector<const void*> cgx, cgy, chh;
+            std::vector<void*> cpx, cpy;
+            std::vector<double> csc;
+            std::vector<int> first(nest), cnt(nest);
+            int base = 0;
+            for (int e = 0; e < nest; base += host_npieces[e], ++e) {
+                first[e] = (int)cgx.size(); cnt[e] = host_npieces[e];
+                for (int i = 0; i < host_npieces[e]; ++i) {
+                    const int idx = base + i;
+                    cgx.push_back(plane(2 * gslot[idx])); cgy.push_back(plane(2 * gslot[idx] + 1)); chh.push_back(plane(2 * ng + hslot[idx]));
+                    cpx.push_back(prod + 2 * (size_t)e * lbk); cpy.push_back(prod + (2 * (size_t)e + 1) * lbk);
+                    csc.push_back(host_signs[idx] * s * s * sy);
+                }
+            }
+            std::vector<unsigned long long> ckey = key;
+            ckey.push_back(0xC4A1ull);
+            const int up = ckey != q->mv_rkey;
+            int rc = qe_rows_chain_w(p, nest, total, cgx.data(), cgy.data(), chh.data(), cpx.data(), cpy.data(), csc.data(), first.data(), cnt.data(),
+                                     q->mv_rtab, up, leg_cols, kappa_cols, mrow, pl, pk, st, my);
+            if (rc > 0) return rc;
+            if (rc == 0) { chained = true; q->mv_rkey = ckey; }
+        }
+        for (int k = 0; k < maxp && rbatch && !chained; ++k) {
             int rc = qe_rows_table_w(p, count[k], tgx.data() + off, tgy.data() + off, th.data() + off, tpx.data() + off, tpy.data() + off,
                                      tsc.data() + off, (char*)q->mv_rtab + off * eb, upload, k > 0, leg_cols, kappa_cols, mrow, pl, pk, st, my);
             if (rc < 0) { rbatch = false; break; }      // (only possible at k = 0: nothing launched yet)
             if (rc) return rc;
             off += count[k];
         }
-        if (rbatch) q->mv_rkey = key;
+        if (rbatch && !chained) q->mv_rkey = key;
     }
     int at = 0;
     for (int e = 0; e < nest && !rbatch; ++e) {

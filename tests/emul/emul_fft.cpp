@@ -73,6 +73,8 @@ struct EmuLauncher {
             using S = decltype(seq);
             if constexpr (seq_total_log<S>() >= 10 && seq_total_log<S>() <= 13)
                 dispatch_pair_nz<S>(pair_first_stage_nz(a.logL, S::rget(0), a.win), [&](auto nzc) {
+                    if (a.chain) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 0, true>(c, a); });
+                    else
                     if (a.lr == 2) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 2>(c, a); });
                     else run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 0>(c, a); });
                 });
@@ -449,6 +451,24 @@ int emu_qe_rows_multi_f64(int ny, int nx, int nmaps, const void* const* gx, cons
         const long oo = nmaps > 1 ? (C*)px[1] - (C*)px[0] : 0;
         hd.p.rows_qe(q, (const C*)gx[0], (const C*)gy[0], (const C*)h[0], (C*)px[0], (C*)py[0], scales[0], accumulate, wi, wo, mrow, 0, 0, nmaps, io, oo, ho);
     }
+    return 0;
+}
+// estimator chains (RowQeArgs::chain): `total` pieces grouped into nest estimators (first[e], count[e]); products into the px / py of each
+// chain's first piece
+int emu_qe_rows_chain_f64(int ny, int nx, int nest, int total, const void* const* gx, const void* const* gy, const void* const* h, void* const* px,
+                          void* const* py, const double* scales, const int* first, const int* count, int win, int wout, int mrow) {
+    Holder<double> hd(ny, nx);
+    EmuLauncher q;
+    const int wi = hd.p.clampw(win), wo = hd.p.clampw(wout);
+    if (!hd.p.rows_qe_is_pair(wi, wo, mrow)) return 1;
+    typedef cx<double> C;
+    std::vector<RowQeMap<double>> tab(total);
+    for (int i = 0; i < total; ++i)
+        tab[i] = RowQeMap<double>{(const C*)gx[i], (const C*)gy[i], (const C*)h[i], (C*)px[i], (C*)py[i], scales[i] * hd.p.row_grid_scale(mrow)};
+    std::vector<int> ch(2 * nest);
+    for (int e = 0; e < nest; ++e) { ch[2 * e] = first[e]; ch[2 * e + 1] = count[e]; }
+    hd.p.rows_qe(q, (const C*)gx[0], (const C*)gy[0], (const C*)h[0], (C*)px[0], (C*)py[0], scales[0], 0, wi, wo, mrow, 0, 0, nest, 0, 0, 0, tab.data(), 0,
+                 ch.data());
     return 0;
 }
 int emu_legs_cols_w_f64(int ny, int nx, const void* kX, const void* kY, const double* FG, const double* FH, const double* lxd,

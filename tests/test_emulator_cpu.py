@@ -213,6 +213,41 @@ def test_row_stage_of_several_maps_per_launch(emu):
     assert np.array_equal(tab, one)
 
 
+def test_row_stage_estimator_chains(emu):
+    """row_qe_pair_body<.., CHAIN>: every estimator's pieces in ONE launch -- per piece three inverse transforms and the real-space
+    product, summed over the pieces in registers, one forward pair per estimator -- against piece-by-piece launches that
+    accumulate in the product planes (the linear forward transform commutes with the sum)."""
+    ny, nx, win, wout, mrow = 8, 4096, 100, 150, 1024
+    rng = np.random.default_rng(78)
+    kp = emu.emu_kpitch(nx)
+    counts = [1, 3, 2]
+    total = sum(counts)
+    G = np.full((2 * total, ny, kp), 1e30 + 0j)
+    H = np.full((total, ny, kp), 1e30 + 0j)
+    for a in (G, H):
+        a[..., :win] = rng.standard_normal(a.shape[:-1] + (win,)) + 1j * rng.standard_normal(a.shape[:-1] + (win,))
+        a[..., 0] = a[..., 0].real
+    scales = rng.uniform(-1.5, 1.5, total)
+    arr = lambda xs: (ctypes.c_void_p * len(xs))(*[x.ctypes.data for x in xs])      # noqa: E731
+    ref = np.zeros((2 * len(counts), ny, kp), dtype=np.complex128)
+    i = 0
+    for e, n in enumerate(counts):
+        for k in range(n):
+            sc = (ctypes.c_double * 1)(scales[i])
+            assert emu.emu_qe_rows_multi_f64(ny, nx, 1, arr([G[2 * i]]), arr([G[2 * i + 1]]), arr([H[i]]), arr([ref[2 * e]]), arr([ref[2 * e + 1]]),
+                                             sc, 1 if k else 0, win, wout, mrow, 0) == 0
+            i += 1
+    got = np.full_like(ref, 9.0)
+    owner = [e for e, n in enumerate(counts) for _ in range(n)]
+    first = (ctypes.c_int * len(counts))(*np.cumsum([0] + counts[:-1]).tolist())
+    cnt = (ctypes.c_int * len(counts))(*counts)
+    assert emu.emu_qe_rows_chain_f64(ny, nx, len(counts), total, arr([G[2 * i] for i in range(total)]), arr([G[2 * i + 1] for i in range(total)]),
+                                     arr([H[i] for i in range(total)]), arr([got[2 * owner[i]] for i in range(total)]),
+                                     arr([got[2 * owner[i] + 1] for i in range(total)]), (ctypes.c_double * total)(*scales), first, cnt, win, wout, mrow) == 0
+    assert np.abs(got[:, :, :wout] - ref[:, :, :wout]).max() < 1e-12 * np.abs(ref[:, :, :wout]).max()
+    assert np.all(got[:, :, wout:] == 9.0)
+
+
 @pytest.mark.parametrize("ny,nx,w,rb", [(64, 64, 0, 0), (64, 128, 21, 0), (128, 64, 32, 9), (256, 64, 7, 40), (64, 64, 0, 5)])
 def test_fused_column_stages(emu, ny, nx, w, rb):
     """col_legs (+ pass 2) = inverse column transforms of (i lx FG kX, i ly FG kX, FH kY);
