@@ -905,9 +905,9 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     if constexpr (CHAIN) {
         static_assert(LAY == 0, "chains read natural-order leg planes");
         const int first = a.chain[2 * m], count = a.chain[2 * m + 1];        // uniform: scalar loads
-        cx<T> accx[EPT], accy[EPT];
-#pragma unroll
-        for (int t = 0; t < EPT; ++t) accx[t] = accy[t] = mk<T>((T)0, (T)0);
+        // the running products of both legs live in LDS behind the twiddle table ([leg][t][thread]: conflict-free), not in 64
+        // more registers (the 256-register build spilled 100 of them: no faster than piece-by-piece launches)
+        cx<T>* accl = twl + tw_lds_size(logM) + tid;
 #pragma unroll 1
         for (int i = 0; i < count; ++i) {
             const RowQeMap<T> e = a.tab[first + i];
@@ -915,20 +915,25 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
 #pragma unroll
             for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * e.scale;
             ctx.sync();
-            pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, e.gx + r0 * a.pitch, e.gx + (r0 + 1) * a.pitch, a.win);
+            for (int leg = 0; leg < 2; ++leg) {
+                const cx<T>* src = leg ? e.gy : e.gx;
+                pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
+                cx<T>* al = accl + leg * EPT * NT;
+                if (i == 0) {
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) accx[t] = accx[t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
-            ctx.sync();
-            pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, e.gy + r0 * a.pitch, e.gy + (r0 + 1) * a.pitch, a.win);
+                    for (int t = 0; t < EPT; ++t) al[t * NT] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                } else {
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) accy[t] = accy[t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
-            ctx.sync();
+                    for (int t = 0; t < EPT; ++t) al[t * NT] = al[t * NT] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                }
+                ctx.sync();
+            }
         }
         const RowQeMap<T> e0 = a.tab[first];
         for (int leg = 0; leg < 2; ++leg) {
             cx<T>* dst = leg ? e0.py : e0.px;
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) v[t] = leg ? accy[t] : accx[t];
+            for (int t = 0; t < EPT; ++t) v[t] = accl[(leg * EPT + t) * NT];
 #pragma unroll
             for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
             stage_out<T, R0, true, false>(work, v, tid, NT, logM, 0, RS, 0, NoStore{});

@@ -167,7 +167,8 @@ struct Fft2dPlan {
             if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
             a.tab = tab;
             a.lr = lr; a.nrows = ny; a.chain = chain;
-            q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
+            const size_t accs = chain ? (size_t)2 * EPT * a.NT : 0;           // estimator chains: running products of both legs in LDS
+            q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM) + accs) * sizeof(cx<T>), a);
             return;
         }
         if (lr) { q.fail_rlayout(); return; }                 // (callers check rows_qe_is_pair first)
