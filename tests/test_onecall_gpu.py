@@ -259,3 +259,87 @@ def test_mc_run_in_batches_equals_one_by_one(N, res, prec):
         np.testing.assert_allclose(mb, m1, rtol=1e-13)
         np.testing.assert_allclose(cb, c1, rtol=1e-9, atol=1e-13 * np.abs(c1).max())
         assert np.array_equal(sb, s1)
+
+
+def test_round3_entries_from_raw_pointers():
+    """The entries added in round 3, driven with raw pointers only: oa_fft_c2r_windowed, oa_hc_derivs + oa_lens_taylor (all
+    Taylor terms of the lensing op in two launches), oa_mc_run_windowed (window == 1 reproduces oa_mc_run), oa_probe_copy /
+    oa_probe_read, oa_plan_rsplit -- against NumPy on the host."""
+    from orphics_amd import _lib
+    from orphics_amd.engine import _ptr
+    lib = _lib.load()
+    check = _lib.check
+    q, g, tmap, tot = _setup(256, 2.0)
+    N = 256
+    e = q._bind()                                   # plan with laxes and the TT filters
+    d = Dev(lib, check)
+    try:
+        kp = e.kp
+        rng = np.random.default_rng(5)
+        # windowed C2R
+        x = rng.standard_normal((N, N)).astype(np.float32)
+        w = rng.uniform(0, 1, (N, N)).astype(np.float32)
+        khc = np.zeros((N, kp), dtype=np.complex64)
+        khc[:, :N // 2 + 1] = np.fft.rfft2(x)
+        out = d.zeros(N * N * 4)
+        check(lib.oa_fft_c2r_windowed(e.plan, d.up(khc), out, 1.0 / (N * N), d.up(w), None))
+        got = d.down(out, (N, N), np.float32)
+        assert np.abs(got - x * w).max() < 2e-5
+        # derivative planes + one-pass Taylor gather (order 3: planes (1,0), (0,1), (2,0), (1,1), (0,2))
+        ly, lx = g.laxes()
+        lyd, lxd = ly.copy(), lx.copy()
+        lyd[N // 2] = 0
+        lxd[N // 2] = 0
+        nd = 5
+        dk = d.zeros(nd * N * kp * 8)
+        check(lib.oa_hc_derivs(e.plan, d.up(khc), 3, dk, N * kp, None))
+        planes = d.down(dk, (nd, N, kp), np.complex64)[:, :, :N // 2 + 1]
+        k0 = np.fft.rfft2(x.astype(np.float64))
+        ilx, ily = 1j * lxd[None, :N // 2 + 1], 1j * lyd[:, None]
+        want = [k0 * ilx, k0 * ily, k0 * ilx ** 2, k0 * ilx * ily, k0 * ily ** 2]          # idx(a, b) = n (n + 1) / 2 - 1 + b
+        for i in range(nd):
+            assert np.abs(planes[i] - want[i]).max() < 3e-6 * np.abs(want[i]).max()
+        dr = np.stack([np.fft.irfft2(wk, s=(N, N)) for wk in want]).astype(np.float32)
+        sx = rng.integers(-3, 4, (N, N)).astype(np.int32)
+        sy = rng.integers(-3, 4, (N, N)).astype(np.int32)
+        ddx = (rng.uniform(-0.5, 0.5, (N, N)) * abs(g.step_x)).astype(np.float32)
+        ddy = (rng.uniform(-0.5, 0.5, (N, N)) * abs(g.step_y)).astype(np.float32)
+        lens = d.zeros(N * N * 4)
+        check(lib.oa_lens_taylor(e.plan, d.up(x), d.up(dr), N * N, 3, d.up(sx), d.up(sy), d.up(ddx), d.up(ddy), lens, None))
+        got = d.down(lens, (N, N), np.float32)
+        yy, xx = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+        gy, gx = (yy + sy) % N, (xx + sx) % N
+        ref = (x[gy, gx] + ddx * dr[0][gy, gx] + ddy * dr[1][gy, gx] + 0.5 * ddx ** 2 * dr[2][gy, gx] + ddx * ddy * dr[3][gy, gx]
+               + 0.5 * ddy ** 2 * dr[4][gy, gx])
+        assert np.abs(got - ref).max() < 1e-5 * np.abs(ref).max()
+        # windowed Monte-Carlo shard with window == 1 against the plain shard (same Philox draws on the leg band)
+        edges = np.linspace(100, 3000, 8)
+        ids = e.modl_digitize(torch.as_tensor(edges, device=e.device), half=True)
+        q.bind_bins(ids, len(edges) + 1, g.area / float(N * N) ** 2)
+        e = q._bind_bins()
+        dd = len(edges) - 1
+        amp = np.zeros((N, kp), dtype=np.float32)
+        amp[:, :N // 2 + 1] = np.sqrt(tot[:, :N // 2 + 1] * float(N * N) ** 2 / g.area)
+        cs = d.up(amp)
+        res = []
+        for windowed in (False, True):
+            n, S, C = d.zeros(8), d.zeros(8 * dd), d.zeros(8 * dd * dd)
+            if windowed:
+                check(lib.oa_mc_run_windowed(e.plan, 7, 0, 5, cs, d.up(np.ones((N, N), dtype=np.float32)), n, S, C, None, None))
+            else:
+                check(lib.oa_mc_run(e.plan, 7, 0, 5, cs, n, S, C, None, None))
+            assert int(d.down(n, (1,), np.int64)[0]) == 5
+            res.append(d.down(S, (dd,), np.float64))
+        assert np.abs(res[1] / res[0] - 1).max() < 2e-4
+        # bandwidth probes run and preserve the data; the R-split query answers for this (small) geometry
+        nb = 1 << 20
+        a = d.up(np.arange(nb // 4, dtype=np.int32))
+        b = d.zeros(nb)
+        check(lib.oa_probe_copy(b, a, nb, None))
+        assert np.array_equal(d.down(b, (nb // 4,), np.int32), np.arange(nb // 4, dtype=np.int32))
+        check(lib.oa_probe_read(a, nb, d.zeros(8 << 20), None))
+        assert lib.oa_plan_rsplit(e.plan) in (0, 4)
+        with pytest.raises(_lib.OrphicsAmdError):
+            check(lib.oa_hc_derivs(e.plan, a, 9, dk, N * kp, None))               # order out of range: loud
+    finally:
+        d.free()
