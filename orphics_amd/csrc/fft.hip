@@ -3,6 +3,7 @@
 #include "fft_launch.hpp"
 #include "fft_r2c_w64.hpp"
 #include "fft_r2c_f64.hpp"
+#include "fft_r2c_rs4096.hpp"
 
 namespace oa {
 
@@ -35,10 +36,20 @@ __global__ __launch_bounds__(128, 1) void row_r2c_f64_kernel(RowF64Args a) {
     row_r2c_f64_body<LR>(c, a);
 }
 
-template <typename T, class SEQ, int LR>
-__global__ __launch_bounds__(row_maxnt<SEQ>(), (sizeof(T) == 8 ? 2 : 3)) void row_r2c_rsplit_kernel(RowArgs<T> a) {
+template <typename T, class SEQ, int LR, bool PF>
+__global__ __launch_bounds__(row_maxnt<SEQ>(), (sizeof(T) == 8 || PF ? 2 : 3)) void row_r2c_rsplit_kernel(RowArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
-    row_r2c_rsplit_body<T, SEQ, LR>(c, a);
+    row_r2c_rsplit_body<T, SEQ, LR, PF>(c, a);
+}
+
+// 8192-point rows, <= 512 columns kept: one cross-wave exchange per row (fft_r2c_rs4096.hpp); two workgroups per CU
+#ifndef OA_RS4096_F32_OCC
+#define OA_RS4096_F32_OCC 3
+#endif
+template <typename T, bool PF>
+__global__ __launch_bounds__(RS4096_NT, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)) void row_r2c_rs4096_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_rs4096_body<T, 2, PF>(c, a);
 }
 
 // single-pass column stage of the R-split path: [My][C] tile, all threads forward, R groups inverse (fft_fband.hpp)
@@ -218,15 +229,62 @@ struct HipLauncher {
         return true;
     }
     bool row_w64r(const RowArgs<double>& a) { return a.lr == 2 && row_f64(a.my << a.lr, a, 2); }
+    // general R-split row pass: one workgroup per group, loads at the top of each row.  OA_RSPLIT_PF=1: persistent workgroups
+    // (each walks groups bid, bid + grid, ...) that prefetch their next row -- measured no faster in float (22.9 vs 23.1 us at
+    // 4096^2) and slower in float64 (43.6 vs 39.9 us: the 16 taps in flight push it past 256 registers), kept for A/B
+    template <typename T, class S>
+    void row_rsplit_seq(int ngroups, int nt, size_t smem, const RowArgs<T>& a) {
+        static const bool nopf = [] { const char* e = getenv("OA_RSPLIT_PF"); return !(e && atoi(e) != 0); }();
+        if (nopf) { go(row_r2c_rsplit_kernel<T, S, 2, false>, dim3(ngroups), nt, smem, a); return; }
+        if (rc) return;
+        auto kern = row_r2c_rsplit_kernel<T, S, 2, true>;
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
+        }
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), nt, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        int grid = cus * per_cu;
+        if (grid > ngroups) grid = ngroups;
+        go(kern, dim3(grid), nt, smem, a);
+    }
+    // 8192-point rows, <= 512 kept columns: the one-cross-wave-exchange kernel (fft_r2c_rs4096.hpp), both precisions.  Measured
+    // at 8192^2 (profiles/r03x_r2c_variants.txt): float64 121 us against 131 us of the general pass, float 65 us against 71 us of
+    // the one-wave-per-row kernel.  The prefetch order pays in float (65 vs 68 us) and costs in float64 (126 vs 121 us: 256
+    // registers, spills): default per precision, OA_RS4096_PF=0/1 overrides.  OA_NO_RS4096=1: the older kernels (A/B).
+    template <typename T>
+    bool row_rs4096(const RowArgs<T>& a) {
+        static const bool off = getenv("OA_NO_RS4096") != nullptr;
+        static const int pfenv = [] { const char* e = getenv("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
+        if (off || rc || !(a.logL == 12 && a.logC == 0 && a.lr == 2 && a.wcols <= 512 && a.logTw >= 13)) return false;
+        const bool nopf = pfenv >= 0 ? pfenv == 0 : sizeof(T) == 8;
+        const size_t smem = rs4096_lds_bytes<T>();
+        auto kern = nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>;
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return true; }
+        }
+        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), RS4096_NT, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        int grid = cus * per_cu;
+        if (grid > a.my) grid = a.my;
+        go(kern, dim3(grid), RS4096_NT, smem, a);
+        return true;
+    }
     template <typename T>
     void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (row_rs4096(a)) return;
         if (row_w64r(a)) return;
         bool ok = false;
         if (a.lr == 2) {
-            if (a.logL == 10) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 4>, 2>, dim3(grid), nt, smem, a); ok = true; }
-            else if (a.logL == 11) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 8>, 2>, dim3(grid), nt, smem, a); ok = true; }
-            else if (a.logL == 12) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 16>, 2>, dim3(grid), nt, smem, a); ok = true; }
-            else if (a.logL == 13) { go(row_r2c_rsplit_kernel<T, Seq<16, 16, 16, 2>, 2>, dim3(grid), nt, smem, a); ok = true; }
+            ok = true;
+            if (a.logL == 10) row_rsplit_seq<T, Seq<16, 16, 4>>(grid, nt, smem, a);
+            else if (a.logL == 11) row_rsplit_seq<T, Seq<16, 16, 8>>(grid, nt, smem, a);
+            else if (a.logL == 12) row_rsplit_seq<T, Seq<16, 16, 16>>(grid, nt, smem, a);
+            else if (a.logL == 13) row_rsplit_seq<T, Seq<16, 16, 16, 2>>(grid, nt, smem, a);
+            else ok = false;
         }
         if (!ok && !rc) rc = fail("fft: unsupported R-split row pass");
     }

@@ -265,6 +265,26 @@ OA_HD void fft_pipeline(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC,
     }
 }
 
+// Stages 1 .. n-1 of the forward sequence, LDS to LDS: the first stage's outputs are in LDS and the workgroup has synced
+// (callers that run the first stage themselves, e.g. on prefetched registers); results end in LDS, synced on exit.
+template <typename T, bool ROWMAJOR, class SEQ, class Ctx>
+OA_HD void fft_pipeline_rest(Ctx& ctx, cx<T>* s, int tid, int NT, int logL, int logC, int rowStride, const cx<T>* tw, int logTw) {
+    constexpr int n = SEQ::n;
+    constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
+    if constexpr (n >= 2) {
+        stage<T, SEQ::r1, ROWMAJOR, false, false>(ctx, s, tid, NT, logL, logC, rowStride, l0, tw, logTw, NoLoad{}, NoStore{});
+        ctx.sync();
+    }
+    if constexpr (n >= 3) {
+        stage<T, SEQ::r2, ROWMAJOR, false, false>(ctx, s, tid, NT, logL, logC, rowStride, l1, tw, logTw, NoLoad{}, NoStore{});
+        ctx.sync();
+    }
+    if constexpr (n >= 4) {
+        stage<T, SEQ::r3, ROWMAJOR, false, false>(ctx, s, tid, NT, logL, logC, rowStride, l2, tw, logTw, NoLoad{}, NoStore{});
+        ctx.sync();
+    }
+}
+
 // host-side dispatch: logL -> radix sequence (greedy 16s, remainder last)
 template <class F>
 inline bool dispatch_seq(int logL, F&& f) {
@@ -520,14 +540,31 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
 // k < wcols <= L / 2 are produced; a thread owns the columns k0 + i * (threads per row), i < RS_MAXS, of one row slot.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RS_MAXS = 2;     // (4 slots spill the f32 build at 4 waves/SIMD; 2 cover every band-limited geometry: wcols <= L / 8)
-template <typename T, class SEQ, int LR, class Ctx>
+
+// first-stage taps of this thread (what stage_in<.., SRC_G = true> gathers), loads only
+template <typename T, int R0, class Ld>
+OA_HD void rsplit_first_taps(cx<T>* v, int tid, int NT, int logL, const Ld& ld) {
+    constexpr int LR0 = Log2c<R0>::v, NB = EPT / R0;
+    const int logLR = logL - LR0;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT, j = b & ((1 << logLR) - 1), c = b >> logLR;
+#pragma unroll
+        for (int t = 0; t < R0; ++t) v[u * R0 + t] = ld.template get<T>(j + (t << logLR), c);
+    }
+}
+
+// PF (prefetch): the workgroup is persistent over its groups (bid, bid + grid, ...) and issues the global loads of the NEXT row
+// right after the first butterfly stage of the current one has left its registers for LDS: they stay in flight across the
+// remaining stages and the untangle (GpuCtx::sync does not drain vmcnt), so a row costs max(arithmetic, HBM) instead of their
+// sum.  !PF: loads at the top of each row (the round-2 order; A/B: OA_RSPLIT_NOPF=1).
+template <typename T, class SEQ, int LR, bool PF = true, class Ctx>
 OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid(), NT = a.NT;
     constexpr int logL = seq_total_log<SEQ>();
-    constexpr int L = 1 << logL, R = 1 << LR;
+    constexpr int L = 1 << logL, R = 1 << LR, R0 = SEQ::r0;
     const int C = 1 << a.logC, RS = a.rowStride;
-    const long r0 = (long)ctx.bid_x() * C;                 // first group of this workgroup
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
     cx<T>* twl = s + C * RS;
@@ -537,51 +574,85 @@ OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
     const int c = tid / tpr, k0 = tid - c * tpr;
     const int sh = a.logTw - (logL + 1);
     static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
-    cx<T> acc[R][RS_MAXS], wy[R];
     const unsigned nym = ((unsigned)a.my << LR) - 1u;
+    const int ngroups = a.my >> a.logC, gstep = ctx.grid_x();
+    cx<T> v[EPT];
+    auto taps = [&](long grp, int n) {
+#if defined(OA_RSPLIT_NOLOAD)      // experiment: arithmetic + LDS only (inputs synthesised in registers)
+        rsplit_first_taps<T, R0>(v, tid, NT, logL, SynLoad{(float)a.scale + (float)(grp + n)});
+#else
+        rsplit_first_taps<T, R0>(v, tid, NT, logL, RowLoadOnce<T>{in + (grp * C + (long)n * a.my) * a.in_pitch, (unsigned)a.in_pitch});
+#endif
+    };
+    // untangle factors W_2L^kk of this thread's columns: row-invariant, loaded once (inside the loop they would queue behind the
+    // prefetch in vmcnt order and the untangle would wait for the whole next row)
+    cx<T> twk[RS_MAXS];
 #pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) {
-        wy[k1] = a.twy[((unsigned)(r0 + (c < C ? c : 0)) * (unsigned)k1) & nym];                     // W_ny^(g k1): loaded before the rows
+    for (int i = 0; i < RS_MAXS; ++i) { const int kk = k0 + i * tpr; twk[i] = a.tw[(kk < a.wcols ? kk : 0) << sh]; }
+    long grp = ctx.bid_x();
+    if (PF && grp < ngroups) taps(grp, 0);
+    for (; grp < ngroups; grp += gstep) {
+        const long r0 = grp * C;                               // first row slot of this group
+        cx<T> acc[R][RS_MAXS];
+        // W_ny^g: issued before the next prefetch (a later load would have to wait for it); its square and cube are formed at the
+        // flush (1 ulp; 12 fewer float64 registers held across the four rows than with three table entries)
+        const cx<T> wy1 = a.twy[(unsigned)(r0 + (c < C ? c : 0)) & nym];
 #pragma unroll
-        for (int i = 0; i < RS_MAXS; ++i) acc[k1][i] = mk<T>((T)0, (T)0);
-    }
+        for (int k1 = 0; k1 < R; ++k1)
+#pragma unroll
+            for (int i = 0; i < RS_MAXS; ++i) acc[k1][i] = mk<T>((T)0, (T)0);
 #pragma unroll 1
-    for (int n = 0; n < R; ++n) {
-        const cx<T>* inb = in + (r0 + (long)n * a.my) * a.in_pitch;
-        fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, RowLoadOnce<T>{inb, (unsigned)a.in_pitch}, NoStore{});
-        if (c < C) {
-            const cx<T>* sr = s + c * RS;
+        for (int n = 0; n < R; ++n) {
+            if (!PF) taps(grp, n);
+            {   // first stage on the taps in v (no twiddles: logNs = 0), results to LDS
+                constexpr int NB = EPT / R0;
 #pragma unroll
-            for (int i = 0; i < RS_MAXS; ++i) {
-                const int kk = k0 + i * tpr;
-                if (kk < a.wcols) {
-                    const int km = (L - kk) & (L - 1);
-                    const cx<T> Zk = sr[kk + (kk >> 4)];
-                    const cx<T> Zm = sr[km + (km >> 4)];
-                    const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
-                    const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
-                    const cx<T> X = (E + a.tw[kk << sh] * O) * a.scale;
+                for (int u = 0; u < NB; ++u) Dft<T, R0>::run(v + u * R0);
+                stage_out<T, R0, true, false>(s, v, tid, NT, logL, a.logC, RS, 0, NoStore{});
+            }
+            if (PF) {
+                if (n + 1 < R) taps(grp, n + 1);
+                else if (grp + gstep < ngroups) taps(grp + gstep, 0);
+            }
+            ctx.sync();
+#if !defined(OA_RSPLIT_NOCOMP)     // experiment (NOCOMP): global loads + first stage + untangle of whatever is in LDS
+            fft_pipeline_rest<T, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL);
+#endif
+            if (c < C) {
+                const cx<T>* sr = s + c * RS;
 #pragma unroll
-                    for (int k1 = 0; k1 < R; ++k1) {
-                        const int e = (n * k1) & 3;                                                  // W_4^(n k1) = (-i)^e, uniform: no table load
-                        const cx<T> w = mk<T>((T)((e == 0) - (e == 2)), (T)((e == 3) - (e == 1)));
-                        acc[k1][i] = acc[k1][i] + X * w;
+                for (int i = 0; i < RS_MAXS; ++i) {
+                    const int kk = k0 + i * tpr;
+                    if (kk < a.wcols) {
+                        const int km = (L - kk) & (L - 1);
+                        const cx<T> Zk = sr[kk + (kk >> 4)];
+                        const cx<T> Zm = sr[km + (km >> 4)];
+                        const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
+                        const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
+                        const cx<T> X = (E + twk[i] * O) * a.scale;
+#pragma unroll
+                        for (int k1 = 0; k1 < R; ++k1) {
+                            const int e = (n * k1) & 3;                                                  // W_4^(n k1) = (-i)^e, uniform: no table load
+                            const cx<T> w = mk<T>((T)((e == 0) - (e == 2)), (T)((e == 3) - (e == 1)));
+                            acc[k1][i] = acc[k1][i] + X * w;
+                        }
                     }
                 }
             }
+            ctx.sync();                                        // these LDS reads precede the next row's first-stage writes
         }
-        ctx.sync();                                        // these LDS reads precede the next row's first-stage writes
-    }
-    if (c < C) {
-        const long g = r0 + c;
+        if (c < C) {
+            const long g = r0 + c;
+            const cx<T> wy2 = wy1 * wy1;
+            const cx<T> wy[R] = {mk<T>((T)1, (T)0), wy1, wy2, wy2 * wy1};
 #pragma unroll
-        for (int k1 = 0; k1 < R; ++k1) {
-            const cx<T> w = wy[k1];
-            cx<T>* row = out + (long)k1 * a.kplane + g * a.out_pitch;
+            for (int k1 = 0; k1 < R; ++k1) {
+                cx<T>* row = out + (long)k1 * a.kplane + g * a.out_pitch;
 #pragma unroll
-            for (int i = 0; i < RS_MAXS; ++i) {
-                const int kk = k0 + i * tpr;
-                if (kk < a.wcols) row[kk] = acc[k1][i] * w;
+                for (int i = 0; i < RS_MAXS; ++i) {
+                    const int kk = k0 + i * tpr;
+                    if (kk < a.wcols) row[kk] = k1 ? acc[k1][i] * wy[k1] : acc[k1][i];
+                }
             }
         }
     }

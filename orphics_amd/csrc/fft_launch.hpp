@@ -22,6 +22,9 @@ struct GpuCtx {
 #else
     OA_D void sync() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
+    // Exchange between the lanes of ONE wave through LDS: the LDS executes a wave's operations in issue order, so only the
+    // compiler has to keep its order (no s_barrier, no wait)
+    OA_D void wsync() const { asm volatile("" ::: "memory"); }
     OA_D void* smem() const { return sm; }
 };
 

@@ -1,0 +1,149 @@
+// R-split row R2C of 8192-point real rows (4096 packed complex points), band-limited output (<= 512 columns), either precision.
+//
+// The general R-split pass (row_r2c_rsplit_body, fft_kernels.hpp) is not HBM-bound: with its global loads removed a float64
+// 8192^2 map still takes 116 of its 131 us (profiles/r03w_r2c_f64.txt) -- three workgroup-wide LDS exchanges and seven
+// barriers per row at two waves per SIMD leave the vector unit 46 % busy.  Here the 4096-point transform is cut
+// 4096 = 16 x 256 so that only ONE exchange crosses waves:
+//   stage 0 (thread j0 = tid): radix-16 butterfly over x[j0 + 256 t], times W_4096^(j0 k0)  ->  Y[k0][j0], k0 < 16
+//   -- workgroup barrier --
+//   the 16 sub-transforms (256 points over j0, one per k0) are independent: wave w owns k0 = 4 w + s, s < 4 (its lanes
+//   16 s + i), as two radix-16 stages with an exchange INSIDE the wave's own quarter of the buffer -- no s_barrier: the
+//   LDS executes one wave's operations in order (Ctx::wsync is a compiler fence on the GPU);
+//   the last stage computes only the bins the consumers keep: columns < 512 and their mirror images (the untangle's
+//   partners), 4 of its 16 outputs;
+//   -- workgroup barrier --   untangle + radix-4 column butterfly accumulation (as the general pass)   -- barrier --
+// Three barriers per row instead of seven, 64 + 64 + 16 KB of LDS stores per float64 row instead of 192, no padding
+// (every access below is conflict-free by layout or by an XOR swizzle), and the next row's global loads are issued as
+// soon as stage 0 has left its registers (prefetch, as row_r2c_rsplit_body<.., PF = true>).
+#pragma once
+#include "fft_kernels.hpp"
+
+namespace oa {
+
+constexpr int RS4096_NT = 256;
+#ifndef OA_RS4096_PFH
+#define OA_RS4096_PFH 16
+#endif
+// sub-transform pitch: 256 points; float adds 16 (128 B) so that the two sub-transforms a 32-lane ds_read_b64 group spans
+// do not start on the same bank
+template <typename T> constexpr int rs4096_sub() { return sizeof(T) == 4 ? 272 : 256; }
+template <typename T> constexpr size_t rs4096_lds_bytes() { return (size_t)(16 * rs4096_sub<T>() + 128 + 256 + 512) * sizeof(cx<T>); }
+
+// position of kept bin (rr, k0, m) in the exchange area: rr = 0, 1 -> r = 0, 1; rr = 2, 3 -> r = 14, 15; inside the owner
+// wave's quarter (1024 (k0 >> 2) ...), the low nibble swizzled by k0 (writes: lanes m consecutive; reads: lanes k0 consecutive)
+template <int SUB>
+OA_HD int rs4096_epos(int rr, int k0, int m) { return (k0 >> 2) * (4 * SUB) + (rr << 6) + ((k0 & 3) << 4) + ((m ^ k0) & 15); }
+
+template <typename T, int LR, bool PF = true, class Ctx>
+OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
+    constexpr int L = 4096, R = 1 << LR, NT = RS4096_NT, SUB = rs4096_sub<T>();
+    static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
+    cx<T>* D = reinterpret_cast<cx<T>*>(ctx.smem());          // [k0][j0]: 16 x 256
+    cx<T>* TW = D + 16 * SUB;                                 // two-level W_4096 table (64 + 64)
+    cx<T>* T256 = TW + 128;                                   // [m][i] = W_256^(i m)
+    const int tid = ctx.tid();
+    tw_lds_fill<T>(ctx, TW, a.tw, a.logTw, 12, NT);
+    T256[tid] = a.tw[((unsigned)((tid >> 4) * (tid & 15)) & 255u) << (a.logTw - 8)];
+    ctx.sync();
+    const int w = tid >> 6, l = tid & 63, s = l >> 4, i = l & 15, k0 = 4 * w + s;
+    cx<T>* Dk = D + SUB * k0;                                 // this thread's sub-transform
+    const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
+    cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
+    const unsigned nym = ((unsigned)a.my << LR) - 1u;
+    const int ngroups = a.my, gstep = ctx.grid_x();
+    // untangle: this thread's columns kk = tid + 256 r, r < 2 (coalesced stores); factors W_8192^kk in LDS (in registers they
+    // cost 8 float64 VGPRs across the whole row; loaded from global inside the loop they would queue behind the prefetch)
+    cx<T>* TWK = T256 + 256;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) TWK[tid + 256 * r] = a.tw[(unsigned)(tid + 256 * r) << (a.logTw - 13)];
+    cx<T> v[16];
+    auto taps = [&](long grp, int n, int t0 = 0, int t1 = 16) {
+#ifdef OA_RS4096_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
+        const cx<T>* src = in + (grp * R + n) * a.in_pitch + tid;
+#else
+        const cx<T>* src = in + (grp + (long)n * a.my) * a.in_pitch + tid;
+#endif
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (t >= t0 && t < t1) v[t] = RowLoadOnce<T>{src, 0u}.template get<T>(256 * t, 0);
+    };
+    // prefetch of the next row in two halves (PFH = taps issued right after stage 0; the rest after the first sub-transform
+    // stage, whose butterfly + 15 factors are the register peak): float64 has no room for all 16 taps across that stage
+    constexpr int PFH = sizeof(T) == 8 ? OA_RS4096_PFH : 16;
+    auto next_taps = [&](long grp, int step, int t0, int t1) {
+        if (step + 1 < R) { const int nn = (((step + 1) & 1) << 1) | ((step + 1) >> 1); taps(grp, nn, t0, t1); }
+        else if (grp + gstep < ngroups) taps(grp + gstep, 0, t0, t1);
+    };
+    long grp = ctx.bid_x();
+    if (PF && grp < ngroups) taps(grp, 0);
+    for (; grp < ngroups; grp += gstep) {
+        // rows in the order n = 0, 2, 1, 3 -- two radix-2 levels: A = X0 + X2, B = X0 - X2, then Y0 = A + c, Y2 = A - c,
+        // Y1 = B - i d, Y3 = B + i d with c = X1 + X3, d = X1 - X3: three live values per column and no products
+        cx<T> A[2], B[2], Cc[2];
+        const cx<T> wy1 = a.twy[(unsigned)grp & nym];          // W_ny^g (issued before the next prefetch)
+#pragma unroll 1
+        for (int step = 0; step < R; ++step) {
+            const int n = ((step & 1) << 1) | (step >> 1);
+            if (!PF) taps(grp, n);
+            // ---- stage 0: residues k0 = t of the 16-point butterfly over x[tid + 256 t], twiddled, to D[k0][tid]
+            Dft<T, 16>::run(v);
+            apply_twiddles<T, 16>(v, TW, tid, 0, 6);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) D[SUB * t + tid] = v[t];
+            if (PF && PFH > 0) next_taps(grp, step, 0, PFH);
+            ctx.sync();
+            // ---- sub-transform k0 (256 points over j0 = i + 16 t), inside this wave's quarter of D
+            cx<T> u[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) u[t] = Dk[i + 16 * t];
+            Dft<T, 16>::run(u);                                // u[m] = sum_t Y[i + 16 t] W_16^(t m)
+#pragma unroll
+            for (int m = 1; m < 16; ++m) {
+                if ((m & 3) == 0) ctx.wsync();                 // (keeps the compiler from fetching all 15 factors at once: registers)
+                u[m] = u[m] * T256[16 * m + i];
+            }
+            ctx.wsync();                                       // every lane's reads precede the in-place writes
+#pragma unroll
+            for (int m = 0; m < 16; ++m) Dk[16 * m + (i ^ m)] = u[m];
+            if (PF && PFH < 16) next_taps(grp, step, PFH, 16);
+            ctx.wsync();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) u[t] = Dk[16 * i + (t ^ i)];   // V[m = i][t]
+            Dft<T, 16>::run(u);                                // u[r] = Z[k0 + 16 i + 256 r]; r = 0, 1, 14, 15 used (the rest is dead code)
+            ctx.wsync();                                       // the reads above precede the exchange writes (same quarter)
+            D[rs4096_epos<SUB>(0, k0, i)] = u[0];
+            D[rs4096_epos<SUB>(1, k0, i)] = u[1];
+            D[rs4096_epos<SUB>(2, k0, i)] = u[14];
+            D[rs4096_epos<SUB>(3, k0, i)] = u[15];
+            ctx.sync();
+            // ---- untangle columns kk = tid + 256 r and accumulate the radix-4 column butterfly
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int kk = tid + 256 * r;
+                if (kk < a.wcols) {
+                    const int P = (L - kk) & (L - 1);          // partner bin: 0 (kk = 0) or in [3585, 4095]
+                    const cx<T> Zk = D[rs4096_epos<SUB>(r, kk & 15, (kk >> 4) & 15)];
+                    const cx<T> Zm = D[rs4096_epos<SUB>(P ? (P >> 8) - 12 : 0, P & 15, (P >> 4) & 15)];
+                    const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
+                    const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
+                    const cx<T> X = (E + TWK[kk] * O) * a.scale;
+                    if (step == 0) A[r] = X;
+                    else if (step == 1) { B[r] = A[r] - X; A[r] = A[r] + X; }
+                    else if (step == 2) Cc[r] = X;
+                    else {
+                        const cx<T> c = Cc[r] + X, d = Cc[r] - X;
+                        const cx<T> wy2 = wy1 * wy1;
+                        cx<T>* dst = out + grp * a.out_pitch + kk;
+                        dst[0] = A[r] + c;
+                        dst[a.kplane] = add_mi(B[r], d) * wy1;
+                        dst[2 * a.kplane] = (A[r] - c) * wy2;
+                        dst[3 * a.kplane] = add_pi(B[r], d) * (wy2 * wy1);
+                    }
+                }
+            }
+            ctx.sync();                                        // the exchange reads precede the next row's stage-0 writes
+        }
+    }
+}
+
+}  // namespace oa

@@ -10,6 +10,7 @@
 #include "../../orphics_amd/csrc/fft_plan.hpp"
 #include "../../orphics_amd/csrc/fft_r2c_w64.hpp"
 #include "../../orphics_amd/csrc/fft_r2c_f64.hpp"
+#include "../../orphics_amd/csrc/fft_r2c_rs4096.hpp"
 
 using namespace oa;
 
@@ -23,10 +24,12 @@ struct EmuCtx {
     int bid_z() const { return bz_; }
     int grid_x() const { return gx_; }
     void sync() const { bar->arrive_and_wait(); }
+    void wsync() const { bar->arrive_and_wait(); }   // (lanes are threads here: a wave-level exchange needs the real barrier)
     void* smem() const { return sm; }
 };
 
-static bool stockham_qe = false;   // which fused-row-stage body the emulator runs (both are tested)
+static bool stockham_qe = false;
+static bool rsplit_pf = false;     // general R-split row pass: persistent workgroups with prefetch order (emu_set_rsplit_pf)   // which fused-row-stage body the emulator runs (both are tested)
 
 struct EmuLauncher {
     template <class F>
@@ -83,9 +86,16 @@ struct EmuLauncher {
     void fail_rlayout() {}
     template <typename T> void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (a.lr != 2) return;
-        if (a.logL == 10) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 4>, 2>(c, a); });
-        else if (a.logL == 11) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 8>, 2>(c, a); });
-        else if (a.logL == 12) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 16>, 2>(c, a); });
+        if (rsplit_pf) {
+            grid = grid > 2 ? (grid + 2) / 3 : grid;     // persistent workgroups: each walks ~3 groups (prefetch across group boundaries)
+            if (a.logL == 10) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 4>, 2, true>(c, a); });
+            else if (a.logL == 11) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 8>, 2, true>(c, a); });
+            else if (a.logL == 12) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 16>, 2, true>(c, a); });
+            return;
+        }
+        if (a.logL == 10) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 4>, 2, false>(c, a); });
+        else if (a.logL == 11) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 8>, 2, false>(c, a); });
+        else if (a.logL == 12) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_r2c_rsplit_body<T, Seq<16, 16, 16>, 2, false>(c, a); });
     }
     template <typename T> void col_fband(int gx, int gy, int gz, size_t smem, int logMy, const ColFBandArgs<T>& a) {
         constexpr int nt = sizeof(T) == 4 ? 1024 : 512;
@@ -268,7 +278,23 @@ static int do_qe_rows_rlayout(int my, int nx, const cx<T>* gx, const cx<T>* gy, 
     return 0;
 }
 
+// R-split R2C of 8192-point rows with one workgroup-wide exchange (fft_r2c_rs4096.hpp): nx = 8192, ny = 4 my, either precision
+template <typename T>
+static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int width, int nwg, int pf) {
+    if (nx != 8192 || width > 512 || (ny & 3)) return 1;
+    auto tw = make_twiddles<T>(nx);
+    auto twy = make_twiddles<T>(ny);
+    RowArgs<T> a{};
+    a.in = in; a.out = out; a.in_pitch = nx / 2; a.out_pitch = pitch; a.logL = 12; a.logC = 0; a.NT = RS4096_NT;
+    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (T)1; a.mode = ROW_R2C; a.wcols = width; a.lr = 2; a.my = ny / 4;
+    a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
+    EmuLauncher q;
+    if (pf) q.run(nwg, 1, RS4096_NT, rs4096_lds_bytes<T>(), [&](EmuCtx& c) { row_r2c_rs4096_body<T, 2, true>(c, a); });
+    else q.run(nwg, 1, RS4096_NT, rs4096_lds_bytes<T>(), [&](EmuCtx& c) { row_r2c_rs4096_body<T, 2, false>(c, a); });
+    return 0;
+}
 extern "C" {
+void emu_set_rsplit_pf(int on) { rsplit_pf = on != 0; }
 int emu_rsplit_rows_f32(int ny, int my, int nx, const float* map, void* Y, long pitch, int width) { return do_rsplit_rows<float>(ny, my, nx, map, (cx<float>*)Y, pitch, width); }
 int emu_rsplit_rows_f64(int ny, int my, int nx, const double* map, void* Y, long pitch, int width) { return do_rsplit_rows<double>(ny, my, nx, map, (cx<double>*)Y, pitch, width); }
 int emu_rsplit_legs_f32(int ny, int my, int nx, const void* Y, long pitch, const float* FG, const float* FH, const float* lxd, const float* lyd, void* gx,
@@ -312,6 +338,8 @@ int emu_rsplit_rows_w64_f32(int ny, int nx, const float* in, void* out, long pit
     q.run(nwg, 1, 64, W64_LDS_BYTES + W64R_ACC_BYTES, [&](EmuCtx& c) { row_r2c_w64_body_t<2>(c, a); });
     return 0;
 }
+int emu_rsplit_rows_rs4096_f32(int ny, int nx, const float* in, void* out, long pitch, int width, int nwg, int pf) { return do_rs4096<float>(ny, nx, in, out, pitch, width, nwg, pf); }
+int emu_rsplit_rows_rs4096_f64(int ny, int nx, const double* in, void* out, long pitch, int width, int nwg, int pf) { return do_rs4096<double>(ny, nx, in, out, pitch, width, nwg, pf); }
 // one-wave-per-row R2C pass (fft_r2c_w64.hpp): nx must be 8192; out has pitch nx/2+16
 int emu_r2c_rows_w64_f32(int ny, int nx, const float* in, void* out, double scale, int width, int nwg) {
     if (nx != 8192 || width > 512) return 1;

@@ -18,7 +18,7 @@ def emu():
     so = os.path.join(EMUL, "libemul_fft.so")
     src = os.path.join(EMUL, "emul_fft.cpp")
     csrc = os.path.join(HERE, "..", "orphics_amd", "csrc")
-    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_f64.hpp", "fft_fband.hpp", "cx.hpp")]
+    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_f64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "cx.hpp")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -553,8 +553,9 @@ def _rsplit_reference(x, my, w):
     return out
 
 
-@pytest.mark.parametrize("prec", ["f64", "f32"])
-def test_rsplit_row_pass(emu, prec):
+@pytest.mark.parametrize("prec,pf", [("f64", 0), ("f32", 0), ("f64", 1)])
+def test_rsplit_row_pass(emu, prec, pf):
+    emu.emu_set_rsplit_pf(pf)                  # 1: persistent workgroups, next row's taps loaded before the current row's later stages
     ny, my, nx, w = 4096, 1024, 2048, 37
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
     rng = np.random.default_rng(5)
@@ -565,6 +566,7 @@ def test_rsplit_row_pass(emu, prec):
     assert fn(ny, my, nx, _p(x), _p(Y), ctypes.c_long(pitch), w) == 0
     ref = _rsplit_reference(x.astype(np.float64), my, w)
     assert np.abs(Y[:, :, :w] - ref).max() < tol * np.abs(ref).max()
+    emu.emu_set_rsplit_pf(0)
     assert np.all(Y[:, :, w:] == 7.0)                                     # nothing beyond the kept columns is written
     # ... and the column transform of plane k1 over g gives the full-resolution modes k1 + 4 k2
     full = np.fft.fft(np.fft.rfft(x.astype(np.float64), axis=1)[:, :w], axis=0)
@@ -583,6 +585,24 @@ def test_rsplit_row_pass_one_wave_per_row(emu):
     assert emu.emu_rsplit_rows_w64_f32(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3) == 0
     ref = _rsplit_reference(x.astype(np.float64), my, w)
     assert np.abs(Y[:, :, :w] - ref).max() < 3e-6 * np.abs(ref).max()
+    assert np.all(Y[:, :, w:] == 7.0)
+
+
+@pytest.mark.parametrize("prec,w,pf", [("f64", 380, 1), ("f64", 512, 0), ("f32", 380, 1), ("f64", 1, 1)])
+def test_rsplit_row_pass_one_crosswave_exchange(emu, prec, w, pf):
+    """row_r2c_rs4096_body: 4096 = 16 x 256 with the sub-transforms inside one wave's quarter of the buffer, pruned last stage,
+    persistent workgroups (3 walk 8 groups) with and without the prefetch order"""
+    ny, nx = 32, 8192
+    my = ny // 4
+    rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((ny, nx)).astype(rdt)
+    pitch = 520
+    Y = np.full((4, my, pitch), 7.0 + 0j, dtype=cdt)
+    fn = emu.emu_rsplit_rows_rs4096_f64 if prec == "f64" else emu.emu_rsplit_rows_rs4096_f32
+    assert fn(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3, pf) == 0
+    ref = _rsplit_reference(x.astype(np.float64), my, w)
+    assert np.abs(Y[:, :, :w] - ref).max() < tol * np.abs(ref).max()
     assert np.all(Y[:, :, w:] == 7.0)
 
 
