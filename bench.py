@@ -418,6 +418,13 @@ def per_kernel_table(torch, P, R, args):
     }
     if rsplit:           # the R-split row pass carries the first column radix: there is no separate forward column pass 1
         del kern["col_fft_kernel<fwd pass1, leg width>"]
+    if int(lib.oa_plan_div_fused(plan)):
+        # binning + moments ride in the tail of the divergence launch (csrc/fft_divbin.hpp): no histogram launches, kappa_hat is
+        # neither written nor re-read: read the 2 product planes + Fn/2 + the int32 ids (= Ah/4 per full half plane) on the band rows
+        del kern["bin_kernel<power>"]
+        del kern[div_name]
+        div_name = "cols_div_bin = col_div_sp_bin_kernel (single-pass forward columns + divergence + radial binning + moments)"
+        kern[div_name] = (4, fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah / 4))
     # Stage durations IN SEQUENCE: whole steps (stages 0..5 back to back on this stream, alternating between the two
     # input maps as the timed loop does) with a HIP event between consecutive stages.  Timing one stage in a tight
     # loop of its own would let its inputs sit in the 256 MB infinity cache / L2 (the 268 MB map re-read 20 times

@@ -43,7 +43,7 @@ typedef struct oa_plan oa_plan;
 const char* oa_last_error(void);
 /* ABI version = 100 x the build round that last changed a signature in this header; bindings must refuse a library
  * that reports less than the version they were written against (OA_ABI_VERSION) */
-#define OA_ABI_VERSION 300
+#define OA_ABI_VERSION 301
 int oa_version(void);
 /* number of HIP devices visible; <0 on error (no compute) */
 int oa_device_count(void);
@@ -179,6 +179,11 @@ int oa_plan_col_grid(const oa_plan* p);
  * the three leg planes -- instead of forward pass 1, [forward pass 2 + filters + inverse pass 1] and inverse pass 2.
  * Same arithmetic up to the order of the column butterflies; results agree with the multi-pass path to rounding. */
 int oa_plan_rsplit(const oa_plan* p);
+/* 1 when this plan's one-call moment entries (oa_qe_tt_moments, oa_qe_tt_moments2, oa_mc_run) bin |kappa_hat|^2 and update
+ * n, S, C in the tail of the single-pass divergence launch (coarse grids of 1024 / 2048 rows, bins bound) instead of two more
+ * launches over the kappa plane; 0: the separate histogram launches.  Same per-mode arithmetic either way; the order of the
+ * float64 sums differs (bandpowers agree to ~1e-15).  OA_NO_DIVBIN=1 in the environment switches it off (A/B). */
+int oa_plan_div_fused(const oa_plan* p);
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);
 void* oa_plan_kappa(oa_plan* p);
 const int64_t* oa_plan_bin_counts(oa_plan* p);

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ORPHICS_AMD_LIB", os.path.join(_HERE, "liborphics_amd
 
 OA_F32 = 0
 OA_F64 = 1
-ABI_VERSION = 300     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
+ABI_VERSION = 301     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -44,6 +44,7 @@ SIGNATURES = {
     "oa_plan_set_col_grid": (c_int, [c_void_p, c_int]),
     "oa_plan_col_grid": (c_int, [c_void_p]),
     "oa_plan_rsplit": (c_int, [c_void_p]),
+    "oa_plan_div_fused": (c_int, [c_void_p]),
     "oa_plan_set_bins": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_plan_kappa": (c_void_p, [c_void_p]),
     "oa_plan_bin_counts": (c_void_p, [c_void_p]),

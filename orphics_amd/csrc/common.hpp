@@ -36,6 +36,22 @@ struct alignas(sizeof(T) * N > 16 ? 16 : sizeof(T) * N) Arr {
     T v[N];
 };
 
+// Request to fold the radial histogram of |kappa|^2 and the moment update (n += maps, S += b, C += b b^T, b = sums / mode
+// counts) into the single-pass divergence launch (fft_divbin.hpp).  Filled by pipeline.hip, honoured by HipLauncher::col_div_sp
+// when the geometry runs that kernel (`done` set); otherwise the caller runs bin_power_moments as before.  Device pointers.
+struct DivBinFuse {
+    const int32_t* ids; long ipitch;      // radial ids of the full-resolution half plane, row pitch
+    double pnorm; int nids, nxh;
+    double* part;                         // [maps][workgroups][nids] partial sums (capacity part_cap doubles)
+    long part_cap;
+    double* sums;                         // [maps][nids]
+    unsigned* ticket;                     // zero before the launch; reset by the last workgroup
+    const int64_t* mcounts; int64_t* n; double* S; double* C;
+    int store;                            // != 0: kappa is also written to `out`
+    int gx;                               // (set by the launcher) workgroups per map
+    bool done;                            // (set by the launcher)
+};
+
 inline int flat_grid(long units, int block = 256, int cap = 8192) {
     long g = (units + block - 1) / block;
     if (g < 1) g = 1;
@@ -100,7 +116,7 @@ int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* 
 // divergence of nmaps estimators in one launch: product planes (A_e, B_e adjacent: B_e = A_e + in_moff / 2) in_moff apart, Fn planes
 // fn_moff apart, outputs out_moff apart (offsets in elements of the respective plane type); tmp: 2 nmaps compact planes
 int qe_cols_div_batch_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, void* tmp, int nmaps, long in_moff,
-                        long fn_moff, long out_moff, int width, int rband, long pk, hipStream_t st, int my = 0);
+                        long fn_moff, long out_moff, int width, int rband, long pk, hipStream_t st, int my = 0, DivBinFuse* fuse = nullptr);
 int sum_region(int dtype, const void* parts, long part_stride, int nparts, void* out, int accumulate, int ny, long kp, int w, int rb,
                hipStream_t st);
 // all leg planes of several estimators in one inverse pass-1 launch (ColLegsArgs::batch); offsets in complex elements
@@ -122,11 +138,11 @@ int qe_legs_pass2_w(oa_plan* p, void* pool, int nplanes, long stride, int width,
 int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int accumulate,
               int win, int wout, int mrow, long pl, long pk, hipStream_t st, int my = 0, int lr = 0);
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
-                  long pk, hipStream_t st, int my = 0);
+                  long pk, hipStream_t st, int my = 0, DivBinFuse* fuse = nullptr);
 // two maps at once (fft.hip); -1 = not available for this geometry
 int qe_tt_pair_w(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0, void* c1,
                  void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow, int my, long pl, long pk,
-                 hipStream_t st);
+                 hipStream_t st, DivBinFuse* fuse = nullptr);
 }
 #define OA_NEED_POW2(p, what) \
     OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

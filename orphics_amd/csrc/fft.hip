@@ -4,6 +4,7 @@
 #include "fft_r2c_w64.hpp"
 #include "fft_r2c_f64.hpp"
 #include "fft_r2c_rs4096.hpp"
+#include "fft_divbin.hpp"
 
 namespace oa {
 
@@ -119,6 +120,13 @@ template <typename T, class SEQ, int LOGC>
 __global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 : 4)) void col_div_sp_kernel(ColDivArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     col_div_body<T, SEQ, GpuCtx, LOGC>(c, a);
+}
+
+// ... with the radial histogram of |kappa|^2 and the moment update in its tail (fft_divbin.hpp)
+template <typename T, class SEQ, int LOGC>
+__global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 : 4)) void col_div_sp_bin_kernel(ColDivArgs<T> a, DivBinFuse f) {
+    GpuCtx c{oa_dyn_smem};
+    col_div_body<T, SEQ, GpuCtx, LOGC, DivBinTail<T>>(c, a, DivBinTail<T>{f});
 }
 
 template <typename T, class SEQ>
@@ -367,9 +375,33 @@ struct HipLauncher {
     }
     // single pass: logL = whole column length (10 or 11), tile of 2^(14 - logL) columns, 1024 threads (f32) / 2^(13 - logL)
     // columns, 512 threads (f64): 128 KB of LDS either way
+    DivBinFuse* fuse = nullptr;     // != nullptr: the caller wants binning + moments in the divergence launch (common.hpp)
+    template <class K, typename T>
+    void go_fused(K kern, int gx, int gz, int nt, size_t smem, ColDivArgs<T> a) {
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
+        }
+        fuse->gx = gx;
+        if (!fuse->store) a.out = nullptr;
+        hipLaunchKernelGGL(kern, dim3(gx, 1, gz), dim3(nt), smem, st, a, *fuse);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+        fuse->done = true;
+    }
     template <typename T>
     bool col_div_sp(int gx, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
         if (rc) return true;
+        if (fuse && !a.accumulate && (long)gx * gz * fuse->nids <= fuse->part_cap && (logL == 10 || logL == 11)) {
+            if constexpr (sizeof(T) == 4) {
+                if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, 3>, gx, gz, 1024, smem, a);
+                else go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, 4>, gx, gz, 1024, smem, a);
+            } else {
+                if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, 2>, gx, gz, 512, smem, a);
+                else go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, 3>, gx, gz, 512, smem, a);
+            }
+            return true;
+        }
         if constexpr (sizeof(T) == 4) {
             if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, 3>, dim3(gx, 1, gz), 1024, smem, a); return true; }
             if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, 4>, dim3(gx, 1, gz), 1024, smem, a); return true; }
@@ -563,10 +595,11 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
 
 template <typename T>
 static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate,
-                         int width, int rband, hipStream_t st, long pin = 0, int my = 0) {
+                         int width, int rband, hipStream_t st, long pin = 0, int my = 0, DivBinFuse* fuse = nullptr) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
+    q.fuse = fuse;
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
     coarse_view<T>(p, my).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd,
@@ -578,8 +611,9 @@ static int cols_div_impl(oa_plan* p, const void* pa, const void* pb, const void*
 // fn_moff apart, each estimator's kappa into its own plane (out_moff apart); tmp: 2 nmaps compact planes for the two-pass path
 template <typename T>
 static int cols_div_batch_impl(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, void* tmp, int nmaps, long in_moff,
-                               long fn_moff, long out_moff, int width, int rband, hipStream_t st, long pin, int my) {
+                               long fn_moff, long out_moff, int width, int rband, hipStream_t st, long pin, int my, DivBinFuse* fuse = nullptr) {
     HipLauncher q{st};
+    q.fuse = fuse;
     cx<T>* tA = (cx<T>*)tmp;
     cx<T>* tB = tA + (in_moff >> 1);
     coarse_view<T>(p, my).cols_div(q, (const cx<T>*)pa, (const cx<T>*)pb, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)out, tA,
@@ -595,7 +629,7 @@ static int cols_div_batch_impl(oa_plan* p, const void* pa, const void* pb, const
 template <typename T>
 static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0,
                            void* c1, void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow,
-                           int my, long pl, long pk, hipStream_t st) {
+                           int my, long pl, long pk, hipStream_t st, DivBinFuse* fuse) {
     auto f = view<T>(p);
     const int lr = rsplit_lr<T>(p, my, wl, wk, mrow);
     if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !(lr || Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my))) return -1;
@@ -608,6 +642,7 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
+    q.fuse = fuse;
     cx<T>* tA = (cx<T>*)p->scratch;
     cx<T>* tB = tA + (size_t)p->ny * p->kp;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = (double)p->ny / my;
@@ -639,9 +674,9 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
 }
 int qe_tt_pair_w(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0, void* c1,
                  void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow, int my, long pl, long pk,
-                 hipStream_t st) {
-    return p->dtype == OA_F32 ? qe_tt_pair_impl<float>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st)
-                              : qe_tt_pair_impl<double>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st);
+                 hipStream_t st, DivBinFuse* fuse) {
+    return p->dtype == OA_F32 ? qe_tt_pair_impl<float>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st, fuse)
+                              : qe_tt_pair_impl<double>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st, fuse);
 }
 
 // ---- the same passes on the plan's COMPACT work planes (pipeline.hip): pl = pitch of the leg planes and of the
@@ -694,9 +729,9 @@ int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* 
                               : legs_subset_impl<double>(p, src, F, a, b, subset, width, rband, st, pl, my);
 }
 int qe_cols_div_batch_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, void* tmp, int nmaps, long in_moff,
-                        long fn_moff, long out_moff, int width, int rband, long pk, hipStream_t st, int my) {
-    return p->dtype == OA_F32 ? cols_div_batch_impl<float>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my)
-                              : cols_div_batch_impl<double>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my);
+                        long fn_moff, long out_moff, int width, int rband, long pk, hipStream_t st, int my, DivBinFuse* fuse) {
+    return p->dtype == OA_F32 ? cols_div_batch_impl<float>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my, fuse)
+                              : cols_div_batch_impl<double>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my, fuse);
 }
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
                     int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my, int selbits) {
@@ -792,9 +827,9 @@ int qe_rows_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* p
                               : qe_rows_impl<double>(p, gx, gy, h, px, py, scale, accumulate, win, wout, mrow, st, pl, pk, my, lr);
 }
 int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, void* out, int accumulate, int width, int rband,
-                  long pk, hipStream_t st, int my) {
-    return p->dtype == OA_F32 ? cols_div_impl<float>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk, my)
-                              : cols_div_impl<double>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk, my);
+                  long pk, hipStream_t st, int my, DivBinFuse* fuse) {
+    return p->dtype == OA_F32 ? cols_div_impl<float>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk, my, fuse)
+                              : cols_div_impl<double>(p, pa, pb, Fn, out, accumulate, width, rband, st, pk, my, fuse);
 }
 
 }  // namespace oa

@@ -1651,8 +1651,19 @@ struct ColDivArgs {
 // LOGC: log2 of the tile width.  The default (32 columns) is the two-pass layout; with a WHOLE column in the tile (SEQ = the
 // full column length, 8 or 16 columns, 1024 threads, in_ns = out_ks = 1, one group) the same body is a SINGLE-PASS forward
 // column transform + divergence: the product planes are read once, no pass-1 plane is written and read back.
-template <typename T, class SEQ, class Ctx, int LOGC = COL_LOGC>
-OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
+// Tail: what else happens to each kappa value while it is in registers.  NoDivTail: nothing.  DivBinTail (fft_divbin.hpp, GPU
+// only): the radial histogram of |kappa|^2 and the moment update of the one-call entries, so that the kappa plane is never
+// re-read (and need not be written at all: a.out == nullptr).
+struct NoDivTail {
+    static constexpr bool active = false;
+    template <class Ctx> OA_HD void begin(Ctx&, void*) {}
+    OA_HD int id_at(unsigned, int) const { return -1; }
+    template <class Ctx, typename T> OA_HD void add(Ctx&, int, T, int) {}
+    template <class Ctx> OA_HD void finish(Ctx&) {}
+};
+
+template <typename T, class SEQ, class Ctx, int LOGC = COL_LOGC, class Tail = NoDivTail>
+OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
     constexpr int n = SEQ::n;
@@ -1704,6 +1715,52 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
     const T* Fnb = a.Fn + zmap * a.fn_moff + oorg;
     cx<T>* outb = a.out + omo + oorg;
     const unsigned ostr = (unsigned)(a.out_ks * a.opitch);
+    if constexpr (Tail::active) {
+        // every lane takes part in every step of the tail (wave-level reductions): no early exits; the tile is free by now
+        ctx.sync();
+        tail.begin(ctx, s);
+        ctx.sync();
+        // phase A, straight-line: every kappa value of this thread, its squared modulus and its bin id (loads batched by the
+        // compiler: inside the wave-level steps of phase B each would be a dependent trip to memory)
+        T pw[EPT];
+        int idv[EPT];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int b = tid + u * NT;
+            const int c = b & ((1 << logC) - 1), j = b >> logC;
+            const bool cok = c < ncols;
+            const int kq = j & ((1 << logNs) - 1);
+            const int base = ((j - kq) << LRL) + kq;
+            const T lx = cok ? a.lxd[c0 + c] : (T)0;
+#pragma unroll
+            for (int t = 0; t < RL; ++t) {
+                const int k = base + (t << logNs);
+                const unsigned y = (unsigned)(g * a.out_gs) + (unsigned)k * (unsigned)a.out_ks;
+                const bool ok = cok && !(a.rband && (int)y >= a.rband && (int)y <= a.ny - a.rband);
+                const unsigned up = (a.yshift && y >= (unsigned)(a.ny >> 1)) ? (unsigned)a.yshift : 0u;
+                const unsigned i = (unsigned)k * ostr + (unsigned)c + up * (unsigned)a.opitch;
+                pw[u * RL + t] = (T)0;
+                idv[u * RL + t] = -1;
+                if (ok) {
+                    cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * Fnb[i];
+                    if (a.out) {
+                        if (a.accumulate) d = d + outb[i];
+                        outb[i] = d;
+                    }
+                    pw[u * RL + t] = d.x * d.x + d.y * d.y;
+                    idv[u * RL + t] = tail.id_at(y + up, c0 + c);
+                }
+            }
+        }
+        // phase B: wave-level accumulation, every lane in every step
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int c = (tid + u * NT) & ((1 << logC) - 1);
+#pragma unroll
+            for (int t = 0; t < RL; ++t) tail.add(ctx, idv[u * RL + t], pw[u * RL + t], c0 + c);
+        }
+        tail.finish(ctx);
+    } else {
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -1723,6 +1780,7 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a) {
             if (a.accumulate) d = d + outb[i];
             outb[i] = d;
         }
+    }
     }
 }
 

@@ -160,6 +160,16 @@ int oa_plan_rsplit(const oa_plan* p) {
     return q->FG ? (1 << qe_rsplit_lr(p, q->my, q->wl, q->wk, q->mrow)) & ~1 : 0;
 }
 
+int oa_plan_div_fused(const oa_plan* p) {
+    if (!p || !p->pipe) return 0;
+    const Pipeline* q = (const Pipeline*)p->pipe;
+    if (!q->FG || !q->ids || getenv("OA_NO_DIVBIN")) return 0;
+    const int rows = q->my ? q->my : p->ny;            // rows of the grid the divergence runs on
+    const bool sp = p->dtype == OA_F32 ? Fft2dPlan<float>::single_pass_div() : Fft2dPlan<double>::single_pass_div();
+    const long tiles = ((q->wk > 0 ? q->wk : p->nx / 2 + 1) + 3) / 4;        // (float64: 4-column tiles; float: 8 or 16)
+    return (sp && (rows == 1024 || rows == 2048) && tiles * MC_BATCH_MAX * q->nids <= (long)(oa_bin_scratch_bytes(q->nids) / 8) * MC_BATCH_MAX) ? 1 : 0;
+}
+
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
                         int leg_rows, int kappa_rows, int mrow) {
     OA_REQUIRE(p && FG && FH && Fnorm, "oa_plan_set_filters: NULL argument");
@@ -200,8 +210,25 @@ int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, v
 void* oa_plan_kappa(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->kk : nullptr; }
 const int64_t* oa_plan_bin_counts(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->counts_full : nullptr; }
 
+// Binning + moments in the tail of the single-pass divergence launch (fft_divbin.hpp): the request the one-call entries hand to
+// the divergence wrappers.  OA_NO_DIVBIN=1: always the separate histogram launches (A/B, tests).
+static bool divbin_enabled() { return getenv("OA_NO_DIVBIN") == nullptr; }     // (per call: tests compare both paths in one process)
+static DivBinFuse make_fuse(const oa_plan* p, const Pipeline* q, int64_t* n, double* S, double* C, int store) {
+    DivBinFuse f{};
+    f.ids = q->ids; f.ipitch = p->kp; f.pnorm = q->norm; f.nids = q->nids; f.nxh = p->nx / 2;
+    f.part = (double*)q->bin_scratch; f.part_cap = (long)(oa_bin_scratch_bytes(q->nids) / (long)sizeof(double)) * MC_BATCH_MAX;
+    f.sums = q->sums; f.ticket = q->ticket; f.mcounts = q->counts_full; f.n = n; f.S = S; f.C = C; f.store = store; f.done = false;
+    return f;
+}
+
+static int qe_tt_impl(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
+                      void* stream, DivBinFuse* fuse);
 int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
              void* stream) {
+    return qe_tt_impl(p, real_map, kX, kY, out_kappa_hc, zero_outside, stream, nullptr);
+}
+static int qe_tt_impl(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
+                      void* stream, DivBinFuse* fuse) {
     OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_qe_tt: call oa_plan_set_filters first");
     OA_REQUIRE((real_map != nullptr) != (kX != nullptr), "oa_qe_tt: pass either a real map or the Fourier-space leg(s)");
     Pipeline* q = (Pipeline*)p->pipe;
@@ -219,7 +246,7 @@ int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, v
     if (rc) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;   // DFT on my rows = my/ny x the full one
     if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my, lr))) return rc;
-    return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st, my);
+    return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, out, 0, q->wk, q->rk, pk, st, my, fuse);
 }
 
 int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* const* host_FG, const void* const* host_FH,
@@ -267,7 +294,9 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_qe_tt_moments: call oa_plan_set_filters and oa_plan_set_bins first");
     OA_REQUIRE(real_map && n && S && C, "oa_qe_tt_moments: NULL argument");
     Pipeline* q = (Pipeline*)p->pipe;
-    if (int rc = oa_qe_tt(p, real_map, nullptr, nullptr, nullptr, 0, stream)) return rc;
+    DivBinFuse f = make_fuse(p, q, n, S, C, 0);
+    if (int rc = qe_tt_impl(p, real_map, nullptr, nullptr, nullptr, 0, stream, divbin_enabled() ? &f : nullptr)) return rc;
+    if (f.done) return 0;                      // binned and accumulated in the divergence launch
     return bandpower_moments(p, q, n, S, C, stream);
 }
 
@@ -514,9 +543,11 @@ int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, 
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     // second kappa plane: the plan-owned input-transform plane (unused on the from-map path); only kappa's active region of
     // it is ever read back (binning)
+    DivBinFuse f = make_fuse(p, q, n, S, C, 0);
     int rc = qe_tt_pair_w(p, real_map0, real_map1, q->FG, q->FH, q->Fn, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], q->kk, q->kT, q->wl,
-                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream);
+                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream, divbin_enabled() ? &f : nullptr);
     if (rc > 0) return rc;
+    if (rc == 0 && f.done) return 0;           // both maps binned and accumulated (map order) in the divergence launch
     if (rc < 0) {
         if ((rc = oa_qe_tt_moments(p, real_map0, n, S, C, stream))) return rc;
         return oa_qe_tt_moments(p, real_map1, n, S, C, stream);
@@ -546,9 +577,16 @@ int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
             OA_REQUIRE(real_map, "oa_qe_tt_stage: stages 0-2 need the map");
             return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my, lr);
         case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my, lr);
-        case 4: return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st, my);
+        case 4: {
+            if (q->ids && divbin_enabled()) {      // as the one-call entries: binning + moments (into dummies) in the divergence launch
+                DivBinFuse f = make_fuse(p, q, (int64_t*)q->kT, (double*)q->kT + 8, (double*)q->kT + 8 + q->nids, 0);
+                return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st, my, &f);
+            }
+            return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st, my);
+        }
         case 5: {
             OA_REQUIRE(q->ids, "oa_qe_tt_stage: stage 5 needs oa_plan_set_bins");
+            if (oa_plan_div_fused(p)) return 0;    // nothing left to do: stage 4 binned
             // dummies: the tail of the (nids-long) sums / counts_tmp buffers is not large enough for C: use the kT plane
             int64_t* n = (int64_t*)q->kT;
             double* S = (double*)q->kT + 8;
@@ -608,10 +646,13 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
                              (long)(2 * lb / es), (long)(lb / es), (long)(2 * lbk / es));
         if (rc < 0) { batched = false; break; }          // this geometry's row stage takes one map per launch: one-by-one loop
         if (rc) return rc;
-        if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my)))
+        DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
+        if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my,
+                                      divbin_enabled() ? &f : nullptr)))
             return rc;
-        // binned power of the B kappa planes + their moment updates in realisation order: two launches; the mean-field stack: one
-        if ((rc = bin_power_moments(p->dtype, q->c[0], q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
+        // binned power of the B kappa planes + their moment updates in realisation order: in the divergence launch, else two
+        // launches; the mean-field stack: one
+        if (!f.done && (rc = bin_power_moments(p->dtype, q->c[0], q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
                                     q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, st, B, (long)(pb / es)))) return rc;
         if (meanfield_acc && (rc = stack_add_region(p->dtype, q->c[0], meanfield_acc, p->ny, p->kp, q->wk, q->rk, st, B, (long)(2 * pb / es)))) return rc;
         i += B;

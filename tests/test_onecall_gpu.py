@@ -343,3 +343,53 @@ def test_round3_entries_from_raw_pointers():
             check(lib.oa_hc_derivs(e.plan, a, 9, dk, N * kp, None))               # order out of range: loud
     finally:
         d.free()
+
+
+@pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (4096, 0.5, "f64"), (2048, 1.0, "f32")])
+def test_binning_in_the_divergence_launch_equals_the_separate_histogram(N, res, prec):
+    """oa_qe_tt_moments / _moments2 with the radial histogram and the moment update in the tail of the single-pass divergence
+    kernel (fft_divbin.hpp) against the same calls with OA_NO_DIVBIN=1 (bin_kernel + bin_final_kernel over the kappa plane):
+    same per-mode arithmetic, other order of the float64 sums -> 1e-13; and against bin2D-style bandpowers of the kappa plane."""
+    import os
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    q = lensing.qest(shape, g, th, noise2d=np.full(shape, cosmology.white_noise_power(1.0)), beam2d=maps.gauss_beam(ml, 1.5),
+                     kmask=maps.mask_kspace(shape, g, lmin=300, lmax=2000), kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=3500),
+                     unlensed_equals_lensed=True, dtype=prec)
+    e = q.eng
+    edges = torch.as_tensor(np.linspace(20, 3500, 20), device=e.device)
+    ids = e.modl_digitize(edges, half=True)
+    q.bind_bins(ids, 21, g.area / float(N * N) ** 2)
+    eb = q._bind_bins()
+    m = [e.irfft(e.grf_hc(9, i), scale=1.0 / N) for i in range(3)]
+
+    def acc():
+        return (torch.zeros(1, dtype=torch.int64, device=e.device), torch.zeros(19, dtype=torch.float64, device=e.device),
+                torch.zeros(19, 19, dtype=torch.float64, device=e.device))
+    assert eb.lib.oa_plan_div_fused(eb.plan) == 1
+    fused = acc()
+    q.tt_moments(m[0], *fused); q.tt_moments2(m[1], m[2], *fused); q.tt_moments(m[1], *fused)
+    torch.cuda.synchronize()
+    os.environ["OA_NO_DIVBIN"] = "1"
+    try:
+        assert eb.lib.oa_plan_div_fused(eb.plan) == 0
+        sep = acc()
+        q.tt_moments(m[0], *sep); q.tt_moments2(m[1], m[2], *sep); q.tt_moments(m[1], *sep)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["OA_NO_DIVBIN"]
+    assert int(fused[0]) == int(sep[0]) == 4
+    assert float(sep[1].abs().min()) > 0
+    np.testing.assert_allclose(fused[1].cpu().numpy(), sep[1].cpu().numpy(), rtol=1e-13)
+    np.testing.assert_allclose(fused[2].cpu().numpy(), sep[2].cpu().numpy(), rtol=1e-12)
+    # one map against the public fine-grained calls: kappa plane -> binned auto power
+    one = acc()
+    q.tt_moments(m[2], *one)
+    kap = q.reconstruct_tt_hc(e.rfft(m[2]))
+    sums, counts = e.bin_power(kap, kap, g.area / float(N * N) ** 2, ids, 21, herm=True)
+    want = (sums / counts.to(torch.float64))[1:-1].cpu().numpy()
+    np.testing.assert_allclose(one[1].cpu().numpy(), want, rtol=(2e-6 if prec == "f32" else 1e-11))

@@ -22,7 +22,7 @@ import shutil
 import statistics
 import sys
 
-MARK = "bin_final_kernel"
+MARK = ("bin_final_kernel", "col_div_sp_bin_kernel")     # last launch of a reconstruction (fused tail: the divergence kernel itself)
 
 
 def find(d, suffix):
@@ -43,7 +43,7 @@ def steps_from(rows, key_time):
     steps, cur = [], []
     for r in rows:
         cur.append(r)
-        if MARK in r["Kernel_Name"]:
+        if any(m in r["Kernel_Name"] for m in MARK):
             steps.append(cur)
             cur = []
     return steps
@@ -108,7 +108,7 @@ def bench_keys(table):
     r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_w64x2_kernel", "row_r2c_w64r_kernel", "row_r2c_rsplit_kernel", "row_r2c_rs4096_kernel")
     c0 = first("col_fft_kernel")
     q = first("row_qe_pair_kernel", "row_qe_kernel")
-    d = first("col_div_kernel", "col_div_sp_kernel")
+    d = first("col_div_kernel", "col_div_sp_kernel", "col_div_sp_bin_kernel")
     fb = first("col_fband_kernel")
     if r0 is not None:
         keys["row_fft_kernel<R2C>"] = [r0]
@@ -122,7 +122,7 @@ def bench_keys(table):
     if q is not None:
         keys["row_qe_kernel"] = [q]
     if q is not None and d is not None and d > q:
-        keys["cols_div"] = list(range(q + 1, d + 1))
+        keys["cols_div_bin" if "_bin_kernel" in names[d] else "cols_div"] = list(range(q + 1, d + 1))
     if d is not None and d + 1 < len(names):
         keys["bin_kernel<power>"] = list(range(d + 1, len(names)))
     return keys

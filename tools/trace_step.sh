@@ -14,11 +14,11 @@ rows = []
 for f in glob.glob(O + '/p_trace/**/*kernel_trace.csv', recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-MARK = 'bin_final_kernel'
+MARK = ('bin_final_kernel', 'col_div_sp_bin_kernel')
 steps, cur = [], []
 for r in rows:
     cur.append(r)
-    if MARK in r['Kernel_Name']:
+    if any(m in r['Kernel_Name'] for m in MARK):
         steps.append(cur); cur = []
 w = {}
 for s in steps:
