@@ -802,7 +802,7 @@ def main():
                     help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
                          "(exact for band-limited filters; library default), full = the map's nx points")
     ap.add_argument("--no-pair", action="store_true", help="one realisation per C-ABI call (oa_qe_tt_moments) instead of two (oa_qe_tt_moments2)")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams: independent realisations are issued round-robin "
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams: independent realisations are issued round-robin "
                     "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap")
     args = ap.parse_args()
 

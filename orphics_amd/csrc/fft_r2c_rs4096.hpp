@@ -45,7 +45,8 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
     tw_lds_fill<T>(ctx, TW, a.tw, a.logTw, 12, NT);
     T256[tid] = a.tw[((unsigned)((tid >> 4) * (tid & 15)) & 255u) << (a.logTw - 8)];
     ctx.sync();
-    const int w = tid >> 6, l = tid & 63, s = l >> 4, i = l & 15, k0 = 4 * w + s;
+    const int w = tid >> 6, l = tid & 63, s = l >> 4, k0 = 4 * w + s;
+    int i = l & 15;
     cx<T>* Dk = D + SUB * k0;                                 // this thread's sub-transform
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
@@ -65,7 +66,11 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
 #endif
 #pragma unroll
         for (int t = 0; t < 16; ++t)
+#ifdef OA_RS4096_NOLOAD       // timing experiment only: arithmetic + LDS without the global loads
+            if (t >= t0 && t < t1) v[t] = mk<T>((T)(grp + t), (T)(n + tid));
+#else
             if (t >= t0 && t < t1) v[t] = RowLoadOnce<T>{src, 0u}.template get<T>(256 * t, 0);
+#endif
     };
     // prefetch of the next row in two halves (PFH = taps issued right after stage 0; the rest after the first sub-transform
     // stage, whose butterfly + 15 factors are the register peak): float64 has no room for all 16 taps across that stage
@@ -85,6 +90,16 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
         for (int step = 0; step < R; ++step) {
             const int n = ((step & 1) << 1) | (step >> 1);
             if (!PF) taps(grp, n);
+#ifdef OA_RS4096_LOADONLY     // timing experiment only: the launch shape and load pattern of this kernel as a pure streaming read
+            {
+                cx<T> sacc = v[0];
+#pragma unroll
+                for (int t = 1; t < 16; ++t) sacc = sacc + v[t];
+                if (PF) next_taps(grp, step, 0, 16);
+                if (sacc.x == (T)1.2345e30) out[tid] = sacc;       // (never true: keeps the loads alive)
+                continue;
+            }
+#endif
             // ---- stage 0: residues k0 = t of the 16-point butterfly over x[tid + 256 t], twiddled, to D[k0][tid]
             Dft<T, 16>::run(v);
             apply_twiddles<T, 16>(v, TW, tid, 0, 6);
@@ -93,6 +108,9 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
             if (PF && PFH > 0) next_taps(grp, step, 0, PFH);
             ctx.sync();
             // ---- sub-transform k0 (256 points over j0 = i + 16 t), inside this wave's quarter of D
+#if defined(__HIP_DEVICE_COMPILE__) && defined(OA_RS4096_OPAQUE)
+            asm volatile("" : "+v"(i));     // the swizzled LDS addresses below are recomputed per row, not kept in ~40 registers
+#endif
             cx<T> u[16];
 #pragma unroll
             for (int t = 0; t < 16; ++t) u[t] = Dk[i + 16 * t];
