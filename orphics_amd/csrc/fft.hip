@@ -277,6 +277,10 @@ struct HipLauncher {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), RS4096_NT, smem) != hipSuccess || per_cu < 1) per_cu = 1;
         int grid = cus * per_cu;
+        // resident workgroups walk the groups.  OA_RS4096_PERSIST=0: one workgroup per group (A/B: so that the scheduler could place
+        // workgroups of another stream's kernels as these retire -- measured 1 % slower in the two-stream job, 5096 vs 5159 /s)
+        static const int persist = [] { const char* e = getenv("OA_RS4096_PERSIST"); return e ? atoi(e) : -1; }();
+        if (persist == 0) grid = a.my;
         if (grid > a.my) grid = a.my;
         go(kern, dim3(grid), RS4096_NT, smem, a);
         return true;
@@ -299,10 +303,13 @@ struct HipLauncher {
     template <typename T>
     void col_fband(int gx, int gy, int gz, size_t smem, int logMy, const ColFBandArgs<T>& a) {
         if (rc) return;
-        constexpr int nt = sizeof(T) == 4 ? 1024 : 512;
+        const int lt = Fft2dPlan<T>::fband_lt(), nt = (1 << lt) / EPT;
         constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
-        if (gy == 4 && logMy == 11) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11>, dim3(gx, gy, gz), nt, smem, a);
-        else if (gy == 4 && logMy == 10) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10>, dim3(gx, gy, gz), nt, smem, a);
+        const bool narrow = lt < (sizeof(T) == 4 ? 14 : 13);
+        if (gy == 4 && logMy == 11 && !narrow) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11>, dim3(gx, gy, gz), nt, smem, a);
+        else if (gy == 4 && logMy == 10 && !narrow) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10>, dim3(gx, gy, gz), nt, smem, a);
+        else if (gy == 4 && logMy == 11) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11 - 1>, dim3(gx, gy, gz), nt, smem, a);
+        else if (gy == 4 && logMy == 10) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10 - 1>, dim3(gx, gy, gz), nt, smem, a);
         else rc = fail("fft: unsupported R-split column stage");
     }
     template <typename T>
@@ -392,23 +399,20 @@ struct HipLauncher {
     template <typename T>
     bool col_div_sp(int gx, size_t smem, int logL, const ColDivArgs<T>& a, int gz = 1) {
         if (rc) return true;
+        const int lt = Fft2dPlan<T>::div_lt(), nt = (1 << lt) / EPT;
+        const bool narrow = lt < (sizeof(T) == 4 ? 14 : 13);
+        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
         if (fuse && !a.accumulate && (long)gx * gz * fuse->nids <= fuse->part_cap && (logL == 10 || logL == 11)) {
-            if constexpr (sizeof(T) == 4) {
-                if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, 3>, gx, gz, 1024, smem, a);
-                else go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, 4>, gx, gz, 1024, smem, a);
-            } else {
-                if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, 2>, gx, gz, 512, smem, a);
-                else go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, 3>, gx, gz, 512, smem, a);
-            }
+            if (logL == 11 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11>, gx, gz, nt, smem, a);
+            else if (logL == 10 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, lc10>, gx, gz, nt, smem, a);
+            else if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11 - 1>, gx, gz, nt, smem, a);
+            else go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, lc10 - 1>, gx, gz, nt, smem, a);
             return true;
         }
-        if constexpr (sizeof(T) == 4) {
-            if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, 3>, dim3(gx, 1, gz), 1024, smem, a); return true; }
-            if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, 4>, dim3(gx, 1, gz), 1024, smem, a); return true; }
-        } else {
-            if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, 2>, dim3(gx, 1, gz), 512, smem, a); return true; }
-            if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, 3>, dim3(gx, 1, gz), 512, smem, a); return true; }
-        }
+        if (logL == 11 && !narrow) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, lc11>, dim3(gx, 1, gz), nt, smem, a); return true; }
+        if (logL == 10 && !narrow) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, lc10>, dim3(gx, 1, gz), nt, smem, a); return true; }
+        if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, lc11 - 1>, dim3(gx, 1, gz), nt, smem, a); return true; }
+        if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, lc10 - 1>, dim3(gx, 1, gz), nt, smem, a); return true; }
         return false;
     }
     template <typename T>

@@ -22,9 +22,14 @@ struct GpuCtx {
 #else
     OA_D void sync() const { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
-    // Exchange between the lanes of ONE wave through LDS: the LDS executes a wave's operations in issue order, so only the
-    // compiler has to keep its order (no s_barrier, no wait)
+    // Exchange between the lanes of ONE wave through LDS: no s_barrier -- the wave waits until its own LDS operations have
+    // completed (lgkmcnt(0): the writes of every lane are in the array before any lane's later read is issued) and the compiler
+    // keeps the order.  -DOA_WSYNC_NOWAIT: compiler fence only (the LDS executes a wave's operations in issue order; A/B)
+#ifdef OA_WSYNC_NOWAIT
     OA_D void wsync() const { asm volatile("" ::: "memory"); }
+#else
+    OA_D void wsync() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
     OA_D void* smem() const { return sm; }
 };
 

@@ -104,6 +104,12 @@ struct Fft2dPlan {
         a.lr = logNy - ilog2(my); a.my = my; a.kplane = kplane; a.twy = tw_y;
         q.row_rsplit(my / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
     }
+    // log2 of the points of a col_fband tile: 128 KB of LDS (8 float / 4 double columns of 2048 rows); OA_FBAND_NARROW=1: half
+    // (twice the workgroups, two per CU: A/B)
+    static int fband_lt() {
+        static const int narrow = [] { const char* e = getenv("OA_FBAND_NARROW"); return e ? atoi(e) : 0; }();
+        return (sizeof(T) == 4 ? 14 : 13) - (narrow > 0 ? 1 : 0);
+    }
     // cv: the coarse view (ny = my rows, tw_y = W_my); Y: the row pass's R planes; leg planes in the R-LAYOUT (row y_lo R + k1)
     template <class Launcher>
     void legs_fband(Launcher& q, const Fft2dPlan<T>& cv, const cx<T>* Y, long kplane, long pin, const T* FG, const T* FH, const T* lxd,
@@ -113,7 +119,7 @@ struct Fft2dPlan {
         a.in = Y; a.kplane = kplane; a.pitch = pin; a.FG = FG; a.FH = FH; a.fpitch = kp; a.lxd = lxd; a.lyd = lyd;
         a.gx = gx; a.gy = gy; a.h = h; a.opitch = pout; a.width = clampw(wmax); a.tw = cv.tw_y; a.ny_full = ny; a.rband = clampr(rband);
         a.in_moff = in_moff; a.out_moff = out_moff;
-        const int lt = sizeof(T) == 4 ? 14 : 13, lc = lt - cv.logNy, Cs = 1 << lc;
+        const int lt = fband_lt(), lc = lt - cv.logNy, Cs = 1 << lc;
         const int logMq = cv.logNy - (logNy - cv.logNy);
         const size_t smem = ((size_t)(1 << lt) + tw_lds_size(cv.logNy) + tw_lds_size(logMq) + (1 << logMq)) * sizeof(cx<T>);
         q.col_fband((a.width + Cs - 1) / Cs, 1 << (logNy - cv.logNy), nmaps, smem, cv.logNy, a);
@@ -340,6 +346,11 @@ struct Fft2dPlan {
         return true;
     }
 
+    // log2 of the points of a single-pass divergence tile (as fband_lt); OA_DIV_NARROW=1: half
+    static int div_lt() {
+        static const int narrow = [] { const char* e = getenv("OA_DIV_NARROW"); return e ? atoi(e) : 0; }();
+        return (sizeof(T) == 4 ? 14 : 13) - (narrow > 0 ? 1 : 0);
+    }
     static bool single_pass_div() {
         static const bool on = [] { const char* e = getenv("OA_SINGLE_PASS_DIV"); return e ? atoi(e) != 0 : true; }();
         return on;
@@ -354,7 +365,7 @@ struct Fft2dPlan {
         if (single_pass_div() && (logNy == 10 || logNy == 11)) {
             // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column (f64: 4- / 8-column) tile in LDS --
             // 128 KB --, the product planes are read once and nothing is written back but kappa's band rows
-            const int lt = sizeof(T) == 4 ? 14 : 13;
+            const int lt = div_lt();
             const int lc = lt - logNy, Cs = 1 << lc;
             ColDivArgs<T> a{};
             a.A = pa; a.B = pb; a.Fn = Fn; a.lxd = lxd; a.lyd = lyd; a.out = out; a.pitch = pi; a.opitch = kp; a.width = clampw(wmax);

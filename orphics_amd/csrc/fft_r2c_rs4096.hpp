@@ -8,7 +8,7 @@
 //   -- workgroup barrier --
 //   the 16 sub-transforms (256 points over j0, one per k0) are independent: wave w owns k0 = 4 w + s, s < 4 (its lanes
 //   16 s + i), as two radix-16 stages with an exchange INSIDE the wave's own quarter of the buffer -- no s_barrier: the
-//   LDS executes one wave's operations in order (Ctx::wsync is a compiler fence on the GPU);
+//   wave only waits for its own LDS operations (Ctx::wsync = s_waitcnt lgkmcnt(0); no measurable cost);
 //   the last stage computes only the bins the consumers keep: columns < 512 and their mirror images (the untangle's
 //   partners), 4 of its 16 outputs;
 //   -- workgroup barrier --   untangle + radix-4 column butterfly accumulation (as the general pass)   -- barrier --
@@ -27,7 +27,7 @@ constexpr int RS4096_NT = 256;
 // sub-transform pitch: 256 points; float adds 16 (128 B) so that the two sub-transforms a 32-lane ds_read_b64 group spans
 // do not start on the same bank
 template <typename T> constexpr int rs4096_sub() { return sizeof(T) == 4 ? 272 : 256; }
-template <typename T> constexpr size_t rs4096_lds_bytes() { return (size_t)(16 * rs4096_sub<T>() + 128 + 256 + 512) * sizeof(cx<T>); }
+template <typename T> constexpr size_t rs4096_lds_bytes() { return (size_t)(16 * rs4096_sub<T>() + 128 + 256 + (sizeof(T) == 8 ? 512 : 0)) * sizeof(cx<T>); }
 
 // position of kept bin (rr, k0, m) in the exchange area: rr = 0, 1 -> r = 0, 1; rr = 2, 3 -> r = 14, 15; inside the owner
 // wave's quarter (1024 (k0 >> 2) ...), the low nibble swizzled by k0 (writes: lanes m consecutive; reads: lanes k0 consecutive)
@@ -55,8 +55,12 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
     // untangle: this thread's columns kk = tid + 256 r, r < 2 (coalesced stores); factors W_8192^kk in LDS (in registers they
     // cost 8 float64 VGPRs across the whole row; loaded from global inside the loop they would queue behind the prefetch)
     cx<T>* TWK = T256 + 256;
+    cx<T> twr[2];                                             // float: the same two factors in registers (37.9 KB of LDS: four workgroups per CU)
 #pragma unroll
-    for (int r = 0; r < 2; ++r) TWK[tid + 256 * r] = a.tw[(unsigned)(tid + 256 * r) << (a.logTw - 13)];
+    for (int r = 0; r < 2; ++r) {
+        twr[r] = a.tw[(unsigned)(tid + 256 * r) << (a.logTw - 13)];
+        if (sizeof(T) == 8) TWK[tid + 256 * r] = twr[r];
+    }
     cx<T> v[16];
     auto taps = [&](long grp, int n, int t0 = 0, int t1 = 16) {
 #ifdef OA_RS4096_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
@@ -144,7 +148,7 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
                     const cx<T> Zm = D[rs4096_epos<SUB>(P ? (P >> 8) - 12 : 0, P & 15, (P >> 4) & 15)];
                     const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
                     const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
-                    const cx<T> X = (E + TWK[kk] * O) * a.scale;
+                    const cx<T> X = (E + (sizeof(T) == 8 ? TWK[kk] : twr[r]) * O) * a.scale;
                     if (step == 0) A[r] = X;
                     else if (step == 1) { B[r] = A[r] - X; A[r] = A[r] + X; }
                     else if (step == 2) Cc[r] = X;

@@ -6,7 +6,8 @@ TAG=${1:-rXX}; shift
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 bench.py --steps 30 --warmup 5 --no-cpu --no-extras --also none --no-pair --streams 1 --batch 1 "$@" > $O/trace_run.json 2> $O/trace.err
+if [ -n "${PAIR:-}" ]; then MODE="--batch 2"; else MODE="--no-pair --batch 1"; fi     # PAIR=1: two maps per call (oa_qe_tt_moments2)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_trace -- python3 bench.py --steps 30 --warmup 5 --no-cpu --no-extras --also none $MODE --streams 1 "$@" > $O/trace_run.json 2> $O/trace.err
 python3 - $O <<'PY'
 import csv, glob, sys, statistics
 O = sys.argv[1]
