@@ -710,8 +710,8 @@ def measure(args, torch, dist, world, rank, prec):
         w64 = os.environ.get("OA_R2C_W64", "1") != "0" and prec == "f32"
         tn = "float" if prec == "f32" else "double"
         if G.get("rsplit"):
-            rs4096 = N == 8192 and wl_ <= 512 and not os.environ.get("OA_NO_RS4096")
-            roofline["kernel_symbol"] = ("row_r2c_rs4096_kernel<%s, ...>" % tn if rs4096 else
+            rs4096 = ((N == 8192 and wl_ <= 512) or (N == 4096 and wl_ <= 256)) and not os.environ.get("OA_NO_RS4096")
+            roofline["kernel_symbol"] = ("row_r2c_rs%d_kernel<%s, ...>" % (N // 2, tn) if rs4096 else
                                          "row_r2c_w64r_kernel<2>" if (w64 and N == 8192 and wl_ <= 512) else "row_r2c_rsplit_kernel<%s, ...>" % tn)
             roofline["rsplit"] = {"R": G["rsplit"], "note": "the row pass also takes the first radix-R butterfly of the column transform (rows g + my n, n < R, "
                                   "per wave / workgroup) and writes R planes Y[k1][g]; one single-pass column kernel follows (include/orphics_amd.h oa_plan_rsplit)"}

@@ -52,6 +52,12 @@ __global__ __launch_bounds__(RS4096_NT, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)
     GpuCtx c{oa_dyn_smem};
     row_r2c_rs4096_body<T, 2, PF>(c, a);
 }
+// 4096-point rows (4096^2 maps), <= 256 columns kept: the same body on 128 threads per row
+template <typename T, bool PF>
+__global__ __launch_bounds__(128, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)) void row_r2c_rs2048_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_rs_body<T, 11, 2, PF>(c, a);
+}
 
 // single-pass column stage of the R-split path: [My][C] tile, all threads forward, R groups inverse (fft_fband.hpp)
 template <typename T, class SEQF, int LR, int LOGC>
@@ -257,7 +263,8 @@ struct HipLauncher {
         if (grid > ngroups) grid = ngroups;
         go(kern, dim3(grid), nt, smem, a);
     }
-    // 8192-point rows, <= 512 kept columns: the one-cross-wave-exchange kernel (fft_r2c_rs4096.hpp), both precisions.  Measured
+    // 8192-point rows, <= 512 kept columns (and 4096-point rows, <= 256: 4096^2 maps, float 18.9 us against 23.5 us of the general
+    // pass, float64 37.2 against 41.0): the one-cross-wave-exchange kernel (fft_r2c_rs4096.hpp), both precisions.  Measured
     // at 8192^2 (profiles/r03x_r2c_variants.txt): float64 121 us against 131 us of the general pass, float 65 us against 71 us of
     // the one-wave-per-row kernel.  The prefetch order pays in float (65 vs 68 us) and costs in float64 (126 vs 121 us: 256
     // registers, spills): default per precision, OA_RS4096_PF=0/1 overrides.  OA_NO_RS4096=1: the older kernels (A/B).
@@ -265,24 +272,27 @@ struct HipLauncher {
     bool row_rs4096(const RowArgs<T>& a) {
         static const bool off = getenv("OA_NO_RS4096") != nullptr;
         static const int pfenv = [] { const char* e = getenv("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
-        if (off || rc || !(a.logL == 12 && a.logC == 0 && a.lr == 2 && a.wcols <= 512 && a.logTw >= 13)) return false;
-        const bool nopf = pfenv >= 0 ? pfenv == 0 : sizeof(T) == 8;
-        const size_t smem = rs4096_lds_bytes<T>();
-        auto kern = nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>;
+        const bool l12 = a.logL == 12 && a.wcols <= 512 && a.logTw >= 13, l11 = a.logL == 11 && a.wcols <= 256 && a.logTw >= 12;
+        if (off || rc || a.lr != 2 || !(l12 || l11)) return false;
+        const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && l12);     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
+        const size_t smem = l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>();
+        const int NTr = l12 ? RS4096_NT : 128;
+        auto kern = l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
+                        : (nopf ? row_r2c_rs2048_kernel<T, false> : row_r2c_rs2048_kernel<T, true>);
         if (smem > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return true; }
         }
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), RS4096_NT, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NTr, smem) != hipSuccess || per_cu < 1) per_cu = 1;
         int grid = cus * per_cu;
         // resident workgroups walk the groups.  OA_RS4096_PERSIST=0: one workgroup per group (A/B: so that the scheduler could place
         // workgroups of another stream's kernels as these retire -- measured 1 % slower in the two-stream job, 5096 vs 5159 /s)
         static const int persist = [] { const char* e = getenv("OA_RS4096_PERSIST"); return e ? atoi(e) : -1; }();
         if (persist == 0) grid = a.my;
         if (grid > a.my) grid = a.my;
-        go(kern, dim3(grid), RS4096_NT, smem, a);
+        go(kern, dim3(grid), NTr, smem, a);
         return true;
     }
     template <typename T>

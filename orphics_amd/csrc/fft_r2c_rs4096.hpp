@@ -20,47 +20,59 @@
 
 namespace oa {
 
+// Row lengths: LOGL = 12 (8192-point rows, 256 threads = 4 waves per row, sub-transforms of 256 = 16 x 16 points, <= 512
+// columns kept) and LOGL = 11 (4096-point rows, 128 threads = 2 waves, sub-transforms of 128 = 16 x 8 points: a lane finishes
+// two of the 16 eight-point butterflies; <= 256 columns kept).  S = L / 16 = threads per row = points per sub-transform.
 constexpr int RS4096_NT = 256;
+template <int LOGL> constexpr int rs_nt() { return (1 << LOGL) / 16; }
 #ifndef OA_RS4096_PFH
 #define OA_RS4096_PFH 16
 #endif
-// sub-transform pitch: 256 points; float adds 16 (128 B) so that the two sub-transforms a 32-lane ds_read_b64 group spans
-// do not start on the same bank
-template <typename T> constexpr int rs4096_sub() { return sizeof(T) == 4 ? 272 : 256; }
-template <typename T> constexpr size_t rs4096_lds_bytes() { return (size_t)(16 * rs4096_sub<T>() + 128 + 256 + (sizeof(T) == 8 ? 512 : 0)) * sizeof(cx<T>); }
+// sub-transform pitch in LDS: S points plus a pad chosen so that the sub-transforms one LDS instruction's lane group spans
+// start on different banks (ds_read_b64: 32 lanes, ds_read_b128: 16 lanes; checked case by case in DESIGN section 3)
+template <typename T, int LOGL> constexpr int rs_sub() { return LOGL == 12 ? (sizeof(T) == 4 ? 272 : 256) : 136; }
+template <typename T> constexpr int rs4096_sub() { return rs_sub<T, 12>(); }
+template <typename T, int LOGL> constexpr size_t rs_lds_bytes() {
+    // data + two-level W_L table + W_S table [m][i] + the untangle factors of the kept columns
+    return (size_t)(16 * rs_sub<T, LOGL>() + 128 + rs_nt<LOGL>() + 2 * rs_nt<LOGL>()) * sizeof(cx<T>);
+}
+template <typename T> constexpr size_t rs4096_lds_bytes() { return rs_lds_bytes<T, 12>(); }
 
-// position of kept bin (rr, k0, m) in the exchange area: rr = 0, 1 -> r = 0, 1; rr = 2, 3 -> r = 14, 15; inside the owner
-// wave's quarter (1024 (k0 >> 2) ...), the low nibble swizzled by k0 (writes: lanes m consecutive; reads: lanes k0 consecutive)
-template <int SUB>
-OA_HD int rs4096_epos(int rr, int k0, int m) { return (k0 >> 2) * (4 * SUB) + (rr << 6) + ((k0 & 3) << 4) + ((m ^ k0) & 15); }
+// V[m][i] of a sub-transform (m < 16 first-stage bins, i < LPS lanes): place of lane i inside row m, chosen so that both the
+// writes (lanes i, fixed m) and the second-stage reads (lanes m, fixed i) hit distinct banks
+template <int LPS> OA_HD int rs_swz(int i, int m) { return LPS == 16 ? ((i ^ m) & 15) : ((i + (m >> 1)) & 7); }
 
-template <typename T, int LR, bool PF = true, class Ctx>
-OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
-    constexpr int L = 4096, R = 1 << LR, NT = RS4096_NT, SUB = rs4096_sub<T>();
+// position of kept bin (rr, k0, m) in the exchange area -- rr < 2 RK: the RK lowest and the RK highest second-stage bins --
+// inside the owner wave's part of the buffer (NSW sub-transforms per wave), the low nibble swizzled by k0 (writes: lanes m
+// consecutive; reads: lanes k0 consecutive)
+template <int SUB, int NSW>
+OA_HD int rs_epos(int rr, int k0, int m) { return (k0 / NSW) * (NSW * SUB) + rr * (NSW * 16) + (k0 % NSW) * 16 + ((m ^ k0) & 15); }
+
+template <typename T, int LOGL, int LR, bool PF = true, class Ctx>
+OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
+    constexpr int L = 1 << LOGL, R = 1 << LR, NT = rs_nt<LOGL>(), S = NT, SUB = rs_sub<T, LOGL>();
+    constexpr int LPS = S / 16, NSW = 64 / LPS, RK = LOGL == 12 ? 2 : 1;      // lanes per sub-transform, sub-transforms per wave, kept bins per side
+    static_assert(LOGL == 12 || LOGL == 11, "row_r2c_rs_body: 8192- or 4096-point rows");
     static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
-    cx<T>* D = reinterpret_cast<cx<T>*>(ctx.smem());          // [k0][j0]: 16 x 256
-    cx<T>* TW = D + 16 * SUB;                                 // two-level W_4096 table (64 + 64)
-    cx<T>* T256 = TW + 128;                                   // [m][i] = W_256^(i m)
+    cx<T>* D = reinterpret_cast<cx<T>*>(ctx.smem());          // [k0][j0]: 16 x S
+    cx<T>* TW = D + 16 * SUB;                                 // two-level W_L table
+    cx<T>* TS = TW + 128;                                     // [m][i] = W_S^(i m), m < 16, i < LPS
     const int tid = ctx.tid();
-    tw_lds_fill<T>(ctx, TW, a.tw, a.logTw, 12, NT);
-    T256[tid] = a.tw[((unsigned)((tid >> 4) * (tid & 15)) & 255u) << (a.logTw - 8)];
+    tw_lds_fill<T>(ctx, TW, a.tw, a.logTw, LOGL, NT);
+    TS[tid] = a.tw[((unsigned)((tid / LPS) * (tid % LPS)) & (unsigned)(S - 1)) << (a.logTw - (LOGL - 4))];
     ctx.sync();
-    const int w = tid >> 6, l = tid & 63, s = l >> 4, k0 = 4 * w + s;
-    int i = l & 15;
+    const int w = tid >> 6, l = tid & 63, s = l / LPS, k0 = NSW * w + s;
+    int i = l % LPS;
     cx<T>* Dk = D + SUB * k0;                                 // this thread's sub-transform
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
     const unsigned nym = ((unsigned)a.my << LR) - 1u;
     const int ngroups = a.my, gstep = ctx.grid_x();
-    // untangle: this thread's columns kk = tid + 256 r, r < 2 (coalesced stores); factors W_8192^kk in LDS (in registers they
-    // cost 8 float64 VGPRs across the whole row; loaded from global inside the loop they would queue behind the prefetch)
-    cx<T>* TWK = T256 + 256;
-    cx<T> twr[2];                                             // float: the same two factors in registers (37.9 KB of LDS: four workgroups per CU)
+    // untangle: this thread's columns kk = tid + NT r, r < 2 (coalesced stores); factors W_2L^kk in LDS (in registers they cost
+    // up to 8 VGPRs across the whole row; loaded from global inside the loop they would queue behind the prefetch)
+    cx<T>* TWK = TS + NT;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        twr[r] = a.tw[(unsigned)(tid + 256 * r) << (a.logTw - 13)];
-        if (sizeof(T) == 8) TWK[tid + 256 * r] = twr[r];
-    }
+    for (int r = 0; r < 2; ++r) TWK[tid + NT * r] = a.tw[(unsigned)(tid + NT * r) << (a.logTw - (LOGL + 1))];
     cx<T> v[16];
     auto taps = [&](long grp, int n, int t0 = 0, int t1 = 16) {
 #ifdef OA_RS4096_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
@@ -73,7 +85,7 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
 #ifdef OA_RS4096_NOLOAD       // timing experiment only: arithmetic + LDS without the global loads
             if (t >= t0 && t < t1) v[t] = mk<T>((T)(grp + t), (T)(n + tid));
 #else
-            if (t >= t0 && t < t1) v[t] = RowLoadOnce<T>{src, 0u}.template get<T>(256 * t, 0);
+            if (t >= t0 && t < t1) v[t] = RowLoadOnce<T>{src, 0u}.template get<T>(S * t, 0);
 #endif
     };
     // prefetch of the next row in two halves (PFH = taps issued right after stage 0; the rest after the first sub-transform
@@ -104,51 +116,66 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
                 continue;
             }
 #endif
-            // ---- stage 0: residues k0 = t of the 16-point butterfly over x[tid + 256 t], twiddled, to D[k0][tid]
+            // ---- stage 0: residues k0 = t of the 16-point butterfly over x[tid + S t], twiddled, to D[k0][tid]
             Dft<T, 16>::run(v);
-            apply_twiddles<T, 16>(v, TW, tid, 0, 6);
+            apply_twiddles<T, 16>(v, TW, tid, 0, tw_lds_h(LOGL));
 #pragma unroll
             for (int t = 0; t < 16; ++t) D[SUB * t + tid] = v[t];
             if (PF && PFH > 0) next_taps(grp, step, 0, PFH);
             ctx.sync();
-            // ---- sub-transform k0 (256 points over j0 = i + 16 t), inside this wave's quarter of D
+            // ---- sub-transform k0 (S points over j0 = i + LPS t), inside this wave's part of D
 #if defined(__HIP_DEVICE_COMPILE__) && defined(OA_RS4096_OPAQUE)
             asm volatile("" : "+v"(i));     // the swizzled LDS addresses below are recomputed per row, not kept in ~40 registers
 #endif
             cx<T> u[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) u[t] = Dk[i + 16 * t];
-            Dft<T, 16>::run(u);                                // u[m] = sum_t Y[i + 16 t] W_16^(t m)
+            for (int t = 0; t < 16; ++t) u[t] = Dk[i + LPS * t];
+            Dft<T, 16>::run(u);                                // u[m] = sum_t Y[i + LPS t] W_16^(t m)
 #pragma unroll
             for (int m = 1; m < 16; ++m) {
                 if ((m & 3) == 0) ctx.wsync();                 // (keeps the compiler from fetching all 15 factors at once: registers)
-                u[m] = u[m] * T256[16 * m + i];
+                u[m] = u[m] * TS[LPS * m + i];
             }
             ctx.wsync();                                       // every lane's reads precede the in-place writes
 #pragma unroll
-            for (int m = 0; m < 16; ++m) Dk[16 * m + (i ^ m)] = u[m];
+            for (int m = 0; m < 16; ++m) Dk[LPS * m + rs_swz<LPS>(i, m)] = u[m];
             if (PF && PFH < 16) next_taps(grp, step, PFH, 16);
             ctx.wsync();
+            if constexpr (LPS == 16) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) u[t] = Dk[16 * i + (t ^ i)];   // V[m = i][t]
-            Dft<T, 16>::run(u);                                // u[r] = Z[k0 + 16 i + 256 r]; r = 0, 1, 14, 15 used (the rest is dead code)
-            ctx.wsync();                                       // the reads above precede the exchange writes (same quarter)
-            D[rs4096_epos<SUB>(0, k0, i)] = u[0];
-            D[rs4096_epos<SUB>(1, k0, i)] = u[1];
-            D[rs4096_epos<SUB>(2, k0, i)] = u[14];
-            D[rs4096_epos<SUB>(3, k0, i)] = u[15];
+                for (int t = 0; t < 16; ++t) u[t] = Dk[16 * i + rs_swz<16>(t, i)];   // V[m = i][t]
+                Dft<T, 16>::run(u);                            // u[r] = Z[k0 + 16 i + 256 r]; r = 0, 1, 14, 15 used (the rest is dead code)
+                ctx.wsync();                                   // the reads above precede the exchange writes (same part of D)
+                D[rs_epos<SUB, NSW>(0, k0, i)] = u[0];
+                D[rs_epos<SUB, NSW>(1, k0, i)] = u[1];
+                D[rs_epos<SUB, NSW>(2, k0, i)] = u[14];
+                D[rs_epos<SUB, NSW>(3, k0, i)] = u[15];
+            } else {
+                // lane i finishes m = 2 i and 2 i + 1: two 8-point butterflies over the lanes' values V[m][t], t < 8
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) u[8 * h + t] = Dk[8 * (2 * i + h) + rs_swz<8>(t, 2 * i + h)];
+                Dft<T, 8>::run(u);                             // u[r] = Z[k0 + 16 (2 i) + 256 r]; r = 0, 7 used
+                Dft<T, 8>::run(u + 8);
+                ctx.wsync();
+                D[rs_epos<SUB, NSW>(0, k0, 2 * i)] = u[0];
+                D[rs_epos<SUB, NSW>(1, k0, 2 * i)] = u[7];
+                D[rs_epos<SUB, NSW>(0, k0, 2 * i + 1)] = u[8];
+                D[rs_epos<SUB, NSW>(1, k0, 2 * i + 1)] = u[15];
+            }
             ctx.sync();
-            // ---- untangle columns kk = tid + 256 r and accumulate the radix-4 column butterfly
+            // ---- untangle columns kk = tid + NT r and accumulate the radix-4 column butterfly
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int kk = tid + 256 * r;
+                const int kk = tid + NT * r;
                 if (kk < a.wcols) {
-                    const int P = (L - kk) & (L - 1);          // partner bin: 0 (kk = 0) or in [3585, 4095]
-                    const cx<T> Zk = D[rs4096_epos<SUB>(r, kk & 15, (kk >> 4) & 15)];
-                    const cx<T> Zm = D[rs4096_epos<SUB>(P ? (P >> 8) - 12 : 0, P & 15, (P >> 4) & 15)];
+                    const int P = (L - kk) & (L - 1);          // partner bin: 0 (kk = 0) or among the RK highest blocks of 256
+                    const cx<T> Zk = D[rs_epos<SUB, NSW>(kk >> 8, kk & 15, (kk >> 4) & 15)];
+                    const cx<T> Zm = D[rs_epos<SUB, NSW>(P ? (P >> 8) - (LPS - 2 * RK) : 0, P & 15, (P >> 4) & 15)];
                     const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
                     const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
-                    const cx<T> X = (E + (sizeof(T) == 8 ? TWK[kk] : twr[r]) * O) * a.scale;
+                    const cx<T> X = (E + TWK[kk] * O) * a.scale;
                     if (step == 0) A[r] = X;
                     else if (step == 1) { B[r] = A[r] - X; A[r] = A[r] + X; }
                     else if (step == 2) Cc[r] = X;
@@ -167,5 +194,7 @@ OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) {
         }
     }
 }
+template <typename T, int LR, bool PF = true, class Ctx>
+OA_HD void row_r2c_rs4096_body(Ctx& ctx, const RowArgs<T>& a) { row_r2c_rs_body<T, 12, LR, PF>(ctx, a); }
 
 }  // namespace oa

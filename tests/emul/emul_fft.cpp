@@ -281,16 +281,21 @@ static int do_qe_rows_rlayout(int my, int nx, const cx<T>* gx, const cx<T>* gy, 
 // R-split R2C of 8192-point rows with one workgroup-wide exchange (fft_r2c_rs4096.hpp): nx = 8192, ny = 4 my, either precision
 template <typename T>
 static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int width, int nwg, int pf) {
-    if (nx != 8192 || width > 512 || (ny & 3)) return 1;
+    if (!((nx == 8192 && width <= 512) || (nx == 4096 && width <= 256)) || (ny & 3)) return 1;
     auto tw = make_twiddles<T>(nx);
     auto twy = make_twiddles<T>(ny);
     RowArgs<T> a{};
-    a.in = in; a.out = out; a.in_pitch = nx / 2; a.out_pitch = pitch; a.logL = 12; a.logC = 0; a.NT = RS4096_NT;
+    a.in = in; a.out = out; a.in_pitch = nx / 2; a.out_pitch = pitch; a.logL = ilog2(nx) - 1; a.logC = 0; a.NT = nx / 32;
     a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (T)1; a.mode = ROW_R2C; a.wcols = width; a.lr = 2; a.my = ny / 4;
     a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
     EmuLauncher q;
-    if (pf) q.run(nwg, 1, RS4096_NT, rs4096_lds_bytes<T>(), [&](EmuCtx& c) { row_r2c_rs4096_body<T, 2, true>(c, a); });
-    else q.run(nwg, 1, RS4096_NT, rs4096_lds_bytes<T>(), [&](EmuCtx& c) { row_r2c_rs4096_body<T, 2, false>(c, a); });
+    if (nx == 8192) {
+        if (pf) q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 2, true>(c, a); });
+        else q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 2, false>(c, a); });
+    } else {
+        if (pf) q.run(nwg, 1, 128, rs_lds_bytes<T, 11>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 11, 2, true>(c, a); });
+        else q.run(nwg, 1, 128, rs_lds_bytes<T, 11>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 11, 2, false>(c, a); });
+    }
     return 0;
 }
 extern "C" {

@@ -588,11 +588,13 @@ def test_rsplit_row_pass_one_wave_per_row(emu):
     assert np.all(Y[:, :, w:] == 7.0)
 
 
-@pytest.mark.parametrize("prec,w,pf", [("f64", 380, 1), ("f64", 512, 0), ("f32", 380, 1), ("f64", 1, 1)])
-def test_rsplit_row_pass_one_crosswave_exchange(emu, prec, w, pf):
-    """row_r2c_rs4096_body: 4096 = 16 x 256 with the sub-transforms inside one wave's quarter of the buffer, pruned last stage,
-    persistent workgroups (3 walk 8 groups) with and without the prefetch order"""
-    ny, nx = 32, 8192
+@pytest.mark.parametrize("nx,prec,w,pf", [(8192, "f64", 380, 1), (8192, "f64", 512, 0), (8192, "f32", 380, 1), (8192, "f64", 1, 1),
+                                          (4096, "f64", 190, 0), (4096, "f32", 256, 1), (4096, "f64", 256, 1), (4096, "f32", 3, 0)])
+def test_rsplit_row_pass_one_crosswave_exchange(emu, nx, prec, w, pf):
+    """row_r2c_rs_body: L = 16 x S with the sub-transforms (S = 256 = 16 x 16 points for 8192-point rows, 128 = 16 x 8 for
+    4096-point rows) inside one wave's part of the buffer, pruned last stage, persistent workgroups (3 walk 8 groups) with and
+    without the prefetch order"""
+    ny = 32
     my = ny // 4
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
     rng = np.random.default_rng(11)
