@@ -141,12 +141,42 @@ __global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_fft_k
     col_fft_body<T, SEQ>(c, a);
 }
 
+// resident workgroups per CU of a persistent kernel, with its dynamic-LDS attribute set: asked of the runtime ONCE per (kernel,
+// workgroup size, LDS bytes) -- both are driver calls of several microseconds, more than a 4096^2 launch leaves the host
+static int resident_per_cu(const void* kern, int nt, size_t smem, std::string* err) {
+    struct Key { const void* k; int dev, nt; size_t smem; int per_cu; };
+    static Key cache[64];
+    static int ncache = 0;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (int i = 0; i < ncache; ++i)
+            if (cache[i].k == kern && cache[i].dev == dev && cache[i].nt == nt && cache[i].smem == smem) return cache[i].per_cu;
+    }
+    const hipError_t e = ensure_dyn_lds(kern, smem);
+    if (e != hipSuccess) { *err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return -1; }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, nt, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ncache < 64) cache[ncache++] = Key{kern, dev, nt, smem, per_cu};
+    return per_cu;
+}
+
 struct HipLauncher {
     hipStream_t st;
     int rc = 0;
 
     template <class K, class A>
     void go(K kern, dim3 grid, int nt, size_t smem, const A& a) { launch_go(rc, st, kern, grid, nt, smem, a); }
+    template <class K, class A>
+    void launch_plain(K kern, dim3 grid, int nt, size_t smem, const A& a) {      // (dynamic-LDS attribute already set: resident_per_cu)
+        if (rc) return;
+        hipLaunchKernelGGL(kern, grid, dim3(nt), smem, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+    }
 
     template <typename T, int MODE, class S>
     void row_mode(int grid, int nt, size_t smem, const RowArgs<T>& a) {
@@ -252,16 +282,13 @@ struct HipLauncher {
         if (nopf) { go(row_r2c_rsplit_kernel<T, S, 2, false>, dim3(ngroups), nt, smem, a); return; }
         if (rc) return;
         auto kern = row_r2c_rsplit_kernel<T, S, 2, true>;
-        if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
-        }
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), nt, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        std::string err;
+        const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), nt, smem, &err);
+        if (per_cu < 0) { rc = fail(err); return; }
         int grid = cus * per_cu;
         if (grid > ngroups) grid = ngroups;
-        go(kern, dim3(grid), nt, smem, a);
+        launch_plain(kern, dim3(grid), nt, smem, a);
     }
     // 8192-point rows, <= 512 kept columns (and 4096-point rows, <= 256: 4096^2 maps, float 18.9 us against 23.5 us of the general
     // pass, float64 37.2 against 41.0): the one-cross-wave-exchange kernel (fft_r2c_rs4096.hpp), both precisions.  Measured
@@ -279,20 +306,17 @@ struct HipLauncher {
         const int NTr = l12 ? RS4096_NT : 128;
         auto kern = l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
                         : (nopf ? row_r2c_rs2048_kernel<T, false> : row_r2c_rs2048_kernel<T, true>);
-        if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return true; }
-        }
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NTr, smem) != hipSuccess || per_cu < 1) per_cu = 1;
+        std::string err;
+        const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), NTr, smem, &err);
+        if (per_cu < 0) { rc = fail(err); return true; }
         int grid = cus * per_cu;
         // resident workgroups walk the groups.  OA_RS4096_PERSIST=0: one workgroup per group (A/B: so that the scheduler could place
         // workgroups of another stream's kernels as these retire -- measured 1 % slower in the two-stream job, 5096 vs 5159 /s)
         static const int persist = [] { const char* e = getenv("OA_RS4096_PERSIST"); return e ? atoi(e) : -1; }();
         if (persist == 0) grid = a.my;
         if (grid > a.my) grid = a.my;
-        go(kern, dim3(grid), NTr, smem, a);
+        launch_plain(kern, dim3(grid), NTr, smem, a);
         return true;
     }
     template <typename T>
@@ -395,8 +419,8 @@ struct HipLauncher {
     DivBinFuse* fuse = nullptr;     // != nullptr: the caller wants binning + moments in the divergence launch (common.hpp)
     template <class K, typename T>
     void go_fused(K kern, int gx, int gz, int nt, size_t smem, ColDivArgs<T> a) {
-        if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        {
+            const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem);
             if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
         }
         fuse->gx = gx;

@@ -1,5 +1,6 @@
 // Shared launch plumbing of the FFT translation units (fft.hip, fft_legs.hip).
 #pragma once
+#include <mutex>
 #include "common.hpp"
 #include "fft_plan.hpp"
 
@@ -60,6 +61,30 @@ template <typename T> constexpr int waves_per_eu() { return sizeof(T) == 8 ? 2 :
 #endif
 template <typename T> constexpr int fused_col_waves_per_eu() { return sizeof(T) == 8 ? 2 : OA_FUSED_COL_WAVES; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize of a kernel, raised once per (kernel, device) and only when a launch needs more than
+// what was set before: the runtime call costs microseconds -- per launch it was a visible part of the host time of the small
+// (4096^2) configurations
+inline hipError_t ensure_dyn_lds(const void* kern, size_t smem) {
+    if (smem <= 48 * 1024) return hipSuccess;
+    struct Ent { const void* k; int dev; size_t smem; };
+    static Ent tab[256];
+    static int n = 0;
+    static std::mutex mu;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < n; ++i)
+        if (tab[i].k == kern && tab[i].dev == dev) {
+            if (tab[i].smem >= smem) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e == hipSuccess) tab[i].smem = smem;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess && n < 256) tab[n++] = Ent{kern, dev, smem};
+    return e;
+}
+
 template <class K, class A>
 inline void launch_go(int& rc, hipStream_t st, K kern, dim3 grid, int nt, size_t smem, const A& a) {
     if (rc) return;
@@ -67,9 +92,8 @@ inline void launch_go(int& rc, hipStream_t st, K kern, dim3 grid, int nt, size_t
         rc = fail("fft: transform size exceeds the LDS / workgroup budget for this dtype");
         return;
     }
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)smem);
+    {
+        const hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), smem);
         if (e != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); return; }
     }
     hipLaunchKernelGGL(kern, grid, dim3(nt), smem, st, a);
