@@ -436,7 +436,9 @@ struct HipLauncher {
         const int lt = Fft2dPlan<T>::div_lt(), nt = (1 << lt) / EPT;
         const bool narrow = lt < (sizeof(T) == 4 ? 14 : 13);
         constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
-        if (fuse && !a.accumulate && (long)gx * gz * fuse->nids <= fuse->part_cap && (logL == 10 || logL == 11)) {
+        // (the wave-private histogram rows of the tail live in the column tile: waves x nids doubles must fit it)
+        if (fuse && !a.accumulate && (long)gx * gz * fuse->nids <= fuse->part_cap && (logL == 10 || logL == 11) &&
+            (size_t)(nt / 64) * fuse->nids * sizeof(double) <= ((size_t)1 << lt) * sizeof(cx<T>)) {
             if (logL == 11 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11>, gx, gz, nt, smem, a);
             else if (logL == 10 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, lc10>, gx, gz, nt, smem, a);
             else if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11 - 1>, gx, gz, nt, smem, a);

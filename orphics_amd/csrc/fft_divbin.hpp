@@ -51,7 +51,11 @@ struct DivBinTail {
         const int nw = blockDim.x >> 6;
         for (int i = threadIdx.x; i < nw * f.nids; i += blockDim.x) rows[i] = 0.0;
     }
+#ifdef OA_DIVBIN_NOIDS      // timing experiment only: no id loads
+    __device__ __forceinline__ int id_at(unsigned yfull, int col) const { return 1 + (int)((yfull + col) & 7u); }
+#else
     __device__ __forceinline__ int id_at(unsigned yfull, int col) const { return f.ids[(long)yfull * f.ipitch + col]; }
+#endif
     // id < 0: this lane has no value in this step; pw = re^2 + im^2 of kappa
     __device__ __forceinline__ void add(GpuCtx&, int id, T pw, int col) {
         const int m = (col == 0 || col == f.nxh) ? 1 : (col < f.nxh ? 2 : 0);
