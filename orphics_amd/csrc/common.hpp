@@ -121,7 +121,8 @@ int sum_region(int dtype, const void* parts, long part_stride, int nparts, void*
                hipStream_t st);
 // all leg planes of several estimators in one inverse pass-1 launch (ColLegsArgs::batch); offsets in complex elements
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
-                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my = 0, int selbits = 2);
+                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my = 0, int selbits = 2,
+                    int* finished = nullptr);      // *finished = 1: single pass (col_legs_sp), the planes need no inverse pass 2
 // row stage of nmaps maps in one launch; -1: this geometry's row stage is not the two-rows-per-transform kernel
 int qe_rows_batch_w(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale, int win, int wout, int mrow,
                     long pl, long pk, hipStream_t st, int my, int nmaps, long in_moff, long h_moff, long out_moff);

@@ -394,6 +394,11 @@ struct HipLauncher {
         rc = launch_col_legs<T>(st, gx, gy, nt, smem, logL, a);   // separate translation unit (fft_legs.hip)
     }
     template <typename T>
+    void col_legs_sp(int gx, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
+        if (rc) return;
+        rc = launch_col_legs_sp<T>(st, gx, nt, smem, logL, a);
+    }
+    template <typename T>
     void col_fwdlegs(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a) {
         if (rc) return;
         rc = launch_col_fwdlegs<T>(st, gx, gy, nt, smem, logL, a);
@@ -748,10 +753,11 @@ static int legs_subset_impl(oa_plan* p, const void* src, const void* F, void* a,
 }
 template <typename T>
 static int legs_batch_impl(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
-                           int ngrad, int nh, void* pool, long ostride, int width, int rband, hipStream_t st, long pout, int my, int selbits) {
+                           int ngrad, int nh, void* pool, long ostride, int width, int rband, hipStream_t st, long pout, int my, int selbits, int* finished) {
     HipLauncher q{st};
-    coarse_view<T>(p, my).legs_cols_batch(q, (const cx<T>*)src0, off1, off2, srcsel, (const T* const*)ftab, ngrad, nh, (const T*)p->lxd,
-                                          (const T*)p->lyd, (cx<T>*)pool, ostride, width, rband, 0, pout, selbits);
+    const bool done = coarse_view<T>(p, my).legs_cols_batch(q, (const cx<T>*)src0, off1, off2, srcsel, (const T* const*)ftab, ngrad, nh, (const T*)p->lxd,
+                                                            (const T*)p->lyd, (cx<T>*)pool, ostride, width, rband, 0, pout, selbits);
+    if (finished) *finished = done ? 1 : 0;
     return q.rc;
 }
 template <typename T>
@@ -774,9 +780,9 @@ int qe_cols_div_batch_w(oa_plan* p, const void* pa, const void* pb, const void* 
                               : cols_div_batch_impl<double>(p, pa, pb, Fn, out, tmp, nmaps, in_moff, fn_moff, out_moff, width, rband, st, pk, my, fuse);
 }
 int qe_legs_batch_w(oa_plan* p, const void* src0, long off1, long off2, unsigned long long srcsel, const void* const* ftab,
-                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my, int selbits) {
-    return p->dtype == OA_F32 ? legs_batch_impl<float>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my, selbits)
-                              : legs_batch_impl<double>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my, selbits);
+                    int ngrad, int nh, void* pool, long ostride, int width, int rband, long pl, hipStream_t st, int my, int selbits, int* finished) {
+    return p->dtype == OA_F32 ? legs_batch_impl<float>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my, selbits, finished)
+                              : legs_batch_impl<double>(p, src0, off1, off2, srcsel, ftab, ngrad, nh, pool, ostride, width, rband, st, pl, my, selbits, finished);
 }
 // the row stage of `nmaps` maps in one launch (two-rows-per-transform kernel only): -1 when this geometry runs another kernel
 template <typename T>

@@ -1310,13 +1310,17 @@ struct ColLegsArgs {
     const T* const* ftab;
 };
 
-template <typename T, class SEQ, class Ctx>
+// LOGC: log2 of the tile width.  The default (32 columns) is the two-pass layout (inverse pass 1; the caller runs pass 2); with a
+// WHOLE column in the tile (SEQ = the full coarse column length, 8 or 16 columns -- f64: 4 or 8 --, in_ns = out_ks = 1, one group,
+// no inter-pass twiddle) the same body is a SINGLE-PASS filtered inverse column transform: the leg plane is written once, in
+// natural order, and no pass-2 launch follows (batch mode: oa_qe_mv, oa_mc_run).
+template <typename T, class SEQ, class Ctx, int LOGC = COL_LOGC>
 OA_HD void col_legs_body(Ctx& ctx, const ColLegsArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
     constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
     constexpr int R0 = SEQ::get(0), LR = Log2x<R0>::v, NB = EPT / R0;
-    constexpr int logC = COL_LOGC;
-    constexpr int NT = ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + COL_LOGC)) / EPT) : 1;
+    constexpr int logC = LOGC;
+    constexpr int NT = ((1 << (seq_total_log<SEQ>() + LOGC)) / EPT) > 0 ? ((1 << (seq_total_log<SEQ>() + LOGC)) / EPT) : 1;
     const int tid = ctx.tid();
     const int c0 = ctx.bid_x() << logC;
     const long g = ctx.bid_y();

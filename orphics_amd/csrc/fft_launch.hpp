@@ -106,6 +106,8 @@ inline void launch_go(int& rc, hipStream_t st, K kern, dim3 grid, int nt, size_t
 template <typename T>
 int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a);
 template <typename T>
+int launch_col_legs_sp(hipStream_t st, int gx, int nt, size_t smem, int logL, const ColLegsArgs<T>& a);
+template <typename T>
 int launch_col_fwdlegs(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a);
 template <typename T>
 int launch_col_fwdlegs_cg(hipStream_t st, int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsCgArgs<T>& a, int gz = 1);

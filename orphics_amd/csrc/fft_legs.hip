@@ -27,6 +27,26 @@ int launch_col_legs(hipStream_t st, int gx, int gy, int nt, size_t smem, int log
     return rc;
 }
 
+// single-pass filtered inverse column transform of a batch of leg planes on short (coarse-grid) columns: a whole column of an
+// 8- / 16-column (f64: 4- / 8-column) tile in 128 KB of LDS, 1024 (f64: 512) threads; grid z = leg plane
+template <typename T, class SEQ, int LOGC>
+__global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 : 4)) void col_legs_sp_kernel(ColLegsArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_legs_body<T, SEQ, GpuCtx, LOGC>(c, a);
+}
+template <typename T>
+int launch_col_legs_sp(hipStream_t st, int gx, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
+    int rc = 0;
+    constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
+    if (!a.batch || nt != (sizeof(T) == 4 ? 1024 : 512)) return fail("fft: col_legs_sp is the batch-mode kernel of 1024 / 512 threads");
+    if (logL == 11) launch_go(rc, st, col_legs_sp_kernel<T, Seq<16, 16, 8>, lc11>, dim3(gx, 1, a.batch), nt, smem, a);
+    else if (logL == 10) launch_go(rc, st, col_legs_sp_kernel<T, Seq<16, 16, 4>, lc10>, dim3(gx, 1, a.batch), nt, smem, a);
+    else rc = fail("fft: col_legs_sp handles 1024- and 2048-row column grids");
+    return rc;
+}
+template int launch_col_legs_sp<float>(hipStream_t, int, int, size_t, int, const ColLegsArgs<float>&);
+template int launch_col_legs_sp<double>(hipStream_t, int, int, size_t, int, const ColLegsArgs<double>&);
+
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_fwdlegs_kernel(ColFwdLegsArgs<T> a) {
     GpuCtx c{oa_dyn_smem};

@@ -269,10 +269,33 @@ struct Fft2dPlan {
     // (A-batch) oa_qe_mv: ngrad gradient fields (2 planes each) and nh H fields in ONE inverse pass-1 launch (grid z = plane);
     //      field f = filter plane ftab[f] (device table) applied to source src0 + {0, off1, off2}[(srcsel >> 2f) & 3]; plane z is
     //      stored at pool + z * ostride.  The caller runs the inverse pass 2 over the pool.
+    //      Returns true when the leg planes are FINISHED (single pass: a coarse grid of 1024 rows holds a whole column of a
+    //      16-column (f64: 8-column) tile in LDS -- col_legs_sp; OA_NO_LEGS_SP=1: off), false when the caller has to run the
+    //      inverse pass 2.
+    static bool legs_single_pass() {
+        static const bool off = getenv("OA_NO_LEGS_SP") != nullptr;
+        return !off;
+    }
     template <class Launcher>
-    void legs_cols_batch(Launcher& q, const cx<T>* src0, long off1, long off2, unsigned long long srcsel, const T* const* ftab, int ngrad, int nh, const T* lxd, const T* lyd, cx<T>* pool, long ostride, int wmax,
+    bool legs_cols_batch(Launcher& q, const cx<T>* src0, long off1, long off2, unsigned long long srcsel, const T* const* ftab, int ngrad, int nh, const T* lxd, const T* lyd, cx<T>* pool, long ostride, int wmax,
                          int rband, long pin, long pout, int selbits = 2) const {
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
+        // (2048-row grids -- 8192^2 maps -- run the kernel too, OA_LEGS_SP_2048=1, but no faster than the two passes: 17 planes x
+        //  48 tiles of 128 KB are 3.2 rounds of workgroups, 2697 vs 2755 MV reconstructions/s; 1024-row grids: +7 % in oa_mc_run)
+        static const bool sp2048 = getenv("OA_LEGS_SP_2048") != nullptr;
+        if (legs_single_pass() && (logNy == 10 || (logNy == 11 && sp2048))) {
+            const int lt = sizeof(T) == 4 ? 14 : 13, lc = lt - logNy, Cs = 1 << lc;
+            ColLegsArgs<T> a{};
+            a.kX = src0; a.kY = src0; a.FG = nullptr; a.FH = nullptr; a.ftab = ftab; a.lxd = lxd; a.lyd = lyd; a.gx = pool; a.gy = pool; a.h = pool;
+            a.pitch = pi; a.fpitch = kp; a.opitch = po;
+            a.width = clampw(wmax); a.logC = lc; a.NT = (1 << lt) / EPT; a.tw = tw_y; a.logTw = logNy;
+            a.in_gs = 1; a.in_ns = 1; a.out_gs = 1; a.out_ks = 1; a.twiddle = 0;
+            a.rband = clampr(rband); a.ny = ny; a.yshift = yshift(); a.xfull = 1;
+            a.split = 1; a.batch = 2 * ngrad + nh; a.ngrad = ngrad; a.selbits = selbits; a.srcsel = srcsel; a.src_off1 = off1; a.src_off2 = off2;
+            a.ostride = ostride;
+            q.col_legs_sp((a.width + Cs - 1) / Cs, a.NT, ((size_t)(1 << lt) + tw_lds_size(logNy) + 1) * sizeof(cx<T>), logNy, a);
+            return true;
+        }
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC;
@@ -287,6 +310,7 @@ struct Fft2dPlan {
         a.split = 1; a.batch = 2 * ngrad + nh; a.ngrad = ngrad; a.selbits = selbits; a.srcsel = srcsel; a.src_off1 = off1; a.src_off2 = off2;
         a.ostride = ostride;
         q.col_legs(tiles, (int)N2, a.NT, ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>), logN1, a);
+        return false;
     }
 
     // (A') legs straight from the forward column pass 1 of the map's row transform (both legs from ONE map):

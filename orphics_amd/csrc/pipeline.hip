@@ -350,6 +350,7 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     std::vector<const void*> srcs;
     unsigned long long srcsel = 0;
     bool batch = ng + nh <= 32 && !getenv("OA_MV_NO_BATCH");        // (A/B and test switch: one launch per field)
+    int legs_done = 0;
     for (int f = 0; f < ng + nh && batch; ++f) {
         const void* sp = f < ng ? grad[f].src : hpl[f - ng].src;
         size_t k = 0;
@@ -373,7 +374,7 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
         for (size_t k = 1; k < srcs.size(); ++k) aligned = aligned && (((const char*)srcs[k] - (const char*)srcs[0]) % (long)es == 0);
         if (aligned) {
             if (int rc = qe_legs_batch_w(p, srcs[0], off1, off2, srcsel, (const void* const*)q->mv_ftab, ng, nh, q->split_legs, (long)(lb / es),
-                                         leg_cols, leg_rows, pl, st, my)) return rc;
+                                         leg_cols, leg_rows, pl, st, my, 2, &legs_done)) return rc;
         } else batch = false;
     }
     if (!batch) {
@@ -382,7 +383,8 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
         for (int h = 0; h < nh; ++h)
             if (int rc = qe_legs_subset_w(p, hpl[h].src, hpl[h].f, plane(2 * ng + h), nullptr, 1, leg_cols, leg_rows, pl, st, my)) return rc;
     }
-    if (int rc = qe_legs_pass2_w(p, q->split_legs, nplanes, (long)(lb / es), leg_cols, pl, st, my)) return rc;
+    if (!legs_done)                  // (single-pass leg kernel on 1024- / 2048-row column grids: nothing left to do)
+        if (int rc = qe_legs_pass2_w(p, q->split_legs, nplanes, (long)(lb / es), leg_cols, pl, st, my)) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
     // divergence of all estimators in ONE launch when their Fnorm planes are evenly spaced (one stacked allocation): each
     // estimator's weighted kappa goes to its own plan-owned plane (c[0..2], g[0..1], kT are contiguous and unused here),
@@ -613,8 +615,10 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p);
     const size_t lb = (size_t)pl * p->ny * es, lbk = (size_t)pk * p->ny * es;
     const int my = q->my;
-    bool batched = BMAX >= 2 && p->pow2 && sim_hi - sim_lo >= 2;
-    while (batched && sim_hi - i >= 2) {
+    // (a batch of ONE goes through the same launches -- OA_MC_BATCH=1 and the last realisation of an odd shard: the same kernels
+    // whatever the batch size, so the moments do not depend on it; the loop further down serves the geometries without them)
+    bool batched = p->pow2;
+    while (batched && i < sim_hi) {
         const int B = (int)std::min<long>(BMAX, sim_hi - i);
         if (q->mc_cap < B) {
             if (q->mc_src) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->mc_src); q->mc_src = nullptr; q->mc_cap = 0; }
@@ -638,9 +642,10 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
         }
         unsigned long long sel = 0;                       // field f (gradient fields 0..B-1, H fields B..2B-1) reads realisation f mod B
         for (int f = 0; f < 2 * B; ++f) sel |= (unsigned long long)(f % B) << (4 * f);
+        int legs_done = 0;
         if ((rc = qe_legs_batch_w(p, q->mc_src, (long)(pb / es), 0, sel, (const void* const*)q->mv_ftab, B, B, legs, (long)(lb / es), q->wl, q->rl,
-                                  pl, st, my, 4))) return rc;
-        if ((rc = qe_legs_pass2_w(p, legs, 3 * B, (long)(lb / es), q->wl, pl, st, my))) return rc;
+                                  pl, st, my, 4, &legs_done))) return rc;
+        if (!legs_done && (rc = qe_legs_pass2_w(p, legs, 3 * B, (long)(lb / es), q->wl, pl, st, my))) return rc;
         const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
         rc = qe_rows_batch_w(p, legs, legs + lb, legs + 2 * (size_t)B * lb, prod, prod + lbk, s * s * sy, q->wl, q->wk, q->mrow, pl, pk, st, my, B,
                              (long)(2 * lb / es), (long)(lb / es), (long)(2 * lbk / es));

@@ -109,6 +109,11 @@ struct EmuLauncher {
             run(gx, gy, nt, smem, [&](EmuCtx& c) { col_legs_body<T, S>(c, a); }, a.batch ? a.batch : (a.split ? (a.zcount ? a.zcount : 3) : 1));
         });
     }
+    template <typename T> void col_legs_sp(int gx, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
+        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
+        if (logL == 11) run(gx, 1, nt, smem, [&](EmuCtx& c) { col_legs_body<T, Seq<16, 16, 8>, EmuCtx, lc11>(c, a); }, a.batch);
+        else if (logL == 10) run(gx, 1, nt, smem, [&](EmuCtx& c) { col_legs_body<T, Seq<16, 16, 4>, EmuCtx, lc10>(c, a); }, a.batch);
+    }
     template <typename T> void col_fwdlegs(int gx, int gy, int nt, size_t smem, int logL, const ColFwdLegsArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
             using S = decltype(seq);
@@ -414,10 +419,11 @@ int emu_legs_batch_cg_f64(int ny_full, int my, int nx, const void* src0, long of
                           int width, int rband) {
     CoarseHolder<double> hd(ny_full, my, nx);
     EmuLauncher q;
-    hd.p.legs_cols_batch(q, (const cx<double>*)src0, off1, off2, srcsel, ftab, ngrad, nh, lxd, lyd, (cx<double>*)pool, ostride, width, rband,
-                         0, 0);
-    hd.p.cols(q, (const cx<double>*)pool, hd.p.kp, (cx<double>*)pool, hd.p.kp, hd.p.clampw(width), true, 1.0, 2, 1, nullptr, nullptr, 0, false,
-              -1, 2 * ngrad + nh, ostride, ostride);
+    // (1024- / 2048-row column grids: single pass, the planes are finished; otherwise the inverse pass 2 over the pool)
+    if (!hd.p.legs_cols_batch(q, (const cx<double>*)src0, off1, off2, srcsel, ftab, ngrad, nh, lxd, lyd, (cx<double>*)pool, ostride, width, rband,
+                              0, 0))
+        hd.p.cols(q, (const cx<double>*)pool, hd.p.kp, (cx<double>*)pool, hd.p.kp, hd.p.clampw(width), true, 1.0, 2, 1, nullptr, nullptr, 0, false,
+                  -1, 2 * ngrad + nh, ostride, ostride);
     return 0;
 }
 int emu_cols_div_batch_cg_f64(int ny_full, int my, int nx, const void* prod, const double* Fn, const double* lxd, const double* lyd, void* out,

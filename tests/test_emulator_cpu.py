@@ -379,7 +379,7 @@ def test_column_grid_views(emu, ny_full, my, w, rb):
         assert np.all(out[:, wv:W] == 3.0)
 
 
-@pytest.mark.parametrize("ny_full,my,w,rb", [(256, 64, 21, 9), (256, 128, 0, 33)])
+@pytest.mark.parametrize("ny_full,my,w,rb", [(256, 64, 21, 9), (256, 128, 0, 33), (4096, 1024, 11, 200)])
 def test_batched_leg_and_divergence_launches(emu, ny_full, my, w, rb):
     """oa_qe_mv's launches (include/orphics_amd.h): every distinct filtered field of several estimators in ONE col_legs launch
     (grid z = leg plane, source by a 2-bit field, filter planes through a pointer table) + one pass-2 launch over the pool;
@@ -413,10 +413,19 @@ def test_batched_leg_and_divergence_launches(emu, ny_full, my, w, rb):
         ref = [_hc(emu, my, nx, fill=3.0) for _ in range(3)]
         k = np.ascontiguousarray(src[which[f]]); F = np.ascontiguousarray(filt[f])
         assert emu.emu_legs_cols_cg_f64(ny_full, my, nx, _p(k), _p(k), _p(F), _p(F), _p(lxd), _p(lyd), _p(ref[0]), _p(ref[1]), _p(ref[2]), w, rb) == 0
-        if f < ngrad:
-            assert np.array_equal(pool[2 * f], ref[0]) and np.array_equal(pool[2 * f + 1], ref[1])
+        if my >= 1024:
+            # single-pass leg kernel (col_legs_sp: a whole 1024-point column in the tile) against the two-pass launches: another
+            # factorisation of the same transform -> rounding; nothing outside the kept columns is written
+            close = lambda a_, b_: np.abs(a_ - b_).max() <= 1e-12 * np.abs(b_).max()      # noqa: E731
         else:
-            assert np.array_equal(pool[ngrad + f], ref[2])
+            close = np.array_equal
+        if f < ngrad:
+            assert close(pool[2 * f], ref[0]) and close(pool[2 * f + 1], ref[1])
+        else:
+            assert close(pool[ngrad + f], ref[2])
+    if my >= 1024:
+        assert np.all(pool[:, :, wv:] == 3.0)
+        return
     # divergence of three estimators in one launch
     ne = 3
     for dt, cdt, fn in ((np.float64, np.complex128, emu.emu_cols_div_batch_cg_f64), (np.float32, np.complex64, emu.emu_cols_div_batch_cg_f32)):
