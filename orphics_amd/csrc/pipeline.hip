@@ -693,8 +693,11 @@ int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi,
         int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
         if (rc) return rc;
         if ((rc = oa_fft_c2r_windowed(p, q->kT, tmap, inv, window_real, stream))) return rc;     // the window rides on the row pass's store
-        if ((rc = oa_qe_tt(p, tmap, nullptr, nullptr, nullptr, 0, stream))) return rc;
-        if ((rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
+        // binning + moments in the divergence launch where the geometry has that kernel (kappa_hat still stored when the mean-field
+        // stack needs it)
+        DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
+        if ((rc = qe_tt_impl(p, tmap, nullptr, nullptr, nullptr, 0, stream, divbin_enabled() ? &f : nullptr))) return rc;
+        if (!f.done && (rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
         if (meanfield_acc && (rc = stack_add_region(p->dtype, q->kk, meanfield_acc, p->ny, p->kp, q->wk, q->rk, (hipStream_t)stream))) return rc;
     }
     return 0;
