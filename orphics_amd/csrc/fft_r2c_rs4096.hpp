@@ -124,8 +124,11 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
             if (PF && PFH > 0) next_taps(grp, step, 0, PFH);
             ctx.sync();
             // ---- sub-transform k0 (S points over j0 = i + LPS t), inside this wave's part of D
-#if defined(__HIP_DEVICE_COMPILE__) && defined(OA_RS4096_OPAQUE)
-            asm volatile("" : "+v"(i));     // the swizzled LDS addresses below are recomputed per row, not kept in ~40 registers
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_RS4096_NO_OPAQUE)
+            // float64: the lane index is made opaque per row, so that the ~40 swizzled LDS addresses below are recomputed (two integer
+            // instructions each) instead of being kept in registers across the rows: 220 -> 200 VGPRs, 123 -> 120 us at 8192^2,
+            // 36.6 -> 34.3 us at 4096^2.  float: measured equal (8192^2) or slower (4096^2: 19.9 -> 21.3 us): left to the compiler.
+            if constexpr (sizeof(T) == 8) asm volatile("" : "+v"(i));
 #endif
             cx<T> u[16];
 #pragma unroll
