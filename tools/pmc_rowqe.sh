@@ -6,7 +6,7 @@ rm -rf $O; mkdir -p $O
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --no-pair --streams 1 --batch 1 --preroll 0.1 > /dev/null 2> $O/err$i.txt
+  rocprofv3 --pmc $set --output-format csv -d $O/p$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras --also none --no-pair --streams 1 --batch 1 --preroll 0.1 ${PREC:+--prec $PREC} > /dev/null 2> $O/err$i.txt
 done
 python3 - <<'PY'
 import csv, glob, statistics, collections
