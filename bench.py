@@ -265,40 +265,6 @@ def side_leg(torch, args, name, ref_p1d, seed, **kw):
     return out, p1d, P, R
 
 
-def bandlimited_leg(P, args, torch, tmaps, ref_p1d):
-    """Same job with the reconstruction on the smallest grid that holds the band-limited legs and their products
-    exactly (opt-in lensing.BandlimitedEstimator)."""
-    from orphics_amd import lensing
-    N = args.n
-    bl = lensing.BandlimitedEstimator((N, N), P["geom"], P["theory"], **P["qkw"])
-    es = bl.q.eng
-    ids = es.modl_digitize(torch.as_tensor(P["edges"], device=es.device), half=True)
-    nrm = bl.gsmall.area / float(bl.n ** 2) ** 2
-    kk = bl.q.new_output()
-    _, counts = es.bin_power(es.hc(), es.hc(), nrm, ids, P["nids"], herm=True)
-    res = {}
-
-    def step(i):
-        bl.reconstruct_tt_from_map(tmaps[i & 1], out=kk)
-        res["sums"], _ = es.bin_power(kk, kk, nrm, ids, P["nids"], herm=True, active_cols=bl.q.kappa_cols, active_rows=bl.q.kappa_rows)
-    for i in range(10):
-        step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nrec = side_count(args)
-    for i in range(nrec):
-        step(i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / nrec
-    step(0)
-    torch.cuda.synchronize()
-    p1d = res["sums"][1:-1] / counts[1:-1]
-    return {"reconstructions_per_s": 1.0 / dt, "internal_grid": bl.n,
-            "max_rel_bandpower_diff": float((p1d / ref_p1d - 1).abs().max().item()),
-            "note": "opt-in lensing.BandlimitedEstimator: input R2C at full resolution (active columns only), estimator "
-                    "on the coarse grid; exact for band-limited filters (coarse Nyquist > ell_max_X + ell_max_Y)"}
-
-
 def time_kernel(torch, fn, reps=20, warm=3):
     """Mean duration (s) of `fn`'s launches on the CURRENT stream (HIP events recorded on that stream)."""
     for _ in range(warm):
@@ -797,7 +763,7 @@ def main():
     ap.add_argument("--check-maps", type=int, default=64, help="resident maps whose bandpowers are recomputed through the fine-grained calls "
                     "and compared with the timed region's accumulated sum")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs reported under 'extra' (never the headline value)")
-    ap.add_argument("--extras", default="fullres_rows,dense,bandlimited,wideband,lensed_loop", help="comma list of side legs to run")
+    ap.add_argument("--extras", default="fullres_rows,dense,wideband,lensed_loop", help="comma list of side legs to run")
     ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
                     help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
                          "(exact for band-limited filters; library default), full = the map's nx points")
@@ -878,8 +844,6 @@ def main():
                 extra["dense"] = leg
                 hbm["dense_pipeline"] = {k: leg[k] for k in leg if k.startswith("pipeline_") or k == "pmc_bytes_per_recon"}
                 torch.cuda.empty_cache()
-            if "bandlimited" in want:
-                extra["bandlimited"] = bandlimited_leg(P, args, torch, tmaps, ref_p1d)
                 torch.cuda.empty_cache()
             if "wideband" in want and args.tlmax < 6000.0:
                 leg, p_w, Pw, Rw = side_leg(torch, args, "wideband", None, seed, tlmax=6000.0)

@@ -43,7 +43,7 @@ typedef struct oa_plan oa_plan;
 const char* oa_last_error(void);
 /* ABI version = 100 x the build round that last changed a signature in this header; bindings must refuse a library
  * that reports less than the version they were written against (OA_ABI_VERSION) */
-#define OA_ABI_VERSION 301
+#define OA_ABI_VERSION 401
 int oa_version(void);
 /* number of HIP devices visible; <0 on error (no compute) */
 int oa_device_count(void);
@@ -183,9 +183,22 @@ int oa_plan_rsplit(const oa_plan* p);
  * n, S, C in the tail of the single-pass divergence launch (coarse grids of 1024 / 2048 rows, bins bound) instead of two more
  * launches over the kappa plane; 0: the separate histogram launches.  Same per-mode arithmetic either way; the order of the
  * float64 sums differs (bandpowers agree to ~1e-15).  When fused, these entries do not write the plan-owned kappa plane
- * (oa_plan_kappa) unless the mean-field stack of oa_mc_run needs it; oa_qe_tt always does.  OA_NO_DIVBIN=1 in the environment
- * switches it off (A/B). */
+ * (oa_plan_kappa) unless the mean-field stack of oa_mc_run needs it; oa_qe_tt always does.  oa_plan_set_option(p, OA_OPT_DIV_BIN, 0)
+ * switches it off. */
 int oa_plan_div_fused(const oa_plan* p);
+/* Which of several EQUIVALENT launch sequences the one-call entries of this plan run.  Every value is a supported configuration
+ * (the non-default ones are what geometries without the batched kernels run anyway) and the GPU tests compare them against each
+ * other; the library never reads the environment for this.
+ *   OA_OPT_MC_BATCH    realisations per launch in oa_mc_run: 1 .. 6 (0 = default, 6); moments and stack do not depend on it
+ *   OA_OPT_MV_BATCH    oa_qe_mv / oa_qe_tt_splits: all leg planes in one launch and all divergences in one launch (default 1);
+ *                      0: one launch per distinct filtered field / per estimator
+ *   OA_OPT_MV_ROWBATCH oa_qe_mv: the row stage of several pieces per launch (default 1); 0: one launch per piece
+ *   OA_OPT_MV_CHAIN    oa_qe_mv: estimator chains -- an estimator's pieces summed in real space inside one row-stage launch
+ *                      (default 1); 0: the k-th piece of every estimator per launch, accumulated in Fourier space
+ *   OA_OPT_DIV_BIN     moment entries: radial binning + moment update in the tail of the single-pass divergence launch
+ *                      (default 1, where the geometry has that kernel: oa_plan_div_fused); 0: the separate histogram launches */
+enum { OA_OPT_MC_BATCH = 1, OA_OPT_MV_BATCH = 2, OA_OPT_MV_ROWBATCH = 3, OA_OPT_MV_CHAIN = 4, OA_OPT_DIV_BIN = 5 };
+int oa_plan_set_option(oa_plan* p, int option, int value);
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);
 void* oa_plan_kappa(oa_plan* p);
 const int64_t* oa_plan_bin_counts(oa_plan* p);
@@ -224,8 +237,8 @@ int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void
 int oa_split_cross_power(int dtype, int nsplits, const void* const* host_kappa, void* out_hcreal, double norm, int ny, long kpitch,
                          int active_cols, int active_rows, void* stream);
 /* oa_mc_run: realisations sim_lo .. sim_hi-1 (Philox stream = realisation index): GRF draw -> TT estimator -> bandpowers ->
- * moments [-> mean-field stack], no host work per realisation.  Up to 6 realisations (environment OA_MC_BATCH, 1 = one by
- * one) share every launch (grid z / y: draw, leg planes, inverse pass 2, row stage, divergence, binned power, moment tail, stack): at
+ * moments [-> mean-field stack], no host work per realisation.  Up to 6 realisations (oa_plan_set_option OA_OPT_MC_BATCH,
+ * 1 = one by one) share every launch (grid z / y: draw, leg planes, inverse pass 2, row stage, divergence, binned power, moment tail, stack): at
  * 4096^2 a realisation is launch latency, not bytes.  Same kernels on the same operands in the same order per realisation:
  * the moments and the stack do not depend on the batch size.  The first call allocates the batch's planes (one device
  * synchronisation). */
@@ -270,13 +283,6 @@ int oa_full_to_hc(oa_plan* p, const void* full_in, void* hc_out, void* stream);
 /* real-valued hc-layout plane (ny,kpitch) <-> full real (ny,nx), even symmetry */
 int oa_hcreal_to_full(oa_plan* p, const void* hcreal_in, void* fullreal_out, void* stream);
 int oa_fullreal_to_hc(oa_plan* p, const void* fullreal_in, void* hcreal_out, void* stream);
-
-/* Fourier-space regridding of an hc plane between two grids of the SAME patch (same delta-ell):
- * out(l) = scale * in(l) for the modes both grids hold, 0 elsewhere; the smaller grid's Nyquist row /
- * column is zeroed.  Crop = exact down-sampling of a band-limited field (enmap.downgrade_fft-like,
- * lensing.py:103), embed = exact up-sampling. */
-int oa_hc_resample(int dtype, const void* in, int ny_in, int nx_in, long kp_in, void* out, int ny_out, int nx_out,
-                   long kp_out, double scale, void* stream);
 
 /* ---- flat elementwise kernels (n = number of elements) --------------------
  * oa_f2power    : out = Re(conj(k1)*k2)*norm        (FourierCalc.f2power, maps.py:1620-1624)

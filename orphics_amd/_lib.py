@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ORPHICS_AMD_LIB", os.path.join(_HERE, "liborphics_amd
 
 OA_F32 = 0
 OA_F64 = 1
-ABI_VERSION = 301     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
+ABI_VERSION = 401     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -45,6 +45,7 @@ SIGNATURES = {
     "oa_plan_col_grid": (c_int, [c_void_p]),
     "oa_plan_rsplit": (c_int, [c_void_p]),
     "oa_plan_div_fused": (c_int, [c_void_p]),
+    "oa_plan_set_option": (c_int, [c_void_p, c_int, c_int]),
     "oa_plan_set_bins": (c_int, [c_void_p, c_void_p, c_int, c_double, c_void_p]),
     "oa_plan_kappa": (c_void_p, [c_void_p]),
     "oa_plan_bin_counts": (c_void_p, [c_void_p]),
@@ -73,7 +74,6 @@ SIGNATURES = {
     "oa_full_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_hcreal_to_full": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_fullreal_to_hc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "oa_hc_resample": (c_int, [c_int, c_void_p, c_int, c_int, c_long, c_void_p, c_int, c_int, c_long, c_double, c_void_p]),
     "oa_f2power": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_long, c_void_p]),
     "oa_cmul_real": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_cmul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
@@ -128,8 +128,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     got = lib.oa_version()
-    if got != ABI_VERSION:
-        raise OrphicsAmdError("orphics_amd: %s reports C-ABI version %d, this binding was written against %d "
+    if got < ABI_VERSION:       # (a later library with additive changes is fine: include/orphics_amd.h)
+        raise OrphicsAmdError("orphics_amd: %s reports C-ABI version %d, older than the %d this binding was written against "
                               "(stale build? run __graft_entry__.build())" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib

@@ -1,6 +1,7 @@
 // Minimal complex arithmetic shared by device kernels and the CPU emulator.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -12,6 +13,18 @@
 #endif
 
 namespace oa {
+
+// Kernel-selection A/B switches (OA_NO_RSPLIT, OA_RS4096_PF, ...) exist only in EXPERIMENT builds (tools/build_variant.sh passes
+// -DOA_EXPERIMENTS): the product library never reads the environment, so a stray variable cannot select an untested path.
+// Alternate paths that tests compare against each other are explicit plan options (oa_plan_set_option).
+inline const char* exp_env(const char* name) {
+#ifdef OA_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 template <typename T>
 struct alignas(2 * sizeof(T)) cx {

@@ -274,28 +274,6 @@ __global__ __launch_bounds__(256) void qe_div_kernel(const cx<T>* __restrict__ P
     out[i] = accumulate ? out[i] + d : d;
 }
 
-// ---------------------------------------------------------------- Fourier-space regridding
-// hc plane on an (ny_in, nx_in) grid -> hc plane on an (ny_out, nx_out) grid of the SAME patch (same
-// delta-ell): low modes are copied (times `scale`), modes that do not exist on the source are zero and
-// the self-conjugate Nyquist row/column of the smaller grid is zeroed.  Cropping a band-limited
-// transform = exact down-sampling of the real-space field; embedding = exact (sinc) up-sampling.
-template <typename T>
-__global__ __launch_bounds__(256) void hc_resample_kernel(const cx<T>* __restrict__ in, int ny_in, int nx_in, long kp_in,
-                                                          cx<T>* __restrict__ out, int ny_out, int nx_out, long kp_out,
-                                                          T scale) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x > nx_out / 2) return;
-    const int nys = ny_in < ny_out ? ny_in : ny_out, nxs = nx_in < nx_out ? nx_in : nx_out;   // the smaller grid
-    const int fy = y < ny_out / 2 ? y : y - ny_out;          // signed frequency index of the output row
-    cx<T> v = mk<T>((T)0, (T)0);
-    const bool inside = (fy > -nys / 2) && (fy < nys / 2) && (x < nxs / 2);
-    if (inside) {
-        const int ys = fy >= 0 ? fy : fy + ny_in;
-        v = in[(long)ys * kp_in + x] * scale;
-    }
-    out[(long)y * kp_out + x] = v;
-}
 
 // ---------------------------------------------------------------- flat-sky lensing op (lensing.py:395-440)
 // displacement (coordinate units) -> nearest-pixel shift + sub-pixel remainder
@@ -611,21 +589,6 @@ int oa_fullreal_to_hc(oa_plan* p, const void* full, void* hc, void* stream) {
     return 0;
 }
 
-int oa_hc_resample(int dtype, const void* in, int ny_in, int nx_in, long kp_in, void* out, int ny_out, int nx_out,
-                   long kp_out, double scale, void* stream) {
-    OA_REQUIRE(in && out && in != out, "oa_hc_resample: bad pointers");
-    OA_REQUIRE(ny_in > 0 && nx_in > 0 && ny_out > 0 && nx_out > 0 && kp_in >= nx_in / 2 + 1 && kp_out >= nx_out / 2 + 1,
-               "oa_hc_resample: bad geometry");
-    hipStream_t st = (hipStream_t)stream;
-    dim3 grid((nx_out / 2 + 1 + 255) / 256, ny_out);
-    DISPATCH(dtype,
-             hipLaunchKernelGGL(hc_resample_kernel<float>, grid, dim3(256), 0, st, (const cx<float>*)in, ny_in, nx_in, kp_in,
-                                (cx<float>*)out, ny_out, nx_out, kp_out, (float)scale),
-             hipLaunchKernelGGL(hc_resample_kernel<double>, grid, dim3(256), 0, st, (const cx<double>*)in, ny_in, nx_in,
-                                kp_in, (cx<double>*)out, ny_out, nx_out, kp_out, scale));
-    OA_LAUNCH_CHECK();
-    return 0;
-}
 
 int oa_lens_split(int dtype, const void* alpha, double step, int32_t* shift, void* delta, long n, void* stream) {
     OA_REQUIRE(alpha && shift && delta && n >= 0 && step != 0.0, "oa_lens_split: bad argument");

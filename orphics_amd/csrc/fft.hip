@@ -2,7 +2,6 @@
 #include <vector>
 #include "fft_launch.hpp"
 #include "fft_r2c_w64.hpp"
-#include "fft_r2c_f64.hpp"
 #include "fft_r2c_rs4096.hpp"
 #include "fft_divbin.hpp"
 
@@ -21,20 +20,6 @@ __global__ __launch_bounds__(row_maxnt<SEQ>(), waves_per_eu<T>()) void row_fft_k
 __global__ __launch_bounds__(64, OA_W64_OCC) void row_r2c_w64_kernel(RowW64Args a) {
     GpuCtx c{oa_dyn_smem};
     row_r2c_w64_body(c, a);
-}
-
-template <int LR>
-__global__ __launch_bounds__(64, OA_W64_OCC) void row_r2c_w64r_kernel(RowW64Args a) {
-    GpuCtx c{oa_dyn_smem};
-    row_r2c_w64_body_t<LR>(c, a);
-}
-
-// (the accumulators live across the row loop: the f32 build spills 27-93 VGPRs at 4 waves/SIMD, none at 3)
-// float64: two waves per row, 32 complex128 points per lane (fft_r2c_f64.hpp); one wave per SIMD
-template <int LR>
-__global__ __launch_bounds__(128, 1) void row_r2c_f64_kernel(RowF64Args a) {
-    GpuCtx c{oa_dyn_smem};
-    row_r2c_f64_body<LR>(c, a);
 }
 
 template <typename T, class SEQ, int LR, bool PF>
@@ -184,7 +169,7 @@ struct HipLauncher {
         go(row_fft_kernel<T, MODE, S>, dim3(grid), nt, smem, a);
     }
     static int r2c_w64_mode() {
-        static const int m = [] { const char* e = getenv("OA_R2C_W64"); return e ? atoi(e) : 1; }();
+        static const int m = [] { const char* e = exp_env("OA_R2C_W64"); return e ? atoi(e) : 1; }();
         return m;
     }
     // band-limited R2C of 8192-point rows (f32): one wave per row (fft_r2c_w64.hpp)
@@ -196,7 +181,7 @@ struct HipLauncher {
         w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
         w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = ny;
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+        static const int per_cu = [] { const char* e = exp_env("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
         w.nwg = cus * per_cu;                              // resident waves: one per SIMD (launch bound; 16.6 KB of LDS each)
         if (two) w.nwg = cus * (int)(LDS_MAX / W64X2_LDS_BYTES);
         if (w.nwg > ny) w.nwg = ny;
@@ -211,37 +196,7 @@ struct HipLauncher {
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
         return true;
     }
-    // MEASURED AND NOT THE DEFAULT (profiles/r03_f64_r2c_variants.txt): 174 us (R-split) / 199 us (plain) per 8192^2 map against
-    // 132 / 128 us of the general pass.  32 complex128 points per lane take 256 VGPRs + ~200 AGPRs: one wave per SIMD, two rows
-    // per CU in flight, and without packed arithmetic the 1400 f64 operations per row half are all issue time.  The general
-    // pass (16 points per thread, four waves per row, eight waves per CU) hides more of its latency.  OA_R2C_F64=1 selects it.
-    static int r2c_f64_mode() {
-        static const int m = [] { const char* e = getenv("OA_R2C_F64"); return e ? atoi(e) : 0; }();
-        return m;
-    }
-    // float64 rows of 8192 points, <= 512 columns kept: two waves per row (fft_r2c_f64.hpp); lr = 2: with the R-split
-    bool row_f64(int nrows, const RowArgs<double>& a, int lr) {
-        if (a.mode != ROW_R2C || !r2c_f64_mode() || rc || !(a.logL == 12 && a.wcols <= 512 && a.logTw >= 13)) return false;
-        RowF64Args w{};
-        w.in = (const cx<double>*)a.in; w.out = (cx<double>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
-        w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = nrows; w.kplane = a.kplane; w.twy = a.twy;
-        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        static const int per_cu = [] { const char* e = getenv("OA_F64_ROWS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
-        const int units = lr ? (nrows >> lr) : nrows;
-        w.nwg = cus * per_cu;
-        if (w.nwg > units) w.nwg = units;
-        const size_t smem = F64_LDS_BYTES + (lr ? F64_ACC_BYTES : 0);
-        if (lr) {
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(row_r2c_f64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(F64_LDS_BYTES + F64_ACC_BYTES));
-            if (attr != hipSuccess) { rc = fail(std::string("hipFuncSetAttribute: ") + hipGetErrorString(attr)); return true; }
-            hipLaunchKernelGGL(row_r2c_f64_kernel<2>, dim3(w.nwg), dim3(128), smem, st, w);
-        } else
-            hipLaunchKernelGGL(row_r2c_f64_kernel<0>, dim3(w.nwg), dim3(128), smem, st, w);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
-        return true;
-    }
-    bool row_w64(int ny, const RowArgs<double>& a) { return row_f64(ny, a, 0); }
+    bool row_w64(int, const RowArgs<double>&) { return false; }
     template <typename T>
     void row(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (row_w64(grid << a.logC, a)) return;
@@ -257,28 +212,12 @@ struct HipLauncher {
         if (!ok && !rc) rc = fail("fft: unsupported row length");
     }
     void fail_rlayout() { if (!rc) rc = fail("fft: the R-layout needs the two-rows-per-transform row stage"); }
-    // R-split row R2C: the one-wave-per-row kernel for f32 rows of 8192 points (<= 512 columns), else the general pass
-    bool row_w64r(const RowArgs<float>& a) {
-        if (!r2c_w64_mode() || rc || !(a.logL == 12 && a.wcols <= 512 && a.lr == 2)) return false;
-        RowW64Args w{};
-        w.in = (const cx<float>*)a.in; w.out = (cx<float>*)a.out; w.in_pitch = a.in_pitch; w.out_pitch = a.out_pitch;
-        w.tw = a.tw; w.logTw = a.logTw; w.scale = a.scale; w.wcols = a.wcols; w.ny = a.my << a.lr; w.kplane = a.kplane; w.twy = a.twy;
-        static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        static const int per_cu = [] { const char* e = getenv("OA_W64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
-        w.nwg = cus * per_cu;
-        if (w.nwg > a.my) w.nwg = a.my;
-        hipLaunchKernelGGL(row_r2c_w64r_kernel<2>, dim3(w.nwg), dim3(64), W64_LDS_BYTES + W64R_ACC_BYTES, st, w);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
-        return true;
-    }
-    bool row_w64r(const RowArgs<double>& a) { return a.lr == 2 && row_f64(a.my << a.lr, a, 2); }
     // general R-split row pass: one workgroup per group, loads at the top of each row.  OA_RSPLIT_PF=1: persistent workgroups
     // (each walks groups bid, bid + grid, ...) that prefetch their next row -- measured no faster in float (22.9 vs 23.1 us at
     // 4096^2) and slower in float64 (43.6 vs 39.9 us: the 16 taps in flight push it past 256 registers), kept for A/B
     template <typename T, class S>
     void row_rsplit_seq(int ngroups, int nt, size_t smem, const RowArgs<T>& a) {
-        static const bool nopf = [] { const char* e = getenv("OA_RSPLIT_PF"); return !(e && atoi(e) != 0); }();
+        static const bool nopf = [] { const char* e = exp_env("OA_RSPLIT_PF"); return !(e && atoi(e) != 0); }();
         if (nopf) { go(row_r2c_rsplit_kernel<T, S, 2, false>, dim3(ngroups), nt, smem, a); return; }
         if (rc) return;
         auto kern = row_r2c_rsplit_kernel<T, S, 2, true>;
@@ -297,8 +236,8 @@ struct HipLauncher {
     // registers, spills): default per precision, OA_RS4096_PF=0/1 overrides.  OA_NO_RS4096=1: the older kernels (A/B).
     template <typename T>
     bool row_rs4096(const RowArgs<T>& a) {
-        static const bool off = getenv("OA_NO_RS4096") != nullptr;
-        static const int pfenv = [] { const char* e = getenv("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
+        static const bool off = exp_env("OA_NO_RS4096") != nullptr;
+        static const int pfenv = [] { const char* e = exp_env("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
         const bool l12 = a.logL == 12 && a.wcols <= 512 && a.logTw >= 13, l11 = a.logL == 11 && a.wcols <= 256 && a.logTw >= 12;
         if (off || rc || a.lr != 2 || !(l12 || l11)) return false;
         const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && l12);     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
@@ -313,7 +252,7 @@ struct HipLauncher {
         int grid = cus * per_cu;
         // resident workgroups walk the groups.  OA_RS4096_PERSIST=0: one workgroup per group (A/B: so that the scheduler could place
         // workgroups of another stream's kernels as these retire -- measured 1 % slower in the two-stream job, 5096 vs 5159 /s)
-        static const int persist = [] { const char* e = getenv("OA_RS4096_PERSIST"); return e ? atoi(e) : -1; }();
+        static const int persist = [] { const char* e = exp_env("OA_RS4096_PERSIST"); return e ? atoi(e) : -1; }();
         if (persist == 0) grid = a.my;
         if (grid > a.my) grid = a.my;
         launch_plain(kern, dim3(grid), NTr, smem, a);
@@ -322,7 +261,6 @@ struct HipLauncher {
     template <typename T>
     void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (row_rs4096(a)) return;
-        if (row_w64r(a)) return;
         bool ok = false;
         if (a.lr == 2) {
             ok = true;
@@ -616,7 +554,7 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
         // their full-resolution positions); legs and inverse transform then run on my rows
         if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 1);
         if (stages & 4) {
-            static const bool nofuse = getenv("OA_NO_FWDLEGS_CG") != nullptr;        // A/B switch
+            static const bool nofuse = exp_env("OA_NO_FWDLEGS_CG") != nullptr;        // A/B switch
             const auto cv = coarse_view<T>(p, my);
             if (nofuse || !f.legs_cols_from_pass1_cg(q, cv, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd,
                                                      (cx<T>*)gx, (cx<T>*)gy, (cx<T>*)h, width, pw, pout)) {

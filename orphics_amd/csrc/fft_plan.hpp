@@ -83,7 +83,7 @@ struct Fft2dPlan {
     //      column grid.  Available for R = ny / my = 4, my = 1024 or 2048, leg widths up to a quarter of the packed row.
     static bool has_rsplit(int logNy, int logNx, int my, int wl) {
         if (my <= 0) return false;
-        static const bool off = getenv("OA_NO_RSPLIT") != nullptr;        // A/B switch
+        static const bool off = exp_env("OA_NO_RSPLIT") != nullptr;        // A/B switch
         const int logMy = ilog2(my), L = 1 << (logNx - 1);
         return !off && is_pow2(my) && logNy - logMy == 2 && (logMy == 10 || logMy == 11) && logNx >= 11 && logNx <= 14 && wl <= L / 4 &&
                wl <= RS_MAXS * (L / EPT);
@@ -107,7 +107,7 @@ struct Fft2dPlan {
     // log2 of the points of a col_fband tile: 128 KB of LDS (8 float / 4 double columns of 2048 rows); OA_FBAND_NARROW=1: half
     // (twice the workgroups, two per CU: A/B)
     static int fband_lt() {
-        static const int narrow = [] { const char* e = getenv("OA_FBAND_NARROW"); return e ? atoi(e) : 0; }();
+        static const int narrow = [] { const char* e = exp_env("OA_FBAND_NARROW"); return e ? atoi(e) : 0; }();
         return (sizeof(T) == 4 ? 14 : 13) - (narrow > 0 ? 1 : 0);
     }
     // cv: the coarse view (ny = my rows, tw_y = W_my); Y: the row pass's R planes; leg planes in the R-LAYOUT (row y_lo R + k1)
@@ -145,7 +145,7 @@ struct Fft2dPlan {
     }
     // rows per workgroup of the fused row stage (tuning hook: OA_QE_ROWS_PER_WG in the environment)
     static int qe_rows_per_wg(int L) {
-        static const int forced = [] { const char* e = getenv("OA_QE_ROWS_PER_WG"); return e ? atoi(e) : 0; }();
+        static const int forced = [] { const char* e = exp_env("OA_QE_ROWS_PER_WG"); return e ? atoi(e) : 0; }();
         if (forced > 0) return forced;
         return 4096 / L;
     }
@@ -273,7 +273,7 @@ struct Fft2dPlan {
     //      16-column (f64: 8-column) tile in LDS -- col_legs_sp; OA_NO_LEGS_SP=1: off), false when the caller has to run the
     //      inverse pass 2.
     static bool legs_single_pass() {
-        static const bool off = getenv("OA_NO_LEGS_SP") != nullptr;
+        static const bool off = exp_env("OA_NO_LEGS_SP") != nullptr;
         return !off;
     }
     template <class Launcher>
@@ -282,7 +282,7 @@ struct Fft2dPlan {
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
         // (2048-row grids -- 8192^2 maps -- run the kernel too, OA_LEGS_SP_2048=1, but no faster than the two passes: 17 planes x
         //  48 tiles of 128 KB are 3.2 rounds of workgroups, 2697 vs 2755 MV reconstructions/s; 1024-row grids: +7 % in oa_mc_run)
-        static const bool sp2048 = getenv("OA_LEGS_SP_2048") != nullptr;
+        static const bool sp2048 = exp_env("OA_LEGS_SP_2048") != nullptr;
         if (legs_single_pass() && (logNy == 10 || (logNy == 11 && sp2048))) {
             const int lt = sizeof(T) == 4 ? 14 : 13, lc = lt - logNy, Cs = 1 << lc;
             ColLegsArgs<T> a{};
@@ -372,11 +372,11 @@ struct Fft2dPlan {
 
     // log2 of the points of a single-pass divergence tile (as fband_lt); OA_DIV_NARROW=1: half
     static int div_lt() {
-        static const int narrow = [] { const char* e = getenv("OA_DIV_NARROW"); return e ? atoi(e) : 0; }();
+        static const int narrow = [] { const char* e = exp_env("OA_DIV_NARROW"); return e ? atoi(e) : 0; }();
         return (sizeof(T) == 4 ? 14 : 13) - (narrow > 0 ? 1 : 0);
     }
     static bool single_pass_div() {
-        static const bool on = [] { const char* e = getenv("OA_SINGLE_PASS_DIV"); return e ? atoi(e) != 0 : true; }();
+        static const bool on = [] { const char* e = exp_env("OA_SINGLE_PASS_DIV"); return e ? atoi(e) != 0 : true; }();
         return on;
     }
     // (B) forward column transforms of two row-transformed planes + divergence * Fnorm

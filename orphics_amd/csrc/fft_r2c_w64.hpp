@@ -81,9 +81,6 @@ struct RowW64Args {
     float scale;
     int wcols;                // columns produced (<= 512)
     int ny, nwg;
-    // R-SPLIT (row_r2c_w64_body_t<LR>): output plane k1 sits kplane elements behind plane 0; twy = W_ny^k
-    long kplane;
-    const cx<float>* twy;
 };
 
 // LDS: the 64 x 64 transpose goes through ONE 64 x 65 plane of 4-byte words, twice (real parts, then imaginary parts:
@@ -101,7 +98,6 @@ struct RowW64Args {
 constexpr int W64_LDS_STRIDE = 65;
 constexpr size_t W64_LDS_BYTES = (size_t)64 * W64_LDS_STRIDE * sizeof(float);
 constexpr size_t W64_LDS_BYTES_CX = (size_t)64 * W64_LDS_STRIDE * sizeof(cx<float>);   // two-waves-per-row kernel below
-constexpr size_t W64R_ACC_BYTES = (size_t)3 * 8 * 64 * sizeof(cx<float>);                 // R-split: [slot][m][lane] partial butterflies
 
 // one row: 4096 packed samples at src (lane j reads src[64 t]) -> X[m] = untangled output column j + 64 m, m < 8 (times scale)
 // W128^m = exp(-2 pi i m / 128): U[m] = W8192^(j + 64 m) = U[0] W128^m
@@ -184,13 +180,8 @@ OA_HD void w64_row(Ctx& ctx, const RowW64Args& a, const cx<float>* src, const cx
     ctx.sync();                                // the partner reads precede the next row's transpose writes
 }
 
-// LR = 0: out row = in row.  LR > 0 (R-SPLIT, RowArgs::lr): this wave transforms the R = 2^LR rows g + my n of its group g one
-// after the other and accumulates the first radix-R butterfly of the column transform per kept column:
-// Y[k1][g] = W_ny^(g k1) sum_n X_n W_R^(n k1) -> plane k1 (kplane elements apart), row g.  32 (R = 4) complex accumulators
-// per lane; the waves stay independent (no cross-wave exchange, no workgroup barrier).
-template <int LR, class Ctx>
-OA_HD void row_r2c_w64_body_t(Ctx& ctx, const RowW64Args& a) {
-    constexpr int R = 1 << LR;
+template <class Ctx>
+OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) {
     const int j = ctx.tid();                       // lane = point residue (stage 1) = bin residue k1 (stage 2)
     const int sh = a.logTw - 12;                   // W4096^e = tw[e << sh]
     // per-lane twiddle bases, kept across the rows of this wave: P[a] = W4096^(j a), Q[b] = W4096^(8 j b);
@@ -202,70 +193,15 @@ OA_HD void row_r2c_w64_body_t(Ctx& ctx, const RowW64Args& a) {
         Q[i] = a.tw[(unsigned)((8 * j * i) & 4095) << sh];
         U[i] = a.tw[(unsigned)(j + 64 * i) << (sh - 1)];
     }
-    if constexpr (LR == 0) {
-        for (long row = ctx.bid_x(); row < a.ny; row += a.nwg) {
-            cx<float> X[8];
-            w64_row(ctx, a, a.in + row * a.in_pitch + j, P, Q, U, X);
-            cx<float>* dst = a.out + row * a.out_pitch + j;
+    for (long row = ctx.bid_x(); row < a.ny; row += a.nwg) {
+        cx<float> X[8];
+        w64_row(ctx, a, a.in + row * a.in_pitch + j, P, Q, U, X);
+        cx<float>* dst = a.out + row * a.out_pitch + j;
 #pragma unroll
-            for (int m = 0; m < 8; ++m)
-                if (j + 64 * m < a.wcols) dst[64 * m] = X[m];
-        }
-    } else {
-        // The partial butterflies live in LDS behind the transpose plane ([slot][m][lane], conflict-free), not in registers: with
-        // 32 more complex registers the wave needs > 256 VGPRs, the allocator parks values in AGPRs and the transform stalls on
-        // its own moves (SQ_WAIT_INST_ANY x 3: 84 us instead of 61, profiles/r03n_pmc_r2c.txt).
-        static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
-        const long ngroups = a.ny >> LR;
-        cx<float>* accl = reinterpret_cast<cx<float>*>(reinterpret_cast<char*>(ctx.smem()) + W64_LDS_BYTES) + j;
-        const int mkeep = (a.wcols + 63) >> 6;           // kept column groups (<= 8)
-        for (long g = ctx.bid_x(); g < ngroups; g += a.nwg) {
-            cx<float> wy[R];
-#pragma unroll
-            for (int k1 = 0; k1 < R; ++k1) wy[k1] = a.twy[((unsigned)g * (unsigned)k1) & (unsigned)(a.ny - 1)];   // W_ny^(g k1): in flight during the rows
-            // rows in the order n = 0, 2, 1, 3 -- two radix-2 levels: a = X0 + X2, b = X0 - X2 (after the second row), then
-            // Y0 = a + c, Y2 = a - c, Y1 = b - i d, Y3 = b + i d with c = X1 + X3, d = X1 - X3 (after the fourth): 64 LDS
-            // operations per lane and group instead of the 192 of four running sums
-#pragma unroll 1
-            for (int step = 0; step < R; ++step) {
-                const int n = ((step & 1) << 1) | (step >> 1);
-                cx<float> X[8];
-#ifdef OA_W64R_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
-                w64_row(ctx, a, a.in + (g * R + n) * a.in_pitch + j, P, Q, U, X);
-#else
-                w64_row(ctx, a, a.in + (g + n * ngroups) * a.in_pitch + j, P, Q, U, X);
-#endif
-                if (step == 0 || step == 2) {            // X0 -> slot 0;  X1 -> slot 2
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-                        if (m < mkeep) accl[((step ? 2 : 0) * 8 + m) * 64] = X[m];
-                } else if (step == 1) {                  // a -> slot 0, b -> slot 1
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-                        if (m < mkeep) {
-                            const cx<float> x0 = accl[m * 64];
-                            accl[m * 64] = x0 + X[m];
-                            accl[(8 + m) * 64] = x0 - X[m];
-                        }
-                } else {
-                    cx<float>* dst = a.out + g * a.out_pitch + j;
-#pragma unroll
-                    for (int m = 0; m < 8; ++m)
-                        if (j + 64 * m < a.wcols) {
-                            const cx<float> aa = accl[m * 64], bb = accl[(8 + m) * 64], x1 = accl[(16 + m) * 64];
-                            const cx<float> c = x1 + X[m], d = x1 - X[m];
-                            dst[64 * m] = (aa + c) * wy[0];
-                            dst[a.kplane + 64 * m] = add_mi(bb, d) * wy[1];
-                            dst[2 * a.kplane + 64 * m] = (aa - c) * wy[2];
-                            dst[3 * a.kplane + 64 * m] = add_pi(bb, d) * wy[3];
-                        }
-                }
-            }
-        }
+        for (int m = 0; m < 8; ++m)
+            if (j + 64 * m < a.wcols) dst[64 * m] = X[m];
     }
 }
-template <class Ctx>
-OA_HD void row_r2c_w64_body(Ctx& ctx, const RowW64Args& a) { row_r2c_w64_body_t<0>(ctx, a); }
 
 
 // ---------------------------------------------------------------------------------------------------------------

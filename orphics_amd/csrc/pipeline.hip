@@ -43,6 +43,12 @@ struct Pipeline {
     int mc_cap = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
+    // oa_plan_set_option (include/orphics_amd.h): which of the equivalent launch sequences the one-call entries run
+    int opt_mc_batch = MC_BATCH_MAX;  // realisations per launch in oa_mc_run
+    bool opt_mv_batch = true;         // oa_qe_mv / oa_qe_tt_splits: all leg planes / all divergences in one launch each
+    bool opt_mv_rowbatch = true;      // oa_qe_mv: the row stage of several pieces per launch
+    bool opt_mv_chain = true;         // oa_qe_mv: estimator chains (pieces summed in real space inside one row-stage launch)
+    bool opt_divbin = true;           // moment entries: radial binning + moments in the tail of the single-pass divergence launch
 };
 
 static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
@@ -154,6 +160,21 @@ int oa_plan_set_col_grid(oa_plan* p, int mcol) {
 }
 
 int oa_plan_col_grid(const oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->my : 0; }
+
+int oa_plan_set_option(oa_plan* p, int option, int value) {
+    OA_REQUIRE(p, "oa_plan_set_option: NULL plan");
+    Pipeline* q = pipe_of(p);
+    switch (option) {
+        case OA_OPT_MC_BATCH:
+            OA_REQUIRE(value >= 0 && value <= MC_BATCH_MAX, "oa_plan_set_option: OA_OPT_MC_BATCH takes 0 (default) .. 6");
+            q->opt_mc_batch = value ? value : MC_BATCH_MAX; return 0;
+        case OA_OPT_MV_BATCH: q->opt_mv_batch = value != 0; return 0;
+        case OA_OPT_MV_ROWBATCH: q->opt_mv_rowbatch = value != 0; return 0;
+        case OA_OPT_MV_CHAIN: q->opt_mv_chain = value != 0; return 0;
+        case OA_OPT_DIV_BIN: q->opt_divbin = value != 0; return 0;
+        default: return fail("oa_plan_set_option: unknown option");
+    }
+}
 int oa_plan_rsplit(const oa_plan* p) {
     if (!p || !p->pipe) return 0;
     const Pipeline* q = (const Pipeline*)p->pipe;
@@ -163,7 +184,7 @@ int oa_plan_rsplit(const oa_plan* p) {
 int oa_plan_div_fused(const oa_plan* p) {
     if (!p || !p->pipe) return 0;
     const Pipeline* q = (const Pipeline*)p->pipe;
-    if (!q->FG || !q->ids || getenv("OA_NO_DIVBIN")) return 0;
+    if (!q->FG || !q->ids || !q->opt_divbin) return 0;
     const int rows = q->my ? q->my : p->ny;            // rows of the grid the divergence runs on
     const bool sp = p->dtype == OA_F32 ? Fft2dPlan<float>::single_pass_div() : Fft2dPlan<double>::single_pass_div();
     const long tiles = ((q->wk > 0 ? q->wk : p->nx / 2 + 1) + 3) / 4;        // (float64: 4-column tiles; float: 8 or 16)
@@ -211,8 +232,8 @@ void* oa_plan_kappa(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->
 const int64_t* oa_plan_bin_counts(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->counts_full : nullptr; }
 
 // Binning + moments in the tail of the single-pass divergence launch (fft_divbin.hpp): the request the one-call entries hand to
-// the divergence wrappers.  OA_NO_DIVBIN=1: always the separate histogram launches (A/B, tests).
-static bool divbin_enabled() { return getenv("OA_NO_DIVBIN") == nullptr; }     // (per call: tests compare both paths in one process)
+// the divergence wrappers.  OA_OPT_DIV_BIN = 0: always the separate histogram launches (the path of the other geometries).
+static bool divbin_enabled(const Pipeline* q) { return q->opt_divbin; }
 static DivBinFuse make_fuse(const oa_plan* p, const Pipeline* q, int64_t* n, double* S, double* C, int store) {
     DivBinFuse f{};
     f.ids = q->ids; f.ipitch = p->kp; f.pnorm = q->norm; f.nids = q->nids; f.nxh = p->nx / 2;
@@ -295,7 +316,7 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     OA_REQUIRE(real_map && n && S && C, "oa_qe_tt_moments: NULL argument");
     Pipeline* q = (Pipeline*)p->pipe;
     DivBinFuse f = make_fuse(p, q, n, S, C, 0);
-    if (int rc = qe_tt_impl(p, real_map, nullptr, nullptr, nullptr, 0, stream, divbin_enabled() ? &f : nullptr)) return rc;
+    if (int rc = qe_tt_impl(p, real_map, nullptr, nullptr, nullptr, 0, stream, divbin_enabled(q) ? &f : nullptr)) return rc;
     if (f.done) return 0;                      // binned and accumulated in the divergence launch
     return bandpower_moments(p, q, n, S, C, stream);
 }
@@ -349,7 +370,7 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     // all leg planes in ONE inverse pass-1 launch when the fields come from at most three sources (T, E, B)
     std::vector<const void*> srcs;
     unsigned long long srcsel = 0;
-    bool batch = ng + nh <= 32 && !getenv("OA_MV_NO_BATCH");        // (A/B and test switch: one launch per field)
+    bool batch = ng + nh <= 32 && q->opt_mv_batch;                  // (OA_OPT_MV_BATCH = 0: one launch per field)
     int legs_done = 0;
     for (int f = 0; f < ng + nh && batch; ++f) {
         const void* sp = f < ng ? grad[f].src : hpl[f - ng].src;
@@ -391,7 +412,7 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     // then one pass sums them in estimator order
     const size_t rs = es / 2, pb = plane_bytes(p);
     long fn_moff = 0;
-    bool dbatch = nest >= 2 && nest <= 6 && !getenv("OA_MV_NO_BATCH");
+    bool dbatch = nest >= 2 && nest <= 6 && q->opt_mv_batch;
     if (dbatch) {
         const long d = (long)((const char*)host_Fnorm[1] - (const char*)host_Fnorm[0]);
         dbatch = d > 0 && d % (long)rs == 0;
@@ -401,7 +422,7 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
     // ROW STAGE: the k-th separable piece of every estimator in ONE launch (they write different product planes; a launch
     // of one piece is 1024 workgroups of two waves and leaves most of the chip's wave slots empty), per-piece planes and
     // scales through a device table; pieces k > 0 accumulate.  Same arithmetic per piece, same order per estimator.
-    bool rbatch = dbatch && total <= 64 && !getenv("OA_MV_NO_ROWBATCH");
+    bool rbatch = dbatch && total <= 64 && q->opt_mv_rowbatch;
     if (rbatch) {
         int maxp = 0;
         for (int e = 0; e < nest; ++e) maxp = std::max(maxp, host_npieces[e]);
@@ -434,9 +455,9 @@ int oa_qe_mv(oa_plan* p, int nest, const int* host_npieces, const double* host_s
         size_t off = 0;
         // ESTIMATOR CHAINS: one launch for all estimators, each workgroup loops over its estimator's pieces and keeps the
         // summed products in registers (3 n + 2 transforms per row pair instead of 5 n; no read-modify-write of the product
-        // planes).  OA_MV_NO_CHAIN: the piece-by-piece launches below (A/B and test switch)
+        // planes).  OA_OPT_MV_CHAIN = 0: the piece-by-piece launches below
         bool chained = false;
-        if (!getenv("OA_MV_NO_CHAIN")) {
+        if (q->opt_mv_chain) {
             std::vector<const void*> cgx, cgy, chh;
             std::vector<void*> cpx, cpy;
             std::vector<double> csc;
@@ -500,7 +521,7 @@ int oa_qe_tt_splits(oa_plan* p, int nsplits, const void* const* host_kmaps, void
     const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), lbk = (size_t)pk * p->ny * es;
     const int npairs = nsplits * nsplits;
     // evenly spaced output planes (one (n, n, Ny, kp) block): the divergence of all pairs runs as ONE launch
-    bool dbatch = npairs >= 2 && !getenv("OA_MV_NO_BATCH");
+    bool dbatch = npairs >= 2 && q->opt_mv_batch;
     long out_moff = 0;
     if (dbatch) {
         const long d = (long)((char*)host_out[1] - (char*)host_out[0]);
@@ -547,7 +568,7 @@ int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, 
     // it is ever read back (binning)
     DivBinFuse f = make_fuse(p, q, n, S, C, 0);
     int rc = qe_tt_pair_w(p, real_map0, real_map1, q->FG, q->FH, q->Fn, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], q->kk, q->kT, q->wl,
-                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream, divbin_enabled() ? &f : nullptr);
+                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream, divbin_enabled(q) ? &f : nullptr);
     if (rc > 0) return rc;
     if (rc == 0 && f.done) return 0;           // both maps binned and accumulated (map order) in the divergence launch
     if (rc < 0) {
@@ -580,7 +601,7 @@ int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
             return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my, lr);
         case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my, lr);
         case 4: {
-            if (q->ids && divbin_enabled()) {      // as the one-call entries: binning + moments (into dummies) in the divergence launch
+            if (q->ids && divbin_enabled(q)) {      // as the one-call entries: binning + moments (into dummies) in the divergence launch
                 DivBinFuse f = make_fuse(p, q, (int64_t*)q->kT, (double*)q->kT + 8, (double*)q->kT + 8 + q->nids, 0);
                 return qe_cols_div_w(p, q->g[0], q->g[1], q->Fn, q->kk, 0, q->wk, q->rk, pk, st, my, &f);
             }
@@ -609,13 +630,12 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     // BATCHES of realisations: at 4096^2 a realisation is ~60 MB of traffic behind ~10 launches, i.e. launch latency; with B
     // realisations per launch (grid z) the column and row stages fill the chip.  Same kernels on the same operands in the same
     // order per realisation as the one-by-one loop below: identical moments.
-    const char* be = getenv("OA_MC_BATCH");                 // (per call: tests compare batch sizes in one process)
-    const int BMAX = be ? std::max(1, std::min(MC_BATCH_MAX, atoi(be))) : MC_BATCH_MAX;     // 1 / 2 / 4 / 6 per launch at 4096^2: 16.5 / 26.0 / 37.6 / 40.3 k realisations/s
+    const int BMAX = std::max(1, std::min(MC_BATCH_MAX, q->opt_mc_batch));     // (OA_OPT_MC_BATCH) 1 / 2 / 4 / 6 per launch at 4096^2: 16.5 / 26.0 / 37.6 / 40.3 k realisations/s
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p);
     const size_t lb = (size_t)pl * p->ny * es, lbk = (size_t)pk * p->ny * es;
     const int my = q->my;
-    // (a batch of ONE goes through the same launches -- OA_MC_BATCH=1 and the last realisation of an odd shard: the same kernels
+    // (a batch of ONE goes through the same launches -- OA_OPT_MC_BATCH = 1 and the last realisation of an odd shard: the same kernels
     // whatever the batch size, so the moments do not depend on it; the loop further down serves the geometries without them)
     bool batched = p->pow2;
     while (batched && i < sim_hi) {
@@ -653,7 +673,7 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
         if (rc) return rc;
         DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
         if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my,
-                                      divbin_enabled() ? &f : nullptr)))
+                                      divbin_enabled(q) ? &f : nullptr)))
             return rc;
         // binned power of the B kappa planes + their moment updates in realisation order: in the divergence launch, else two
         // launches; the mean-field stack: one
@@ -696,7 +716,7 @@ int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi,
         // binning + moments in the divergence launch where the geometry has that kernel (kappa_hat still stored when the mean-field
         // stack needs it)
         DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
-        if ((rc = qe_tt_impl(p, tmap, nullptr, nullptr, nullptr, 0, stream, divbin_enabled() ? &f : nullptr))) return rc;
+        if ((rc = qe_tt_impl(p, tmap, nullptr, nullptr, nullptr, 0, stream, divbin_enabled(q) ? &f : nullptr))) return rc;
         if (!f.done && (rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
         if (meanfield_acc && (rc = stack_add_region(p->dtype, q->kk, meanfield_acc, p->ny, p->kp, q->wk, q->rk, (hipStream_t)stream))) return rc;
     }

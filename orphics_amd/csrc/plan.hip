@@ -40,7 +40,7 @@ extern "C" {
 
 const char* oa_last_error(void) { return last_error_ref().c_str(); }
 
-int oa_version(void) { return 301; }   // round number x 100: bumped whenever a signature in include/orphics_amd.h changes
+int oa_version(void) { return OA_ABI_VERSION; }   // round number x 100: bumped whenever a signature in include/orphics_amd.h changes
 
 int oa_device_count(void) {
     int n = 0;

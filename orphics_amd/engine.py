@@ -161,17 +161,6 @@ def dev_bin_power(k1, k2, norm, ids, nids, herm_pitch=0, herm_nxh=-1, active_col
     return sums, counts
 
 
-def hc_resample(src_eng, k, dst_eng, scale=1.0, out=None):
-    """Move an hc plane between two grids of the same patch (crop / zero-embed in Fourier space)."""
-    src_eng._chk(k, "hc")
-    if src_eng.prec != dst_eng.prec:
-        raise ValueError("hc_resample: precision mismatch")
-    out = dst_eng.hc() if out is None else _dirty(dst_eng._chk(out, "hc"))
-    check(src_eng.lib.oa_hc_resample(src_eng.code, _ptr(k), src_eng.ny, src_eng.nx, src_eng.kp, _ptr(out), dst_eng.ny,
-                                     dst_eng.nx, dst_eng.kp, float(scale), _stream()))
-    return out
-
-
 class Engine(object):
     _cache = {}
 
@@ -435,6 +424,14 @@ class Engine(object):
         return o1, o2
 
     # ---- QE legs --------------------------------------------------------------------
+    # oa_plan_set_option (include/orphics_amd.h): equivalent launch sequences of the one-call entries of THIS plan
+    OPTIONS = {"mc_batch": 1, "mv_batch": 2, "mv_rowbatch": 3, "mv_chain": 4, "div_bin": 5}
+
+    def set_option(self, name, value):
+        if name not in self.OPTIONS:
+            raise ValueError("unknown plan option %r (one of %s)" % (name, sorted(self.OPTIONS)))
+        check(self.lib.oa_plan_set_option(self.plan, self.OPTIONS[name], int(value)))
+
     def set_laxes(self, ly, lx):
         ly = np.ascontiguousarray(ly, dtype=np.float64)
         lx = np.ascontiguousarray(lx, dtype=np.float64)

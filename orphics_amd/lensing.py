@@ -846,106 +846,8 @@ class Estimator(object):
         return self._full(self.Nlkk[XY])
 
 
-class BandlimitedEstimator(object):
-    """Exact reconstruction on a coarser internal grid for band-limited filters.
-
-    The legs are zero above the filter ell_max, so they -- and their real-space products (band limit
-    ell_max_X + ell_max_Y) -- are represented exactly on any grid whose Nyquist frequency exceeds that band
-    limit: the estimator can run on an (n_small x n_small) grid of the same patch, 1/(N/n_small)^2 of the work,
-    and returns the same kappa_hat modes (all L below the coarse Nyquist) up to rounding.  Opt-in: the default
-    ``Estimator`` path and bench.py always run at the full map resolution."""
-
-    def __init__(self, shape, wcs, theory, n_small=None, **kwargs):
-        from .engine import Engine
-        from .geometry import FlatGeometry
-        self.shape = tuple(shape[-2:])
-        self.geom = as_geometry(self.shape, wcs)
-        N = self.shape[0]
-        assert self.shape[0] == self.shape[1], "square maps only"
-        lnyq = np.pi / abs(self.geom.step_y)
-        lmaxs = []
-        for key in ("kmask", "kmask_P"):
-            m = kwargs.get(key)
-            if m is not None:
-                ml = self.geom.modlmap()
-                lmaxs.append(float(ml[np.asarray(m) > 0].max()))
-        if not lmaxs:
-            raise ValueError("band-limited mode needs a k-space mask (kmask / kmask_P) to bound the legs")
-        band = 2.0 * max(lmaxs)
-        if n_small is None:
-            n_small = N
-            while n_small // 2 >= 32 and lnyq * (n_small // 2) / N > band * 1.02:
-                n_small //= 2
-        self.n = int(n_small)
-        f = N // self.n
-        if lnyq / f <= band:
-            raise ValueError("n_small=%d aliases the leg products (band limit %.0f, coarse Nyquist %.0f)" % (self.n, band, lnyq / f))
-        self.gsmall = FlatGeometry((self.n, self.n), self.geom.step_y * f, self.geom.step_x * f, self.geom.area)
-
-        def crop(a):
-            if a is None:
-                return None
-            a = np.asarray(a)
-            h = self.n // 2
-            idx = np.r_[0:h, N - h:N]
-            return np.ascontiguousarray(a[np.ix_(idx, idx)])
-        kw = dict(kwargs)
-        for key in ("noise2d", "beam2d", "kmask", "noise2d_P", "kmask_P", "kmask_K"):
-            if kw.get(key) is not None:
-                kw[key] = crop(kw[key])
-        # no kappa above the coarse Nyquist: restrict the kappa mask accordingly
-        mlc = self.gsmall.modlmap()
-        km = np.ones((self.n, self.n)) if kw.get("kmask_K") is None else kw["kmask_K"].astype(np.float64)
-        kw["kmask_K"] = km * (mlc < lnyq / f)
-        self.q = Estimator((self.n, self.n), self.gsmall, theory, **kw)
-        self.big = maps._engine(self.shape, self.q.prec)
-        self.scale = (self.n / float(N)) ** 2          # DFT on the coarse grid = (n/N)^2 x the full-grid DFT
-        self._kc = self.q.eng.hc()
-
-    def reconstruct_tt_hc(self, kT_full, out=None):
-        """Full-resolution hc transform of the map in; kappa_hat DFT on the COARSE grid out (HalfPlane-able with
-        ``self.q.eng``); its bandpowers with ``self.gsmall`` equal the full-resolution ones."""
-        from .engine import hc_resample
-        hc_resample(self.big, kT_full, self.q.eng, self.scale, out=self._kc)
-        return self.q.reconstruct_tt_hc(self._kc, out=out)
-
-    def reconstruct_tt_from_map(self, tmap, out=None):
-        """Real full-resolution map in: only the columns the leg filters keep are transformed, then cropped."""
-        if getattr(self, "_kbig", None) is None:
-            self._kbig = self.big.hc()
-        self.big.rfft(tmap, out=self._kbig, width=self.q.leg_cols, rband=self.q.leg_rows)
-        return self.reconstruct_tt_hc(self._kbig, out=out)
-
-    def kappa_full_hc(self, kappa_small):
-        """Embed the coarse kappa_hat DFT into the full-resolution hc grid."""
-        from .engine import hc_resample
-        return hc_resample(self.q.eng, kappa_small, self.big, 1.0 / self.scale)
-
-
-    def kappa_from_map(self, XY, T2DData, alreadyFTed=False, returnFt=False, **unused):
-        """``qest.kappa_from_map("TT", map)`` (lensing.py:973) with full-resolution containers in and out, the
-        reconstruction itself on the coarse grid: NumPy map in -> NumPy kappa map (or full-plane FT) out, device
-        tensor in -> device tensor out."""
-        if XY != "TT":
-            raise NotImplementedError("BandlimitedEstimator: TT only (use Estimator for polarisation)")
-        torch = _torch()
-        e = self.big
-        as_np = isinstance(T2DData, np.ndarray)
-        if alreadyFTed:
-            small = self.reconstruct_tt_hc(e.full_to_hc(e.to_complex(T2DData)))
-        else:
-            small = self.reconstruct_tt_from_map(e.to_real(T2DData))
-        kfull = self.kappa_full_hc(small)
-        out = e.hc_to_full(kfull) if returnFt else e.irfft(kfull)
-        return out.cpu().numpy() if as_np else out
-
-
-def qest(shape, wcs, theory, internal_grid=None, **kwargs):
-    """``lensing.qest(...)`` constructor name used by the reference notebooks.  ``internal_grid="auto"`` (or a
-    power-of-two side) returns the :class:`BandlimitedEstimator` (TT, band-limited masks required)."""
-    if internal_grid is not None:
-        return BandlimitedEstimator(shape, wcs, theory, n_small=None if internal_grid == "auto" else int(internal_grid),
-                                    **kwargs)
+def qest(shape, wcs, theory, **kwargs):
+    """``lensing.qest(...)`` constructor name used by the reference notebooks (tutorials/tt_verification.ipynb cell 3)."""
     return Estimator(shape, wcs, theory, **kwargs)
 
 
@@ -1078,18 +980,17 @@ class FlatLenser(object):
         return e.irfft(e.cmul_real(e.rfft(e.to_real(kappa)), self._fphi))
 
     def split(self, alpha):
-        """Nearest-pixel shifts and sub-pixel remainders of a deflection field (alpha_y, alpha_x): computed once per
-        deflection and reused for every map lensed by it (T, Q, U of one realisation)."""
+        """Nearest-pixel shifts and sub-pixel remainders of a deflection field (alpha_y, alpha_x).  Pure function of the
+        tensors' CONTENTS at call time: nothing is cached (a cache keyed on buffer addresses returned a previous
+        realisation's split once the allocator reused the blocks).  Callers that lens several maps by one deflection
+        (T, Q, U of a realisation: ``FlatLensingSims.lens_maps``) compute it once and pass ``lens(..., split=...)``."""
         e = self.eng
         ay, ax = alpha
-        key = (ay.data_ptr(), ax.data_ptr(), ay._version, ax._version)
-        if getattr(self, "_split", None) is None or self._split[0] != key:
-            sx, dx = e.lens_split(ax, self.geom.step_x)
-            sy, dy = e.lens_split(ay, self.geom.step_y)
-            self._split = (key, (sx, sy, dx, dy))
-        return self._split[1]
+        sx, dx = e.lens_split(ax, self.geom.step_x)
+        sy, dy = e.lens_split(ay, self.geom.step_y)
+        return sx, sy, dx, dy
 
-    def lens(self, imap, alpha, taylor_order=5, fused=True):
+    def lens(self, imap, alpha, taylor_order=5, fused=True, split=None):
         """flat_taylens (lensing.py:395-440): T(x + alpha) by nearest-pixel remap + Taylor series in FFT derivatives.
         fused (default): ONE derivative kernel for all 14 terms (``oa_hc_derivs``), their C2Rs, ONE gather pass over all
         of them (``oa_lens_taylor``); fused=False: one derivative kernel, C2R and gather per term (the first
@@ -1098,7 +999,7 @@ class FlatLenser(object):
         from ._lib import check
         from .engine import _ptr, _stream
         e = self.eng
-        sx, sy, dx, dy = self.split(alpha)
+        sx, sy, dx, dy = split if split is not None else self.split(alpha)
         src = e.to_real(imap)
         out = e.real()
         if fused and 2 <= taylor_order <= 8:
@@ -1186,15 +1087,17 @@ class FlatLensingSims(object):
         pixell.lensing.displace_map(order=lens_order) (lensing.py:512); here the FFT-only Taylens of lensing.py:395-440 is
         used (same Taylor order)."""
         torch = _torch()
+        sp = self.lenser.split(alpha)                       # once per deflection, shared by every component
         if unlensed.ndim == 2:
-            return self.lenser.lens(unlensed, alpha, taylor_order=lens_order)
-        return torch.stack([self.lenser.lens(unlensed[i].contiguous(), alpha, taylor_order=lens_order) for i in range(unlensed.shape[0])])
+            return self.lenser.lens(unlensed, alpha, taylor_order=lens_order, split=sp)
+        return torch.stack([self.lenser.lens(unlensed[i].contiguous(), alpha, taylor_order=lens_order, split=sp) for i in range(unlensed.shape[0])])
 
     def beam_maps(self, lensed):
         """filter_map(lensed, kbeam) (lensing.py:513) with the beam plane resident on the device"""
-        if getattr(self, "_kbeam_dev", None) is None:      # the beam plane goes to the device once, not per realisation
-            self._kbeam_dev = maps.prepare_filter(self.shape[-2:], self.kbeam, dtype=self.lenser.eng.prec)
-        return maps.filter_map(lensed, self._kbeam_dev)
+        cached = getattr(self, "_kbeam_dev", None)         # the beam plane goes to the device once per kbeam OBJECT, not per realisation
+        if cached is None or cached[0] is not self.kbeam:
+            self._kbeam_dev = (self.kbeam, maps.prepare_filter(self.shape[-2:], self.kbeam, dtype=self.lenser.eng.prec))
+        return maps.filter_map(lensed, self._kbeam_dev[1])
 
     def get_kappa(self, seed=None):
         return self.kgen.get_map(seed=seed, scalar=True)

@@ -481,6 +481,17 @@ def spec2flat(shape, wcs, cov, exp=1.0, mode="constant", smooth="auto"):
     return out
 
 
+def Ny_Nx_not_divisible(shape, ndown):
+    Ny, Nx = tuple(shape)[-2:]
+    nd = np.array(ndown).ravel()
+    if nd.size == 1:
+        other = int(nd[0] * max(Ny, Nx) * 1. / min(Ny, Nx))
+        fy, fx = (other, int(nd[0])) if Ny > Nx else (int(nd[0]), other)
+    else:
+        fy, fx = int(nd[0]), int(nd[1])
+    return fy < 1 or fx < 1 or Ny % max(fy, 1) != 0 or Nx % max(fx, 1) != 0
+
+
 def downsample_power(shape, wcs, cov, ndown=16, order=0, exp=None, fftshift=True, fft=False, logfunc=lambda x: x,
                      ilogfunc=lambda x: x, fft_up=False):
     """maps.py:1501-1550: smooth a 2-D power spectrum (..., Ny, Nx) by averaging it over blocks of ``ndown`` Fourier
@@ -499,6 +510,12 @@ def downsample_power(shape, wcs, cov, ndown=16, order=0, exp=None, fftshift=True
         return cov
     if fft or fft_up:
         raise NotImplementedError("downsample_power(fft=True / fft_up=True): Fourier resampling (pixell.resample) is outside the hot path")
+    if order > 0 or Ny_Nx_not_divisible(shape, ndown):
+        import warnings
+        warnings.warn("downsample_power: the block-mean / order-%d sampling step restates pixell's enmap.downgrade and "
+                      "ndmap.at from their documented behaviour (pixell is absent: parity unpinned, SURVEY.md F3); at the "
+                      "plane edges and for sides that are not multiples of ndown the result may differ from the reference's"
+                      % order, stacklevel=2)
     Ny, Nx = tuple(shape)[-2:]
     nd = np.array(ndown).ravel()
     if nd.size == 1:

@@ -9,7 +9,6 @@
 #include <vector>
 #include "../../orphics_amd/csrc/fft_plan.hpp"
 #include "../../orphics_amd/csrc/fft_r2c_w64.hpp"
-#include "../../orphics_amd/csrc/fft_r2c_f64.hpp"
 #include "../../orphics_amd/csrc/fft_r2c_rs4096.hpp"
 
 using namespace oa;
@@ -322,31 +321,6 @@ int emu_qe_rows_rlayout_f64(int my, int nx, const void* gx, const void* gy, cons
 }
 int emu_qe_rows_rlayout_f32(int my, int nx, const void* gx, const void* gy, const void* h, void* px, void* py, double s, int win, int wout, int mrow, int lr) {
     return do_qe_rows_rlayout<float>(my, nx, (const cx<float>*)gx, (const cx<float>*)gy, (const cx<float>*)h, (cx<float>*)px, (cx<float>*)py, s, win, wout, mrow, lr);
-}
-// float64 two-waves-per-row R2C (fft_r2c_f64.hpp): nx = 8192; lr = 0 (out: ny rows of `pitch`) or 2 (R-split, ny = 4 my: four planes)
-int emu_r2c_rows_f64x2(int ny, int nx, const double* in, void* out, long pitch, int width, int nwg, int lr) {
-    if (nx != 8192 || width > 512 || (lr && (ny & 3))) return 1;
-    auto tw = make_twiddles<double>(nx);
-    auto twy = make_twiddles<double>(ny);
-    RowF64Args a{};
-    a.in = (const cx<double>*)in; a.out = (cx<double>*)out; a.in_pitch = nx / 2; a.out_pitch = pitch;
-    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = 1.0; a.wcols = width; a.ny = ny; a.nwg = nwg; a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
-    EmuLauncher q;
-    if (lr == 2) q.run(nwg, 1, 128, F64_LDS_BYTES + F64_ACC_BYTES, [&](EmuCtx& c) { row_r2c_f64_body<2>(c, a); });
-    else q.run(nwg, 1, 128, F64_LDS_BYTES, [&](EmuCtx& c) { row_r2c_f64_body<0>(c, a); });
-    return 0;
-}
-// one-wave-per-row R-split R2C (row_r2c_w64_body_t<2>): nx = 8192, ny = 4 my
-int emu_rsplit_rows_w64_f32(int ny, int nx, const float* in, void* out, long pitch, int width, int nwg) {
-    if (nx != 8192 || width > 512 || (ny & 3)) return 1;
-    auto tw = make_twiddles<float>(nx);
-    auto twy = make_twiddles<float>(ny);
-    RowW64Args a{};
-    a.in = (const cx<float>*)in; a.out = (cx<float>*)out; a.in_pitch = nx / 2; a.out_pitch = pitch;
-    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = 1.0f; a.wcols = width; a.ny = ny; a.nwg = nwg; a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
-    EmuLauncher q;
-    q.run(nwg, 1, 64, W64_LDS_BYTES + W64R_ACC_BYTES, [&](EmuCtx& c) { row_r2c_w64_body_t<2>(c, a); });
-    return 0;
 }
 int emu_rsplit_rows_rs4096_f32(int ny, int nx, const float* in, void* out, long pitch, int width, int nwg, int pf) { return do_rs4096<float>(ny, nx, in, out, pitch, width, nwg, pf); }
 int emu_rsplit_rows_rs4096_f64(int ny, int nx, const double* in, void* out, long pitch, int width, int nwg, int pf) { return do_rs4096<double>(ny, nx, in, out, pitch, width, nwg, pf); }

@@ -18,7 +18,7 @@ def emu():
     so = os.path.join(EMUL, "libemul_fft.so")
     src = os.path.join(EMUL, "emul_fft.cpp")
     csrc = os.path.join(HERE, "..", "orphics_amd", "csrc")
-    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_f64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "cx.hpp")]
+    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "cx.hpp")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -583,20 +583,6 @@ def test_rsplit_row_pass(emu, prec, pf):
         assert np.abs(np.fft.fft(ref[k1], axis=0) - full[k1::4]).max() < 1e-9 * np.abs(full).max()
 
 
-def test_rsplit_row_pass_one_wave_per_row(emu):
-    """row_r2c_w64_body_t<2>: the persistent wave walks the four rows of its group and keeps the butterfly in registers"""
-    ny, nx, w = 32, 8192, 380
-    my = ny // 4
-    rng = np.random.default_rng(8)
-    x = rng.standard_normal((ny, nx)).astype(np.float32)
-    pitch = 384
-    Y = np.full((4, my, pitch), 7.0 + 0j, dtype=np.complex64)
-    assert emu.emu_rsplit_rows_w64_f32(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3) == 0
-    ref = _rsplit_reference(x.astype(np.float64), my, w)
-    assert np.abs(Y[:, :, :w] - ref).max() < 3e-6 * np.abs(ref).max()
-    assert np.all(Y[:, :, w:] == 7.0)
-
-
 @pytest.mark.parametrize("nx,prec,w,pf", [(8192, "f64", 380, 1), (8192, "f64", 512, 0), (8192, "f32", 380, 1), (8192, "f64", 1, 1),
                                           (4096, "f64", 190, 0), (4096, "f32", 256, 1), (4096, "f64", 256, 1), (4096, "f32", 3, 0)])
 def test_rsplit_row_pass_one_crosswave_exchange(emu, nx, prec, w, pf):
@@ -703,26 +689,3 @@ def test_row_stage_on_r_layout_planes(emu, prec):
     for a, b in zip(res[0], res[1]):
         assert np.abs(a[:, :wout] - b[:, :wout]).max() < tol * np.abs(a[:, :wout]).max()
         assert np.all(b[:, wout:] == 3.0)
-
-
-@pytest.mark.parametrize("lr,w", [(0, 380), (0, 512), (2, 380), (2, 100)])
-def test_float64_two_waves_per_row_r2c(emu, lr, w):
-    """fft_r2c_f64.hpp: rows of 8192 reals in float64, two waves per row (32 complex128 points per lane, pruned second
-    stage, even / odd exchange, untangle) -- plain and with the R-split butterfly of the column transform."""
-    ny, nx = (12, 8192) if lr == 0 else (16, 8192)
-    rng = np.random.default_rng(17 + lr + w)
-    x = rng.standard_normal((ny, nx))
-    pitch = 520
-    if lr == 0:
-        out = np.full((ny, pitch), 7.0 + 0j, dtype=np.complex128)
-        assert emu.emu_r2c_rows_f64x2(ny, nx, _p(x), _p(out), ctypes.c_long(pitch), w, 5, 0) == 0
-        ref = np.fft.rfft(x, axis=1)[:, :w]
-        assert np.abs(out[:, :w] - ref).max() < 1e-12 * np.abs(ref).max()
-        assert np.all(out[:, w:] == 7.0)
-    else:
-        my = ny // 4
-        Y = np.full((4, my, pitch), 7.0 + 0j, dtype=np.complex128)
-        assert emu.emu_r2c_rows_f64x2(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3, 2) == 0
-        ref = _rsplit_reference(x, my, w)
-        assert np.abs(Y[:, :, :w] - ref).max() < 1e-12 * np.abs(ref).max()
-        assert np.all(Y[:, :, w:] == 7.0)

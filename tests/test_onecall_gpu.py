@@ -226,7 +226,7 @@ def test_two_maps_per_call_equals_two_calls(N, res, prec):
 
 @pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (2048, 1.0, "f64"), (512, 2.0, "f32")])
 def test_mc_run_in_batches_equals_one_by_one(N, res, prec):
-    """oa_mc_run hands OA_MC_BATCH realisations to every launch (grid z: GRF draw, leg planes, inverse pass 2, row stage,
+    """oa_mc_run hands OA_OPT_MC_BATCH realisations to every launch (grid z: GRF draw, leg planes, inverse pass 2, row stage,
     divergence); the moments and the mean-field stack are those of the one-realisation-per-launch loop (same kernels on the
     same operands, accumulated in the same order).  512^2: geometry without the batched row stage -> falls back."""
     import os
@@ -244,13 +244,13 @@ def test_mc_run_in_batches_equals_one_by_one(N, res, prec):
     edges = np.linspace(20, 3500, 20)
     res_ = {}
     for batch in ("1", "4", "3", "6"):
-        os.environ["OA_MC_BATCH"] = batch
+        q.eng.set_option("mc_batch", int(batch))
         try:
             drv = mc.GaussianN0MonteCarlo(q, tot, edges, comm=None, base_seed=21, mean_field=True)
             st = drv.run(11)                                       # 11 = 4 + 4 + 3 (batch 4), 6 + 5, 3 + 3 + 3 + 2, ...
             res_[batch] = (st.count("n0"), np.array(st.mean("n0")), np.array(st.cov("n0")), st.stack_sum("mf").copy())
         finally:
-            del os.environ["OA_MC_BATCH"]
+            q.eng.set_option("mc_batch", 0)
     n1, m1, c1, s1 = res_["1"]
     assert n1 == 11 and np.all(m1 > 0)
     for batch in ("4", "3", "6"):
@@ -348,7 +348,7 @@ def test_round3_entries_from_raw_pointers():
 @pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (4096, 0.5, "f64"), (2048, 1.0, "f32")])
 def test_binning_in_the_divergence_launch_equals_the_separate_histogram(N, res, prec):
     """oa_qe_tt_moments / _moments2 with the radial histogram and the moment update in the tail of the single-pass divergence
-    kernel (fft_divbin.hpp) against the same calls with OA_NO_DIVBIN=1 (bin_kernel + bin_final_kernel over the kappa plane):
+    kernel (fft_divbin.hpp) against the same calls with plan option div_bin = 0 (bin_kernel + bin_final_kernel over the kappa plane):
     same per-mode arithmetic, other order of the float64 sums -> 1e-13; and against bin2D-style bandpowers of the kappa plane."""
     import os
     from orphics_amd import cosmology, lensing, maps
@@ -374,14 +374,14 @@ def test_binning_in_the_divergence_launch_equals_the_separate_histogram(N, res, 
     fused = acc()
     q.tt_moments(m[0], *fused); q.tt_moments2(m[1], m[2], *fused); q.tt_moments(m[1], *fused)
     torch.cuda.synchronize()
-    os.environ["OA_NO_DIVBIN"] = "1"
+    eb.set_option("div_bin", 0)
     try:
         assert eb.lib.oa_plan_div_fused(eb.plan) == 0
         sep = acc()
         q.tt_moments(m[0], *sep); q.tt_moments2(m[1], m[2], *sep); q.tt_moments(m[1], *sep)
         torch.cuda.synchronize()
     finally:
-        del os.environ["OA_NO_DIVBIN"]
+        eb.set_option("div_bin", 1)
     assert int(fused[0]) == int(sep[0]) == 4
     assert float(sep[1].abs().min()) > 0
     np.testing.assert_allclose(fused[1].cpu().numpy(), sep[1].cpu().numpy(), rtol=1e-13)

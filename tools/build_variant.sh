@@ -5,10 +5,10 @@ set -e
 NAME=$1; FLAGS=$2
 cd "$(dirname "$0")/../orphics_amd/csrc"
 mkdir -p build_$NAME ../variants
-CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function"
-for f in fft fft_legs; do $CXX $FLAGS -c $f.hip -o build_$NAME/$f.o & done
+CXX="/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -DOA_EXPERIMENTS"
+for f in fft fft_legs pipeline; do $CXX $FLAGS -c $f.hip -o build_$NAME/$f.o & done
 wait
-OBJS="build_$NAME/fft.o build_$NAME/fft_legs.o"
-for f in plan czt elementwise bin rng pipeline; do OBJS="$OBJS build/$f.o"; done
+OBJS="build_$NAME/fft.o build_$NAME/fft_legs.o build_$NAME/pipeline.o"
+for f in plan czt elementwise bin rng; do OBJS="$OBJS build/$f.o"; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../variants/liborphics_amd_$NAME.so $OBJS
 echo built ../variants/liborphics_amd_$NAME.so
