@@ -417,7 +417,8 @@ def per_kernel_table(torch, P, R, args):
     flops *= cg                                   # the row stage visits my of the N rows
     rq = per["row_qe_kernel"]
     rq.update({"executed_GFLOP": flops / 1e9, "flop_count": how, "row_grid": mrow, "TFLOPs": flops / (rq["avg_ms"] * 1e-3) / 1e12,
-               "valu_frac": flops / (rq["avg_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+               "valu_frac": flops / (rq["avg_ms"] * 1e-3) / 1e12 / (VALU_PEAK_TFLOPS if P["prec"] == "f32" else VALU_PEAK_TFLOPS / 2.0),
+               "valu_peak_TFLOPs": VALU_PEAK_TFLOPS if P["prec"] == "f32" else VALU_PEAK_TFLOPS / 2.0,
                "arithmetic_intensity_flop_per_B": flops / (rq["hbm_min_GB"] * 1e9)})
     return per, dict(A=A, Ah=Ah, fl=fl, fk=fk, W=W, wl=wl, wk=wk, rl=rl, rk=rk, mrow=mrow, mcol=my, rsplit=rsplit)
 
@@ -507,6 +508,230 @@ def lensed_loop_leg(torch, args, side=4096, nsims=12, estimators=("TT", "EB")):
             "nsims_timed": nsims, "stage_ms_per_sim": drv.stage_ms,
             "note": "mc.LensedSimsMonteCarlo: get_sim (unlensed T,Q,U + kappa + noise GRFs, order-5 flat-sky lensing of 3 maps, beam) -> "
                     "T,E,B -> TT + EB reconstructions -> cross / auto bandpowers -> device-side Statistics; one HIP stream"}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Legs of the other BASELINE configs at the reference's precision AND in float32: config 3 (8192^2 MV),
+# config 4 (4096^2 Gaussian N0 + mean-field Monte Carlo, unwindowed and windowed), and the kappa-producing TT entry
+# --------------------------------------------------------------------------------------------------------------
+def _timeit(torch, fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def kappa_out_leg(torch, args, R):
+    """The reference's contract ``kappa_from_map(..., returnFt=True)`` (lensing.py:973-976): oa_qe_tt from the real map with
+    kappa_hat's transform WRITTEN to an estimator-owned plane (the headline's moment entries never store it), issued like the
+    headline: resident maps round-robin over the runner's streams / handles."""
+    M, ns = len(R.tmaps), R.ns
+    count = int(min(max(args.steps * max(1, args.batch), 40), 640))
+
+    def run():
+        for i in range(count):
+            j = i % ns
+            with torch.cuda.stream(R.streams[j]):
+                R.qs[j].reconstruct_tt_from_map(R.tmaps[i % M], out=R.kks[j])
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / count
+    # the stored plane of the last call on stream 0, binned by the public histogram call, against the one-call bandpowers
+    last0 = ((count - 1) // ns) * ns
+    kk = R.kks[0]
+    e, P, q = R.eng, R.P, R.q
+    sums, _ = e.bin_power(kk, kk, R.norm, P["ids"], P["nids"], herm=True, active_cols=q.kappa_cols, active_rows=q.kappa_rows)
+    got = (sums[1:-1] / R.counts[1:-1]).double()
+    n, S, C = R.mom_n[0].clone().zero_(), R.mom_S[0].clone().zero_(), R.mom_C[0].clone().zero_()
+    q.tt_moments(R.tmaps[last0 % M], n, S, C)
+    torch.cuda.synchronize()
+    return {"reconstructions_per_s": 1.0 / dt, "streams_per_gpu": ns, "reconstructions_timed": count,
+            "max_rel_bandpower_diff_vs_moment_entry": float((got / S - 1).abs().max().item()),
+            "note": "oa_qe_tt (Estimator.reconstruct_tt_from_map): real map -> kappa_hat DFT stored in an estimator-owned hc plane"}
+
+
+def mv_leg(torch, args, N=8192, reps=10):
+    """BASELINE config 3: 8192^2 five-estimator minimum-variance reconstruction (one oa_qe_mv call) in float64 and float32;
+    bandpowers of the two precisions compared."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, args.res)
+    th = cosmology.default_theory()
+    nxh = N // 2
+    ly, lx = g.laxes()
+    ml_h = np.sqrt(ly[:, None] ** 2 + lx[None, :nxh + 1] ** 2)
+
+    def full(a_h):
+        o = np.empty(shape, dtype=a_h.dtype)
+        o[:, :nxh + 1] = a_h
+        o[:, nxh + 1:] = a_h[(-np.arange(N)) % N][:, 1:nxh][:, ::-1]
+        return o
+    beam_h = maps.gauss_beam(ml_h, 1.5)
+    nT = cosmology.white_noise_power(1.0)
+    noise = np.full(shape, nT)
+    tmask = full(((ml_h > 300) & (ml_h < 2000)).astype(np.int64))
+    kmask = full(((ml_h > 20) & (ml_h < 3500)).astype(np.int64))
+    q64 = lensing.qest(shape, g, th, noise2d=noise, beam2d=full(beam_h), kmask=tmask, kmask_P=tmask, noise2d_P=2 * noise, kmask_K=kmask,
+                       pol=True, unlensed_equals_lensed=True, dtype="f64")
+    e64 = q64.eng
+    ks64 = []
+    for i, (sp, nz) in enumerate((("TT", nT), ("EE", 2 * nT), ("BB", 2 * nT))):
+        cs = e64.hcreal()
+        cs[:, :nxh + 1] = torch.as_tensor(np.sqrt((th.lCl(sp, ml_h) * beam_h ** 2 + nz) * float(N * N) ** 2 / g.area), device=e64.device)
+        ks64.append(e64.grf_hc(77, i, cs))
+        del cs
+    edges = np.linspace(20, 3500, 20)
+    out, bp = {}, {}
+    for prec in ("f64", "f32"):
+        q = q64 if prec == "f64" else q64.astype("f32")
+        e = q.eng
+        ks = [k.to(e.cdt) for k in ks64]
+        own = q.new_output()
+        q.reconstruct_mv_hc(*ks, out=own)
+        dt = _timeit(torch, lambda: q.reconstruct_mv_hc(*ks, out=own), reps)
+        ids = e.modl_digitize(torch.as_tensor(edges, device=e.device), half=True)
+        s, c = e.bin_power(own, own, g.area / float(N * N) ** 2, ids, len(edges) + 1, herm=True)
+        bp[prec] = (s[1:-1] / c[1:-1].double()).cpu().numpy()
+        npieces = sum(len(q._gen[x]["pieces"]) for x in ("TT", "TE", "EE", "EB", "TB") if x in q._gen)
+        out[prec] = {"mv_reconstructions_per_s": 1.0 / dt, "ms_per_mv_reconstruction": dt * 1e3, "separable_pieces": npieces}
+        del ks, own
+        if prec == "f32":
+            del q
+        torch.cuda.empty_cache()
+    out["max_rel_bandpower_diff_f32_vs_f64"] = float(np.max(np.abs(bp["f32"] / bp["f64"] - 1)))
+    out["config"] = "BASELINE config 3: %dx%d %.2f' TT+TE+EE+EB+TB minimum-variance combination, one oa_qe_mv call per reconstruction into an estimator-owned plane, one stream" % (N, N, args.res)
+    return out
+
+
+def mc_leg(torch, args, N=4096, nsims=480):
+    """BASELINE config 4 per GPU: Gaussian N0 (+ mean-field stack) Monte Carlo at 4096^2 through oa_mc_run, unwindowed and with
+    the reference's apodisation taper (oa_mc_run_windowed), float64 and float32; Monte-Carlo N0 against the analytic N_L."""
+    from orphics_amd import cosmology, lensing, maps, mc, stats
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, args.res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = ((ml > 300) & (ml < 2000)).astype(np.int64)
+    kmask = ((ml > 20) & (ml < 3500)).astype(np.int64)
+    q64 = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True, dtype="f64")
+    tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(20, 3500, 20)
+    _, nl = stats.bin2D(ml, edges).bin(q64.N_kappa("TT"))
+    taper, w2 = maps.get_taper(shape, g)
+    out, means = {}, {}
+    for prec in ("f64", "f32"):
+        q = q64 if prec == "f64" else q64.astype("f32")
+        blk = {}
+        for key, kw, ns_ in (("n0", dict(mean_field=False), nsims), ("n0_mean_field", dict(mean_field=True), nsims),
+                             ("windowed_n0_mean_field", dict(mean_field=True, window=taper), max(60, nsims // 4))):
+            drv = mc.GaussianN0MonteCarlo(q, tot, edges, comm=None, base_seed=1234, **kw)
+            drv.run_local(range(12))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            drv.run_local(range(12, 12 + ns_))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / ns_
+            blk[key] = {"sims_per_s": 1.0 / dt, "ms_per_sim": dt * 1e3, "sims_timed": ns_}
+            if key == "n0":
+                m = drv.acc.mean("n0")
+                sem = np.sqrt(drv.acc.var("n0") / drv.acc.count("n0"))
+                means[prec] = m
+                blk[key]["max_abs_pull_vs_analytic_N0"] = float(np.max(np.abs((m - nl) / sem)))
+                blk[key]["max_rel_dev_vs_analytic_N0"] = float(np.max(np.abs(m / nl - 1)))
+            del drv
+            torch.cuda.empty_cache()
+        out[prec] = blk
+        if prec == "f32":
+            del q
+    out["max_rel_diff_mean_bandpowers_f32_vs_f64"] = float(np.max(np.abs(means["f32"] / means["f64"] - 1)))
+    out["window"] = {"kind": "maps.get_taper default cosine taper", "mean_w2": float(w2)}
+    out["config"] = ("BASELINE config 4, one GPU's shard: %dx%d %.2f' Gaussian realisations (Philox, key = (seed, index)) -> TT estimator -> 19 "
+                     "bandpowers -> device-side moments [+ mean-field stack], oa_mc_run / oa_mc_run_windowed, one stream" % (N, N, args.res))
+    return out
+
+
+
+def run_mc_config(args, torch, dist, world, rank):
+    """``bench.py --gpus N --config mc``: BASELINE config 4 as the sharded job it is -- ``--mc-sims`` Gaussian realisations at
+    ``--mc-n``^2 split over the ranks by the reference's rule (mpi.mpi_distribute: contiguous blocks, remainder on the last
+    ranks), every rank's shard ONE oa_mc_run call with device-resident moments + mean-field stack, then Statistics.allreduce
+    (one packed all-reduce of the moments + the region-only reduce of the mean-field stack).  Reports the whole-job rate
+    (barrier + synchronize on both sides, MAX over ranks), every rank's compute time and the reduce time separately."""
+    from orphics_amd import cosmology, lensing, maps, mc, mpi, stats
+    from orphics_amd.geometry import FlatGeometry
+    N, nsims, prec = args.mc_n, args.mc_sims, args.prec
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, args.res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=((ml > 300) & (ml < 2000)).astype(np.int64),
+                     kmask_K=((ml > 20) & (ml < 3500)).astype(np.int64), unlensed_equals_lensed=True, dtype=prec)
+    tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(20, 3500, 20)
+    comm = mpi.TorchComm() if world > 1 else None
+    window = maps.get_taper(shape, g)[0] if args.mc_windowed else None
+    # warm-up on a throw-away driver: code objects, plans, batch planes, and one rehearsal of the reduction (first use of the
+    # communicator opens its connections)
+    warm = mc.GaussianN0MonteCarlo(q, tot, edges, comm=comm, base_seed=99, mean_field=True, window=window)
+    warm.run_local(range(rank * 16, rank * 16 + 16))
+    warm.acc.allreduce()
+    torch.cuda.synchronize()
+    del warm
+    drv = mc.GaussianN0MonteCarlo(q, tot, edges, comm=comm, base_seed=1234, mean_field=True, window=window)
+    _, tasks = mpi.mpi_distribute(nsims, max(world, 1), allow_empty=True)
+    mine = tasks[rank]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.run_local(mine)
+    torch.cuda.synchronize()
+    t_compute = time.perf_counter() - t0
+    drv.acc.allreduce()
+    torch.cuda.synchronize()
+    t_reduce = time.perf_counter() - t0 - t_compute
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [(rank, len(mine), t_compute, t_reduce)]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=q.eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
+    st = drv.acc
+    assert st.count("n0") == nsims and st.stack_count("mf") == nsims, (st.count("n0"), st.stack_count("mf"), nsims)
+    if rank != 0:
+        return None
+    _, nl = stats.bin2D(ml, edges).bin(q.N_kappa("TT"))
+    mean = drv.debiased_mean()
+    sem = np.sqrt(st.var("n0") / nsims) / drv.window_moments[1]
+    return {"metric": "Monte-Carlo N0 + mean-field simulations/sec on %d^2 maps" % N, "value": nsims / elapsed, "unit": "simulations/s",
+            "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": "BASELINE config 4: %d-simulation Gaussian N0 + mean-field Monte Carlo on %dx%d %.2f-arcmin maps%s, "
+                                   "simulations sharded by mpi_distribute, one ensemble reduce" % (nsims, N, N, args.res, ", 12 % cosine taper" if window is not None else ""),
+                       "map_side": N, "nsims": nsims, "windowed": window is not None, "parallelism": "sims sharded over %d rank(s), no data-path collective; "
+                       "Statistics.allreduce at the end (packed moments + mean-field stack on kappa's active region)" % max(world, 1)},
+            "per_rank": [{"rank": r, "sims": n_, "compute_s": tc, "reduce_s": tr} for (r, n_, tc, tr) in per_rank],
+            "reduce_s_rank0": t_reduce, "elapsed_s": elapsed,
+            "check": {"max_rel_dev_vs_analytic_N0": float(np.max(np.abs(mean / nl - 1))), "max_abs_pull": float(np.max(np.abs((mean - nl) / sem))),
+                      "sims_counted": int(st.count("n0")), "stacked": int(st.stack_count("mf"))}}
 
 
 def bandwidth_ceiling(torch, gb=2.0, reps=12):
@@ -713,6 +938,11 @@ def measure(args, torch, dist, world, rank, prec):
         hbm["whole_pipeline_on_pmc_bytes"] = {"bytes_per_recon": bpr, "GBs": bpr * rate / 1e9, "frac": bpr * rate / 1e9 / HBM_PEAK_GBS,
                                               "pmc_source": "profiles/traffic_%s_%s.json (not measured in this run)" % (PROFILE_TAG, prec)}
     res.update({"roofline": roofline, "hbm": hbm, "G": G, "per": per, "A": A, "W": W})
+    if world == 1 and not args.no_extras:
+        try:
+            res["kappa_out"] = kappa_out_leg(torch, args, R)
+        except Exception as ex:          # a side leg never takes the headline down
+            res["kappa_out"] = {"error": repr(ex)}
     return res
 
 
@@ -730,7 +960,7 @@ def block_of(args, res, world, dist):
                        "maps_per_step": max(1, args.batch), "distinct_resident_maps": len(res["tmaps"]),
                        "streams_per_gpu": R.ns, "realisations_per_call": 2 if R.pair else 1,
                        "parallelism": "independent realisations per GPU + 1 all-reduce of bandpower moments"},
-            "roofline": res.get("roofline"), "hbm": res.get("hbm")}
+            "roofline": res.get("roofline"), "hbm": res.get("hbm"), "kappa_out": res.get("kappa_out")}
 
 
 def release(res, torch):
@@ -763,7 +993,7 @@ def main():
     ap.add_argument("--check-maps", type=int, default=64, help="resident maps whose bandpowers are recomputed through the fine-grained calls "
                     "and compared with the timed region's accumulated sum")
     ap.add_argument("--no-extras", action="store_true", help="skip the side legs reported under 'extra' (never the headline value)")
-    ap.add_argument("--extras", default="fullres_rows,dense,wideband,lensed_loop", help="comma list of side legs to run")
+    ap.add_argument("--extras", default="fullres_rows,dense,wideband,lensed_loop,mv,mc", help="comma list of side legs to run")
     ap.add_argument("--row-grid", default="auto", choices=["auto", "full"],
                     help="grid of the fused row stage's real-space products: auto = smallest alias-free power of two "
                          "(exact for band-limited filters; library default), full = the map's nx points")
@@ -771,6 +1001,11 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="HIP streams: independent realisations are issued round-robin "
                     "on this many streams (each with its own plan/workspace) so latency-bound and bandwidth-bound kernels overlap; "
                     "0 = auto: 2 for sides >= 8192 (5205 vs 5114 recon/s with 3, f64), 3 below (4096^2 f32: 37.2 k vs 30.7 k with 2)")
+    ap.add_argument("--config", default="qe", choices=["qe", "mc"], help="qe (default): the headline metric; mc: BASELINE config 4 as a "
+                    "sharded job (--mc-sims realisations at --mc-n^2 split over --gpus ranks, one ensemble reduce), its own JSON line")
+    ap.add_argument("--mc-n", type=int, default=4096)
+    ap.add_argument("--mc-sims", type=int, default=1000)
+    ap.add_argument("--mc-windowed", action="store_true", help="--config mc with the reference's apodisation taper (oa_mc_run_windowed)")
     args = ap.parse_args()
     if args.streams <= 0:
         args.streams = 2 if args.n >= 8192 else 3
@@ -796,6 +1031,14 @@ def main():
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
 
+    if args.config == "mc":
+        line = run_mc_config(args, torch, dist, world, rank)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     N = args.n
     other = {"auto": "f32" if args.prec == "f64" else "f64", "none": None}.get(args.also, args.also)
     if other == args.prec:
@@ -866,6 +1109,7 @@ def main():
                 except Exception as ex:      # a side leg never takes the headline down
                     extra["lensed_loop"] = {"error": repr(ex)}
                 torch.cuda.empty_cache()
+            extra["kappa_out"] = blk.get("kappa_out")
             out["extra"] = extra
         out["hbm"] = hbm
     ref_head = head["R"].bandpowers(0).double().cpu() if rank == 0 else None
@@ -880,6 +1124,19 @@ def main():
             out[other] = blk2
         release(sec, torch)
     if rank == 0:
+        if world == 1 and not args.no_extras and not args.no_prune:
+            want = [w for w in args.extras.split(",") if w]
+            for name, fn in (("mv", mv_leg), ("mc", mc_leg)):
+                if name in want:
+                    try:
+                        out.setdefault("extra", {})[name] = fn(torch, args)
+                    except Exception as ex:      # a side leg never takes the headline down
+                        out.setdefault("extra", {})[name] = {"error": repr(ex)}
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
+            if other and other in out and "extra" in out:
+                out["extra"]["kappa_out_" + other] = out[other].get("kappa_out")
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, args.res)
         print(json.dumps(out))

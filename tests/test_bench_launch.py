@@ -64,6 +64,31 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("windowed", [False, True])
+def test_bench_config_mc_two_ranks_rehearsal(windowed):
+    """``bench.py --gpus 2 --config mc`` (BASELINE config 4 as the sharded job: mpi_distribute split, one oa_mc_run call per
+    rank, packed moment all-reduce + region-only mean-field reduce, per-rank compute and reduce times reported): 2 ranks
+    started by bench.py itself on whatever GPUs exist (gloo on a 1-GPU box, RCCL on two)."""
+    import json
+    import torch
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if torch.cuda.device_count() < 2:
+        env["OA_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "mc", "--mc-n", "1024", "--mc-sims", "61", "--res", "2.0",
+           "--prec", "f64"] + (["--mc-windowed"] if windowed else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["nsims"] == 61 and d["check"]["sims_counted"] == 61 and d["check"]["stacked"] == 61
+    assert [x["sims"] for x in sorted(d["per_rank"], key=lambda x: x["rank"])] == [30, 31]      # remainder on the last rank (mpi.py:81-83)
+    assert d["value"] > 0 and d["check"]["max_abs_pull"] < 6.0
+    if not windowed:
+        assert d["check"]["max_rel_dev_vs_analytic_N0"] < 0.5
+
+
+@pytest.mark.gpu
 def test_mc_two_ranks_rccl():
     """mc.GaussianN0MonteCarlo.run sharded over 2 ranks with the RCCL all-reduce (needs >= 2 visible GPUs)."""
     import torch

@@ -40,10 +40,11 @@ def test_fft_round_trip_parseval_linearity(N):
     assert (m.double() - expect).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("N,res", [(4096, 0.5), (8192, 0.5)])
+@pytest.mark.parametrize("N,res", [(4096, 0.5), (8192, 0.5), (16384, 0.25)])
 def test_bin_ids_bit_exact_with_numpy_at_full_size(N, res):
     """H2: Delta ell = 21600/4096 makes grid modes land exactly on integer edges; device ids must equal
-    np.digitize(right=True) of NumPy's modlmap everywhere, and counts must sum to Npix."""
+    np.digitize(right=True) of NumPy's modlmap everywhere, and counts must sum to Npix.  16384^2 0.25' (BASELINE config 5)
+    has the same Delta ell = 5.2734375 tie structure as 8192^2 0.5'."""
     from orphics_amd.geometry import FlatGeometry
     e = eng(N, "f32")
     g = FlatGeometry.from_res((N, N), res)
@@ -136,12 +137,14 @@ def test_config5_16384_tt_qe_runs_and_matches_knox_scatter():
     assert abs(mean.mean() / nl[sel].mean() - 1) < 0.25    # N0 level
 
 
-@pytest.mark.parametrize("N", [2048, 4096, 8192])
-def test_tt_bandpowers_match_numpy_oracle_at_full_size(N):
+@pytest.mark.parametrize("N,tlmax", [(2048, 2000), (4096, 2000), (8192, 2000), (4096, 6000)])
+def test_tt_bandpowers_match_numpy_oracle_at_full_size(N, tlmax):
     """The north-star parity statement checked directly at BASELINE config-2 size: the default (pruned, f32) device
     path -- R2C of the map, fused estimator, |kappa_hat|^2 bandpowers -- against the float64 full-plane NumPy
     oracle on the same map: bin ids bit-exact, bandpowers within 1e-5 relative (f64 kernels: 1e-9).  8192 is the
-    size the headline metric is quoted on."""
+    size the headline metric is quoted on.  tlmax = 6000: SURVEY 8(d)'s high-resolution variant (T filter ell in (300, 6000):
+    569 leg columns at 4096^2, column grid 2048 = ny / 2, row grid 2048) -- the geometry class that runs other kernels than
+    the headline's (R = 2)."""
     import time
     from orphics_amd import cosmology, lensing, maps
     from orphics_amd.geometry import FlatGeometry
@@ -155,7 +158,7 @@ def test_tt_bandpowers_match_numpy_oracle_at_full_size(N):
     ml = g.modlmap()
     beam = maps.gauss_beam(ml, 1.5)
     noise = np.full(shape, cosmology.white_noise_power(1.0))
-    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=tlmax)
     kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
     cltt = th.lCl("TT", ml)
     rng = np.random.default_rng(11)
@@ -321,3 +324,145 @@ def test_config4_mc_n0_and_mean_field_1000_sims_4096():
     sel = (mlh > 300) & (mlh < 3000)
     ratio = p_mf[sel].mean() / (q.Nlkk["TT"][sel].mean() / nsims)
     assert 0.8 < ratio < 1.2, ratio
+
+
+def _full_from_half(a_h, N):
+    """real even plane on the half grid (N, N/2+1) -> full (N, N)"""
+    nxh = N // 2
+    o = np.empty((N, N), dtype=a_h.dtype)
+    o[:, :nxh + 1] = a_h
+    o[:, nxh + 1:] = a_h[(-np.arange(N)) % N][:, 1:nxh][:, ::-1]
+    return o
+
+
+def test_config5_16384_strict_from_map_path_vs_dense_and_f32_vs_f64():
+    """BASELINE config 5 geometry (16384^2 0.25'), the strict gate: ONE map through the benchmarked from-map call
+    (``tt_moments``: row R2C with the R-split, single-pass column stage, row stage on the coarse grids, divergence + binning)
+    in float64 against (i) the DENSE float64 pipeline (prune=False: every column and row, the multi-pass kernels whose
+    oracle parity is pinned at 2048..8192^2) on the same map: bandpowers within 1e-9, and (ii) the float32 kernels: within
+    1e-5 (the north-star tolerance).  Bin ids at this size are covered bit-exactly by
+    test_bin_ids_bit_exact_with_numpy_at_full_size."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N, res = 16384, 0.25
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    nxh = N // 2
+    ly, lx = g.laxes()
+    ml_h = np.sqrt(ly[:, None] ** 2 + lx[None, :nxh + 1] ** 2)
+    beam = _full_from_half(maps.gauss_beam(ml_h, 1.5), N)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    tmask = _full_from_half(((ml_h > 300) & (ml_h < 2000)).astype(np.int64), N)
+    kmask = _full_from_half(((ml_h > 20) & (ml_h < 3500)).astype(np.int64), N)
+    del ml_h
+    kw = dict(noise2d=noise, beam2d=beam, kmask=tmask, kmask_K=kmask, unlensed_equals_lensed=True)
+    edges = np.linspace(20, 3500, 20)
+    d = len(edges) - 1
+    q64 = lensing.qest(shape, g, th, dtype="f64", **kw)
+    e = q64.eng
+    x = e.randn(7, 0)
+    ids = e.modl_digitize(torch.as_tensor(edges, device=e.device), half=True)
+    norm = g.area / float(N * N) ** 2
+    out = {}
+    for prec in ("f64", "f32"):
+        q = q64 if prec == "f64" else q64.astype("f32")
+        ee = q.eng
+        xx = x if prec == "f64" else x.float()
+        n = torch.zeros(1, dtype=torch.int64, device=ee.device)
+        S = torch.zeros(d, dtype=torch.float64, device=ee.device)
+        C = torch.zeros(d, d, dtype=torch.float64, device=ee.device)
+        q.bind_bins(ids, len(edges) + 1, norm)
+        q.tt_moments(xx, n, S, C)
+        torch.cuda.synchronize()
+        assert int(n.item()) == 1
+        out[prec] = S.cpu().numpy().copy()
+        # the kappa-producing entry (oa_qe_tt from the map) binned by the public histogram call: same bandpowers
+        kk = q.reconstruct_tt_from_map(xx)
+        s2, c2 = ee.bin_power(kk, kk, norm, ids, len(edges) + 1, herm=True)
+        np.testing.assert_allclose((s2[1:-1] / c2[1:-1].double()).cpu().numpy(), out[prec], rtol=(1e-12 if prec == "f64" else 2e-6))
+        del kk, xx
+        if prec == "f32":
+            del q
+        torch.cuda.empty_cache()
+    assert np.all(out["f64"] > 0)
+    err32 = np.max(np.abs(out["f32"] / out["f64"] - 1))
+    assert err32 < 1e-5, "16384^2: f32 bandpowers differ from f64 by %.3g" % err32
+    del q64
+    torch.cuda.empty_cache()
+    qd = lensing.qest(shape, g, th, dtype="f64", prune=False, **kw)
+    ed = qd.eng
+    kk = qd.reconstruct_tt_hc(ed.rfft(x))
+    s, c = ed.bin_power(kk, kk, norm, ids, len(edges) + 1, herm=True)
+    dense = (s[1:-1] / c[1:-1].double()).cpu().numpy()
+    err = np.max(np.abs(out["f64"] / dense - 1))
+    assert err < 1e-9, "16384^2: pruned from-map path differs from the dense pipeline by %.3g" % err
+
+
+def test_config3_mv_8192_f64_matches_numpy_oracle_per_map_arithmetic():
+    """BASELINE config 3 at its configured size, against NumPy: the five-estimator MV reconstruction of ONE (T, E, B) set at
+    8192^2 0.5' in float64 -- one ``oa_qe_mv`` call: 17 batched leg planes, the estimator-chain row stage on the 2048-point row
+    grid / 2048-row column grid (other template instances than the 2048^2 oracle test's), batched divergence -- against
+    ``oracle.QEOracle.unnormalized_ft`` (full-plane complex128 NumPy legs, real-space products, divergence) for every
+    estimator, combined with the device estimator's per-mode weight x normalisation planes (geometry-generic float64 FFT
+    convolutions, pinned against the oracle's A_L / N_L at 128..2048^2 in test_lensing_gpu.py): kappa bandpowers within 1e-9,
+    per estimator and for the MV sum."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    from oracle import maps_oracle as mo
+    from oracle import qe_oracle as qo
+    from oracle import stats_oracle as so
+    N, res = 8192, 0.5
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    nT = np.full(shape, cosmology.white_noise_power(1.0))
+    nP = 2 * nT
+    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    ests = ("TT", "TE", "EE", "EB", "TB")
+    q = lensing.qest(shape, g, th, noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask, pol=True,
+                     unlensed_equals_lensed=True, dtype="f64")
+    e = q.eng
+    k64 = _pol_inputs(N, res, th, beam[:, :N // 2 + 1], float(nT[0, 0]))
+    kmv = q.reconstruct_mv_hc(*k64, estimators=ests).clone()
+    kone = {XY: q.reconstruct_hc(XY, k64["TEB".index(XY[0])], k64["TEB".index(XY[1])]).clone() for XY in ("TE", "EB")}
+    edges = np.linspace(20, 3500, 20)
+    ids = e.modl_digitize(torch.as_tensor(edges, device=e.device), half=True)
+    norm = g.area / float(N * N) ** 2
+
+    def bp(kk):
+        s, c = e.bin_power(kk, kk, norm, ids, len(edges) + 1, herm=True)
+        return (s[1:-1] / c[1:-1].double()).cpu().numpy()
+    got = {"MV": bp(kmv), "TE": bp(kone["TE"]), "EB": bp(kone["EB"])}
+    # weight x normalisation planes of the MV sum and the plain normalisations (half-plane host arrays)
+    w = q.mv_weights(ests)
+    L = q.modl_h
+    fn_mv = {XY: _full_from_half(-(L * (L + 1.) / 2.) * q.AL[XY] * q.mask_K * w[XY], N) for XY in ests}
+    fn_one = {XY: _full_from_half(-(L * (L + 1.) / 2.) * q.AL[XY] * q.mask_K, N) for XY in ("TE", "EB")}
+    kfull = {X: e.hc_to_full(k64[i]).cpu().numpy() for i, X in enumerate("TEB")}
+    del kmv, kone, k64, q
+    torch.cuda.empty_cache()
+    mo.set_workers(16)
+    try:
+        cl = {k: th.lCl(k, ml) for k in ("TT", "EE", "BB", "TE")}
+        qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)
+        bo = so.bin2D(ml, edges)
+        fo = mo.FourierCalc(shape, g.step_y, g.step_x)
+        acc = np.zeros(shape, dtype=np.complex128)
+        ref = {}
+        for XY in ests:
+            u = qr.unnormalized_ft(XY, kfull[XY[0]], kfull[XY[1]])
+            acc += fn_mv[XY] * u
+            if XY in fn_one:
+                kr = fn_one[XY] * u
+                ref[XY] = bo.bin(fo.f2power(kr, kr))[1]
+            del u
+        ref["MV"] = bo.bin(fo.f2power(acc, acc))[1]
+    finally:
+        mo.set_workers(1)
+    for key in ("MV", "TE", "EB"):
+        err = np.max(np.abs(got[key] / ref[key] - 1))
+        assert err < 1e-9, "%s at 8192^2 f64: bandpowers differ from the NumPy oracle arithmetic by %.3g" % (key, err)

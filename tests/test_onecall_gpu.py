@@ -393,3 +393,79 @@ def test_binning_in_the_divergence_launch_equals_the_separate_histogram(N, res, 
     sums, counts = e.bin_power(kap, kap, g.area / float(N * N) ** 2, ids, 21, herm=True)
     want = (sums / counts.to(torch.float64))[1:-1].cpu().numpy()
     np.testing.assert_allclose(one[1].cpu().numpy(), want, rtol=(2e-6 if prec == "f32" else 1e-11))
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_ticket_tail_stress_on_three_streams_is_bit_reproducible(prec):
+    """The last-workgroup hand-over of the fused binning tail (fft_divbin.hpp: write-through partial sums, ticket counter, no
+    device fence) under load: 3 x 3400 = 10 200 one-call moment launches on three HIP streams (three forked handles: own
+    plans, own tickets, shared read-only filters) without any host synchronisation, alternating one- and two-map calls over
+    a pool of maps.  Every lane's (n, S, C) must equal BIT FOR BIT the same launch sequence issued serially with a device
+    synchronisation after each call: a stale partial sum read by a last workgroup would change low bits of S.  The serial
+    fused moments are tied to the separate-histogram path (plan option div_bin = 0: other summation order) at 1e-13."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N, res, per_lane = 2048, 1.0, 3400
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    q0 = lensing.qest(shape, g, th, noise2d=np.full(shape, cosmology.white_noise_power(1.0)), beam2d=maps.gauss_beam(ml, 1.5),
+                      kmask=maps.mask_kspace(shape, g, lmin=300, lmax=2000), kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=3000),
+                      unlensed_equals_lensed=True, dtype=prec)
+    e0 = q0.eng
+    edges = torch.as_tensor(np.linspace(40, 2900, 20), device=e0.device)
+    ids = e0.modl_digitize(edges, half=True)
+    lanes = [q0, q0.fork(), q0.fork()]
+    for q in lanes:
+        q.bind_bins(ids, 21, g.area / float(N * N) ** 2)
+        assert q._bind_bins().lib.oa_plan_div_fused(q.eng.plan) == 1
+    pool = [e0.irfft(e0.grf_hc(31, i), scale=1.0 / N) for i in range(5)]
+
+    def acc():
+        return (torch.zeros(1, dtype=torch.int64, device=e0.device), torch.zeros(19, dtype=torch.float64, device=e0.device),
+                torch.zeros(19, 19, dtype=torch.float64, device=e0.device))
+
+    def issue(q, a, k):
+        # call k of a lane: two-map call every third time, maps walking the pool at lane-independent strides
+        if k % 3 == 2:
+            q.tt_moments2(pool[k % 5], pool[(3 * k + 1) % 5], *a)
+        else:
+            q.tt_moments(pool[(2 * k) % 5], *a)
+    # reference: the same sequences one lane after the other, with a device synchronisation after EVERY call (S and C are
+    # float sums in launch order, so the reference runs the full length too)
+    ref = []
+    for q in lanes:
+        a = acc()
+        for k in range(per_lane):
+            issue(q, a, k)
+            torch.cuda.synchronize()
+        ref.append([t.clone() for t in a])
+    # stress: three streams, round-robin issue, no synchronisation until the end
+    streams = [torch.cuda.Stream() for _ in lanes]
+    accs = [acc() for _ in lanes]
+    torch.cuda.synchronize()
+    for k in range(per_lane):
+        for q, st, a in zip(lanes, streams, accs):
+            with torch.cuda.stream(st):
+                issue(q, a, k)
+    torch.cuda.synchronize()
+    for j, (a, r) in enumerate(zip(accs, ref)):
+        assert int(a[0]) == int(r[0]) == per_lane + per_lane // 3
+        assert torch.equal(a[1], r[1]), "lane %d: S differs by %g" % (j, float((a[1] - r[1]).abs().max() / r[1].abs().max()))
+        assert torch.equal(a[2], r[2]), "lane %d: C differs" % j
+    # the serial fused moments against the separate histogram launches (another order of the float64 sums)
+    lanes[0].eng.set_option("div_bin", 0)
+    try:
+        sep = acc()
+        for k in range(60):
+            issue(lanes[0], sep, k)
+        torch.cuda.synchronize()
+    finally:
+        lanes[0].eng.set_option("div_bin", 1)
+    fus = acc()
+    for k in range(60):
+        issue(lanes[0], fus, k)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(fus[1].cpu().numpy(), sep[1].cpu().numpy(), rtol=1e-13)
+    np.testing.assert_allclose(fus[2].cpu().numpy(), sep[2].cpu().numpy(), rtol=1e-12)
