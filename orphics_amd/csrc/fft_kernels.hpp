@@ -934,6 +934,27 @@ inline void dispatch_pair_nz(int nz, F&& f) {
     }
 }
 
+// L2 warm-up of data a small workgroup will read a few microseconds later (the two gradient-leg planes of a row pair while its H
+// plane is being transformed: two waves per workgroup, nothing else hides those loads; their first-stage registers cannot be
+// held in advance -- the float kernel is at 244 of 256 VGPRs).  One 4-byte load per 128-byte line into a register that
+// touch_done() keeps reserved until the data have certainly arrived; issued BEFORE the kernel's own loads (in-order return: the
+// compiler's waits for those are then merely conservative).  No-op on the CPU emulator.
+struct L2Touch {
+    unsigned d[4] = {0u, 0u, 0u, 0u};
+    OA_HD void touch(int slot, const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_NO_L2_TOUCH)
+        asm volatile("global_load_dword %0, %1, off" : "+v"(d[slot]) : "v"(p) : "memory");
+#else
+        (void)slot; (void)p;
+#endif
+    }
+    OA_HD void done() {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_NO_L2_TOUCH)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : : "memory");
+#endif
+    }
+};
+
 template <typename T, class SEQ, int NZ, int LAY = 0, bool CHAIN = false, class Ctx>
 OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
@@ -971,6 +992,21 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     constexpr int R0 = SEQ::get(0);
     cx<T> hreg[EPT], v[EPT];
     cx<T>* twl = work + RS;
+    L2Touch warm;
+    if constexpr (!CHAIN) {
+        // the rows of Gx and Gy this workgroup reads after H: 2 (natural layout) or 2^LAY (R-layout) rows x win columns each
+        constexpr int LINE = 128 / (int)sizeof(cx<T>);
+        const int lpr = (a.win + LINE - 1) / LINE, total = (LAY ? (1 << LAY) : 2) * lpr;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = tid + it * NT;
+            if (i < total) {
+                const int rr = i / lpr, cc = (i - rr * lpr) * LINE;
+                warm.touch(2 * it, gxp + (r0 + rr) * a.pitch + cc);
+                warm.touch(2 * it + 1, gyp + (r0 + rr) * a.pitch + cc);
+            }
+        }
+    }
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
     if constexpr (CHAIN) {
@@ -1027,6 +1063,7 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * scale;
+    warm.done();
     ctx.sync();
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? gyp : gxp;
@@ -1267,6 +1304,44 @@ OA_HD void col_pipeline_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, i
         constexpr int ll = (n == 2) ? l0 : ((n == 3) ? l1 : l2);
         stage_in<T, RL, false, false>(s, v, tid, NT, logL, logC, 0, ll, tw, logTw, NoLoad{});
     }
+}
+
+// ---- first-stage taps of a COLUMN tile, loads only (what stage_in<.., SRC_G = true> gathers): issued at the very top of the
+//      single-pass kernels, before the twiddle tables are filled, so that the tile's global latency overlaps the table fill and --
+//      for the second plane of col_div_body -- the whole transform of the first
+template <typename T, int R0, class Ld>
+OA_HD void col_first_taps(cx<T>* v, int tid, int NT, int logL, int logC, const Ld& ld) {
+    constexpr int LR0 = Log2c<R0>::v, NB = EPT / R0;
+    const int logLR = logL - LR0;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT, c = b & ((1 << logC) - 1), j = b >> logC;
+#pragma unroll
+        for (int t = 0; t < R0; ++t) v[u * R0 + t] = ld.template get<T>(j + (t << logLR), c);
+    }
+}
+// the forward pipeline from first-stage taps already in registers to the last stage's registers (col_pipeline_to_regs without
+// its loads): v[u*RL + t] = bin (base_u + t*Ns) on return
+template <typename T, class SEQ, class Ctx>
+OA_HD void col_pipeline_regs_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logC, const cx<T>* tw, int logTw) {
+    constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
+    constexpr int n = SEQ::n, R0 = SEQ::get(0), RL = SEQ::get(n - 1);
+    static_assert(n >= 2, "col_pipeline_regs_to_regs: at least two stages");
+#pragma unroll
+    for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
+    stage_out<T, R0, false, false>(s, v, tid, NT, logL, logC, 0, 0, NoStore{});
+    ctx.sync();
+    constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
+    if constexpr (n >= 3) {
+        stage<T, SEQ::r1, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l0, tw, logTw, NoLoad{}, NoStore{});
+        ctx.sync();
+    }
+    if constexpr (n >= 4) {
+        stage<T, SEQ::r2, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l1, tw, logTw, NoLoad{}, NoStore{});
+        ctx.sync();
+    }
+    constexpr int ll = (n == 2) ? l0 : ((n == 3) ? l1 : l2);
+    stage_in<T, RL, false, false>(s, v, tid, NT, logL, logC, 0, ll, tw, logTw, NoLoad{});
 }
 
 // ===========================================================================
@@ -1690,12 +1765,18 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
     if (ncols > (1 << logC)) ncols = 1 << logC;
     cx<T> va[EPT], vb[EPT];
     cx<T>* twl = s + (1 << (logL + logC));
-    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
-    ctx.sync();
     const long zmap = ctx.bid_z();
     const long imo = zmap * a.in_moff, omo = zmap * a.out_moff;
     const ColLoad<T> la{a.A + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     const ColLoad<T> lb{a.B + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
+    if constexpr (n >= 3) {
+        // SINGLE-PASS launches (one workgroup per CU: nothing else hides a load): the first-stage taps of BOTH product planes are
+        // requested before anything else -- the twiddle-table fill and the whole transform of A run under B's latency
+        col_first_taps<T, SEQ::get(0)>(va, tid, NT, logL, logC, la);
+        col_first_taps<T, SEQ::get(0)>(vb, tid, NT, logL, logC, lb);
+    }
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    ctx.sync();
     if constexpr (n == 2) {
         // both tiles' global loads are issued back to back (twice the bytes in flight per workgroup) before either
         // plane goes through LDS
@@ -1710,6 +1791,10 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
         stage_out<T, R0, false, false>(s, vb, tid, NT, logL, logC, 0, 0, NoStore{});
         ctx.sync();
         stage_in<T, RL, false, false>(s, vb, tid, NT, logL, logC, 0, l0, twl, logL, NoLoad{});
+    } else if constexpr (n >= 3) {
+        col_pipeline_regs_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL);
+        ctx.sync();
+        col_pipeline_regs_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL);
     } else {
         col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL, la);
         ctx.sync();

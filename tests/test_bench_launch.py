@@ -83,9 +83,9 @@ def test_bench_config_mc_two_ranks_rehearsal(windowed):
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["nsims"] == 61 and d["check"]["sims_counted"] == 61 and d["check"]["stacked"] == 61
     assert [x["sims"] for x in sorted(d["per_rank"], key=lambda x: x["rank"])] == [30, 31]      # remainder on the last rank (mpi.py:81-83)
-    assert d["value"] > 0 and d["check"]["max_abs_pull"] < 6.0
-    if not windowed:
-        assert d["check"]["max_rel_dev_vs_analytic_N0"] < 0.5
+    assert d["value"] > 0
+    if not windowed:      # (a tapered 1024^2 patch couples modes: its debiased N0 is not the analytic full-plane N_L)
+        assert d["check"]["max_abs_pull"] < 6.0 and d["check"]["max_rel_dev_vs_analytic_N0"] < 0.5
 
 
 @pytest.mark.gpu
