@@ -196,8 +196,10 @@ int oa_plan_div_fused(const oa_plan* p);
  *   OA_OPT_MV_CHAIN    oa_qe_mv: estimator chains -- an estimator's pieces summed in real space inside one row-stage launch
  *                      (default 1); 0: the k-th piece of every estimator per launch, accumulated in Fourier space
  *   OA_OPT_DIV_BIN     moment entries: radial binning + moment update in the tail of the single-pass divergence launch
- *                      (default 1, where the geometry has that kernel: oa_plan_div_fused); 0: the separate histogram launches */
-enum { OA_OPT_MC_BATCH = 1, OA_OPT_MV_BATCH = 2, OA_OPT_MV_ROWBATCH = 3, OA_OPT_MV_CHAIN = 4, OA_OPT_DIV_BIN = 5 };
+ *                      (default 1, where the geometry has that kernel: oa_plan_div_fused); 0: the separate histogram launches
+ *   OA_OPT_WIN_FUSED   oa_mc_run_windowed: inverse columns, then C2R x window -> R2C of every row in ONE kernel (default 1: the
+ *                      real map exists in LDS only); 0: C2R with the window at its store, real map in HBM, from-map estimator path */
+enum { OA_OPT_MC_BATCH = 1, OA_OPT_MV_BATCH = 2, OA_OPT_MV_ROWBATCH = 3, OA_OPT_MV_CHAIN = 4, OA_OPT_DIV_BIN = 5, OA_OPT_WIN_FUSED = 6 };
 int oa_plan_set_option(oa_plan* p, int option, int value);
 int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, void* stream);
 void* oa_plan_kappa(oa_plan* p);

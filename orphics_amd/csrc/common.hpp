@@ -110,6 +110,9 @@ int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* 
                        int rband, long pl, hipStream_t st, int stages = 7, int my = 0, int lr = 0);
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my = 0);
+// windowed simulation front end: hc spectrum -> inverse columns -> fused C2R x window -> R2C rows onto the plan's scratch plane
+// (then qe_map_legs_cols_w with stages = 6, lr = 0)
+int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st);
 // one filtered field (subset 1: H plane into a; 2: gradient pair into a, b), inverse pass 1 only; then pass 2 over a pool of planes
 int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* b, int subset, int width, int rband, long pl,
                      hipStream_t st, int my = 0);

@@ -43,6 +43,17 @@ __global__ __launch_bounds__(128, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)) void
     GpuCtx c{oa_dyn_smem};
     row_r2c_rs_body<T, 11, 2, PF>(c, a);
 }
+// 16384-point rows (16384^2 maps: BASELINE config 5), <= 512 columns kept, R = 8 column butterfly on top: the same body on 512
+// threads per row (float64: 150 KB of LDS, one workgroup per CU -- the prefetch order is what overlaps its loads with its
+// arithmetic; float: 75 KB, two per CU when the registers allow)
+#ifndef OA_RS8192_F32_OCC
+#define OA_RS8192_F32_OCC 2
+#endif
+template <typename T, bool PF>
+__global__ __launch_bounds__(512, (sizeof(T) == 8 ? 2 : OA_RS8192_F32_OCC)) void row_r2c_rs8192_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_rs_body<T, 13, 3, PF>(c, a);
+}
 
 // single-pass column stage of the R-split path: [My][C] tile, all threads forward, R groups inverse (fft_fband.hpp)
 template <typename T, class SEQF, int LR, int LOGC>
@@ -206,6 +217,7 @@ struct HipLauncher {
                 case ROW_R2C: row_mode<T, ROW_R2C, S>(grid, nt, smem, a); break;
                 case ROW_C2R: row_mode<T, ROW_C2R, S>(grid, nt, smem, a); break;
                 case ROW_C2C_F: row_mode<T, ROW_C2C_F, S>(grid, nt, smem, a); break;
+                case ROW_WIN: row_mode<T, ROW_WIN, S>(grid, nt, smem, a); break;
                 default: row_mode<T, ROW_C2C_I, S>(grid, nt, smem, a); break;
             }
         });
@@ -238,12 +250,14 @@ struct HipLauncher {
     bool row_rs4096(const RowArgs<T>& a) {
         static const bool off = exp_env("OA_NO_RS4096") != nullptr;
         static const int pfenv = [] { const char* e = exp_env("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
-        const bool l12 = a.logL == 12 && a.wcols <= 512 && a.logTw >= 13, l11 = a.logL == 11 && a.wcols <= 256 && a.logTw >= 12;
-        if (off || rc || a.lr != 2 || !(l12 || l11)) return false;
+        const bool l12 = a.lr == 2 && a.logL == 12 && a.wcols <= 512 && a.logTw >= 13, l11 = a.lr == 2 && a.logL == 11 && a.wcols <= 256 && a.logTw >= 12;
+        const bool l13 = a.lr == 3 && a.logL == 13 && a.wcols <= 512 && a.logTw >= 14;      // 16384-point rows, R = 8
+        if (off || rc || !(l12 || l11 || l13)) return false;
         const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && l12);     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
-        const size_t smem = l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>();
-        const int NTr = l12 ? RS4096_NT : 128;
-        auto kern = l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
+        const size_t smem = l13 ? rs_lds_bytes<T, 13>() : (l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>());
+        const int NTr = l13 ? 512 : (l12 ? RS4096_NT : 128);
+        auto kern = l13 ? (nopf ? row_r2c_rs8192_kernel<T, false> : row_r2c_rs8192_kernel<T, true>)
+                  : l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
                         : (nopf ? row_r2c_rs2048_kernel<T, false> : row_r2c_rs2048_kernel<T, true>);
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         std::string err;
@@ -282,6 +296,7 @@ struct HipLauncher {
         else if (gy == 4 && logMy == 10 && !narrow) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10>, dim3(gx, gy, gz), nt, smem, a);
         else if (gy == 4 && logMy == 11) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11 - 1>, dim3(gx, gy, gz), nt, smem, a);
         else if (gy == 4 && logMy == 10) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10 - 1>, dim3(gx, gy, gz), nt, smem, a);
+        else if (gy == 8 && logMy == 11 && !narrow) go(col_fband_kernel<T, Seq<16, 8, 16>, 3, lc11>, dim3(gx, gy, gz), nt, smem, a);   // 16384 rows on the 2048-row grid
         else rc = fail("fft: unsupported R-split column stage");
     }
     template <typename T>
@@ -319,7 +334,10 @@ struct HipLauncher {
                         else if (!rc) rc = fail("fft: estimator chains: unsupported row grid");
                     } else
                     if (a.lr == 2) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 2>, dim3(grid), nt, smem, a);
-                    else if (a.lr == 0) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 0>, dim3(grid), nt, smem, a);
+                    else if (a.lr == 3) {
+                        if constexpr (seq_logl<S>() == 11) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 3>, dim3(grid), nt, smem, a);
+                        else if (!rc) rc = fail("fft: the R = 8 layout of the pair row stage is built for 2048-point row grids");
+                    } else if (a.lr == 0) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 0>, dim3(grid), nt, smem, a);
                     else if (!rc) rc = fail("fft: unsupported R-layout of the pair row stage");
                 });
             } else if (!rc) rc = fail("fft: unsupported row grid for the pair row stage");
@@ -671,6 +689,24 @@ int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* 
                        int rband, long pl, hipStream_t st, int stages, int my, int lr) {
     return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr)
                               : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr);
+}
+// Windowed simulation front end (oa_mc_run_windowed): full-plane hc spectrum -> inverse column transform (into `cols_tmp`, a full
+// hc plane) -> ONE fused row pass C2R x window -> R2C (ROW_WIN) that leaves the row-transformed windowed map on the plan's first
+// scratch plane at the compact pitch `pl`, active columns only -- exactly what the row R2C of qe_map_legs_cols_w (stage 1) leaves
+// there, so the caller continues with stages 2 | 4.  The real map never exists in HBM.
+template <typename T>
+static int windowed_rows_impl(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st) {
+    const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
+    if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
+    HipLauncher q{st};
+    auto f = view<T>(p);
+    f.cols(q, (const cx<T>*)hc_in, p->kp, (cx<T>*)cols_tmp, p->kp, p->nx / 2 + 1, true, (T)1);
+    f.rows(q, ROW_WIN, cols_tmp, p->kp, p->scratch, pl > 0 ? pl : p->kp, (T)scale, f.clampw(width), window);
+    return q.rc;
+}
+int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st) {
+    return p->dtype == OA_F32 ? windowed_rows_impl<float>(p, hc_in, cols_tmp, window, width, pl, scale, st)
+                              : windowed_rows_impl<double>(p, hc_in, cols_tmp, window, width, pl, scale, st);
 }
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my) {

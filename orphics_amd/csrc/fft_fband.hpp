@@ -66,39 +66,13 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     cx<T>* twl = s + (1 << (logL + LOGC));                   // forward stage twiddles (W_My)
     cx<T>* twq = twl + tw_lds_size(logL);                    // inverse stage twiddles (W_Mq)
     cx<T>* ti = twq + tw_lds_size(logMq);                    // W_My^(k1 y_lo), y_lo < Mq
-    const long zmap = ctx.bid_z();
-    const ColLoad<T> ld{a.in + zmap * a.in_moff + (long)k1 * a.kplane + c0, (unsigned)a.pitch, ncols, false};
-    // One workgroup per CU: nothing else hides a load.  Everything this workgroup reads from global memory is requested up
-    // front -- the tile's first-stage taps, then the filter values of the two kept bins of each butterfly (they depend on the
-    // thread's position only, not on the transform) -- so the table fill and the forward transform run under their latency
-    // instead of three dependent trips (tables, tile, filters) in a row.
-    col_first_taps<T, SEQF::get(0)>(gv, tid, NT, logL, LOGC, ld);
-    T pfg[2 * NB], pfh[2 * NB], ply[2 * NB], plx[NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        const int b = tid + u * NT;
-        const int c = b & (C - 1), j = b >> LOGC;
-        const bool ok = c < ncols;
-        plx[u] = ok ? a.lxd[c0 + c] : (T)0;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int k2 = side ? j + (RL - 1) * Ns : j;
-            const int yf = k1 + R * k2;
-            bool live = ok;
-            if (a.rband) live = ok && !(yf >= a.rband && yf <= a.ny_full - a.rband);
-            T fg = 0, fh = 0, ly = 0;
-            if (live) {
-                const long fi = (long)yf * a.fpitch + (c0 + c);
-                fg = a.FG[fi]; fh = a.FH[fi]; ly = a.lyd[yf];
-            }
-            pfg[2 * u + side] = fg; pfh[2 * u + side] = fh; ply[2 * u + side] = ly;
-        }
-    }
     tw_lds_fill<T>(ctx, twl, a.tw, logL, logL, NT);
     tw_lds_fill<T>(ctx, twq, a.tw, logL, logMq, NT);
     for (int i = tid; i < Mq; i += NT) ti[i] = a.tw[((unsigned)k1 * (unsigned)i) & (unsigned)(L - 1)];
     ctx.sync();
-    col_pipeline_regs_to_regs<T, SEQF>(ctx, s, gv, tid, NT, LOGC, twl, logL);
+    const long zmap = ctx.bid_z();
+    const ColLoad<T> ld{a.in + zmap * a.in_moff + (long)k1 * a.kplane + c0, (unsigned)a.pitch, ncols, false};
+    col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, LOGC, twl, logL, ld);
     ctx.sync();                                              // every LDS read of the forward precedes the leg buffers' writes
     cx<T>* bh = s;
     cx<T>* bx = s + (Mq << LOGC);
@@ -107,15 +81,26 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
         const int c = b & (C - 1), j = b >> LOGC;            // j < Ns = Mq / 2
+        const bool ok = c < ncols;
+        const T lx = ok ? a.lxd[c0 + c] : (T)0;
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const cx<T> x = side ? gv[u * RL + RL - 1] : gv[u * RL];
-            const int k2p = side ? j + Ns : j;               // place of bin k2 (= j or j + (RL - 1) Ns) in the Mq-point coarse spectrum of this k1
-            const cx<T> g = mul_pi(x * pfg[2 * u + side]);
+            const int k2 = side ? j + (RL - 1) * Ns : j;     // bin of the My-point forward transform
+            const int k2p = side ? j + Ns : j;               // its place in the Mq-point coarse spectrum of this k1
+            const int yf = k1 + R * k2;                      // row of the full-resolution grid
+            bool live = ok;
+            if (a.rband) live = ok && !(yf >= a.rband && yf <= a.ny_full - a.rband);
+            T fg = 0, fh = 0, ly = 0;
+            if (live) {
+                const long fi = (long)yf * a.fpitch + (c0 + c);
+                fg = a.FG[fi]; fh = a.FH[fi]; ly = a.lyd[yf];
+            }
+            const cx<T> g = mul_pi(x * fg);
             const int at = (k2p << LOGC) + c;
-            bh[at] = swp(x * pfh[2 * u + side]);             // inverse transform = forward transform of the swapped data
-            bx[at] = swp(g * plx[u]);
-            by[at] = swp(g * ply[2 * u + side]);
+            bh[at] = swp(x * fh);                            // inverse transform = forward transform of the swapped data
+            bx[at] = swp(g * lx);
+            by[at] = swp(g * ly);
         }
     }
     ctx.sync();

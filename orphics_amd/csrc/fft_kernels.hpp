@@ -35,7 +35,9 @@ constexpr int EPT = 16;        // complex points per thread per stage
 #endif
 constexpr int COL_LOGC = OA_COL_LOGC;  // log2 columns per column tile (compile-time: index math folds to masks/shifts)
 
-enum RowMode { ROW_R2C = 0, ROW_C2R = 1, ROW_C2C_F = 2, ROW_C2C_I = 3 };
+// ROW_WIN: half-complex rows -> C2R -> x real-space window -> R2C -> half-complex rows in ONE pass: the real rows exist in LDS only
+// (oa_mc_run_windowed: every simulated map is multiplied by the apodisation taper before its transform, maps.py:1350-1361)
+enum RowMode { ROW_R2C = 0, ROW_C2R = 1, ROW_C2C_F = 2, ROW_C2C_I = 3, ROW_WIN = 4 };
 
 // ---- constant twiddles W16^k = exp(-2 pi i k / 16), k = 0..7 -------------
 template <typename T>
@@ -526,6 +528,24 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
                                                 RowLoadOnce<T>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
 #endif
         r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale, false, a.wcols);
+    } else if constexpr (MODE == ROW_WIN) {
+        // inverse packed transform with its result left in LDS (natural order, swapped: the inverse runs as a forward transform of
+        // the swapped data), window multiply in place, forward packed transform from LDS, untangle of the kept columns.  Same
+        // arithmetic as ROW_C2R (with `mul`) followed by ROW_R2C; the real rows never leave the CU.
+        constexpr int L = 1 << logL;
+        const cx<T>* win = reinterpret_cast<const cx<T>*>(a.mul) + r0 * (long)L;      // real plane: L packed pairs per row, no padding
+        c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, 0x7fffffff);
+        ctx.sync();
+        fft_pipeline<T, true, false, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{}, NoStore{});
+        for (int i = tid; i < (C << logL); i += NT) {
+            const int c = i >> logL, n = i & (L - 1);
+            const cx<T> v = swp(s[lds_addr<true>(n, c, 0, RS)]) * a.scale;
+            const cx<T> m = win[(unsigned)c * (unsigned)L + (unsigned)n];
+            s[lds_addr<true>(n, c, 0, RS)] = mk<T>(v.x * m.x, v.y * m.y);
+        }
+        ctx.sync();
+        fft_pipeline<T, true, false, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{}, NoStore{});
+        r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, (T)1, false, a.wcols);
     } else {
         c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.wcols);
         ctx.sync();
@@ -860,10 +880,35 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
 // sum_k1 W_R^(-k1 y_hi) B[k1][y_lo] -- the last radix-R butterfly of the inverse column transform, taken here at the load;
 // the pair (y_hi = 2 p, 2 p + 1) of group y_lo: with s02 = B0 + B2, d02 = B0 - B2, s13 = B1 + B3, d13 = B1 - B3 and
 // sg = +1 (p = 0) / -1 (p = 1):  a0 = s02 + sg s13,  a1 = d02 + sg i d13.
+// multiply by i^q (q uniform across the workgroup)
+template <typename T> OA_HD cx<T> rot_i(cx<T> x, int q) {
+    switch (q & 3) {
+        case 0: return x;
+        case 1: return mk<T>(-x.y, x.x);
+        case 2: return mk<T>(-x.x, -x.y);
+        default: return mk<T>(x.y, -x.x);
+    }
+}
+// LAY = 3 (R = 8: 16384-row maps on the 2048-row column grid): the plane holds B[k1][y_lo] at row 8 y_lo + k1; workgroup p < 4 of
+// group y_lo forms the rows y_hi = 2 p and 2 p + 1:  a0 = sum_k W_8^(-2 p k) b_k,  a1 = sum_k W_8^(-(2 p + 1) k) b_k.  With
+// s_k = b_k + b_(k+4), d_k = b_k - b_(k+4) (k < 4):  a0 = (s0 + i^(2p) s2) + i^p (s1 + i^(2p) s3),
+// a1 = (d0 + i^(2p+1) d2) + th (d1 + i^(2p+1) d3),  th = exp(+i pi (2 p + 1) / 4): one complex product per tap and row pair.
 template <typename T, int LAY>
-OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, int idx, cx<T>& a0, cx<T>& a1) {
-    static_assert(LAY == 0 || LAY == 2, "pair_rows_at: natural layout or R = 4");
+OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, int idx, cx<T>& a0, cx<T>& a1, int p = 0) {
+    static_assert(LAY == 0 || LAY == 2 || LAY == 3, "pair_rows_at: natural layout, R = 4 or R = 8");
     if (LAY == 0) { a0 = row0[idx]; a1 = row1[idx]; return; }
+    if (LAY == 3) {
+        cx<T> b[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) b[k] = row0[k * pitch + idx];
+        const cx<T> s0 = b[0] + b[4], s1 = b[1] + b[5], s2 = b[2] + b[6], s3 = b[3] + b[7];
+        const cx<T> d0 = b[0] - b[4], d1 = b[1] - b[5], d2 = b[2] - b[6], d3 = b[3] - b[7];
+        a0 = (s0 + rot_i(s2, 2 * p)) + rot_i(s1 + rot_i(s3, 2 * p), p);
+        const T h = (T)0.70710678118654752440L;
+        const cx<T> th = mk<T>((p == 0 || p == 3) ? h : -h, (p < 2) ? h : -h);
+        a1 = (d0 + rot_i(d2, 2 * p + 1)) + th * (d1 + rot_i(d3, 2 * p + 1));
+        return;
+    }
     const cx<T> b0 = row0[idx], b1 = row0[pitch + idx], b2 = row0[2 * pitch + idx], b3 = row0[3 * pitch + idx];
     const cx<T> s02 = b0 + b2, d02 = b0 - b2, s13 = (b1 + b3) * sg, d13 = (b1 - b3) * sg;
     a0 = s02 + s13;
@@ -872,7 +917,7 @@ OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, 
 
 template <typename T, class SEQ, int NZ, int LAY = 0, class Ctx>
 OA_HD void pair_inverse_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int RS, const cx<T>* tw,
-                                const cx<T>* row0, const cx<T>* row1, int win, long pitch = 0, T sg = (T)1) {
+                                const cx<T>* row0, const cx<T>* row1, int win, long pitch = 0, T sg = (T)1, int p = 0) {
     constexpr int n = SEQ::n;
     constexpr int logM = seq_total_log<SEQ>();
     constexpr int R = SEQ::rget(0), LR = Log2c<R>::v, NB = EPT / R;
@@ -890,7 +935,7 @@ OA_HD void pair_inverse_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, i
                     const bool ok = nn < win;
                     const int idx = ok ? nn : 0;    // unconditional loads from a valid address, masked afterwards
                     cx<T> a0, a1;
-                    pair_rows_at<T, LAY>(row0, row1, pitch, sg, idx, a0, a1);
+                    pair_rows_at<T, LAY>(row0, row1, pitch, sg, idx, a0, a1, p);
                     const cx<T> z = add_pi(a0, a1);
                     w[u * R + t] = ok ? swp(z) : mk<T>((T)0, (T)0);
                 } else if (t >= R - NZ) {            // high side: Z[n] = conj X0[M-n] + i conj X1[M-n], M - n < win
@@ -898,7 +943,7 @@ OA_HD void pair_inverse_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, i
                     const bool ok = m < win;
                     const int idx = ok ? m : 0;
                     cx<T> a0, a1;
-                    pair_rows_at<T, LAY>(row0, row1, pitch, sg, idx, a0, a1);
+                    pair_rows_at<T, LAY>(row0, row1, pitch, sg, idx, a0, a1, p);
                     const cx<T> z = mk<T>(a0.x + a1.y, a1.x - a0.y);
                     w[u * R + t] = ok ? swp(z) : mk<T>((T)0, (T)0);
                 } else {
@@ -934,27 +979,6 @@ inline void dispatch_pair_nz(int nz, F&& f) {
     }
 }
 
-// L2 warm-up of data a small workgroup will read a few microseconds later (the two gradient-leg planes of a row pair while its H
-// plane is being transformed: two waves per workgroup, nothing else hides those loads; their first-stage registers cannot be
-// held in advance -- the float kernel is at 244 of 256 VGPRs).  One 4-byte load per 128-byte line into a register that
-// touch_done() keeps reserved until the data have certainly arrived; issued BEFORE the kernel's own loads (in-order return: the
-// compiler's waits for those are then merely conservative).  No-op on the CPU emulator.
-struct L2Touch {
-    unsigned d[4] = {0u, 0u, 0u, 0u};
-    OA_HD void touch(int slot, const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_NO_L2_TOUCH)
-        asm volatile("global_load_dword %0, %1, off" : "+v"(d[slot]) : "v"(p) : "memory");
-#else
-        (void)slot; (void)p;
-#endif
-    }
-    OA_HD void done() {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(OA_NO_L2_TOUCH)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]) : : "memory");
-#endif
-    }
-};
-
 template <typename T, class SEQ, int NZ, int LAY = 0, bool CHAIN = false, class Ctx>
 OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T>* work = reinterpret_cast<cx<T>*>(ctx.smem());
@@ -978,7 +1002,17 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     // rows y_lo + Mq (2 p), y_lo + Mq (2 p + 1) of the field, Mq = rows / 4, which is where its products go.
     long r0 = wg * 2, ra = wg * 2, rb = wg * 2 + 1;
     T sg = (T)1;
-    if (LAY > 0) {
+    int pp = 0;
+    if (LAY == 3) {
+        // R = 8: the FOUR workgroups of a group read the same eight rows: workgroups b, b + 8, b + 16, b + 24 of a block of 32 (same XCD)
+        const long blk = wg & ~31L;
+        const int r = (int)(wg & 31);
+        pp = r >> 3;
+        const long ylo = (blk >> 2) + (r & 7), mq = a.nrows >> 3;
+        r0 = ylo << 3;
+        ra = ylo + mq * (2 * pp);
+        rb = ra + mq;
+    } else if (LAY > 0) {
         // the two workgroups of a group read the same four rows: they are workgroups b and b + 8 of a block of 16 -- the same
         // XCD under the round-robin dispatch, a few slots apart -- so the second read is an L2 hit, not a second trip over the fabric
         const long blk = wg & ~15L;
@@ -992,21 +1026,6 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     constexpr int R0 = SEQ::get(0);
     cx<T> hreg[EPT], v[EPT];
     cx<T>* twl = work + RS;
-    L2Touch warm;
-    if constexpr (!CHAIN) {
-        // the rows of Gx and Gy this workgroup reads after H: 2 (natural layout) or 2^LAY (R-layout) rows x win columns each
-        constexpr int LINE = 128 / (int)sizeof(cx<T>);
-        const int lpr = (a.win + LINE - 1) / LINE, total = (LAY ? (1 << LAY) : 2) * lpr;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int i = tid + it * NT;
-            if (i < total) {
-                const int rr = i / lpr, cc = (i - rr * lpr) * LINE;
-                warm.touch(2 * it, gxp + (r0 + rr) * a.pitch + cc);
-                warm.touch(2 * it + 1, gyp + (r0 + rr) * a.pitch + cc);
-            }
-        }
-    }
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logM, NT);
     ctx.sync();
     if constexpr (CHAIN) {
@@ -1059,16 +1078,15 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
         }
         return;
     }
-    pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, hreg, tid, NT, RS, twl, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg);
+    pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, hreg, tid, NT, RS, twl, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
     for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * scale;
-    warm.done();
     ctx.sync();
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? gyp : gxp;
         cx<T>* dst = leg ? pyp : pxp;
-        pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg);
+        pair_inverse_to_regs<T, SEQ, NZ, LAY>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp);
         // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
 #pragma unroll
         for (int t = 0; t < EPT; ++t) v[t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
@@ -1304,44 +1322,6 @@ OA_HD void col_pipeline_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, i
         constexpr int ll = (n == 2) ? l0 : ((n == 3) ? l1 : l2);
         stage_in<T, RL, false, false>(s, v, tid, NT, logL, logC, 0, ll, tw, logTw, NoLoad{});
     }
-}
-
-// ---- first-stage taps of a COLUMN tile, loads only (what stage_in<.., SRC_G = true> gathers): issued at the very top of the
-//      single-pass kernels, before the twiddle tables are filled, so that the tile's global latency overlaps the table fill and --
-//      for the second plane of col_div_body -- the whole transform of the first
-template <typename T, int R0, class Ld>
-OA_HD void col_first_taps(cx<T>* v, int tid, int NT, int logL, int logC, const Ld& ld) {
-    constexpr int LR0 = Log2c<R0>::v, NB = EPT / R0;
-    const int logLR = logL - LR0;
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-        const int b = tid + u * NT, c = b & ((1 << logC) - 1), j = b >> logC;
-#pragma unroll
-        for (int t = 0; t < R0; ++t) v[u * R0 + t] = ld.template get<T>(j + (t << logLR), c);
-    }
-}
-// the forward pipeline from first-stage taps already in registers to the last stage's registers (col_pipeline_to_regs without
-// its loads): v[u*RL + t] = bin (base_u + t*Ns) on return
-template <typename T, class SEQ, class Ctx>
-OA_HD void col_pipeline_regs_to_regs(Ctx& ctx, cx<T>* s, cx<T>* v, int tid, int NT, int logC, const cx<T>* tw, int logTw) {
-    constexpr int logL = Log2x<SEQ::r0>::v + Log2x<SEQ::r1>::v + Log2x<SEQ::r2>::v + Log2x<SEQ::r3>::v;
-    constexpr int n = SEQ::n, R0 = SEQ::get(0), RL = SEQ::get(n - 1);
-    static_assert(n >= 2, "col_pipeline_regs_to_regs: at least two stages");
-#pragma unroll
-    for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
-    stage_out<T, R0, false, false>(s, v, tid, NT, logL, logC, 0, 0, NoStore{});
-    ctx.sync();
-    constexpr int l0 = Log2x<SEQ::r0>::v, l1 = l0 + Log2x<SEQ::r1>::v, l2 = l1 + Log2x<SEQ::r2>::v;
-    if constexpr (n >= 3) {
-        stage<T, SEQ::r1, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l0, tw, logTw, NoLoad{}, NoStore{});
-        ctx.sync();
-    }
-    if constexpr (n >= 4) {
-        stage<T, SEQ::r2, false, false, false>(ctx, s, tid, NT, logL, logC, 0, l1, tw, logTw, NoLoad{}, NoStore{});
-        ctx.sync();
-    }
-    constexpr int ll = (n == 2) ? l0 : ((n == 3) ? l1 : l2);
-    stage_in<T, RL, false, false>(s, v, tid, NT, logL, logC, 0, ll, tw, logTw, NoLoad{});
 }
 
 // ===========================================================================
@@ -1765,18 +1745,12 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
     if (ncols > (1 << logC)) ncols = 1 << logC;
     cx<T> va[EPT], vb[EPT];
     cx<T>* twl = s + (1 << (logL + logC));
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
+    ctx.sync();
     const long zmap = ctx.bid_z();
     const long imo = zmap * a.in_moff, omo = zmap * a.out_moff;
     const ColLoad<T> la{a.A + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
     const ColLoad<T> lb{a.B + imo + g * a.in_gs * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, false};
-    if constexpr (n >= 3) {
-        // SINGLE-PASS launches (one workgroup per CU: nothing else hides a load): the first-stage taps of BOTH product planes are
-        // requested before anything else -- the twiddle-table fill and the whole transform of A run under B's latency
-        col_first_taps<T, SEQ::get(0)>(va, tid, NT, logL, logC, la);
-        col_first_taps<T, SEQ::get(0)>(vb, tid, NT, logL, logC, lb);
-    }
-    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
-    ctx.sync();
     if constexpr (n == 2) {
         // both tiles' global loads are issued back to back (twice the bytes in flight per workgroup) before either
         // plane goes through LDS
@@ -1791,10 +1765,6 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
         stage_out<T, R0, false, false>(s, vb, tid, NT, logL, logC, 0, 0, NoStore{});
         ctx.sync();
         stage_in<T, RL, false, false>(s, vb, tid, NT, logL, logC, 0, l0, twl, logL, NoLoad{});
-    } else if constexpr (n >= 3) {
-        col_pipeline_regs_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL);
-        ctx.sync();
-        col_pipeline_regs_to_regs<T, SEQ>(ctx, s, vb, tid, NT, logC, twl, logL);
     } else {
         col_pipeline_to_regs<T, SEQ>(ctx, s, va, tid, NT, logC, twl, logL, la);
         ctx.sync();

@@ -59,7 +59,7 @@ struct Fft2dPlan {
               int wcols = 0x7fffffff, const void* mul = nullptr) const {
         RowArgs<T> a{};
         a.mul = mul;
-        const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R);
+        const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R || mode == ROW_WIN);
         a.logL = real_mode ? logNx - 1 : logNx;
         const int L = 1 << a.logL;
         int C = 4096 / L;
@@ -85,8 +85,10 @@ struct Fft2dPlan {
         if (my <= 0) return false;
         static const bool off = exp_env("OA_NO_RSPLIT") != nullptr;        // A/B switch
         const int logMy = ilog2(my), L = 1 << (logNx - 1);
-        return !off && is_pow2(my) && logNy - logMy == 2 && (logMy == 10 || logMy == 11) && logNx >= 11 && logNx <= 14 && wl <= L / 4 &&
-               wl <= RS_MAXS * (L / EPT);
+        if (off || !is_pow2(my)) return false;
+        // R = 8: 16384^2 maps on the 2048-row column grid (row_r2c_rs_body<T, 13, 3>: 16384-point rows, <= 512 kept columns)
+        if (logNy - logMy == 3) return logMy == 11 && logNx == 14 && wl <= 512;
+        return logNy - logMy == 2 && (logMy == 10 || logMy == 11) && logNx >= 11 && logNx <= 14 && wl <= L / 4 && wl <= RS_MAXS * (L / EPT);
     }
     template <class Launcher>
     void rows_rsplit(Launcher& q, const void* in, void* out, long out_pitch, long kplane, int wcols, int my) const {

@@ -21,42 +21,71 @@
 namespace oa {
 
 // Row lengths: LOGL = 12 (8192-point rows, 256 threads = 4 waves per row, sub-transforms of 256 = 16 x 16 points, <= 512
-// columns kept) and LOGL = 11 (4096-point rows, 128 threads = 2 waves, sub-transforms of 128 = 16 x 8 points: a lane finishes
-// two of the 16 eight-point butterflies; <= 256 columns kept).  S = L / 16 = threads per row = points per sub-transform.
+// columns kept), LOGL = 11 (4096-point rows, 128 threads = 2 waves, sub-transforms of 128 = 16 x 8 points: a lane finishes
+// two of the 16 eight-point butterflies; <= 256 columns kept) and LOGL = 13 (16384-point rows -- BASELINE config 5 --, 512
+// threads = 8 waves, sub-transforms of 512 = 16 x 32 points: a PAIR of lanes finishes one 32-point butterfly, each lane the
+// 16-point transform of its even / odd samples, pruned to the 4 kept bins; the two halves meet as a sum of two exchange entries
+// at the untangle; <= 512 columns kept, one per thread).  S = L / 16 = threads per row = points per sub-transform.
+// Column butterfly on top: R = 4 (LR = 2: two radix-2 levels, three live values per column) or R = 8 (LR = 3, 16384^2 maps on the
+// 2048-row column grid: eight running sums per column -- one column per thread there).
 constexpr int RS4096_NT = 256;
 template <int LOGL> constexpr int rs_nt() { return (1 << LOGL) / 16; }
+template <int LOGL> constexpr int rs_ncol() { return LOGL == 13 ? 1 : 2; }          // kept columns per thread
+template <int LOGL> constexpr int rs_twn() { return LOGL == 13 ? 192 : 128; }       // entries reserved for the two-level W_L table
 #ifndef OA_RS4096_PFH
 #define OA_RS4096_PFH 16
 #endif
+#ifndef OA_RS8192_PFH
+#define OA_RS8192_PFH 8      // (float64, 16384-point rows: all 16 taps across the first sub-transform stage spill 14 registers)
+#endif
 // sub-transform pitch in LDS: S points plus a pad chosen so that the sub-transforms one LDS instruction's lane group spans
-// start on different banks (ds_read_b64: 32 lanes, ds_read_b128: 16 lanes; checked case by case in DESIGN section 3)
-template <typename T, int LOGL> constexpr int rs_sub() { return LOGL == 12 ? (sizeof(T) == 4 ? 272 : 256) : 136; }
+// start on different banks (ds_read_b64: 32 lanes, ds_read_b128: 16 lanes; checked case by case in DESIGN section 3).  S = 512: a
+// lane group never spans two sub-transforms (32 lanes each): no pad
+template <typename T, int LOGL> constexpr int rs_sub() { return LOGL == 13 ? 512 : (LOGL == 12 ? (sizeof(T) == 4 ? 272 : 256) : 136); }
 template <typename T> constexpr int rs4096_sub() { return rs_sub<T, 12>(); }
 template <typename T, int LOGL> constexpr size_t rs_lds_bytes() {
     // data + two-level W_L table + W_S table [m][i] + the untangle factors of the kept columns
-    return (size_t)(16 * rs_sub<T, LOGL>() + 128 + rs_nt<LOGL>() + 2 * rs_nt<LOGL>()) * sizeof(cx<T>);
+    return (size_t)(16 * rs_sub<T, LOGL>() + rs_twn<LOGL>() + rs_nt<LOGL>() + rs_ncol<LOGL>() * rs_nt<LOGL>()) * sizeof(cx<T>);
 }
 template <typename T> constexpr size_t rs4096_lds_bytes() { return rs_lds_bytes<T, 12>(); }
 
 // V[m][i] of a sub-transform (m < 16 first-stage bins, i < LPS lanes): place of lane i inside row m, chosen so that both the
-// writes (lanes i, fixed m) and the second-stage reads (lanes m, fixed i) hit distinct banks
-template <int LPS> OA_HD int rs_swz(int i, int m) { return LPS == 16 ? ((i ^ m) & 15) : ((i + (m >> 1)) & 7); }
+// writes (lanes i, fixed m) and the second-stage reads (lanes m, fixed i; LPS = 32: lanes (m, parity), fixed t: i = 2 t + parity)
+// hit distinct banks
+template <int LPS> OA_HD int rs_swz(int i, int m) { return LPS == 32 ? ((i ^ (2 * m)) & 31) : (LPS == 16 ? ((i ^ m) & 15) : ((i + (m >> 1)) & 7)); }
 
-// position of kept bin (rr, k0, m) in the exchange area -- rr < 2 RK: the RK lowest and the RK highest second-stage bins --
-// inside the owner wave's part of the buffer (NSW sub-transforms per wave), the low nibble swizzled by k0 (writes: lanes m
-// consecutive; reads: lanes k0 consecutive)
+// position of kept bin (rr, k0, m) in the exchange area -- rr < 2 RK: the RK lowest and the RK highest second-stage bins (LPS =
+// 32: rr = 2 x that + the lane's parity: the two partial sums of a bin) -- inside the owner wave's part of the buffer (NSW
+// sub-transforms per wave), the low nibble swizzled by k0 (writes: lanes m consecutive; reads: lanes k0 consecutive)
 template <int SUB, int NSW>
 OA_HD int rs_epos(int rr, int k0, int m) { return (k0 / NSW) * (NSW * SUB) + rr * (NSW * 16) + (k0 % NSW) * 16 + ((m ^ k0) & 15); }
+
+// W_8^e = exp(-2 pi i e / 8)
+template <typename T>
+OA_HD cx<T> w8(int e) {
+    const T h = (T)0.70710678118654752440L;
+    switch (e & 7) {
+        case 0: return mk<T>((T)1, (T)0);
+        case 1: return mk<T>(h, -h);
+        case 2: return mk<T>((T)0, (T)-1);
+        case 3: return mk<T>(-h, -h);
+        case 4: return mk<T>((T)-1, (T)0);
+        case 5: return mk<T>(-h, h);
+        case 6: return mk<T>((T)0, (T)1);
+        default: return mk<T>(h, h);
+    }
+}
 
 template <typename T, int LOGL, int LR, bool PF = true, class Ctx>
 OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
     constexpr int L = 1 << LOGL, R = 1 << LR, NT = rs_nt<LOGL>(), S = NT, SUB = rs_sub<T, LOGL>();
-    constexpr int LPS = S / 16, NSW = 64 / LPS, RK = LOGL == 12 ? 2 : 1;      // lanes per sub-transform, sub-transforms per wave, kept bins per side
-    static_assert(LOGL == 12 || LOGL == 11, "row_r2c_rs_body: 8192- or 4096-point rows");
-    static_assert(R == 4, "the butterfly factors below are W_4^e = (-i)^e");
+    constexpr int LPS = S / 16, NSW = 64 / LPS, RK = LOGL >= 12 ? 2 : 1;      // lanes per sub-transform, sub-transforms per wave, kept bins per side
+    constexpr int NCOL = rs_ncol<LOGL>();
+    static_assert(LOGL == 13 || LOGL == 12 || LOGL == 11, "row_r2c_rs_body: 16384-, 8192- or 4096-point rows");
+    static_assert(R == 4 || (R == 8 && NCOL == 1), "column butterfly: R = 4, or R = 8 with one column per thread");
     cx<T>* D = reinterpret_cast<cx<T>*>(ctx.smem());          // [k0][j0]: 16 x S
     cx<T>* TW = D + 16 * SUB;                                 // two-level W_L table
-    cx<T>* TS = TW + 128;                                     // [m][i] = W_S^(i m), m < 16, i < LPS
+    cx<T>* TS = TW + rs_twn<LOGL>();                          // [m][i] = W_S^(i m), m < 16, i < LPS
     const int tid = ctx.tid();
     tw_lds_fill<T>(ctx, TW, a.tw, a.logTw, LOGL, NT);
     TS[tid] = a.tw[((unsigned)((tid / LPS) * (tid % LPS)) & (unsigned)(S - 1)) << (a.logTw - (LOGL - 4))];
@@ -68,11 +97,11 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
     const unsigned nym = ((unsigned)a.my << LR) - 1u;
     const int ngroups = a.my, gstep = ctx.grid_x();
-    // untangle: this thread's columns kk = tid + NT r, r < 2 (coalesced stores); factors W_2L^kk in LDS (in registers they cost
+    // untangle: this thread's columns kk = tid + NT r, r < NCOL (coalesced stores); factors W_2L^kk in LDS (in registers they cost
     // up to 8 VGPRs across the whole row; loaded from global inside the loop they would queue behind the prefetch)
     cx<T>* TWK = TS + NT;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) TWK[tid + NT * r] = a.tw[(unsigned)(tid + NT * r) << (a.logTw - (LOGL + 1))];
+    for (int r = 0; r < NCOL; ++r) TWK[tid + NT * r] = a.tw[(unsigned)(tid + NT * r) << (a.logTw - (LOGL + 1))];
     cx<T> v[16];
     auto taps = [&](long grp, int n, int t0 = 0, int t1 = 16) {
 #ifdef OA_RS4096_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
@@ -88,23 +117,32 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
             if (t >= t0 && t < t1) v[t] = RowLoadOnce<T>{src, 0u}.template get<T>(S * t, 0);
 #endif
     };
+    // row of the group taken at step `step`: R = 4: n = 0, 2, 1, 3 (two radix-2 levels, below); R = 8: natural order
+    auto row_of = [](int step) { return R == 4 ? (((step & 1) << 1) | (step >> 1)) : step; };
     // prefetch of the next row in two halves (PFH = taps issued right after stage 0; the rest after the first sub-transform
     // stage, whose butterfly + 15 factors are the register peak): float64 has no room for all 16 taps across that stage
-    constexpr int PFH = sizeof(T) == 8 ? OA_RS4096_PFH : 16;
+    constexpr int PFH = sizeof(T) == 8 ? (LOGL == 13 ? OA_RS8192_PFH : OA_RS4096_PFH) : 16;
     auto next_taps = [&](long grp, int step, int t0, int t1) {
-        if (step + 1 < R) { const int nn = (((step + 1) & 1) << 1) | ((step + 1) >> 1); taps(grp, nn, t0, t1); }
+        if (step + 1 < R) taps(grp, row_of(step + 1), t0, t1);
         else if (grp + gstep < ngroups) taps(grp + gstep, 0, t0, t1);
+    };
+    // kept bin (rr, k0, m) of the exchange area: one entry, or the sum of the two lanes' partial sums (LPS = 32)
+    auto kept = [&](int rr, int kk0, int m) {
+        if constexpr (LPS == 32) return D[rs_epos<SUB, NSW>(2 * rr, kk0, m)] + D[rs_epos<SUB, NSW>(2 * rr + 1, kk0, m)];
+        else return D[rs_epos<SUB, NSW>(rr, kk0, m)];
     };
     long grp = ctx.bid_x();
     if (PF && grp < ngroups) taps(grp, 0);
     for (; grp < ngroups; grp += gstep) {
-        // rows in the order n = 0, 2, 1, 3 -- two radix-2 levels: A = X0 + X2, B = X0 - X2, then Y0 = A + c, Y2 = A - c,
-        // Y1 = B - i d, Y3 = B + i d with c = X1 + X3, d = X1 - X3: three live values per column and no products
-        cx<T> A[2], B[2], Cc[2];
+        // R = 4: rows in the order n = 0, 2, 1, 3 -- two radix-2 levels: A = X0 + X2, B = X0 - X2, then Y0 = A + c, Y2 = A - c,
+        // Y1 = B - i d, Y3 = B + i d with c = X1 + X3, d = X1 - X3: three live values per column and no products.
+        // R = 8: acc[k1] = sum_n X_n W_8^(n k1), eight running sums of this thread's one column
+        cx<T> A[NCOL], B[NCOL], Cc[NCOL];
+        cx<T> acc[R == 8 ? 8 : 1];
         const cx<T> wy1 = a.twy[(unsigned)grp & nym];          // W_ny^g (issued before the next prefetch)
 #pragma unroll 1
         for (int step = 0; step < R; ++step) {
-            const int n = ((step & 1) << 1) | (step >> 1);
+            const int n = row_of(step);
             if (!PF) taps(grp, n);
 #ifdef OA_RS4096_LOADONLY     // timing experiment only: the launch shape and load pattern of this kernel as a pure streaming read
             {
@@ -144,7 +182,27 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
             for (int m = 0; m < 16; ++m) Dk[LPS * m + rs_swz<LPS>(i, m)] = u[m];
             if (PF && PFH < 16) next_taps(grp, step, PFH, 16);
             ctx.wsync();
-            if constexpr (LPS == 16) {
+            if constexpr (LPS == 32) {
+                // lanes (m2, par) of this sub-transform: the 16-point transform of the even (par = 0) / odd (par = 1) samples of row
+                // m2, pruned to the bins q = 0, 1, 14, 15; Z[k0 + 16 m2 + 256 r] = E[r mod 16] + W_32^r O[r mod 16], r = 0, 1, 30, 31:
+                // the odd lane carries the factor, the two halves are added at the untangle (two exchange entries per bin)
+                const int m2 = i >> 1, par = i & 1;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) u[t] = Dk[32 * m2 + rs_swz<32>(2 * t + par, m2)];
+                Dft<T, 16>::run(u);
+                const T c1 = (T)0.98078528040323044913L, s1 = (T)0.19509032201612826785L;      // cos, sin(pi / 16)
+                const T c2 = (T)0.92387953251128675613L, s2 = (T)0.38268343236508977173L;      // cos, sin(pi / 8)
+                if (par) {
+                    u[1] = u[1] * mk<T>(c1, -s1);              // W_32^1
+                    u[14] = u[14] * mk<T>(c2, s2);             // W_32^30 = conj W_32^2
+                    u[15] = u[15] * mk<T>(c1, s1);             // W_32^31 = conj W_32^1
+                }
+                ctx.wsync();                                   // the reads above precede the exchange writes (same part of D)
+                D[rs_epos<SUB, NSW>(0 + par, k0, m2)] = u[0];
+                D[rs_epos<SUB, NSW>(2 + par, k0, m2)] = u[1];
+                D[rs_epos<SUB, NSW>(4 + par, k0, m2)] = u[14];
+                D[rs_epos<SUB, NSW>(6 + par, k0, m2)] = u[15];
+            } else if constexpr (LPS == 16) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) u[t] = Dk[16 * i + rs_swz<16>(t, i)];   // V[m = i][t]
                 Dft<T, 16>::run(u);                            // u[r] = Z[k0 + 16 i + 256 r]; r = 0, 1, 14, 15 used (the rest is dead code)
@@ -168,28 +226,49 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
                 D[rs_epos<SUB, NSW>(1, k0, 2 * i + 1)] = u[15];
             }
             ctx.sync();
-            // ---- untangle columns kk = tid + NT r and accumulate the radix-4 column butterfly
+            // ---- untangle columns kk = tid + NT r and accumulate the radix-R column butterfly
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < NCOL; ++r) {
                 const int kk = tid + NT * r;
                 if (kk < a.wcols) {
                     const int P = (L - kk) & (L - 1);          // partner bin: 0 (kk = 0) or among the RK highest blocks of 256
-                    const cx<T> Zk = D[rs_epos<SUB, NSW>(kk >> 8, kk & 15, (kk >> 4) & 15)];
-                    const cx<T> Zm = D[rs_epos<SUB, NSW>(P ? (P >> 8) - (LPS - 2 * RK) : 0, P & 15, (P >> 4) & 15)];
+                    const cx<T> Zk = kept(kk >> 8, kk & 15, (kk >> 4) & 15);
+                    const cx<T> Zm = kept(P ? (P >> 8) - (LPS - 2 * RK) : 0, P & 15, (P >> 4) & 15);
                     const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
                     const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
                     const cx<T> X = (E + TWK[kk] * O) * a.scale;
-                    if (step == 0) A[r] = X;
-                    else if (step == 1) { B[r] = A[r] - X; A[r] = A[r] + X; }
-                    else if (step == 2) Cc[r] = X;
-                    else {
-                        const cx<T> c = Cc[r] + X, d = Cc[r] - X;
-                        const cx<T> wy2 = wy1 * wy1;
-                        cx<T>* dst = out + grp * a.out_pitch + kk;
-                        dst[0] = A[r] + c;
-                        dst[a.kplane] = add_mi(B[r], d) * wy1;
-                        dst[2 * a.kplane] = (A[r] - c) * wy2;
-                        dst[3 * a.kplane] = add_pi(B[r], d) * (wy2 * wy1);
+                    if constexpr (R == 8) {
+                        if (step == 0) {
+#pragma unroll
+                            for (int k1 = 0; k1 < 8; ++k1) acc[k1] = X;
+                        } else {
+#pragma unroll
+                            for (int k1 = 1; k1 < 8; ++k1) acc[k1] = acc[k1] + X * w8<T>(n * k1);       // (n uniform: scalar selects)
+                            acc[0] = acc[0] + X;
+                        }
+                        if (step == R - 1) {
+                            cx<T>* dst = out + grp * a.out_pitch + kk;
+                            cx<T> wp = wy1;
+                            dst[0] = acc[0];
+#pragma unroll
+                            for (int k1 = 1; k1 < 8; ++k1) {
+                                dst[(long)k1 * a.kplane] = acc[k1] * wp;
+                                wp = wp * wy1;
+                            }
+                        }
+                    } else {
+                        if (step == 0) A[r] = X;
+                        else if (step == 1) { B[r] = A[r] - X; A[r] = A[r] + X; }
+                        else if (step == 2) Cc[r] = X;
+                        else {
+                            const cx<T> c = Cc[r] + X, d = Cc[r] - X;
+                            const cx<T> wy2 = wy1 * wy1;
+                            cx<T>* dst = out + grp * a.out_pitch + kk;
+                            dst[0] = A[r] + c;
+                            dst[a.kplane] = add_mi(B[r], d) * wy1;
+                            dst[2 * a.kplane] = (A[r] - c) * wy2;
+                            dst[3 * a.kplane] = add_pi(B[r], d) * (wy2 * wy1);
+                        }
                     }
                 }
             }

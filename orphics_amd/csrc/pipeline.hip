@@ -49,6 +49,7 @@ struct Pipeline {
     bool opt_mv_rowbatch = true;      // oa_qe_mv: the row stage of several pieces per launch
     bool opt_mv_chain = true;         // oa_qe_mv: estimator chains (pieces summed in real space inside one row-stage launch)
     bool opt_divbin = true;           // moment entries: radial binning + moments in the tail of the single-pass divergence launch
+    bool opt_win_fused = true;        // oa_mc_run_windowed: C2R x window -> R2C as one row pass (the real map stays in LDS)
 };
 
 static size_t plane_bytes(const oa_plan* p) { return (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8); }
@@ -172,6 +173,7 @@ int oa_plan_set_option(oa_plan* p, int option, int value) {
         case OA_OPT_MV_ROWBATCH: q->opt_mv_rowbatch = value != 0; return 0;
         case OA_OPT_MV_CHAIN: q->opt_mv_chain = value != 0; return 0;
         case OA_OPT_DIV_BIN: q->opt_divbin = value != 0; return 0;
+        case OA_OPT_WIN_FUSED: q->opt_win_fused = value != 0; return 0;
         default: return fail("oa_plan_set_option: unknown option");
     }
 }
@@ -243,13 +245,14 @@ static DivBinFuse make_fuse(const oa_plan* p, const Pipeline* q, int64_t* n, dou
 }
 
 static int qe_tt_impl(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
-                      void* stream, DivBinFuse* fuse);
+                      void* stream, DivBinFuse* fuse, int rows_done = 0);
 int oa_qe_tt(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
              void* stream) {
     return qe_tt_impl(p, real_map, kX, kY, out_kappa_hc, zero_outside, stream, nullptr);
 }
+// rows_done: the row-transformed map already sits on the plan's scratch plane (qe_windowed_rows_w): column stages only, multi-pass
 static int qe_tt_impl(oa_plan* p, const void* real_map, const void* kX, const void* kY, void* out_kappa_hc, int zero_outside,
-                      void* stream, DivBinFuse* fuse) {
+                      void* stream, DivBinFuse* fuse, int rows_done) {
     OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG, "oa_qe_tt: call oa_plan_set_filters first");
     OA_REQUIRE((real_map != nullptr) != (kX != nullptr), "oa_qe_tt: pass either a real map or the Fourier-space leg(s)");
     Pipeline* q = (Pipeline*)p->pipe;
@@ -261,8 +264,8 @@ static int qe_tt_impl(oa_plan* p, const void* real_map, const void* kX, const vo
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const int my = q->my;
-    const int lr = real_map ? qe_rsplit_lr(p, my, q->wl, q->wk, q->mrow) : 0;     // from a map: R-split row pass + one column kernel
-    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 7, my, lr);
+    const int lr = (real_map && !rows_done) ? qe_rsplit_lr(p, my, q->wl, q->wk, q->mrow) : 0;     // from a map: R-split row pass + one column kernel
+    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, rows_done ? 6 : 7, my, lr);
     else rc = qe_legs_cols_w(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, my);
     if (rc) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;   // DFT on my rows = my/ny x the full one
@@ -709,14 +712,21 @@ int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi,
     Pipeline* q = (Pipeline*)p->pipe;
     void* tmap = q->c[0];
     const double inv = 1.0 / ((double)p->ny * p->nx);
+    const long pl = work_pitch(p, q->wl);
     for (long i = sim_lo; i < sim_hi; ++i) {
         int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
         if (rc) return rc;
-        if ((rc = oa_fft_c2r_windowed(p, q->kT, tmap, inv, window_real, stream))) return rc;     // the window rides on the row pass's store
+        // FUSED ROW PASS (default): inverse columns of the drawn spectrum (into the first leg plane, free until the leg stage), then
+        // C2R x window -> R2C per row in ONE kernel -- the real map exists in LDS only -- onto the scratch plane the column stages
+        // read.  OA_OPT_WIN_FUSED = 0: C2R with the window at its store -> real map in HBM -> the from-map estimator path.
+        const int fused_rows = q->opt_win_fused ? 1 : 0;
+        if (fused_rows) rc = qe_windowed_rows_w(p, q->kT, tmap, window_real, q->wl, pl, inv, (hipStream_t)stream);
+        else rc = oa_fft_c2r_windowed(p, q->kT, tmap, inv, window_real, stream);     // the window rides on the row pass's store
+        if (rc) return rc;
         // binning + moments in the divergence launch where the geometry has that kernel (kappa_hat still stored when the mean-field
         // stack needs it)
         DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
-        if ((rc = qe_tt_impl(p, tmap, nullptr, nullptr, nullptr, 0, stream, divbin_enabled(q) ? &f : nullptr))) return rc;
+        if ((rc = qe_tt_impl(p, tmap, nullptr, nullptr, nullptr, 0, stream, divbin_enabled(q) ? &f : nullptr, fused_rows))) return rc;
         if (!f.done && (rc = bandpower_moments(p, q, n, S, C, stream))) return rc;
         if (meanfield_acc && (rc = stack_add_region(p->dtype, q->kk, meanfield_acc, p->ny, p->kp, q->wk, q->rk, (hipStream_t)stream))) return rc;
     }

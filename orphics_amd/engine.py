@@ -425,7 +425,7 @@ class Engine(object):
 
     # ---- QE legs --------------------------------------------------------------------
     # oa_plan_set_option (include/orphics_amd.h): equivalent launch sequences of the one-call entries of THIS plan
-    OPTIONS = {"mc_batch": 1, "mv_batch": 2, "mv_rowbatch": 3, "mv_chain": 4, "div_bin": 5}
+    OPTIONS = {"mc_batch": 1, "mv_batch": 2, "mv_rowbatch": 3, "mv_chain": 4, "div_bin": 5, "win_fused": 6}
 
     def set_option(self, name, value):
         if name not in self.OPTIONS:

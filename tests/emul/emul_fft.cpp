@@ -55,6 +55,7 @@ struct EmuLauncher {
                 case ROW_R2C: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_R2C, S>(c, a); }); break;
                 case ROW_C2R: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2R, S>(c, a); }); break;
                 case ROW_C2C_F: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2C_F, S>(c, a); }); break;
+                case ROW_WIN: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_WIN, S>(c, a); }); break;
                 default: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2C_I, S>(c, a); }); break;
             }
         });
@@ -78,6 +79,7 @@ struct EmuLauncher {
                     if (a.chain) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 0, true>(c, a); });
                     else
                     if (a.lr == 2) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 2>(c, a); });
+                    else if (a.lr == 3) run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 3>(c, a); });
                     else run(grid, 1, nt, smem, [&](EmuCtx& c) { row_qe_pair_body<T, S, decltype(nzc)::value, 0>(c, a); });
                 });
         });
@@ -101,6 +103,7 @@ struct EmuLauncher {
         constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
         if (gy == 4 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 8>, 2, lc11>(c, a); }, gz);
         else if (gy == 4 && logMy == 10) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 8>, 2, lc10>(c, a); }, gz);
+        else if (gy == 8 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 16>, 3, lc11>(c, a); }, gz);
     }
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
@@ -165,6 +168,14 @@ static int do_r2c(int ny, int nx, const T* in, cx<T>* out, double scale, int wid
     std::vector<cx<T>> tmp((size_t)ny * h.p.kp);
     EmuLauncher q;
     h.p.r2c(q, in, out, tmp.data(), (T)scale, width, rband);
+    return 0;
+}
+// fused windowed row pass (ROW_WIN): hc rows (pitch kp) -> C2R -> x window -> R2C -> hc rows (pitch opitch), wcols kept
+template <typename T>
+static int do_rows_win(int ny, int nx, const cx<T>* in, const T* window, cx<T>* out, long opitch, double scale, int wcols) {
+    Holder<T> h(ny, nx);
+    EmuLauncher q;
+    h.p.rows(q, ROW_WIN, in, h.p.kp, out, opitch, (T)scale, wcols, window);
     return 0;
 }
 template <typename T>
@@ -282,18 +293,23 @@ static int do_qe_rows_rlayout(int my, int nx, const cx<T>* gx, const cx<T>* gy, 
     return 0;
 }
 
-// R-split R2C of 8192-point rows with one workgroup-wide exchange (fft_r2c_rs4096.hpp): nx = 8192, ny = 4 my, either precision
+// R-split R2C with one workgroup-wide exchange (fft_r2c_rs4096.hpp): nx = 8192 / 4096 with ny = 4 my (R = 4), nx = 16384 with ny = 8 my
+// (R = 8), either precision
 template <typename T>
 static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int width, int nwg, int pf) {
-    if (!((nx == 8192 && width <= 512) || (nx == 4096 && width <= 256)) || (ny & 3)) return 1;
+    const int R = nx == 16384 ? 8 : 4;
+    if (!((nx == 16384 && width <= 512) || (nx == 8192 && width <= 512) || (nx == 4096 && width <= 256)) || (ny % R)) return 1;
     auto tw = make_twiddles<T>(nx);
     auto twy = make_twiddles<T>(ny);
     RowArgs<T> a{};
     a.in = in; a.out = out; a.in_pitch = nx / 2; a.out_pitch = pitch; a.logL = ilog2(nx) - 1; a.logC = 0; a.NT = nx / 32;
-    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (T)1; a.mode = ROW_R2C; a.wcols = width; a.lr = 2; a.my = ny / 4;
-    a.kplane = (long)(ny / 4) * pitch; a.twy = twy.data();
+    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (T)1; a.mode = ROW_R2C; a.wcols = width; a.lr = R == 8 ? 3 : 2; a.my = ny / R;
+    a.kplane = (long)(ny / R) * pitch; a.twy = twy.data();
     EmuLauncher q;
-    if (nx == 8192) {
+    if (nx == 16384) {
+        if (pf) q.run(nwg, 1, 512, rs_lds_bytes<T, 13>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 13, 3, true>(c, a); });
+        else q.run(nwg, 1, 512, rs_lds_bytes<T, 13>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 13, 3, false>(c, a); });
+    } else if (nx == 8192) {
         if (pf) q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 2, true>(c, a); });
         else q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 2, false>(c, a); });
     } else {
@@ -303,6 +319,8 @@ static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int wid
     return 0;
 }
 extern "C" {
+int emu_rows_win_f64(int ny, int nx, const void* in, const double* w, void* out, long opitch, double s, int wcols) { return do_rows_win<double>(ny, nx, (const cx<double>*)in, w, (cx<double>*)out, opitch, s, wcols); }
+int emu_rows_win_f32(int ny, int nx, const void* in, const float* w, void* out, long opitch, double s, int wcols) { return do_rows_win<float>(ny, nx, (const cx<float>*)in, w, (cx<float>*)out, opitch, s, wcols); }
 void emu_set_rsplit_pf(int on) { rsplit_pf = on != 0; }
 int emu_rsplit_rows_f32(int ny, int my, int nx, const float* map, void* Y, long pitch, int width) { return do_rsplit_rows<float>(ny, my, nx, map, (cx<float>*)Y, pitch, width); }
 int emu_rsplit_rows_f64(int ny, int my, int nx, const double* map, void* Y, long pitch, int width) { return do_rsplit_rows<double>(ny, my, nx, map, (cx<double>*)Y, pitch, width); }

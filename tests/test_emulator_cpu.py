@@ -551,13 +551,14 @@ def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb, nx,
 # one-wave-per-row kernel), the single-pass column stage (fft_fband.hpp) and the row stage on its R-LAYOUT planes
 # ---------------------------------------------------------------------------------------------------------------
 def _rsplit_reference(x, my, w):
-    """Y[k1][g][k] = W_ny^(g k1) sum_n rfft(x[g + my n])[k] W_4^(n k1), k < w"""
+    """Y[k1][g][k] = W_ny^(g k1) sum_n rfft(x[g + my n])[k] W_R^(n k1), k < w, R = ny / my"""
     ny = x.shape[0]
+    R = ny // my
     X = np.fft.rfft(x, axis=1)[:, :w]
     g = np.arange(my)
-    out = np.zeros((4, my, w), dtype=np.complex128)
-    for k1 in range(4):
-        acc = sum(X[n * my:(n + 1) * my] * np.exp(-2j * np.pi * n * k1 / 4.) for n in range(4))
+    out = np.zeros((R, my, w), dtype=np.complex128)
+    for k1 in range(R):
+        acc = sum(X[n * my:(n + 1) * my] * np.exp(-2j * np.pi * n * k1 / float(R)) for n in range(R))
         out[k1] = acc * np.exp(-2j * np.pi * g * k1 / ny)[:, None]
     return out
 
@@ -584,18 +585,21 @@ def test_rsplit_row_pass(emu, prec, pf):
 
 
 @pytest.mark.parametrize("nx,prec,w,pf", [(8192, "f64", 380, 1), (8192, "f64", 512, 0), (8192, "f32", 380, 1), (8192, "f64", 1, 1),
-                                          (4096, "f64", 190, 0), (4096, "f32", 256, 1), (4096, "f64", 256, 1), (4096, "f32", 3, 0)])
+                                          (4096, "f64", 190, 0), (4096, "f32", 256, 1), (4096, "f64", 256, 1), (4096, "f32", 3, 0),
+                                          (16384, "f64", 380, 1), (16384, "f64", 512, 0), (16384, "f32", 380, 1), (16384, "f32", 2, 0)])
 def test_rsplit_row_pass_one_crosswave_exchange(emu, nx, prec, w, pf):
     """row_r2c_rs_body: L = 16 x S with the sub-transforms (S = 256 = 16 x 16 points for 8192-point rows, 128 = 16 x 8 for
-    4096-point rows) inside one wave's part of the buffer, pruned last stage, persistent workgroups (3 walk 8 groups) with and
-    without the prefetch order"""
-    ny = 32
-    my = ny // 4
+    4096-point rows, 512 = 16 x 32 for 16384-point rows: lane pairs share a 32-point butterfly) inside one wave's part of the
+    buffer, pruned last stage, persistent workgroups (3 walk 8 groups) with and without the prefetch order; the column butterfly
+    on top is R = 4, for 16384-point rows R = 8"""
+    R = 8 if nx == 16384 else 4
+    ny = 8 * R
+    my = ny // R
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
     rng = np.random.default_rng(11)
     x = rng.standard_normal((ny, nx)).astype(rdt)
     pitch = 520
-    Y = np.full((4, my, pitch), 7.0 + 0j, dtype=cdt)
+    Y = np.full((R, my, pitch), 7.0 + 0j, dtype=cdt)
     fn = emu.emu_rsplit_rows_rs4096_f64 if prec == "f64" else emu.emu_rsplit_rows_rs4096_f32
     assert fn(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3, pf) == 0
     ref = _rsplit_reference(x.astype(np.float64), my, w)
@@ -604,11 +608,12 @@ def test_rsplit_row_pass_one_crosswave_exchange(emu, nx, prec, w, pf):
 
 
 def _fband_reference(Y, my, FG, FH, lxd, lyd, w, ny):
-    """leg planes in the R-LAYOUT (row y_lo 4 + k1) from the row pass's planes Y[k1][g][k]"""
-    mq = my // 4
+    """leg planes in the R-LAYOUT (row y_lo R + k1) from the row pass's planes Y[k1][g][k], R = ny / my"""
+    R = ny // my
+    mq = my // R
     full = np.zeros((ny, w), dtype=np.complex128)
-    for k1 in range(4):
-        full[k1::4] = np.fft.fft(Y[k1][:, :w], axis=0)
+    for k1 in range(R):
+        full[k1::R] = np.fft.fft(Y[k1][:, :w], axis=0)
     legs = [full * FH[:, :w], 1j * lxd[None, :w] * FG[:, :w] * full, 1j * lyd[:, None] * FG[:, :w] * full]    # H, Gx, Gy
     outs, fields = [], []
     for leg in legs:
@@ -616,16 +621,17 @@ def _fband_reference(Y, my, FG, FH, lxd, lyd, w, ny):
         fields.append(np.fft.ifft(coarse, axis=0) * my)
         plane = np.zeros((my, w), dtype=np.complex128)
         ylo = np.arange(mq)
-        for k1 in range(4):
-            B = np.fft.ifft(coarse[k1::4], axis=0) * mq * np.exp(2j * np.pi * k1 * ylo / my)[:, None]
-            plane[k1::4] = B                                                     # row y_lo * 4 + k1
+        for k1 in range(R):
+            B = np.fft.ifft(coarse[k1::R], axis=0) * mq * np.exp(2j * np.pi * k1 * ylo / my)[:, None]
+            plane[k1::R] = B                                                     # row y_lo * R + k1
         outs.append(plane)
     return outs, fields
 
 
-@pytest.mark.parametrize("prec,nmaps", [("f64", 1), ("f32", 2)])
-def test_rsplit_single_pass_column_stage(emu, prec, nmaps):
-    ny, my, nx, w, rb = 4096, 1024, 2048, 21, 150
+@pytest.mark.parametrize("prec,nmaps,ny,my", [("f64", 1, 4096, 1024), ("f32", 2, 4096, 1024), ("f64", 1, 16384, 2048), ("f32", 1, 16384, 2048)])
+def test_rsplit_single_pass_column_stage(emu, prec, nmaps, ny, my):
+    nx, w, rb = 2048, 21, 150
+    R = ny // my
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 4e-6)
     rng = np.random.default_rng(9)
     kp = emu.emu_kpitch(nx)
@@ -639,29 +645,31 @@ def test_rsplit_single_pass_column_stage(emu, prec, nmaps):
     FG = np.zeros((ny, kp)); FH = np.zeros((ny, kp))
     FG[band, :w] = rng.uniform(0.5, 1.5, (band.size, w))
     FH[band, :w] = rng.uniform(0.5, 1.5, (band.size, w))
-    Y = np.zeros((nmaps, 4, my, pitch), dtype=cdt)
-    Y[..., :w] = (rng.standard_normal((nmaps, 4, my, w)) + 1j * rng.standard_normal((nmaps, 4, my, w))).astype(cdt)
+    Y = np.zeros((nmaps, R, my, pitch), dtype=cdt)
+    Y[..., :w] = (rng.standard_normal((nmaps, R, my, w)) + 1j * rng.standard_normal((nmaps, R, my, w))).astype(cdt)
     outs = [np.full((nmaps, my, opitch), 5.0 + 0j, dtype=cdt) for _ in range(3)]           # gx, gy, h
     fn = emu.emu_rsplit_legs_f64 if prec == "f64" else emu.emu_rsplit_legs_f32
     args = [a.astype(rdt) for a in (FG, FH, lxd, lyd)]
     assert fn(ny, my, nx, _p(Y), ctypes.c_long(pitch), _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(outs[0]), _p(outs[1]), _p(outs[2]),
-              ctypes.c_long(opitch), w, rb, nmaps, ctypes.c_long(4 * my * pitch), ctypes.c_long(my * opitch)) == 0
+              ctypes.c_long(opitch), w, rb, nmaps, ctypes.c_long(R * my * pitch), ctypes.c_long(my * opitch)) == 0
     for m in range(nmaps):
         (rh, rgx, rgy), fields = _fband_reference(Y[m].astype(np.complex128), my, FG, FH, lxd, lyd, w, ny)
         for got, want in ((outs[2][m], rh), (outs[0][m], rgx), (outs[1][m], rgy)):
             assert np.abs(got[:, :w] - want).max() < tol * np.abs(want).max()
             assert np.all(got[:, w:] == 5.0)
-        # the R-layout really encodes the field: x[y_lo + Mq y_hi] = sum_k1 i^(k1 y_hi) B[k1][y_lo]
-        mq = my // 4
-        B = rh.reshape(mq, 4, w)
-        x = np.stack([sum(B[:, k1] * (1j) ** (k1 * yh) for k1 in range(4)) for yh in range(4)]).reshape(my, w)
+        # the R-layout really encodes the field: x[y_lo + Mq y_hi] = sum_k1 W_R^(-k1 y_hi) B[k1][y_lo]
+        mq = my // R
+        B = rh.reshape(mq, R, w)
+        x = np.stack([sum(B[:, k1] * np.exp(2j * np.pi * k1 * yh / float(R)) for k1 in range(R)) for yh in range(R)]).reshape(my, w)
         assert np.abs(x - fields[0]).max() < 1e-9 * np.abs(fields[0]).max()
 
 
-@pytest.mark.parametrize("prec", ["f64", "f32"])
-def test_row_stage_on_r_layout_planes(emu, prec):
-    """row_qe_pair_body<.., LAY = 2>: the same products from leg planes in the R-LAYOUT as from natural-order planes"""
-    my, nx, win, wout, M = 64, 4096, 20, 30, 1024
+@pytest.mark.parametrize("prec,R,M,win,wout", [("f64", 4, 1024, 20, 30), ("f32", 4, 1024, 20, 30), ("f64", 8, 2048, 20, 30), ("f32", 8, 2048, 20, 30),
+                                               ("f64", 8, 2048, 380, 664), ("f64", 4, 2048, 380, 664)])
+def test_row_stage_on_r_layout_planes(emu, prec, R, M, win, wout):
+    """row_qe_pair_body<.., LAY = 2 / 3>: the same products from leg planes in the R-LAYOUT (R = 4, R = 8) as from natural-order planes
+    (380 / 664 columns: the headline's band limits -- four live taps per side of the first inverse stage)"""
+    my, nx = 64, 4096
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 2e-5)
     rng = np.random.default_rng(12)
     kp = emu.emu_kpitch(nx)
@@ -671,17 +679,17 @@ def test_row_stage_on_r_layout_planes(emu, prec):
         a[:, :win] = rng.standard_normal((my, win)) + 1j * rng.standard_normal((my, win))
         a[:, 0] = a[:, 0].real                       # (a real row's transform is real at k = 0)
         nat.append(a)
-    mq = my // 4
+    mq = my // R
 
-    def to_r(a):                                     # B[k1][y_lo] = (1/4) sum_yh x[y_lo + Mq yh] (-i)^(k1 yh), stored at row y_lo 4 + k1
-        x = a.reshape(4, mq, kp)
+    def to_r(a):                                     # B[k1][y_lo] = (1/R) sum_yh x[y_lo + Mq yh] W_R^(k1 yh), stored at row y_lo R + k1
+        x = a.reshape(R, mq, kp)
         out = np.zeros_like(a)
-        for k1 in range(4):
-            out[k1::4] = sum(x[yh] * (-1j) ** (k1 * yh) for yh in range(4)) / 4.
+        for k1 in range(R):
+            out[k1::R] = sum(x[yh] * np.exp(-2j * np.pi * k1 * yh / float(R)) for yh in range(R)) / float(R)
         return out
     fn = emu.emu_qe_rows_rlayout_f64 if prec == "f64" else emu.emu_qe_rows_rlayout_f32
     res = []
-    for lr, planes in ((0, nat), (2, [to_r(a) for a in nat])):
+    for lr, planes in ((0, nat), (2 if R == 4 else 3, [to_r(a) for a in nat])):
         pl = [np.ascontiguousarray(a.astype(cdt)) for a in planes]
         px = np.full((my, kp), 3.0 + 0j, dtype=cdt); py = np.full((my, kp), 3.0 + 0j, dtype=cdt)
         assert fn(my, nx, _p(pl[0]), _p(pl[1]), _p(pl[2]), _p(px), _p(py), ctypes.c_double(1.0 / nx ** 2), win, wout, M, lr) == 0
@@ -689,3 +697,24 @@ def test_row_stage_on_r_layout_planes(emu, prec):
     for a, b in zip(res[0], res[1]):
         assert np.abs(a[:, :wout] - b[:, :wout]).max() < tol * np.abs(a[:, :wout]).max()
         assert np.all(b[:, wout:] == 3.0)
+
+
+@pytest.mark.parametrize("ny,nx,wc,prec", [(8, 4096, 190, "f64"), (16, 1024, 513, "f64"), (8, 8192, 380, "f32"), (4, 16384, 300, "f64")])
+def test_fused_windowed_row_pass(emu, ny, nx, wc, prec):
+    """ROW_WIN: half-complex rows -> C2R -> x real-space window -> R2C (kept columns only) in one pass, the real rows in LDS only
+    (oa_mc_run_windowed; maps.py:1350-1361 multiplies every map by its taper before the transform)"""
+    rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 4e-6)
+    rng = np.random.default_rng(23)
+    kp = emu.emu_kpitch(nx)
+    x = rng.standard_normal((ny, nx))
+    hc = np.zeros((ny, kp), dtype=cdt)
+    hc[:, :nx // 2 + 1] = np.fft.rfft(x, axis=1)
+    w = (0.5 + rng.uniform(size=(ny, nx))).astype(rdt)
+    opitch = 640
+    out = np.full((ny, opitch), 7.0 + 0j, dtype=cdt)
+    fn = emu.emu_rows_win_f64 if prec == "f64" else emu.emu_rows_win_f32
+    assert fn(ny, nx, _p(hc), _p(w), _p(out), ctypes.c_long(opitch), ctypes.c_double(1.0 / nx), wc) == 0
+    ref = np.fft.rfft(x * w.astype(np.float64), axis=1)[:, :wc]
+    assert np.abs(out[:, :wc] - ref).max() < tol * np.abs(ref).max()
+    assert np.all(out[:, wc:] == 7.0)
+

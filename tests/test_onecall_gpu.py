@@ -469,3 +469,38 @@ def test_ticket_tail_stress_on_three_streams_is_bit_reproducible(prec):
     torch.cuda.synchronize()
     np.testing.assert_allclose(fus[1].cpu().numpy(), sep[1].cpu().numpy(), rtol=1e-13)
     np.testing.assert_allclose(fus[2].cpu().numpy(), sep[2].cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("N,res,prec", [(4096, 0.5, "f32"), (4096, 0.5, "f64"), (512, 2.0, "f64"), (2048, 1.0, "f32")])
+def test_windowed_mc_fused_row_pass_equals_the_two_pass_flow(N, res, prec):
+    """oa_mc_run_windowed with the fused row pass (inverse columns, then C2R x window -> R2C per row in ONE kernel, real map in LDS
+    only; plan option win_fused = 1, the default) against the flow it replaces (C2R with the window at its store -> real map in
+    HBM -> row R2C of the from-map estimator path): same draws, same window, same estimator arithmetic up to the order of the row
+    transforms' butterflies -> bandpower moments and mean-field stack agree to rounding.  (The two-pass flow is itself compared
+    with the NumPy oracle on the same maps in test_windowed_monte_carlo_mean_field_matches_oracle_on_the_same_maps.)"""
+    from orphics_amd import cosmology, lensing, maps, mc
+    from orphics_amd.geometry import FlatGeometry
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+    beam = maps.gauss_beam(ml, 1.5)
+    noise = np.full(shape, cosmology.white_noise_power(1.0))
+    q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=maps.mask_kspace(shape, g, lmin=300, lmax=2000),
+                     kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=3500), unlensed_equals_lensed=True, dtype=prec)
+    tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :N // 2 + 1]
+    edges = np.linspace(20, 3500, 20)
+    taper, _ = maps.get_taper(shape, g, taper_percent=12.0, pad_percent=3.0)
+    res_ = {}
+    for fused in (1, 0):
+        q.eng.set_option("win_fused", fused)
+        try:
+            st = mc.GaussianN0MonteCarlo(q, tot, edges, comm=None, base_seed=77, mean_field=True, window=taper).run(7)
+            res_[fused] = (st.count("n0"), np.array(st.mean("n0")), np.array(st.cov("n0")), st.stack_sum("mf").copy())
+        finally:
+            q.eng.set_option("win_fused", 1)
+    (n1, m1, c1, s1), (n0, m0, c0, s0) = res_[1], res_[0]
+    assert n1 == n0 == 7 and np.all(m0 > 0)
+    tol = 1e-10 if prec == "f64" else 3e-5
+    np.testing.assert_allclose(m1, m0, rtol=tol)
+    assert np.abs(s1 - s0).max() < tol * np.abs(s0).max()
