@@ -334,6 +334,18 @@ int oa_lens_gather(oa_plan* p, const void* src, const int32_t* shift_x, const in
 int oa_hc_derivs(oa_plan* p, const void* hc_in, int order, void* hc_out_planes, long plane_stride, void* stream);
 int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long plane_stride, int order, const int32_t* shift_x,
                    const int32_t* shift_y, const void* dx, const void* dy, void* out, void* stream);
+/* flat_taylens (lensing.py:395-440) of nmaps real maps (in_stride / out_stride elements apart) by ONE deflection field, given as
+ * its nearest-pixel shifts and sub-pixel remainders (oa_lens_split; shared by all maps: T, Q, U of a realisation): nmaps R2Cs, then
+ * the inverse transforms of all nmaps * nd derivative fields (nd = order (order + 1) / 2 - 1), three launches per chunk of planes
+ * -- inverse column pass 1 with the factor (i lx)^a (i ly)^b applied at its load (the derivative spectra never exist in HBM),
+ * column pass 2, row C2R; a chunk is sized for the 256 MB infinity cache, so its intermediates never travel to HBM -- and one
+ * gather pass per map (oa_lens_taylor).  Same results as oa_hc_derivs + C2R per term + oa_lens_taylor.  The planes live in a
+ * plan-owned pool allocated / grown on first use (that call synchronises the device once): nmaps * (1 + nd) planes + one chunk,
+ * e.g. 6.2 GB for T, Q, U at 4096^2 float64 and order 5; oa_plan_release_pools frees it (and the pools of oa_qe_mv /
+ * oa_qe_tt_splits / oa_mc_run), the next call reallocates. */
+int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int order, const int32_t* shift_x, const int32_t* shift_y,
+                 const void* dx, const void* dy, void* real_out, long out_stride, void* stream);
+int oa_plan_release_pools(oa_plan* p);
 
 /* ---- radial binning (stats.bin2D, stats.py:782-811) ------------------------
  * oa_digitize : ids[i] = np.digitize(x[i], edges, right=True) (stats.py:786):

@@ -83,6 +83,8 @@ SIGNATURES = {
     "oa_qe_legs": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int, c_void_p]),
     "oa_qe_div": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "oa_lens_split": (c_int, [c_int, c_void_p, c_double, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_lens_maps": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_plan_release_pools": (c_int, [c_void_p]),
     "oa_lens_gather": (c_int, [c_void_p] * 6 + [c_int, c_int, c_double, c_void_p, c_int, c_void_p]),
     "oa_hc_derivs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "oa_lens_taylor": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

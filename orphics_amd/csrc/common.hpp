@@ -110,6 +110,9 @@ int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* 
                        int rband, long pl, hipStream_t st, int stages = 7, int my = 0, int lr = 0);
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my = 0);
+// flat-sky Taylor lensing, FFT part: R2C of nmaps maps, then all nmaps * nd derivative fields inverse-transformed in three launches
+int lens_chunk_planes(const oa_plan* p);      // derivative planes per launch triple (a chunk that fits the infinity cache)
+int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st);
 // windowed simulation front end: hc spectrum -> inverse columns -> fused C2R x window -> R2C rows onto the plan's scratch plane
 // (then qe_map_legs_cols_w with stages = 6, lr = 0)
 int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st);

@@ -132,6 +132,12 @@ __global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 
 }
 
 template <typename T, class SEQ>
+__global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_deriv_kernel(ColDerivArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    col_deriv_body<T, SEQ>(c, a);
+}
+
+template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), waves_per_eu<T>()) void col_fft_kernel(ColArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     col_fft_body<T, SEQ>(c, a);
@@ -177,7 +183,7 @@ struct HipLauncher {
     template <typename T, int MODE, class S>
     void row_mode(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (nt > row_maxnt<S>()) { if (!rc) rc = fail("fft: row workgroup size exceeds its launch bound"); return; }
-        go(row_fft_kernel<T, MODE, S>, dim3(grid), nt, smem, a);
+        go(row_fft_kernel<T, MODE, S>, dim3(grid, a.nz > 0 ? a.nz : 1), nt, smem, a);
     }
     static int r2c_w64_mode() {
         static const int m = [] { const char* e = exp_env("OA_R2C_W64"); return e ? atoi(e) : 1; }();
@@ -251,14 +257,16 @@ struct HipLauncher {
         static const bool off = exp_env("OA_NO_RS4096") != nullptr;
         static const int pfenv = [] { const char* e = exp_env("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
         const bool l12 = a.lr == 2 && a.logL == 12 && a.wcols <= 512 && a.logTw >= 13, l11 = a.lr == 2 && a.logL == 11 && a.wcols <= 256 && a.logTw >= 12;
-        const bool l13 = a.lr == 3 && a.logL == 13 && a.wcols <= 512 && a.logTw >= 14;      // 16384-point rows, R = 8
+        const bool l13 = sizeof(T) == 8 && a.lr == 3 && a.logL == 13 && a.wcols <= 512 && a.logTw >= 14;      // 16384-point rows, R = 8 (float64)
         if (off || rc || !(l12 || l11 || l13)) return false;
         const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && l12);     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
         const size_t smem = l13 ? rs_lds_bytes<T, 13>() : (l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>());
         const int NTr = l13 ? 512 : (l12 ? RS4096_NT : 128);
-        auto kern = l13 ? (nopf ? row_r2c_rs8192_kernel<T, false> : row_r2c_rs8192_kernel<T, true>)
-                  : l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
-                        : (nopf ? row_r2c_rs2048_kernel<T, false> : row_r2c_rs2048_kernel<T, true>);
+        void (*kern)(RowArgs<T>) = l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
+                                       : (nopf ? row_r2c_rs2048_kernel<T, false> : row_r2c_rs2048_kernel<T, true>);
+        // (float at 16384^2 keeps the two-waves-per-row kernel + multi-pass columns: measured 274 us / 2743 recon/s against 306 us /
+        //  2698 for the float build of this body -- 194 registers leave one 512-thread workgroup per CU; profiles/r04e_16384_f32_variants.txt)
+        if constexpr (sizeof(T) == 8) { if (l13) kern = nopf ? row_r2c_rs8192_kernel<T, false> : row_r2c_rs8192_kernel<T, true>; }
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         std::string err;
         const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), NTr, smem, &err);
@@ -296,8 +304,9 @@ struct HipLauncher {
         else if (gy == 4 && logMy == 10 && !narrow) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10>, dim3(gx, gy, gz), nt, smem, a);
         else if (gy == 4 && logMy == 11) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11 - 1>, dim3(gx, gy, gz), nt, smem, a);
         else if (gy == 4 && logMy == 10) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10 - 1>, dim3(gx, gy, gz), nt, smem, a);
-        else if (gy == 8 && logMy == 11 && !narrow) go(col_fband_kernel<T, Seq<16, 8, 16>, 3, lc11>, dim3(gx, gy, gz), nt, smem, a);   // 16384 rows on the 2048-row grid
-        else rc = fail("fft: unsupported R-split column stage");
+        else if (sizeof(T) == 8 && gy == 8 && logMy == 11 && !narrow) {        // 16384 rows on the 2048-row grid (float64 only: see row_rs4096)
+            if constexpr (sizeof(T) == 8) go(col_fband_kernel<T, Seq<16, 8, 16>, 3, lc11>, dim3(gx, gy, gz), nt, smem, a);
+        } else rc = fail("fft: unsupported R-split column stage");
     }
     template <typename T>
     void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
@@ -335,8 +344,8 @@ struct HipLauncher {
                     } else
                     if (a.lr == 2) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 2>, dim3(grid), nt, smem, a);
                     else if (a.lr == 3) {
-                        if constexpr (seq_logl<S>() == 11) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 3>, dim3(grid), nt, smem, a);
-                        else if (!rc) rc = fail("fft: the R = 8 layout of the pair row stage is built for 2048-point row grids");
+                        if constexpr (seq_logl<S>() == 11 && sizeof(T) == 8) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 3>, dim3(grid), nt, smem, a);
+                        else if (!rc) rc = fail("fft: the R = 8 layout of the pair row stage is built for float64 on 2048-point row grids");
                     } else if (a.lr == 0) go(row_qe_pair_kernel<T, S, decltype(nzc)::value, 0>, dim3(grid), nt, smem, a);
                     else if (!rc) rc = fail("fft: unsupported R-layout of the pair row stage");
                 });
@@ -411,6 +420,17 @@ struct HipLauncher {
         if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, lc11 - 1>, dim3(gx, 1, gz), nt, smem, a); return true; }
         if (logL == 10) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, lc10 - 1>, dim3(gx, 1, gz), nt, smem, a); return true; }
         return false;
+    }
+    template <typename T>
+    void col_deriv(int gx, int gy, int nt, size_t smem, const ColDerivArgs<T>& a, int nz) {
+        const bool ok = dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_logl<S>() <= 8) {
+                if (nt > col_maxnt<S>()) { if (!rc) rc = fail("fft: column workgroup size exceeds its launch bound"); return; }
+                go(col_deriv_kernel<T, S>, dim3(gx, gy, nz), nt, smem, a);
+            } else if (!rc) rc = fail("fft: unsupported column sub-length");
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported column length");
     }
     template <typename T>
     void col(int gx, int gy, int nt, size_t smem, const ColArgs<T>& a, int nz = 1) {
@@ -586,10 +606,12 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
         if (stages & 4)
             f.legs_cols_from_pass1(q, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx,
                                    (cx<T>*)gy, (cx<T>*)h, width, rband, pw, pout);
-    } else if (stages == 7) {
-        f.cols(q, tA, pw, tB, pw, w, false, (T)1, 0, 1, nullptr, nullptr, rband);
-        f.legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
-                    (cx<T>*)h, width, rband, pw, pout);
+    } else {
+        // (short columns: both forward column passes count as stage 2, the leg kernel + inverse pass 2 as stage 4)
+        if (stages & 2) f.cols(q, tA, pw, tB, pw, w, false, (T)1, 0, 1, nullptr, nullptr, rband);
+        if (stages & 4)
+            f.legs_cols(q, tB, tB, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
+                        (cx<T>*)h, width, rband, pw, pout);
     }
     return q.rc;
 }
@@ -707,6 +729,41 @@ static int windowed_rows_impl(oa_plan* p, const void* hc_in, void* cols_tmp, con
 int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st) {
     return p->dtype == OA_F32 ? windowed_rows_impl<float>(p, hc_in, cols_tmp, window, width, pl, scale, st)
                               : windowed_rows_impl<double>(p, hc_in, cols_tmp, window, width, pl, scale, st);
+}
+// flat-sky Taylor lensing, FFT part (oa_lens_maps): nmaps real maps -> their transforms (k0: nmaps hc planes) -> the nd derivative
+// fields of each, inverse-transformed: ONE pass-1 launch with the derivative factor at the load, ONE pass-2 launch, ONE row C2R
+// launch per chunk of planes (hc_pool: lens_chunk_planes(p) hc planes; real_pool: nmaps * nd real planes, 1 / Npix applied)
+template <typename T>
+static int lens_derivs_impl(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd,
+                            hipStream_t st) {
+    const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
+    if (int rc = plan_ensure_scratch(p, plane)) return rc;
+    HipLauncher q{st};
+    auto f = view<T>(p);
+    const long hcp = (long)p->ny * p->kp, rp = (long)p->ny * (p->nx / 2);       // plane strides in complex elements
+    for (int m = 0; m < nmaps; ++m)
+        f.r2c(q, (const T*)real_in + (long)m * in_stride, (cx<T>*)k0 + (long)m * hcp, (cx<T>*)p->scratch, (T)1);
+    // CHUNKS of planes small enough for the infinity cache (256 MB): column pass 1 -> column pass 2 -> row C2R of a chunk back to
+    // back, so the chunk's intermediates are cache hits (measured at 4096^2 float64: a column pass over ONE plane 49 us, the same
+    // pass over 42 planes in one launch 71-77 us per plane -- profiles/r04f_lensloop_kernel_stats_f64_batched.txt)
+    // (hc_pool therefore holds ONE chunk: lens_chunk_planes(p) planes)
+    const int total = nmaps * nd, G = lens_chunk_planes(p) < total ? lens_chunk_planes(p) : total;
+    for (int z0 = 0; z0 < total; z0 += G) {
+        const int nz = z0 + G <= total ? G : total - z0;
+        f.cols_derivs(q, (const cx<T>*)k0, hcp, (cx<T>*)hc_pool, hcp, nmaps, nd, (const T*)p->lxd, (const T*)p->lyd, z0, nz);
+        f.rows(q, ROW_C2R, hc_pool, p->kp, (cx<T>*)real_pool + (long)z0 * rp, p->nx / 2, (T)(1.0 / ((double)p->ny * p->nx)), 0x7fffffff, nullptr,
+               nz, hcp, rp);
+    }
+    return q.rc;
+}
+int lens_chunk_planes(const oa_plan* p) {
+    const size_t plane = (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8);
+    const int G = (int)((size_t)96 * 1024 * 1024 / plane);
+    return G < 1 ? 1 : G;
+}
+int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st) {
+    return p->dtype == OA_F32 ? lens_derivs_impl<float>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st)
+                              : lens_derivs_impl<double>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st);
 }
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my) {

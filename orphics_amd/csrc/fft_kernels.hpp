@@ -358,6 +358,10 @@ struct RowArgs {
     int lr, my;
     long kplane;
     const cx<T>* twy;          // W_ny^k, ny = my << lr
+    // SEVERAL PLANES PER LAUNCH (row_fft_body, grid y = plane): plane z reads z * in_zoff and writes z * out_zoff complex elements
+    // behind the first (oa_lens_maps: the C2R of every derivative field of every map in one launch).  nz = 0: one plane.
+    int nz;
+    long in_zoff, out_zoff;
 };
 
 template <typename T, bool SWAP>
@@ -429,6 +433,11 @@ OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, lo
                 A = row[kk];
                 B = row[L - kk];
             }
+            // the columns kx = 0 and kx = nx/2 of a REAL field's transform are real once the column transform has been inverted;
+            // whatever imaginary part arrives here comes from a non-Hermitian input column (e.g. the Nyquist column of Q, U =
+            // R^-1 (E, B): the rotation's sine is odd there) and is DROPPED -- the reference's `ifft(...).real` (maps.py:1585)
+            // symmetrises each column on its own; packed into Z'[0] it would leak from the Nyquist column into kx = 0
+            if (kk == 0) { A.y = (T)0; B.y = (T)0; }
             const cx<T> w = tw[kk << sh];  // W_N^k
             const cx<T> d1 = A - conj(B), d2 = B - conj(A);
             const cx<T> z1 = (A + conj(B)) + mul_pi(conj(w) * d1);
@@ -500,8 +509,8 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     constexpr int logL = seq_total_log<SEQ>();   // compile-time: LDS offsets of the 16 taps become immediates
     const int C = 1 << a.logC, RS = a.rowStride;
     const long r0 = (long)ctx.bid_x() * C;
-    const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in);
-    cx<T>* out = reinterpret_cast<cx<T>*>(a.out);
+    const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (a.nz ? (long)ctx.bid_y() * a.in_zoff : 0L);
+    cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (a.nz ? (long)ctx.bid_y() * a.out_zoff : 0L);
     cx<T>* twl = s + C * RS;                      // two-level stage-twiddle table (LDS)
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
     ctx.sync();
@@ -1841,6 +1850,88 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
         }
     }
     }
+}
+
+// ===========================================================================
+// Inverse column pass 1 of the Fourier-space DERIVATIVES of a map (flat-sky Taylor lensing, lensing.py:395-440): the factor
+// (i lx)^a (i ly)^b is applied at the load, so the derivative spectra never exist in HBM.  grid z = map * nd + plane; plane
+// idx(a, b) = n (n + 1) / 2 - 1 + b, n = a + b = 1 .. order - 1 (the order of hc_derivs_kernel / lens_taylor_kernel).  Same
+// four-step layout as col_fft_body's pass 1 (the caller runs the in-place pass 2 over all planes in one launch).
+// ===========================================================================
+template <typename T>
+struct ColDerivArgs {
+    const cx<T>* in;            // nmaps source transforms, in_mstride elements apart, row pitch `pitch`
+    cx<T>* out;                 // the planes of THIS launch (grid z of them), out_pstride elements apart, row pitch `pitch`
+    long in_mstride, out_pstride, pitch;
+    int width, nd, logL;
+    int zbase;                  // first plane of this launch (chunked launches: plane index = zbase + grid z)
+    const cx<T>* tw;            // W_ny^k
+    int logTw;
+    long in_ns, out_gs;         // pass-1 strides (rows): point n of group g is row g + n in_ns; bin k goes to row g out_gs + k
+    const T* lxd; const T* lyd;
+};
+
+template <typename T>
+struct ColDerivLoad {
+    static constexpr bool reads_lds = false;    // (the factor tables sit behind the tile, filled and synced before the pipeline: no hazard with its writes)
+    const cx<T>* base;
+    unsigned nstride;
+    int ncols;
+    const T* fx;                // LDS: lx^a of the tile's columns
+    const T* fy;                // LDS: ly^b of the tile's rows (point n of this group)
+    T cr, ci;                   // i^(a + b)
+    template <typename U> OA_HD cx<U> get(int n, int c) const {
+        cx<U> x = mk<U>((U)0, (U)0);
+        if (c < ncols) {
+            const cx<U> v = base[(unsigned)n * nstride + (unsigned)c];
+            const U f = fx[c] * fy[n];
+            x = mk<U>((v.x * cr - v.y * ci) * f, (v.x * ci + v.y * cr) * f);
+        }
+        return swp(x);          // inverse transform = forward transform of the swapped data
+    }
+};
+
+template <typename T, class SEQ, class Ctx>
+OA_HD void col_deriv_body(Ctx& ctx, const ColDerivArgs<T>& a) {
+    cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
+    const int tid = ctx.tid();
+    constexpr int CLC = COL_LOGC;
+    constexpr int logL = seq_total_log<SEQ>();
+    constexpr int CNT = ((1 << (logL + COL_LOGC)) / EPT) > 0 ? ((1 << (logL + COL_LOGC)) / EPT) : 1;
+    const int c0 = ctx.bid_x() << CLC;
+    const long g = ctx.bid_y();
+    int ncols = a.width - c0;
+    if (ncols > (1 << CLC)) ncols = 1 << CLC;
+    cx<T>* twl = s + (1 << (logL + CLC));
+    cx<T>* ti = twl + tw_lds_size(logL);
+    T* fy = reinterpret_cast<T*>(ti + (1 << logL));         // [L]: ly^b at the rows of this group's points
+    T* fx = fy + (1 << logL);                               // [C]: lx^a of the tile's columns
+    const int z = a.zbase + ctx.bid_z(), m = z / a.nd, d = z - m * a.nd;
+    // plane d -> (n, b): n (n + 1) / 2 - 1 <= d < (n + 1)(n + 2) / 2 - 1
+    int n = 1;
+    while ((n + 1) * (n + 2) / 2 - 1 <= d) ++n;
+    const int b = d - (n * (n + 1) / 2 - 1), aa = n - b;
+    tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, CNT);
+    for (int i = tid; i < (1 << logL); i += CNT) {
+        ti[i] = a.tw[(unsigned)g * (unsigned)i];
+        const T ly = a.lyd[(unsigned)g + (unsigned)i * (unsigned)a.in_ns];
+        T f = (T)1;
+        for (int k = 0; k < b; ++k) f *= ly;
+        fy[i] = f;
+    }
+    for (int i = tid; i < (1 << CLC); i += CNT) {
+        const T lx = (c0 + i < a.width) ? a.lxd[c0 + i] : (T)0;
+        T f = (T)1;
+        for (int k = 0; k < aa; ++k) f *= lx;
+        fx[i] = f;
+    }
+    ctx.sync();
+    const int q = n & 3;                                     // i^n
+    const T cr = (T)((q == 0) - (q == 2)), ci = (T)((q == 1) - (q == 3));
+    const ColDerivLoad<T> ld{a.in + (long)m * a.in_mstride + g * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, fx, fy, cr, ci};
+    const ColStore<T> st{a.out + (long)ctx.bid_z() * a.out_pstride + g * a.out_gs * a.pitch + c0, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1,
+                         0, 0, 0, 0};
+    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
 }
 
 template <typename T, class SEQ, class Ctx>

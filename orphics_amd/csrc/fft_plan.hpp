@@ -56,9 +56,10 @@ struct Fft2dPlan {
     // ---- row passes -------------------------------------------------------
     template <class Launcher>
     void rows(Launcher& q, int mode, const void* in, long in_pitch, void* out, long out_pitch, T scale,
-              int wcols = 0x7fffffff, const void* mul = nullptr) const {
+              int wcols = 0x7fffffff, const void* mul = nullptr, int nz = 0, long in_zoff = 0, long out_zoff = 0) const {
         RowArgs<T> a{};
         a.mul = mul;
+        a.nz = nz; a.in_zoff = in_zoff; a.out_zoff = out_zoff;     // nz > 0: that many planes in one launch (grid y)
         const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R || mode == ROW_WIN);
         a.logL = real_mode ? logNx - 1 : logNx;
         const int L = 1 << a.logL;
@@ -87,7 +88,8 @@ struct Fft2dPlan {
         const int logMy = ilog2(my), L = 1 << (logNx - 1);
         if (off || !is_pow2(my)) return false;
         // R = 8: 16384^2 maps on the 2048-row column grid (row_r2c_rs_body<T, 13, 3>: 16384-point rows, <= 512 kept columns)
-        if (logNy - logMy == 3) return logMy == 11 && logNx == 14 && wl <= 512;
+        // (float64: the float build measured slower than the two-waves-per-row kernel + multi-pass columns, which float keeps)
+        if (logNy - logMy == 3) return sizeof(T) == 8 && logMy == 11 && logNx == 14 && wl <= 512;
         return logNy - logMy == 2 && (logMy == 10 || logMy == 11) && logNx >= 11 && logNx <= 14 && wl <= L / 4 && wl <= RS_MAXS * (L / EPT);
     }
     template <class Launcher>
@@ -190,6 +192,24 @@ struct Fft2dPlan {
         if (a.NT < 1) a.NT = 1;
         a.rowStride = L + (L >> 4) + 2;
         q.row_qe(ny / C, a.NT, ((size_t)C * a.rowStride + tw_lds_size(a.logL)) * sizeof(cx<T>), a);
+    }
+
+    // ---- inverse column transform of the nd Fourier-space derivative fields (i lx)^a (i ly)^b k of each of nmaps transforms
+    //      (col_deriv_body: the factor rides on pass 1's load), all planes per launch: pass 1, then the in-place pass 2
+    // z0, nz: the planes [z0, z0 + nz) of the nmaps * nd only, written to out[0 .. nz) (chunked launches: a chunk small enough for the 256 MB infinity cache
+    // goes through pass 1, pass 2 and the row pass back to back and its intermediates never leave the cache)
+    template <class Launcher>
+    void cols_derivs(Launcher& q, const cx<T>* in, long in_mstride, cx<T>* out, long out_pstride, int nmaps, int nd, const T* lxd,
+                     const T* lyd, int z0 = 0, int nz = -1) const {
+        if (nz < 0) nz = nmaps * nd;
+        const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
+        const long N1 = 1L << logN1, N2 = 1L << logN2;
+        const int C = 1 << COLC, width = nx / 2 + 1, tiles = (width + C - 1) / C;
+        ColDerivArgs<T> a{};
+        a.in = in; a.out = out; a.in_mstride = in_mstride; a.out_pstride = out_pstride; a.pitch = kp; a.width = width; a.nd = nd;
+        a.logL = logN1; a.tw = tw_y; a.logTw = logNy; a.in_ns = N2; a.out_gs = N1; a.lxd = lxd; a.lyd = lyd; a.zbase = z0;
+        q.col_deriv(tiles, (int)N2, (int)((N1 * C) / EPT), ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>) + (size_t)(N1 + C) * sizeof(T), a, nz);
+        cols(q, out, kp, out, kp, width, true, (T)1, 2, 1, nullptr, nullptr, 0, false, -1, nz, out_pstride, out_pstride);
     }
 
     // ---- full column transform of `width` columns (two passes) -------------

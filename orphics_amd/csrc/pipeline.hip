@@ -41,6 +41,8 @@ struct Pipeline {
     std::vector<unsigned long long> mv_rkey;
     void* mc_src = nullptr;           // oa_mc_run: hc planes of a batch of realisations
     int mc_cap = 0;
+    void* lens_pool = nullptr;        // oa_lens_maps: transforms + derivative planes (hc and real) of the maps of one call
+    size_t lens_bytes = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
     // oa_plan_set_option (include/orphics_amd.h): which of the equivalent launch sequences the one-call entries run
@@ -72,6 +74,7 @@ void pipeline_release(oa_plan* p) {
     if (q->mv_ftab) (void)hipFree(q->mv_ftab);
     if (q->mc_src) (void)hipFree(q->mc_src);
     if (q->mv_rtab) (void)hipFree(q->mv_rtab);
+    if (q->lens_pool) (void)hipFree(q->lens_pool);
     delete q;
     p->pipe = nullptr;
 }
@@ -295,6 +298,61 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
         if ((rc = qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], host_signs[i] * s * s * sy, i > 0, leg_cols, kappa_cols, mrow, pl, pk, st, my))) return rc;
     }
     return qe_cols_div_w(p, q->g[0], q->g[1], Fnorm, out, accumulate, kappa_cols, kappa_rows, pk, st, my);
+}
+
+/* flat_taylens (lensing.py:395-440) of nmaps real maps by ONE deflection field, given as its nearest-pixel shifts and sub-pixel
+ * remainders (oa_lens_split): out_m(x) = sum_{a + b < order} dx^a dy^b / (a! b!) D_ab[m](x + shift).  Per call: nmaps R2Cs, then the
+ * inverse transforms of all nmaps * nd derivative fields (nd = order (order + 1) / 2 - 1), three launches per cache-sized chunk of
+ * planes -- column pass 1 with the factor (i lx)^a (i ly)^b applied at its load (the derivative spectra never exist in HBM),
+ * column pass 2, row C2R -- and one gather pass per map.  The planes live in a plan-owned pool (allocated / grown on first use: that call synchronises the device
+ * once; oa_plan_release_pools frees it). */
+int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int order, const int32_t* shift_x, const int32_t* shift_y,
+                 const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
+    OA_REQUIRE(p && real_in && shift_x && shift_y && dx && dy && real_out && nmaps >= 1, "oa_lens_maps: bad argument");
+    OA_NEED_POW2(p, "oa_lens_maps");
+    OA_REQUIRE(p->have_laxes, "oa_lens_maps: call oa_plan_set_laxes first");
+    OA_REQUIRE(order >= 1 && order <= 8, "oa_lens_maps: order must be 1..8");
+    OA_REQUIRE(real_in != real_out, "oa_lens_maps: in-place not supported");
+    const long rplane = (long)p->ny * p->nx;
+    OA_REQUIRE(in_stride >= rplane && out_stride >= rplane, "oa_lens_maps: plane stride smaller than a plane");
+    Pipeline* q = pipe_of(p);
+    const size_t rs = p->dtype == OA_F32 ? 4 : 8;
+    const int nd = order * (order + 1) / 2 - 1;
+    hipStream_t st = (hipStream_t)stream;
+    char* realp = nullptr;
+    if (nd > 0) {
+        const size_t hcb = plane_bytes(p), rb = (size_t)rplane * rs;
+        const int chunk = std::min(lens_chunk_planes(p), nmaps * nd);
+        const size_t need = (size_t)nmaps * hcb + (size_t)chunk * hcb + (size_t)nmaps * nd * rb;
+        if (q->lens_bytes < need) {
+            if (q->lens_pool) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->lens_pool); q->lens_pool = nullptr; q->lens_bytes = 0; }
+            OA_HIP(hipMalloc(&q->lens_pool, need));
+            q->lens_bytes = need;
+        }
+        char* k0 = (char*)q->lens_pool;
+        char* hcp = k0 + (size_t)nmaps * hcb;
+        realp = hcp + (size_t)chunk * hcb;
+        if (int rc = qe_lens_derivs_w(p, nmaps, real_in, in_stride, k0, hcp, realp, nd, st)) return rc;
+    }
+    for (int m = 0; m < nmaps; ++m) {
+        const void* src = (const char*)real_in + (size_t)m * in_stride * rs;
+        void* dst = (char*)real_out + (size_t)m * out_stride * rs;
+        if (int rc = oa_lens_taylor(p, src, nd > 0 ? realp + (size_t)m * nd * rplane * rs : nullptr, rplane, order, shift_x, shift_y, dx, dy, dst, stream)) return rc;
+    }
+    return 0;
+}
+
+/* frees the plan-owned pools that the multi-map entries grow on demand (oa_lens_maps, oa_qe_mv / oa_qe_tt_splits, oa_mc_run): they
+ * are reallocated by the next call that needs them.  Synchronises the device. */
+int oa_plan_release_pools(oa_plan* p) {
+    OA_REQUIRE(p, "oa_plan_release_pools: NULL plan");
+    if (!p->pipe) return 0;
+    Pipeline* q = (Pipeline*)p->pipe;
+    OA_HIP(hipDeviceSynchronize());
+    if (q->lens_pool) { (void)hipFree(q->lens_pool); q->lens_pool = nullptr; q->lens_bytes = 0; }
+    if (q->split_legs) { (void)hipFree(q->split_legs); q->split_legs = nullptr; q->split_bytes = 0; }
+    if (q->mc_src) { (void)hipFree(q->mc_src); q->mc_src = nullptr; q->mc_cap = 0; }
+    return 0;
 }
 
 int oa_filter_map(oa_plan* p, const void* real_in, const void* filt_hcreal, void* real_out, void* stream) {

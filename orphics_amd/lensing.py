@@ -971,7 +971,11 @@ class FlatLenser(object):
     def alpha_from_kappa(self, kappa):
         """grad(phi) with phi = IDFT[2 kappa_l/(l(l+1))]: returns (alpha_y, alpha_x) device maps."""
         e = self.eng
-        kk = e.rfft(e.to_real(kappa))
+        return self.alpha_from_kappa_hc(e.rfft(e.to_real(kappa)))
+
+    def alpha_from_kappa_hc(self, kk):
+        """the same from kappa's (unnormalised) hc transform -- a simulation that drew kappa in harmonic space has it already"""
+        e = self.eng
         gx, gy, _ = e.qe_legs(kk, kk, self._fphi, self._fphi)
         return e.irfft(gy), e.irfft(gx)
 
@@ -990,32 +994,43 @@ class FlatLenser(object):
         sy, dy = e.lens_split(ay, self.geom.step_y)
         return sx, sy, dx, dy
 
-    def lens(self, imap, alpha, taylor_order=5, fused=True, split=None):
-        """flat_taylens (lensing.py:395-440): T(x + alpha) by nearest-pixel remap + Taylor series in FFT derivatives.
-        fused (default): ONE derivative kernel for all 14 terms (``oa_hc_derivs``), their C2Rs, ONE gather pass over all
-        of them (``oa_lens_taylor``); fused=False: one derivative kernel, C2R and gather per term (the first
-        implementation, kept as the cross-check)."""
-        from math import factorial
+    def lens_many(self, imaps, alpha, taylor_order=5, split=None, out=None):
+        """flat_taylens (lensing.py:395-440) of several maps -- ``imaps``: (n, Ny, Nx) device tensor, e.g. T, Q, U of one
+        realisation -- by ONE deflection, in one C-ABI call (``oa_lens_maps``): the R2C of every map, then the inverse transforms
+        of all n * nd derivative fields in three launches (the factor (i lx)^a (i ly)^b rides on the load of the inverse column
+        pass: no derivative spectrum in HBM, no Python loop over terms), one gather pass per map.  The work planes belong to
+        the plan (n * (1 + nd) planes + one cache-sized chunk: 6.2 GB for n = 3 at 4096^2 float64, order 5; ``release()`` frees
+        them)."""
         from ._lib import check
         from .engine import _ptr, _stream
         e = self.eng
+        torch = _torch()
+        sx, sy, dx, dy = split if split is not None else self.split(alpha)
+        src = imaps if (torch.is_tensor(imaps) and imaps.is_cuda and imaps.dtype == e.rdt) else torch.as_tensor(np.asarray(imaps), dtype=e.rdt, device=e.device)
+        src = src.contiguous()
+        if src.ndim != 3 or tuple(src.shape[-2:]) != (e.ny, e.nx):
+            raise ValueError("lens_many: expected (n, %d, %d) maps" % (e.ny, e.nx))
+        if out is None:
+            out = torch.empty_like(src)
+        check(e.lib.oa_lens_maps(e.plan, int(src.shape[0]), _ptr(src), e.ny * e.nx, int(taylor_order), _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy),
+                                 _ptr(out), e.ny * e.nx, _stream()))
+        return out
+
+    def release(self):
+        """free the plan-owned work planes of ``lens`` / ``lens_many`` (they are reallocated by the next call)"""
+        self.eng.release_pools()
+
+    def lens(self, imap, alpha, taylor_order=5, fused=True, split=None):
+        """flat_taylens (lensing.py:395-440): T(x + alpha) by nearest-pixel remap + Taylor series in FFT derivatives.
+        fused (default): one ``oa_lens_maps`` call (see :meth:`lens_many`); fused=False: one derivative kernel, C2R and gather
+        per term through the public fine-grained calls (the first implementation, kept as the cross-check)."""
+        from math import factorial
+        e = self.eng
         sx, sy, dx, dy = split if split is not None else self.split(alpha)
         src = e.to_real(imap)
+        if fused and 1 <= taylor_order <= 8 and e.pow2:
+            return self.lens_many(src[None], alpha, taylor_order=taylor_order, split=(sx, sy, dx, dy))[0]
         out = e.real()
-        if fused and 2 <= taylor_order <= 8:
-            torch = _torch()
-            nd = taylor_order * (taylor_order + 1) // 2 - 1
-            if getattr(self, "_pool", None) is None or self._pool[0].shape[0] != nd:
-                self._pool = (torch.empty((nd, e.ny, e.kp), dtype=e.cdt, device=e.device),
-                              torch.empty((nd, e.ny, e.nx), dtype=e.rdt, device=e.device))
-            dk, dr = self._pool
-            k0 = e.rfft(src)
-            check(e.lib.oa_hc_derivs(e.plan, _ptr(k0), int(taylor_order), _ptr(dk), e.ny * e.kp, _stream()))
-            for i in range(nd):
-                e.irfft(dk[i], out=dr[i])
-            check(e.lib.oa_lens_taylor(e.plan, _ptr(src), _ptr(dr), e.ny * e.nx, int(taylor_order), _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy),
-                                       _ptr(out), _stream()))
-            return out
         e.lens_gather(src, sx, sy, dx, dy, 0, 0, 1.0, out, False)
         k0 = e.rfft(src)
         # D[a][b] = (i lx)^a (i ly)^b k0, built incrementally with the derivative kernel
@@ -1090,6 +1105,8 @@ class FlatLensingSims(object):
         sp = self.lenser.split(alpha)                       # once per deflection, shared by every component
         if unlensed.ndim == 2:
             return self.lenser.lens(unlensed, alpha, taylor_order=lens_order, split=sp)
+        if self.lenser.eng.pow2 and 1 <= lens_order <= 8:   # all components in ONE oa_lens_maps call
+            return self.lenser.lens_many(unlensed, alpha, taylor_order=lens_order, split=sp)
         return torch.stack([self.lenser.lens(unlensed[i].contiguous(), alpha, taylor_order=lens_order, split=sp) for i in range(unlensed.shape[0])])
 
     def beam_maps(self, lensed):
@@ -1101,6 +1118,46 @@ class FlatLensingSims(object):
 
     def get_kappa(self, seed=None):
         return self.kgen.get_map(seed=seed, scalar=True)
+
+    def iau_mismatch(self, qest):
+        """get_sim_teb rotates Q, U -> E, B with the convention the maps were drawn in (MapGen.get_map: iau=False); an estimator
+        set up with the other sign convention needs the observed MAPS (get_sim) and its own rotation"""
+        return bool(getattr(qest, "iau", False))
+
+    def get_sim_teb(self, seed_cmb=None, seed_kappa=None, seed_noise=None, lens_order=5):
+        """What the verification loop feeds to the estimators (tutorials/tt_verification.ipynb cell 4: ``FourierCalc.iqu2teb`` of
+        the observed maps and the transform of the input kappa) WITHOUT taking any transform twice.  ``get_sim`` draws every field
+        in harmonic space, inverse-transforms it, and the loop transforms the results forward again; here
+          * kappa's drawn transform goes straight to ``alpha_from_kappa_hc`` and is returned as the loop's ``kappa_in`` transform,
+          * the beam multiplies the transform of the lensed maps and the noise -- drawn as T, E, B transforms -- is added there
+            (per-mode linear operations commute with the transform; the Q, U -> E, B rotation is applied to the beamed signal),
+        so a polarised simulation costs 3 R2Cs + (3 + 2 + 3 nd) C2Rs instead of 11 + (12 + 3 nd).  Same realisations as
+        ``get_sim`` with the same seeds; T, E, B agree with ``iqu2teb(get_sim(...))`` to rounding below the Nyquist modes.
+        Returns (teb: (ncomp, Ny, kp) unnormalised hc transforms, kappa_hc: unnormalised hc transform of the input kappa)."""
+        torch = _torch()
+        e = self.lenser.eng
+        rt = float(np.sqrt(e.npix))                       # MapGen draws are unitary: rfft(map) = sqrt(Npix) x the drawn transform
+        assert not self._fixed, "get_sim_teb draws its own kappa"
+        unl = self.get_unlensed(seed_cmb)
+        kin = self.kgen.get_map(seed=seed_kappa, scalar=True, harm=True).t * rt
+        self.alpha = self.lenser.alpha_from_kappa_hc(kin)
+        lensed = self.lens_maps(unl, self.alpha, lens_order)
+        pol = lensed.ndim == 3
+        planes = [lensed[i] for i in range(lensed.shape[0])] if pol else [lensed]
+        cached = getattr(self, "_kbeam_hc", None)
+        if cached is None or cached[0] is not self.kbeam:
+            self._kbeam_hc = (self.kbeam, e.fullreal_to_hc(e.to_real(self.kbeam)))
+        beam = self._kbeam_hc[1]
+        ks = [e.cmul_real(e.rfft(p.contiguous()), beam) for p in planes]
+        if pol:
+            if getattr(self, "_fc_half", None) is None:
+                self._fc_half = maps.FourierCalc(self.shape, self.wcs, layout="half")
+            c, s = self._fc_half._rot_planes(e, True)
+            ks[1], ks[2] = e.rot2(c, s, ks[1], ks[2])
+        nk = self.ngen.get_map(seed=seed_noise, harm=True).t
+        nk = [nk[i] for i in range(nk.shape[0])] if pol else [nk]
+        teb = torch.stack([k.add_(n, alpha=rt) for k, n in zip(ks, nk)])
+        return teb, kin
 
     def get_sim(self, seed_cmb=None, seed_kappa=None, seed_noise=None, lens_order=5, return_intermediate=False,
                 skip_lensing=False, cfrac=None):

@@ -99,7 +99,11 @@ class GaussianN0MonteCarlo(object):
             prev = i
         # (with the mean-field stack the one-stream loop measured faster -- 16.0k vs 14.1k sims/s at 4096^2 -- so the
         # lanes are used for the bandpower moments only)
-        if self.window is not None:
+        if self.window is not None and self.streams > 1 and len(sims) >= 4 * self.streams:
+            # windowed realisations are a chain of ~10 launches, half of them latency-bound (draw, leg kernel, row stage,
+            # divergence + binning): independent realisations on several streams overlap them with the bandwidth-bound passes
+            self._run_blocks_on_streams(blocks, n, S, C, mf)
+        elif self.window is not None:
             for lo, hi in blocks:
                 check(e.lib.oa_mc_run_windowed(e.plan, self.base_seed, lo, hi, _ptr(self.cs), _ptr(self.window), _ptr(n), _ptr(S), _ptr(C),
                                                _ptr(mf), _stream()))
@@ -150,8 +154,12 @@ class GaussianN0MonteCarlo(object):
                 lo = prev = mine[0]
                 for i in mine[1:] + [None]:
                     if i is None or i != prev + 1:
-                        check(ej.lib.oa_mc_run(ej.plan, self.base_seed, lo, prev + 1, _ptr(self.cs), _ptr(nj), _ptr(Sj), _ptr(Cj),
-                                               _ptr(mfj), stream.cuda_stream))
+                        if self.window is not None:
+                            check(ej.lib.oa_mc_run_windowed(ej.plan, self.base_seed, lo, prev + 1, _ptr(self.cs), _ptr(self.window), _ptr(nj),
+                                                            _ptr(Sj), _ptr(Cj), _ptr(mfj), stream.cuda_stream))
+                        else:
+                            check(ej.lib.oa_mc_run(ej.plan, self.base_seed, lo, prev + 1, _ptr(self.cs), _ptr(nj), _ptr(Sj), _ptr(Cj),
+                                                   _ptr(mfj), stream.cuda_stream))
                         lo = i
                     prev = i
             if j:
@@ -223,6 +231,7 @@ class LensedSimsMonteCarlo(object):
         self.norm = geom.area / float(e.npix) ** 2
         self.acc = Statistics(comm=self.comm if hasattr(self.comm, "dist") else None, device=e.device)
         self.stage_ms = {}
+        self.fast_sims = True         # FlatLensingSims.get_sim_teb (no transform taken twice); False: get_sim + iqu2teb, as the notebook writes it
 
     def _seed(self, kind, i):
         return (self.base_seed, kind, int(i))
@@ -242,15 +251,22 @@ class LensedSimsMonteCarlo(object):
             if self.paired:
                 self._paired_sample(i)
                 continue
-            parts = self.sims.get_sim(seed_cmb=self._seed(1, i), seed_kappa=self._seed(2, i), seed_noise=self._seed(3, i),
-                                      lens_order=self.lens_order, return_intermediate=True)
-            kappa, observed = parts[1], parts[5]
-            mark("get_sim")
-            teb = self.fc.iqu2teb(observed, normalize=False).t      # (3, Ny, kp) or (Ny, kp) hc planes: T, E, B
-            if teb.ndim == 2:
-                teb = teb[None]
-            kin = e.rfft(kappa.contiguous())
-            mark("transforms")
+            if self.fast_sims and hasattr(self.sims, "get_sim_teb") and not self.sims._fixed and not self.sims.iau_mismatch(q):
+                # no transform taken twice (FlatLensingSims.get_sim_teb): the observed T, E, B transforms and kappa_in's directly
+                teb, kin = self.sims.get_sim_teb(seed_cmb=self._seed(1, i), seed_kappa=self._seed(2, i), seed_noise=self._seed(3, i),
+                                                 lens_order=self.lens_order)
+                mark("get_sim")
+                mark("transforms")
+            else:
+                parts = self.sims.get_sim(seed_cmb=self._seed(1, i), seed_kappa=self._seed(2, i), seed_noise=self._seed(3, i),
+                                          lens_order=self.lens_order, return_intermediate=True)
+                kappa, observed = parts[1], parts[5]
+                mark("get_sim")
+                teb = self.fc.iqu2teb(observed, normalize=False).t      # (3, Ny, kp) or (Ny, kp) hc planes: T, E, B
+                if teb.ndim == 2:
+                    teb = teb[None]
+                kin = e.rfft(kappa.contiguous())
+                mark("transforms")
             s_in, counts = e.bin_power(kin, kin, self.norm, self.ids, self.nids, herm=True)
             auto = s_in[1:-1] / counts[1:-1].double()
             self.acc.add("input", auto)

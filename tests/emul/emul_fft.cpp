@@ -53,7 +53,7 @@ struct EmuLauncher {
             using S = decltype(seq);
             switch (a.mode) {
                 case ROW_R2C: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_R2C, S>(c, a); }); break;
-                case ROW_C2R: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2R, S>(c, a); }); break;
+                case ROW_C2R: run(grid, a.nz > 0 ? a.nz : 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2R, S>(c, a); }); break;
                 case ROW_C2C_F: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2C_F, S>(c, a); }); break;
                 case ROW_WIN: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_WIN, S>(c, a); }); break;
                 default: run(grid, 1, nt, smem, [&](EmuCtx& c) { row_fft_body<T, ROW_C2C_I, S>(c, a); }); break;
@@ -104,6 +104,12 @@ struct EmuLauncher {
         if (gy == 4 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 8>, 2, lc11>(c, a); }, gz);
         else if (gy == 4 && logMy == 10) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 8>, 2, lc10>(c, a); }, gz);
         else if (gy == 8 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 16>, 3, lc11>(c, a); }, gz);
+    }
+    template <typename T> void col_deriv(int gx, int gy, int nt, size_t smem, const ColDerivArgs<T>& a, int nz) {
+        dispatch_seq(a.logL, [&](auto seq) {
+            using S = decltype(seq);
+            if constexpr (seq_total_log<S>() <= 8) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_deriv_body<T, S>(c, a); }, nz);
+        });
     }
     template <typename T> void col_legs(int gx, int gy, int nt, size_t smem, int logL, const ColLegsArgs<T>& a) {
         dispatch_seq(logL, [&](auto seq) {
@@ -318,7 +324,19 @@ static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int wid
     }
     return 0;
 }
+// all nd derivative fields of ONE transform, inverse-transformed (cols_derivs + batched row C2R): out = nd real planes
+template <typename T>
+static int do_lens_derivs(int ny, int nx, const cx<T>* k0, const T* lxd, const T* lyd, T* out, int nd) {
+    Holder<T> h(ny, nx);
+    const long hcp = (long)ny * h.p.kp, rp = (long)ny * (nx / 2);
+    std::vector<cx<T>> pool((size_t)nd * hcp);
+    EmuLauncher q;
+    h.p.cols_derivs(q, k0, hcp, pool.data(), hcp, 1, nd, lxd, lyd);
+    h.p.rows(q, ROW_C2R, pool.data(), h.p.kp, out, nx / 2, (T)(1.0 / ((double)ny * nx)), 0x7fffffff, nullptr, nd, hcp, rp);
+    return 0;
+}
 extern "C" {
+int emu_lens_derivs_f64(int ny, int nx, const void* k0, const double* lxd, const double* lyd, double* out, int nd) { return do_lens_derivs<double>(ny, nx, (const cx<double>*)k0, lxd, lyd, out, nd); }
 int emu_rows_win_f64(int ny, int nx, const void* in, const double* w, void* out, long opitch, double s, int wcols) { return do_rows_win<double>(ny, nx, (const cx<double>*)in, w, (cx<double>*)out, opitch, s, wcols); }
 int emu_rows_win_f32(int ny, int nx, const void* in, const float* w, void* out, long opitch, double s, int wcols) { return do_rows_win<float>(ny, nx, (const cx<float>*)in, w, (cx<float>*)out, opitch, s, wcols); }
 void emu_set_rsplit_pf(int on) { rsplit_pf = on != 0; }

@@ -718,3 +718,49 @@ def test_fused_windowed_row_pass(emu, ny, nx, wc, prec):
     assert np.abs(out[:, :wc] - ref).max() < tol * np.abs(ref).max()
     assert np.all(out[:, wc:] == 7.0)
 
+
+@pytest.mark.parametrize("ny,nx,order", [(64, 128, 5), (256, 64, 3)])
+def test_batched_derivative_inverse_transforms(emu, ny, nx, order):
+    """col_deriv_body + batched row C2R (oa_lens_maps): every Fourier-space derivative (i lx)^a (i ly)^b k, a + b < order, of a
+    transform inverse-transformed with the factor applied at the load of the inverse column pass; plane idx(a, b) =
+    n (n + 1) / 2 - 1 + b, n = a + b (the order lens_taylor_kernel reads)"""
+    rng = np.random.default_rng(31)
+    kp = emu.emu_kpitch(nx)
+    x = rng.standard_normal((ny, nx))
+    k0 = np.zeros((ny, kp), dtype=np.complex128)
+    k0[:, :nx // 2 + 1] = np.fft.rfft2(x)
+    ly = 2 * np.pi * np.fft.fftfreq(ny) * 3.0
+    lx = 2 * np.pi * np.fft.fftfreq(nx) * 5.0
+    lyd, lxd = ly.copy(), lx.copy()
+    lyd[ny // 2] = 0
+    lxd[nx // 2] = 0
+    nd = order * (order + 1) // 2 - 1
+    out = np.zeros((nd, ny, nx))
+    assert emu.emu_lens_derivs_f64(ny, nx, _p(k0), _p(lxd), _p(lyd), _p(out), nd) == 0
+    kf = np.fft.rfft2(x)
+    for n in range(1, order):
+        for b in range(n + 1):
+            a = n - b
+            ref = np.fft.irfft2(kf * (1j * lxd[None, :nx // 2 + 1]) ** a * (1j * lyd[:, None]) ** b, s=(ny, nx))
+            got = out[n * (n + 1) // 2 - 1 + b]
+            assert np.abs(got - ref).max() < 1e-11 * max(np.abs(ref).max(), 1e-30), (a, b)
+
+
+def test_c2r_drops_the_non_hermitian_part_of_the_self_conjugate_columns(emu):
+    """C2R of a half-complex plane whose kx = 0 and kx = nx/2 columns are NOT Hermitian in y (e.g. Q, U = R^-1 (E, B): the
+    rotation's sine is odd on the Nyquist column): the result is the real part of the inverse transform of the Hermitian-completed
+    plane, column by column -- numpy.fft.irfft2's and the reference's `ifft(...).real` semantics (maps.py:1585) -- and in
+    particular the Nyquist column's antisymmetric part does not leak into kx = 0."""
+    ny, nx = 32, 64
+    rng = np.random.default_rng(41)
+    kp = emu.emu_kpitch(nx)
+    hc = np.zeros((ny, kp), dtype=np.complex128)
+    hc[:, :nx // 2 + 1] = rng.standard_normal((ny, nx // 2 + 1)) + 1j * rng.standard_normal((ny, nx // 2 + 1))
+    out = np.zeros((ny, nx))
+    assert emu.emu_c2r_f64(ny, nx, _p(hc), _p(out), ctypes.c_double(1.0 / (ny * nx))) == 0
+    ref = np.fft.irfft2(hc[:, :nx // 2 + 1], s=(ny, nx))
+    assert np.abs(out - ref).max() < 1e-13 * np.abs(ref).max()
+    back = np.fft.rfft2(out)
+    herm0 = 0.5 * (hc[:, 0] + np.conj(hc[(-np.arange(ny)) % ny, 0]))
+    assert np.abs(back[:, 0] - herm0).max() < 1e-12 * np.abs(herm0).max()      # kx = 0 holds ITS OWN Hermitian part only
+

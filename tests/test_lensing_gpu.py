@@ -301,6 +301,16 @@ def test_mc_driver_on_several_streams_equals_one_stream():
     assert a.count("n0") == b.count("n0") == 40
     np.testing.assert_allclose(b.mean("n0"), a.mean("n0"), rtol=1e-12)
     np.testing.assert_allclose(b.cov("n0"), a.cov("n0"), rtol=1e-9, atol=1e-30)
+    # the windowed flow (oa_mc_run_windowed) on three lanes, with the mean-field stack
+    from orphics_amd import maps
+    taper, _ = maps.get_taper(shape, g, taper_percent=12.0, pad_percent=3.0)
+    aw = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=6, mean_field=True, window=taper).run(30)
+    dw = mc.GaussianN0MonteCarlo(q, tot_h, edges, base_seed=6, mean_field=True, window=taper, streams=3)
+    bw = dw.run(30)
+    assert getattr(dw, "_lanes", None) is not None and aw.count("n0") == bw.count("n0") == 30 and bw.stack_count("mf") == 30
+    np.testing.assert_allclose(bw.mean("n0"), aw.mean("n0"), rtol=1e-12)
+    sa, sb = aw.stack_sum("mf"), bw.stack_sum("mf")
+    assert np.abs(sa - sb).max() < 1e-5 * np.abs(sa).max()
 
 
 def pol_setup(N, res_arcmin, seed=0):
@@ -525,6 +535,26 @@ def test_flat_lensing_op_matches_oracle_and_remaps():
     # the fused path (one derivative kernel for all 14 terms, one gather pass) against the term-by-term one, and a lower order
     per_term = L.lens(T, (ay, ax), taylor_order=5, fused=False).cpu().numpy()
     assert np.abs(lensed - per_term).max() / np.abs(ref).max() < 1e-12
+    # the fine-grained C-ABI sequence oa_lens_maps replaces (oa_hc_derivs -> C2R per term -> oa_lens_taylor): same result; and
+    # several maps per call (T, 2 T, -T by the same deflection) == one map per call
+    from orphics_amd._lib import check
+    from orphics_amd.engine import _ptr, _stream
+    e = L.eng
+    sx, sy, dx, dy = L.split((ay, ax))
+    src = e.to_real(T)
+    dk = torch.empty((14, e.ny, e.kp), dtype=e.cdt, device=e.device)
+    dr = torch.empty((14, e.ny, e.nx), dtype=e.rdt, device=e.device)
+    check(e.lib.oa_hc_derivs(e.plan, _ptr(e.rfft(src)), 5, _ptr(dk), e.ny * e.kp, _stream()))
+    for i in range(14):
+        e.irfft(dk[i], out=dr[i])
+    fine = e.real()
+    check(e.lib.oa_lens_taylor(e.plan, _ptr(src), _ptr(dr), e.ny * e.nx, 5, _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy), _ptr(fine), _stream()))
+    assert np.abs(fine.cpu().numpy() - lensed).max() / np.abs(ref).max() < 1e-13
+    three = L.lens_many(torch.stack([src, 2 * src, -src]), (ay, ax), taylor_order=5).cpu().numpy()
+    assert np.abs(three[0] - lensed).max() / np.abs(ref).max() < 1e-14
+    assert np.abs(three[1] - 2 * lensed).max() / np.abs(ref).max() < 1e-13 and np.abs(three[2] + lensed).max() / np.abs(ref).max() < 1e-14
+    L.release()                                                 # the plan-owned planes come back on the next call
+    assert np.abs(L.lens(T, (ay, ax), taylor_order=5).cpu().numpy() - lensed).max() == 0
     ref3 = qo.flat_taylens((ray, rax), T, g.step_y, g.step_x, taylor_order=3)
     assert np.abs(L.lens(T, (ay, ax), taylor_order=3).cpu().numpy() - ref3).max() / np.abs(ref3).max() < 1e-10
     L32 = lensing.FlatLenser((N, N), g, dtype="f32")
@@ -984,3 +1014,29 @@ def test_rectangular_maps_fused_equals_modular_and_oracle(ny, nx):
         ref = qo.QEOracleTT(shape, g.step_y, g.step_x, cltt, cltt, noise, beam, tmask, kmask_K=kmask).kappa_from_map("TT", tmap)
         rec = q.kappa_from_map("TT", tmap)
         assert np.abs(rec - ref).max() < 1e-8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-10), ("f32", 2e-4)])
+def test_get_sim_teb_equals_iqu2teb_of_get_sim(prec, tol):
+    """FlatLensingSims.get_sim_teb (kappa's drawn transform used directly, beam and noise applied in Fourier space, no transform
+    taken twice) against the notebook's sequence on the same seeds: iqu2teb(get_sim(...)) and fft(kappa) -- same realisation, T, E,
+    B equal to rounding on every mode below the Nyquist row / column (where a real-space round trip symmetrises the rotation)."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N = 256
+    shape = (3, N, N)
+    g = FlatGeometry.from_res(shape, 1.5)
+    th = cosmology.default_theory()
+    sims = lensing.FlatLensingSims(shape, g, th, 1.5, 1.0, pol=True, dtype=prec)
+    fc = maps.FourierCalc(shape, g, layout="half")
+    teb, kin = sims.get_sim_teb(seed_cmb=(3, 1, 0), seed_kappa=(3, 2, 0), seed_noise=(3, 3, 0), lens_order=5)
+    parts = sims.get_sim(seed_cmb=(3, 1, 0), seed_kappa=(3, 2, 0), seed_noise=(3, 3, 0), lens_order=5, return_intermediate=True)
+    e = sims.lenser.eng
+    ref = fc.iqu2teb(parts[5], normalize=False).t
+    kref = e.rfft(parts[1].contiguous())
+    w = N // 2                                        # columns 0 .. N/2 - 1 and rows != N/2: below Nyquist
+    rows = torch.arange(N, device=e.device) != N // 2
+    assert float((kin - kref)[rows][:, :w].abs().max() / kref.abs().max()) < tol
+    for i in range(3):
+        d = (teb[i] - ref[i])[rows][:, :w].abs().max() / ref[i].abs().max()
+        assert float(d) < tol, (i, float(d))
