@@ -49,7 +49,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = 157.3   # f32 vector peak (MI355X_MICROARCH.md chip table)
-PROFILE_TAG = "r03"        # profiles/traffic_<tag>_<prec>[_dense|_fullrows].json (tools/collect_profiles.sh)
+PROFILE_TAG = "r04"        # profiles/traffic_<tag>_<prec>[_dense|_fullrows].json (tools/collect_profiles.sh)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -354,7 +354,7 @@ def per_kernel_table(torch, P, R, args):
                      "inverse %d-point columns -> 3 leg planes on the %d-row column grid)" % (my, my // rsplit, my))
         # read the row pass's output once (R planes = ny rows) + 2 real filter planes on the band rows, write 3 planes of my rows
         legs_bytes = fl * (Ah + gl * Ah + 3 * cg * Ah)
-    elif my and logn // 2 == 6 and (my >> (logn - 6)) == 16 and not os.environ.get("OA_NO_FWDLEGS_CG"):
+    elif my and logn // 2 == 6 and (my >> (logn - 6)) == 16:
         legs_name = "fwdlegs_cols = col_fwdlegs_cg_kernel (fwd pass2 + legs + inv pass1) + col_fft_kernel<inv pass2 x3> on the %d-row column grid" % my
         # fused kernel: read the pass-1 plane + 2 real filter planes on the band rows, write 3 planes of my rows; then the
         # 3-plane inverse pass 2 on my rows (r + w)
@@ -368,7 +368,7 @@ def per_kernel_table(torch, P, R, args):
         legs_name = "fwdlegs_cols = col_fwdlegs_kernel + col_fft_kernel<inv pass2 x3>"
         # col_fwdlegs (read the pass-1 plane + 2 real filter planes on the band rows, write 3) + 3-plane inverse pass 2 (r + w)
         legs_bytes = fl * (Ah + gl * Ah + 3 * Ah) + 6 * fl * Ah
-    if my in (1024, 2048) and os.environ.get("OA_SINGLE_PASS_DIV", "1") != "0":
+    if my in (1024, 2048):
         # single pass: read the 2 product planes of my rows + Fn/2 on the band rows, write the band rows of kappa_hat
         div_name, div_bytes = "cols_div = col_div_sp_kernel (single-pass forward columns + divergence)", fk * (2 * Ah * cg + gk * Ah / 2 + gk * Ah)
     else:
@@ -644,6 +644,7 @@ def mc_leg(torch, args, N=4096, nsims=480):
             dt = (time.perf_counter() - t0) / ns_
             blk[key] = {"sims_per_s": 1.0 / dt, "ms_per_sim": dt * 1e3, "sims_timed": ns_}
             if key == "n0":
+                drv.acc.allreduce()                     # (single rank: makes the reduced view)
                 m = drv.acc.mean("n0")
                 sem = np.sqrt(drv.acc.var("n0") / drv.acc.count("n0"))
                 means[prec] = m
@@ -898,14 +899,13 @@ def measure(args, torch, dist, world, rank, prec):
     if dom.startswith("row_fft_kernel<R2C>"):
         # the stage name above is bench.py's; the launch behind it, as rocprofv3 lists it (fft.hip HipLauncher::row_w64)
         wl_ = G["wl"] or W
-        w64 = os.environ.get("OA_R2C_W64", "1") != "0" and prec == "f32"
+        w64 = prec == "f32"
         tn = "float" if prec == "f32" else "double"
         if G.get("rsplit"):
-            rs4096 = ((N == 8192 and wl_ <= 512) or (N == 4096 and wl_ <= 256)) and not os.environ.get("OA_NO_RS4096")
-            roofline["kernel_symbol"] = ("row_r2c_rs%d_kernel<%s, ...>" % (N // 2, tn) if rs4096 else
-                                         "row_r2c_w64r_kernel<2>" if (w64 and N == 8192 and wl_ <= 512) else "row_r2c_rsplit_kernel<%s, ...>" % tn)
+            rs = (N == 16384 and wl_ <= 512 and prec == "f64") or (N == 8192 and wl_ <= 512) or (N == 4096 and wl_ <= 256)
+            roofline["kernel_symbol"] = ("row_r2c_rs%d_kernel<%s, ...>" % (N // 2, tn) if rs else "row_r2c_rsplit_kernel<%s, ...>" % tn)
             roofline["rsplit"] = {"R": G["rsplit"], "note": "the row pass also takes the first radix-R butterfly of the column transform (rows g + my n, n < R, "
-                                  "per wave / workgroup) and writes R planes Y[k1][g]; one single-pass column kernel follows (include/orphics_amd.h oa_plan_rsplit)"}
+                                  "per workgroup) and writes R planes Y[k1][g]; one single-pass column kernel follows (include/orphics_amd.h oa_plan_rsplit)"}
         else:
             roofline["kernel_symbol"] = ("row_r2c_w64_kernel" if (w64 and N == 8192 and wl_ <= 512) else
                                          "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel<%s, R2C>" % tn)

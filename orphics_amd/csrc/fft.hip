@@ -272,6 +272,10 @@ struct HipLauncher {
         const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), NTr, smem, &err);
         if (per_cu < 0) { rc = fail(err); return true; }
         int grid = cus * per_cu;
+        // (experiment builds: OA_RS4096_WGS = resident workgroups per CU x 2, e.g. 2 = one per CU, 3 = one and a half: leaves LDS and
+        //  registers on every CU for the coarse-grid kernels of another stream)
+        static const int halfwgs = [] { const char* e = exp_env("OA_RS4096_WGS"); return e ? atoi(e) : 0; }();
+        if (halfwgs > 0 && halfwgs < 2 * per_cu) grid = cus * halfwgs / 2;
         // resident workgroups walk the groups.  OA_RS4096_PERSIST=0: one workgroup per group (A/B: so that the scheduler could place
         // workgroups of another stream's kernels as these retire -- measured 1 % slower in the two-stream job, 5096 vs 5159 /s)
         static const int persist = [] { const char* e = exp_env("OA_RS4096_PERSIST"); return e ? atoi(e) : -1; }();
