@@ -115,7 +115,9 @@ int lens_chunk_planes(const oa_plan* p);      // derivative planes per launch tr
 int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st);
 // windowed simulation front end: hc spectrum -> inverse columns -> fused C2R x window -> R2C rows onto the plan's scratch plane
 // (then qe_map_legs_cols_w with stages = 6, lr = 0)
-int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st);
+int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st,
+                       void* out = nullptr);
+int qe_fwd_cols_batch_w(oa_plan* p, const void* in, long pin, void* out, int B, long in_moff, long out_moff, int width, int rband, hipStream_t st);
 // one filtered field (subset 1: H plane into a; 2: gradient pair into a, b), inverse pass 1 only; then pass 2 over a pool of planes
 int qe_legs_subset_w(oa_plan* p, const void* src, const void* F, void* a, void* b, int subset, int width, int rband, long pl,
                      hipStream_t st, int my = 0);

@@ -1,4 +1,5 @@
 // HIP launchers for the LDS-staged 2-D FFT passes (K1) + oa_fft_* entry points.
+#include <cmath>
 #include <vector>
 #include "fft_launch.hpp"
 #include "fft_r2c_w64.hpp"
@@ -721,22 +722,37 @@ int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* 
 // scratch plane at the compact pitch `pl`, active columns only -- exactly what the row R2C of qe_map_legs_cols_w (stage 1) leaves
 // there, so the caller continues with stages 2 | 4.  The real map never exists in HBM.
 template <typename T>
-static int windowed_rows_impl(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st) {
+static int windowed_rows_impl(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st,
+                              void* out) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
     auto f = view<T>(p);
     f.cols(q, (const cx<T>*)hc_in, p->kp, (cx<T>*)cols_tmp, p->kp, p->nx / 2 + 1, true, (T)1);
-    f.rows(q, ROW_WIN, cols_tmp, p->kp, p->scratch, pl > 0 ? pl : p->kp, (T)scale, f.clampw(width), window);
+    f.rows(q, ROW_WIN, cols_tmp, p->kp, out ? out : p->scratch, pl > 0 ? pl : p->kp, (T)scale, f.clampw(width), window);
     return q.rc;
 }
-int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st) {
-    return p->dtype == OA_F32 ? windowed_rows_impl<float>(p, hc_in, cols_tmp, window, width, pl, scale, st)
-                              : windowed_rows_impl<double>(p, hc_in, cols_tmp, window, width, pl, scale, st);
+// out = nullptr: the plan's first scratch plane (what qe_map_legs_cols_w stages 2 | 4 read); else a caller plane of pitch pl
+int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st, void* out) {
+    return p->dtype == OA_F32 ? windowed_rows_impl<float>(p, hc_in, cols_tmp, window, width, pl, scale, st, out)
+                              : windowed_rows_impl<double>(p, hc_in, cols_tmp, window, width, pl, scale, st, out);
+}
+// forward column transform of B row-transformed compact planes (pitch pin, in_moff apart) onto the leg band (columns < width, rows
+// |ky index| < rband, natural order) of B full-pitch hc planes out_moff apart: two launches for the batch
+template <typename T>
+static int fwd_cols_batch_impl(oa_plan* p, const void* in, long pin, void* out, int B, long in_moff, long out_moff, int width, int rband, hipStream_t st) {
+    HipLauncher q{st};
+    auto f = view<T>(p);
+    f.cols(q, (const cx<T>*)in, pin, (cx<T>*)out, p->kp, f.clampw(width), false, (T)1, 0, 1, nullptr, nullptr, rband, false, -1, B, in_moff, out_moff);
+    return q.rc;
+}
+int qe_fwd_cols_batch_w(oa_plan* p, const void* in, long pin, void* out, int B, long in_moff, long out_moff, int width, int rband, hipStream_t st) {
+    return p->dtype == OA_F32 ? fwd_cols_batch_impl<float>(p, in, pin, out, B, in_moff, out_moff, width, rband, st)
+                              : fwd_cols_batch_impl<double>(p, in, pin, out, B, in_moff, out_moff, width, rband, st);
 }
 // flat-sky Taylor lensing, FFT part (oa_lens_maps): nmaps real maps -> their transforms (k0: nmaps hc planes) -> the nd derivative
 // fields of each, inverse-transformed: ONE pass-1 launch with the derivative factor at the load, ONE pass-2 launch, ONE row C2R
-// launch per chunk of planes (hc_pool: lens_chunk_planes(p) hc planes; real_pool: nmaps * nd real planes, 1 / Npix applied)
+// launch per (map, y-derivative order) (hc_pool: one hc plane at least; real_pool: nmaps * nd real planes, 1 / Npix applied)
 template <typename T>
 static int lens_derivs_impl(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd,
                             hipStream_t st) {
@@ -747,17 +763,22 @@ static int lens_derivs_impl(oa_plan* p, int nmaps, const void* real_in, long in_
     const long hcp = (long)p->ny * p->kp, rp = (long)p->ny * (p->nx / 2);       // plane strides in complex elements
     for (int m = 0; m < nmaps; ++m)
         f.r2c(q, (const T*)real_in + (long)m * in_stride, (cx<T>*)k0 + (long)m * hcp, (cx<T>*)p->scratch, (T)1);
-    // CHUNKS of planes small enough for the infinity cache (256 MB): column pass 1 -> column pass 2 -> row C2R of a chunk back to
-    // back, so the chunk's intermediates are cache hits (measured at 4096^2 float64: a column pass over ONE plane 49 us, the same
-    // pass over 42 planes in one launch 71-77 us per plane -- profiles/r04f_lensloop_kernel_stats_f64_batched.txt)
-    // (hc_pool therefore holds ONE chunk: lens_chunk_planes(p) planes)
-    const int total = nmaps * nd, G = lens_chunk_planes(p) < total ? lens_chunk_planes(p) : total;
-    for (int z0 = 0; z0 < total; z0 += G) {
-        const int nz = z0 + G <= total ? G : total - z0;
-        f.cols_derivs(q, (const cx<T>*)k0, hcp, (cx<T>*)hc_pool, hcp, nmaps, nd, (const T*)p->lxd, (const T*)p->lyd, z0, nz);
-        f.rows(q, ROW_C2R, hc_pool, p->kp, (cx<T>*)real_pool + (long)z0 * rp, p->nx / 2, (T)(1.0 / ((double)p->ny * p->nx)), 0x7fffffff, nullptr,
-               nz, hcp, rp);
-    }
+    // SEPARABLE derivatives: (i lx)^a (i ly)^b k0 -- the column transform of (i ly)^b k0 does not depend on a, so a map needs `order`
+    // column transforms (b = 0 .. order - 1; col_deriv_body, b-only mode) instead of nd = order (order + 1) / 2 - 1, and every
+    // x-derivative is a row C2R of that column-transformed plane with (i lx)^a applied at its load (RowArgs::dlx): per b ONE launch
+    // for a = (b == 0) .. order - 1 - b.  The column-transformed plane (one hc plane: the chunk buffer) is written by pass 1,
+    // transformed in place by pass 2 and read by the row launch back to back: it stays in the 256 MB infinity cache (a column pass
+    // over one cache-resident float64 plane at 4096^2 takes 49-52 us, over planes streamed from HBM 71-83 us:
+    // profiles/r04f_lensloop_kernel_stats_f64_batched.txt, r04_lensloop_step.txt).
+    const int order = (int)((std::sqrt(8.0 * (nd + 1) + 1.0) - 1.0) / 2.0 + 0.5);      // nd = order (order + 1) / 2 - 1
+    for (int m = 0; m < nmaps; ++m)
+        for (int b = 0; b < order; ++b) {
+            const int a0 = b == 0 ? 1 : 0, na = order - b - a0;
+            if (na <= 0) continue;
+            f.cols_derivs(q, (const cx<T>*)k0, hcp, (cx<T>*)hc_pool, hcp, nmaps, order, (const T*)p->lxd, (const T*)p->lyd, m * order + b, 1, 1);
+            f.rows(q, ROW_C2R, hc_pool, p->kp, (cx<T>*)real_pool + (long)m * nd * rp, p->nx / 2, (T)(1.0 / ((double)p->ny * p->nx)), 0x7fffffff,
+                   nullptr, na, 0, rp, (const T*)p->lxd, a0, b);
+        }
     return q.rc;
 }
 int lens_chunk_planes(const oa_plan* p) {

@@ -87,6 +87,16 @@ struct Dft<T, 1> {
     static OA_HD void run(cx<T>*) {}
 };
 
+// multiply by i^q (q uniform across the workgroup)
+template <typename T> OA_HD cx<T> rot_i(cx<T> x, int q) {
+    switch (q & 3) {
+        case 0: return x;
+        case 1: return mk<T>(-x.y, x.x);
+        case 2: return mk<T>(-x.x, -x.y);
+        default: return mk<T>(x.y, -x.x);
+    }
+}
+
 template <int R> struct Log2c;
 template <> struct Log2c<2> { static constexpr int v = 1; };
 template <> struct Log2c<4> { static constexpr int v = 2; };
@@ -362,6 +372,11 @@ struct RowArgs {
     // behind the first (oa_lens_maps: the C2R of every derivative field of every map in one launch).  nz = 0: one plane.
     int nz;
     long in_zoff, out_zoff;
+    // X-DERIVATIVE C2R (oa_lens_maps): dlx != nullptr -> plane z of the launch is the C2R of (i lx)^(dpow0 + z) x the SAME input
+    // (a column-transformed field that already carries (i ly)^dcol_b) and goes to output plane idx(a, b) = n (n + 1) / 2 - 1 + b,
+    // n = a + b (the order lens_taylor_kernel reads), out_zoff elements per plane
+    const void* dlx;
+    int dpow0, dcol_b;
 };
 
 template <typename T, bool SWAP>
@@ -408,9 +423,11 @@ struct RowStore {
 // stored SWAPPED in LDS (the inverse runs as a forward transform of the swapped data).  Caller syncs.
 // GUARD: columns >= win are zero and never read (active-column mode); the unguarded body keeps every load
 // unconditional so the compiler batches them (dense mode is HBM-latency bound).
+// dlx != nullptr: the x-derivative (i lx)^apow is applied to the spectrum at the load (dlx = the derivative axis lx per column, Nyquist
+// entry zero; apow uniform) -- the Taylor lensing op takes every x-derivative of a column-transformed field in the row pass
 template <typename T, bool GUARD, class Ctx>
 OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
-                             const cx<T>* tw, int logTw, int win) {
+                             const cx<T>* tw, int logTw, int win, const T* dlx = nullptr, int apow = 0) {
     const int tid = ctx.tid(), L = 1 << logL, C = 1 << logC;
     const int sh = logTw - (logL + 1);
     for (int i = tid; i < (C << (logL - 1)); i += NT) {
@@ -437,6 +454,13 @@ OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, lo
             // whatever imaginary part arrives here comes from a non-Hermitian input column (e.g. the Nyquist column of Q, U =
             // R^-1 (E, B): the rotation's sine is odd there) and is DROPPED -- the reference's `ifft(...).real` (maps.py:1585)
             // symmetrises each column on its own; packed into Z'[0] it would leak from the Nyquist column into kx = 0
+            if (dlx) {
+                T fa = (T)1, fb = (T)1;
+                const T la = dlx[kk], lb = dlx[L - kk];
+                for (int i = 0; i < apow; ++i) { fa *= la; fb *= lb; }
+                A = rot_i(A, apow) * fa;
+                B = rot_i(B, apow) * fb;
+            }
             if (kk == 0) { A.y = (T)0; B.y = (T)0; }
             const cx<T> w = tw[kk << sh];  // W_N^k
             const cx<T> d1 = A - conj(B), d2 = B - conj(A);
@@ -449,9 +473,9 @@ OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, lo
 }
 template <typename T, class Ctx>
 OA_HD void c2r_prologue(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, long r0, int logL, int logC, int NT, int RS,
-                        const cx<T>* tw, int logTw, int win = 0x7fffffff) {
-    if (win > (1 << logL)) c2r_prologue_impl<T, false>(ctx, s, in, pitch, r0, logL, logC, NT, RS, tw, logTw, win);
-    else c2r_prologue_impl<T, true>(ctx, s, in, pitch, r0, logL, logC, NT, RS, tw, logTw, win);
+                        const cx<T>* tw, int logTw, int win = 0x7fffffff, const T* dlx = nullptr, int apow = 0) {
+    if (win > (1 << logL)) c2r_prologue_impl<T, false>(ctx, s, in, pitch, r0, logL, logC, NT, RS, tw, logTw, win, dlx, apow);
+    else c2r_prologue_impl<T, true>(ctx, s, in, pitch, r0, logL, logC, NT, RS, tw, logTw, win, dlx, apow);
 }
 
 // R2C epilogue: packed transform Z in LDS -> X[k] = E + W_N^k O, X[L-k] = conj(E - W_N^k O), straight to global.
@@ -511,6 +535,13 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     const long r0 = (long)ctx.bid_x() * C;
     const cx<T>* in = reinterpret_cast<const cx<T>*>(a.in) + (a.nz ? (long)ctx.bid_y() * a.in_zoff : 0L);
     cx<T>* out = reinterpret_cast<cx<T>*>(a.out) + (a.nz ? (long)ctx.bid_y() * a.out_zoff : 0L);
+    int apow = 0;
+    if (a.dlx) {
+        apow = a.dpow0 + (a.nz ? ctx.bid_y() : 0);
+        const int nn = apow + a.dcol_b;
+        in = reinterpret_cast<const cx<T>*>(a.in);
+        out = reinterpret_cast<cx<T>*>(a.out) + (long)(nn * (nn + 1) / 2 - 1 + a.dcol_b) * a.out_zoff;
+    }
     cx<T>* twl = s + C * RS;                      // two-level stage-twiddle table (LDS)
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, NT);
     ctx.sync();
@@ -556,7 +587,7 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
         fft_pipeline<T, true, false, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{}, NoStore{});
         r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, (T)1, false, a.wcols);
     } else {
-        c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.wcols);
+        c2r_prologue<T>(ctx, s, in, a.in_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.wcols, reinterpret_cast<const T*>(a.dlx), apow);
         ctx.sync();
         fft_pipeline<T, true, false, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, NoLoad{},
                                                 RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale,
@@ -889,15 +920,6 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
 // sum_k1 W_R^(-k1 y_hi) B[k1][y_lo] -- the last radix-R butterfly of the inverse column transform, taken here at the load;
 // the pair (y_hi = 2 p, 2 p + 1) of group y_lo: with s02 = B0 + B2, d02 = B0 - B2, s13 = B1 + B3, d13 = B1 - B3 and
 // sg = +1 (p = 0) / -1 (p = 1):  a0 = s02 + sg s13,  a1 = d02 + sg i d13.
-// multiply by i^q (q uniform across the workgroup)
-template <typename T> OA_HD cx<T> rot_i(cx<T> x, int q) {
-    switch (q & 3) {
-        case 0: return x;
-        case 1: return mk<T>(-x.y, x.x);
-        case 2: return mk<T>(-x.x, -x.y);
-        default: return mk<T>(x.y, -x.x);
-    }
-}
 // LAY = 3 (R = 8: 16384-row maps on the 2048-row column grid): the plane holds B[k1][y_lo] at row 8 y_lo + k1; workgroup p < 4 of
 // group y_lo forms the rows y_hi = 2 p and 2 p + 1:  a0 = sum_k W_8^(-2 p k) b_k,  a1 = sum_k W_8^(-(2 p + 1) k) b_k.  With
 // s_k = b_k + b_(k+4), d_k = b_k - b_(k+4) (k < 4):  a0 = (s0 + i^(2p) s2) + i^p (s1 + i^(2p) s3),
@@ -1869,6 +1891,7 @@ struct ColDerivArgs {
     long in_mstride, out_pstride, pitch;
     int width, nd, logL;
     int zbase;                  // first plane of this launch (chunked launches: plane index = zbase + grid z)
+    int bonly;                  // != 0: plane d of a map carries (i ly)^d only (d < nd = order): the x-derivatives ride on the row pass
     const cx<T>* tw;            // W_ny^k
     int logTw;
     long in_ns, out_gs;         // pass-1 strides (rows): point n of group g is row g + n in_ns; bin k goes to row g out_gs + k
@@ -1914,7 +1937,8 @@ OA_HD void col_deriv_body(Ctx& ctx, const ColDerivArgs<T>& a) {
     // plane d -> (n, b): n (n + 1) / 2 - 1 <= d < (n + 1)(n + 2) / 2 - 1
     int n = 1;
     while ((n + 1) * (n + 2) / 2 - 1 <= d) ++n;
-    const int b = d - (n * (n + 1) / 2 - 1), aa = n - b;
+    int b = d - (n * (n + 1) / 2 - 1), aa = n - b;
+    if (a.bonly) { b = d; aa = 0; n = d; }
     tw_lds_fill<T>(ctx, twl, a.tw, a.logTw, logL, CNT);
     for (int i = tid; i < (1 << logL); i += CNT) {
         ti[i] = a.tw[(unsigned)g * (unsigned)i];

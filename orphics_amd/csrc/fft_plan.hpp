@@ -56,10 +56,12 @@ struct Fft2dPlan {
     // ---- row passes -------------------------------------------------------
     template <class Launcher>
     void rows(Launcher& q, int mode, const void* in, long in_pitch, void* out, long out_pitch, T scale,
-              int wcols = 0x7fffffff, const void* mul = nullptr, int nz = 0, long in_zoff = 0, long out_zoff = 0) const {
+              int wcols = 0x7fffffff, const void* mul = nullptr, int nz = 0, long in_zoff = 0, long out_zoff = 0,
+              const T* dlx = nullptr, int dpow0 = 0, int dcol_b = 0) const {
         RowArgs<T> a{};
         a.mul = mul;
         a.nz = nz; a.in_zoff = in_zoff; a.out_zoff = out_zoff;     // nz > 0: that many planes in one launch (grid y)
+        a.dlx = dlx; a.dpow0 = dpow0; a.dcol_b = dcol_b;           // x-derivative C2R (RowArgs::dlx)
         const bool real_mode = (mode == ROW_R2C || mode == ROW_C2R || mode == ROW_WIN);
         a.logL = real_mode ? logNx - 1 : logNx;
         const int L = 1 << a.logL;
@@ -200,14 +202,14 @@ struct Fft2dPlan {
     // goes through pass 1, pass 2 and the row pass back to back and its intermediates never leave the cache)
     template <class Launcher>
     void cols_derivs(Launcher& q, const cx<T>* in, long in_mstride, cx<T>* out, long out_pstride, int nmaps, int nd, const T* lxd,
-                     const T* lyd, int z0 = 0, int nz = -1) const {
+                     const T* lyd, int z0 = 0, int nz = -1, int bonly = 0) const {
         if (nz < 0) nz = nmaps * nd;
         const int logN1 = (logNy + 1) / 2, logN2 = logNy - logN1;
         const long N1 = 1L << logN1, N2 = 1L << logN2;
         const int C = 1 << COLC, width = nx / 2 + 1, tiles = (width + C - 1) / C;
         ColDerivArgs<T> a{};
         a.in = in; a.out = out; a.in_mstride = in_mstride; a.out_pstride = out_pstride; a.pitch = kp; a.width = width; a.nd = nd;
-        a.logL = logN1; a.tw = tw_y; a.logTw = logNy; a.in_ns = N2; a.out_gs = N1; a.lxd = lxd; a.lyd = lyd; a.zbase = z0;
+        a.logL = logN1; a.tw = tw_y; a.logTw = logNy; a.in_ns = N2; a.out_gs = N1; a.lxd = lxd; a.lyd = lyd; a.zbase = z0; a.bonly = bonly;
         q.col_deriv(tiles, (int)N2, (int)((N1 * C) / EPT), ((size_t)N1 * C + tw_lds_size(logN1) + N1) * sizeof(cx<T>) + (size_t)(N1 + C) * sizeof(T), a, nz);
         cols(q, out, kp, out, kp, width, true, (T)1, 2, 1, nullptr, nullptr, 0, false, -1, nz, out_pstride, out_pstride);
     }

@@ -681,6 +681,70 @@ int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
     }
 }
 
+}  // extern "C"
+
+namespace oa {
+static int ensure_mc_src(oa_plan* p, Pipeline* q) {
+    if (q->mc_cap >= MC_BATCH_MAX) return 0;
+    if (q->mc_src) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->mc_src); q->mc_src = nullptr; q->mc_cap = 0; }
+    OA_HIP(hipMalloc(&q->mc_src, (size_t)MC_BATCH_MAX * plane_bytes(p)));
+    q->mc_cap = MC_BATCH_MAX;
+    return 0;
+}
+// pool bytes of a batch of B realisations: 3 B leg planes (gx_b, gy_b at 2b, 2b + 1; h_b at 2B + b) | 2 B product planes | 2 B pass-1 planes
+static size_t mc_pool_bytes(const oa_plan* p, const Pipeline* q, int B) {
+    const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8);
+    return 3 * (size_t)B * work_pitch(p, q->wl) * p->ny * es + 4 * (size_t)B * work_pitch(p, q->wk) * p->ny * es;
+}
+/* Everything behind the transforms of a BATCH of B realisations (q->mc_src: their hc planes, leg band filled): leg planes, row
+ * stage, divergence, binned power + moments in realisation order, mean-field stack -- each ONE launch for the batch (oa_mc_run and,
+ * behind its windowed front end, oa_mc_run_windowed).  *fallback = 1: this geometry's row stage takes one map per launch (nothing
+ * was launched). */
+static int mc_batch_tail(oa_plan* p, Pipeline* q, int B, int64_t* n, double* S, double* C, double* meanfield_acc, hipStream_t st, int* fallback) {
+    *fallback = 0;
+    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
+    const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p);
+    const size_t lb = (size_t)pl * p->ny * es, lbk = (size_t)pk * p->ny * es;
+    const int my = q->my;
+    if (int rc = ensure_pool(q, mc_pool_bytes(p, q, B))) return rc;
+    char* const legs = (char*)q->split_legs;
+    char* const prod = legs + 3 * (size_t)B * lb;
+    char* const tmp = prod + 2 * (size_t)B * lbk;
+    std::vector<const void*> key;
+    for (int b = 0; b < B; ++b) key.push_back(q->FG);
+    for (int b = 0; b < B; ++b) key.push_back(q->FH);
+    if (!q->mv_ftab) OA_HIP(hipMalloc((void**)&q->mv_ftab, 32 * sizeof(void*)));
+    if (key != q->mv_fkey) {
+        OA_HIP(hipMemcpyAsync(q->mv_ftab, key.data(), key.size() * sizeof(void*), hipMemcpyHostToDevice, st));
+        q->mv_fkey = key;
+    }
+    unsigned long long sel = 0;                       // field f (gradient fields 0..B-1, H fields B..2B-1) reads realisation f mod B
+    for (int f = 0; f < 2 * B; ++f) sel |= (unsigned long long)(f % B) << (4 * f);
+    // (the row stage's geometry check first: nothing may have been launched when this batch falls back)
+    const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
+    int legs_done = 0, rc;
+    if ((rc = qe_legs_batch_w(p, q->mc_src, (long)(pb / es), 0, sel, (const void* const*)q->mv_ftab, B, B, legs, (long)(lb / es), q->wl, q->rl,
+                              pl, st, my, 4, &legs_done))) return rc;
+    if (!legs_done && (rc = qe_legs_pass2_w(p, legs, 3 * B, (long)(lb / es), q->wl, pl, st, my))) return rc;
+    rc = qe_rows_batch_w(p, legs, legs + lb, legs + 2 * (size_t)B * lb, prod, prod + lbk, s * s * sy, q->wl, q->wk, q->mrow, pl, pk, st, my, B,
+                         (long)(2 * lb / es), (long)(lb / es), (long)(2 * lbk / es));
+    if (rc < 0) { *fallback = 1; return 0; }          // this geometry's row stage takes one map per launch: one-by-one loop
+    if (rc) return rc;
+    DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
+    if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my,
+                                  divbin_enabled(q) ? &f : nullptr)))
+        return rc;
+    // binned power of the B kappa planes + their moment updates in realisation order: in the divergence launch, else two
+    // launches; the mean-field stack: one
+    if (!f.done && (rc = bin_power_moments(p->dtype, q->c[0], q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
+                                q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, st, B, (long)(pb / es)))) return rc;
+    if (meanfield_acc && (rc = stack_add_region(p->dtype, q->c[0], meanfield_acc, p->ny, p->kp, q->wk, q->rk, st, B, (long)(2 * pb / es)))) return rc;
+    return 0;
+}
+}  // namespace oa
+
+extern "C" {
+
 int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const void* covsqrt_hc, int64_t* n, double* S, double* C,
               double* meanfield_acc, void* stream) {
     OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_mc_run: call oa_plan_set_filters and oa_plan_set_bins first");
@@ -692,55 +756,21 @@ int oa_mc_run(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi, const vo
     // realisations per launch (grid z) the column and row stages fill the chip.  Same kernels on the same operands in the same
     // order per realisation as the one-by-one loop below: identical moments.
     const int BMAX = std::max(1, std::min(MC_BATCH_MAX, q->opt_mc_batch));     // (OA_OPT_MC_BATCH) 1 / 2 / 4 / 6 per launch at 4096^2: 16.5 / 26.0 / 37.6 / 40.3 k realisations/s
-    const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p);
-    const size_t lb = (size_t)pl * p->ny * es, lbk = (size_t)pk * p->ny * es;
-    const int my = q->my;
     // (a batch of ONE goes through the same launches -- OA_OPT_MC_BATCH = 1 and the last realisation of an odd shard: the same kernels
     // whatever the batch size, so the moments do not depend on it; the loop further down serves the geometries without them)
     bool batched = p->pow2;
     while (batched && i < sim_hi) {
         const int B = (int)std::min<long>(BMAX, sim_hi - i);
-        if (q->mc_cap < B) {
-            if (q->mc_src) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->mc_src); q->mc_src = nullptr; q->mc_cap = 0; }
-            OA_HIP(hipMalloc(&q->mc_src, (size_t)MC_BATCH_MAX * pb));
-            q->mc_cap = MC_BATCH_MAX;
-        }
-        // pool: 3 B leg planes (gx_b, gy_b at 2b, 2b + 1; h_b at 2B + b) | 2 B product planes | 2 B pass-1 planes
-        if (int rc = ensure_pool(q, 3 * (size_t)B * lb + 4 * (size_t)B * lbk)) return rc;
-        char* const legs = (char*)q->split_legs;
-        char* const prod = legs + 3 * (size_t)B * lb;
-        char* const tmp = prod + 2 * (size_t)B * lbk;
+        if (int rc = ensure_mc_src(p, q)) return rc;
+        if (int rc = ensure_pool(q, mc_pool_bytes(p, q, B))) return rc;       // (before the draw: growing the pool synchronises the device)
+        // the first batch of a geometry without the batched row stage must not have drawn anything it then abandons: the tail checks
+        // before its first launch only AFTER the leg launches -- those write plan-owned planes only, harmless
         int rc = grf_hc_band_batch(p, base_seed, (uint64_t)i, B, covsqrt_hc, q->mc_src, (long)(pb / es), q->wl, q->rl, st);
         if (rc) return rc;
-        std::vector<const void*> key;
-        for (int b = 0; b < B; ++b) key.push_back(q->FG);
-        for (int b = 0; b < B; ++b) key.push_back(q->FH);
-        if (!q->mv_ftab) OA_HIP(hipMalloc((void**)&q->mv_ftab, 32 * sizeof(void*)));
-        if (key != q->mv_fkey) {
-            OA_HIP(hipMemcpyAsync(q->mv_ftab, key.data(), key.size() * sizeof(void*), hipMemcpyHostToDevice, st));
-            q->mv_fkey = key;
-        }
-        unsigned long long sel = 0;                       // field f (gradient fields 0..B-1, H fields B..2B-1) reads realisation f mod B
-        for (int f = 0; f < 2 * B; ++f) sel |= (unsigned long long)(f % B) << (4 * f);
-        int legs_done = 0;
-        if ((rc = qe_legs_batch_w(p, q->mc_src, (long)(pb / es), 0, sel, (const void* const*)q->mv_ftab, B, B, legs, (long)(lb / es), q->wl, q->rl,
-                                  pl, st, my, 4, &legs_done))) return rc;
-        if (!legs_done && (rc = qe_legs_pass2_w(p, legs, 3 * B, (long)(lb / es), q->wl, pl, st, my))) return rc;
-        const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;
-        rc = qe_rows_batch_w(p, legs, legs + lb, legs + 2 * (size_t)B * lb, prod, prod + lbk, s * s * sy, q->wl, q->wk, q->mrow, pl, pk, st, my, B,
-                             (long)(2 * lb / es), (long)(lb / es), (long)(2 * lbk / es));
-        if (rc < 0) { batched = false; break; }          // this geometry's row stage takes one map per launch: one-by-one loop
-        if (rc) return rc;
-        DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
-        if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my,
-                                      divbin_enabled(q) ? &f : nullptr)))
-            return rc;
-        // binned power of the B kappa planes + their moment updates in realisation order: in the divergence launch, else two
-        // launches; the mean-field stack: one
-        if (!f.done && (rc = bin_power_moments(p->dtype, q->c[0], q->norm, q->ids, (long)p->ny * p->kp, q->nids, p->kp, p->nx / 2, q->sums, q->counts_tmp,
-                                    q->bin_scratch, q->wk, q->rk, q->ticket, q->counts_full, n, S, C, st, B, (long)(pb / es)))) return rc;
-        if (meanfield_acc && (rc = stack_add_region(p->dtype, q->c[0], meanfield_acc, p->ny, p->kp, q->wk, q->rk, st, B, (long)(2 * pb / es)))) return rc;
+        int fallback = 0;
+        if ((rc = mc_batch_tail(p, q, B, n, S, C, meanfield_acc, st, &fallback))) return rc;
+        if (fallback) { batched = false; break; }
         i += B;
     }
     for (; i < sim_hi; ++i) {
@@ -771,7 +801,36 @@ int oa_mc_run_windowed(oa_plan* p, uint64_t base_seed, long sim_lo, long sim_hi,
     void* tmap = q->c[0];
     const double inv = 1.0 / ((double)p->ny * p->nx);
     const long pl = work_pitch(p, q->wl);
-    for (long i = sim_lo; i < sim_hi; ++i) {
+    long i = sim_lo;
+    // BATCHES (fused row pass only): per realisation the full-plane part -- draw, inverse columns, C2R x window -> R2C rows onto a
+    // compact plane --, then for the batch ONE forward column transform onto the leg band of its hc planes and the launches of
+    // oa_mc_run's batches behind it (legs, row stage, divergence + binning + moments, stack): the latency-bound coarse-grid work of a
+    // realisation (70 of its 205 us at 4096^2 float) is shared by up to six
+    {
+        hipStream_t st = (hipStream_t)stream;
+        const size_t es = 2 * (p->dtype == OA_F32 ? 4 : 8), pb = plane_bytes(p), lb = (size_t)pl * p->ny * es;
+        const int BMAX = std::max(1, std::min(MC_BATCH_MAX, q->opt_mc_batch));
+        bool batched = q->opt_win_fused && p->pow2;
+        while (batched && i < sim_hi) {
+            const int B = (int)std::min<long>(BMAX, sim_hi - i);
+            if (int rc = ensure_mc_src(p, q)) return rc;
+            const size_t tail = mc_pool_bytes(p, q, B);
+            if (int rc = ensure_pool(q, tail + (size_t)B * lb)) return rc;      // the row-transformed planes sit behind the tail's region
+            char* const rowT = (char*)q->split_legs + tail;
+            for (int b = 0; b < B; ++b) {
+                int rc = oa_grf_hc(p, base_seed, (uint64_t)(i + b), covsqrt_hc, q->kT, stream);
+                if (rc) return rc;
+                if ((rc = qe_windowed_rows_w(p, q->kT, tmap, window_real, q->wl, pl, inv, st, rowT + (size_t)b * lb))) return rc;
+            }
+            int rc = qe_fwd_cols_batch_w(p, rowT, pl, q->mc_src, B, (long)(lb / es), (long)(pb / es), q->wl, q->rl, st);
+            if (rc) return rc;
+            int fallback = 0;
+            if ((rc = mc_batch_tail(p, q, B, n, S, C, meanfield_acc, st, &fallback))) return rc;
+            if (fallback) { batched = false; break; }         // (geometry without the batched row stage: one by one below)
+            i += B;
+        }
+    }
+    for (; i < sim_hi; ++i) {
         int rc = oa_grf_hc(p, base_seed, (uint64_t)i, covsqrt_hc, q->kT, stream);
         if (rc) return rc;
         // FUSED ROW PASS (default): inverse columns of the drawn spectrum (into the first leg plane, free until the leg stage), then

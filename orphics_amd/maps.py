@@ -605,12 +605,20 @@ class MapGen(object):
             seed = int(np.random.SeedSequence(list(seed)).generate_state(1, dtype=np.uint64)[0] >> 1)
         cs = self._covsqrt_hc(eng)
         nc = self.ncomp
+        # a component that couples to no other (its row and column of covsqrt hold the diagonal entry only: white noise, kappa, the
+        # B mode of the unlensed CMB) is drawn WITH its amplitude (the draw kernel multiplies by covsqrt): no white plane, no
+        # separate multiply
+        alone = [all((not self._nz[i][j]) and (not self._nz[j][i]) for j in range(nc) if j != i) and bool(self._nz[i][i]) for i in range(nc)]
         if real:
             white = [eng.rfft(eng.randn(seed, c), scale=1.0 / np.sqrt(eng.npix)) for c in range(nc)]
+            alone = [False] * nc
         else:
-            white = [eng.grf_hc(seed, c) for c in range(nc)]
+            white = [None if alone[c] else eng.grf_hc(seed, c) for c in range(nc)]
         ks = []
         for i in range(nc):
+            if alone[i]:
+                ks.append(eng.grf_hc(seed, i, cs[i][i]))
+                continue
             acc = None
             for j in range(nc):
                 if not self._nz[i][j]:
@@ -628,10 +636,12 @@ class MapGen(object):
                 self._rot_dev[key] = (eng.fullreal_to_hc(eng.to_real(rot[0, 0])), eng.fullreal_to_hc(eng.to_real(rot[1, 0])))
             c, s = self._rot_dev[key]
             ks[1], ks[2] = eng.rot2(c, s, ks[1], ks[2])
-        outs = [eng.irfft(k, scale=1.0 / np.sqrt(eng.npix)) for k in ks]
         if len(self.shape) > 2:
-            return torch.stack(outs)
-        return outs[0]
+            out = torch.empty((nc, eng.ny, eng.nx), dtype=eng.rdt, device=eng.device)     # one allocation, no stack copy
+            for i, k in enumerate(ks):
+                eng.irfft(k, scale=1.0 / np.sqrt(eng.npix), out=out[i])
+            return out
+        return eng.irfft(ks[0], scale=1.0 / np.sqrt(eng.npix))
 
     def get_map_from_rand(self, rand, scalar=False, iau=False, harm=False):
         """Reference arithmetic (maps.py:1579-1587) on a caller-supplied complex

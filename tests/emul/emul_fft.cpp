@@ -324,19 +324,33 @@ static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int wid
     }
     return 0;
 }
-// all nd derivative fields of ONE transform, inverse-transformed (cols_derivs + batched row C2R): out = nd real planes
+// all nd derivative fields of ONE transform, inverse-transformed, the way fft.hip lens_derivs_impl does it: per y-derivative order b
+// one column transform of (i ly)^b k0 (col_deriv_body, b-only) and ONE row launch for the x-derivative orders a (RowArgs::dlx);
+// separable = 0: the first implementation (one column transform per (a, b), plain row C2Rs).  out = nd real planes
 template <typename T>
-static int do_lens_derivs(int ny, int nx, const cx<T>* k0, const T* lxd, const T* lyd, T* out, int nd) {
+static int do_lens_derivs(int ny, int nx, const cx<T>* k0, const T* lxd, const T* lyd, T* out, int nd, int separable) {
     Holder<T> h(ny, nx);
     const long hcp = (long)ny * h.p.kp, rp = (long)ny * (nx / 2);
-    std::vector<cx<T>> pool((size_t)nd * hcp);
     EmuLauncher q;
-    h.p.cols_derivs(q, k0, hcp, pool.data(), hcp, 1, nd, lxd, lyd);
-    h.p.rows(q, ROW_C2R, pool.data(), h.p.kp, out, nx / 2, (T)(1.0 / ((double)ny * nx)), 0x7fffffff, nullptr, nd, hcp, rp);
+    if (!separable) {
+        std::vector<cx<T>> pool((size_t)nd * hcp);
+        h.p.cols_derivs(q, k0, hcp, pool.data(), hcp, 1, nd, lxd, lyd);
+        h.p.rows(q, ROW_C2R, pool.data(), h.p.kp, out, nx / 2, (T)(1.0 / ((double)ny * nx)), 0x7fffffff, nullptr, nd, hcp, rp);
+        return 0;
+    }
+    int order = 1;
+    while (order * (order + 1) / 2 - 1 < nd) ++order;
+    std::vector<cx<T>> plane((size_t)hcp);
+    for (int b = 0; b < order; ++b) {
+        const int a0 = b == 0 ? 1 : 0, na = order - b - a0;
+        if (na <= 0) continue;
+        h.p.cols_derivs(q, k0, hcp, plane.data(), hcp, 1, order, lxd, lyd, b, 1, 1);
+        h.p.rows(q, ROW_C2R, plane.data(), h.p.kp, out, nx / 2, (T)(1.0 / ((double)ny * nx)), 0x7fffffff, nullptr, na, 0, rp, lxd, a0, b);
+    }
     return 0;
 }
 extern "C" {
-int emu_lens_derivs_f64(int ny, int nx, const void* k0, const double* lxd, const double* lyd, double* out, int nd) { return do_lens_derivs<double>(ny, nx, (const cx<double>*)k0, lxd, lyd, out, nd); }
+int emu_lens_derivs_f64(int ny, int nx, const void* k0, const double* lxd, const double* lyd, double* out, int nd, int separable) { return do_lens_derivs<double>(ny, nx, (const cx<double>*)k0, lxd, lyd, out, nd, separable); }
 int emu_rows_win_f64(int ny, int nx, const void* in, const double* w, void* out, long opitch, double s, int wcols) { return do_rows_win<double>(ny, nx, (const cx<double>*)in, w, (cx<double>*)out, opitch, s, wcols); }
 int emu_rows_win_f32(int ny, int nx, const void* in, const float* w, void* out, long opitch, double s, int wcols) { return do_rows_win<float>(ny, nx, (const cx<float>*)in, w, (cx<float>*)out, opitch, s, wcols); }
 void emu_set_rsplit_pf(int on) { rsplit_pf = on != 0; }

@@ -719,11 +719,12 @@ def test_fused_windowed_row_pass(emu, ny, nx, wc, prec):
     assert np.all(out[:, wc:] == 7.0)
 
 
-@pytest.mark.parametrize("ny,nx,order", [(64, 128, 5), (256, 64, 3)])
-def test_batched_derivative_inverse_transforms(emu, ny, nx, order):
+@pytest.mark.parametrize("ny,nx,order,separable", [(64, 128, 5, 1), (256, 64, 3, 1), (64, 128, 5, 0), (32, 256, 6, 1)])
+def test_batched_derivative_inverse_transforms(emu, ny, nx, order, separable):
     """col_deriv_body + batched row C2R (oa_lens_maps): every Fourier-space derivative (i lx)^a (i ly)^b k, a + b < order, of a
     transform inverse-transformed with the factor applied at the load of the inverse column pass; plane idx(a, b) =
-    n (n + 1) / 2 - 1 + b, n = a + b (the order lens_taylor_kernel reads)"""
+    n (n + 1) / 2 - 1 + b, n = a + b (the order lens_taylor_kernel reads).  separable (what oa_lens_maps runs): one column transform per
+    y-derivative order b, the x-derivative orders as ONE row launch with (i lx)^a at the load of the C2R"""
     rng = np.random.default_rng(31)
     kp = emu.emu_kpitch(nx)
     x = rng.standard_normal((ny, nx))
@@ -736,7 +737,7 @@ def test_batched_derivative_inverse_transforms(emu, ny, nx, order):
     lxd[nx // 2] = 0
     nd = order * (order + 1) // 2 - 1
     out = np.zeros((nd, ny, nx))
-    assert emu.emu_lens_derivs_f64(ny, nx, _p(k0), _p(lxd), _p(lyd), _p(out), nd) == 0
+    assert emu.emu_lens_derivs_f64(ny, nx, _p(k0), _p(lxd), _p(lyd), _p(out), nd, separable) == 0
     kf = np.fft.rfft2(x)
     for n in range(1, order):
         for b in range(n + 1):
