@@ -41,6 +41,9 @@ struct alignas(sizeof(T) * N > 16 ? 16 : sizeof(T) * N) Arr {
 // when the geometry runs that kernel (`done` set); otherwise the caller runs bin_power_moments as before.  Device pointers.
 struct DivBinFuse {
     const int32_t* ids; long ipitch;      // radial ids of the full-resolution half plane, row pitch
+    const int32_t* ids_t;                 // tile-major copy on the coarse grid of the single-pass divergence launch, or nullptr
+    const void* fn_t;                     // ... and of Fnorm (handed to ColDivArgs::Fn_t by the launcher)
+    int tab_logc, tab_rows;               // tile shape the two copies were made for: log2 columns per tile, coarse rows
     double pnorm; int nids, nxh;
     double* part;                         // [maps][workgroups][nids] partial sums (capacity part_cap doubles)
     long part_cap;
@@ -112,6 +115,10 @@ int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, c
                    int width, int rband, long pl, hipStream_t st, int my = 0);
 // flat-sky Taylor lensing, FFT part: R2C of nmaps maps, then all nmaps * nd derivative fields inverse-transformed in three launches
 int lens_chunk_planes(const oa_plan* p);      // derivative planes per launch triple (a chunk that fits the infinity cache)
+// tile-major copy of a full-pitch real / int32 hc-layout plane on the coarse grid of `rows` rows: dst[(tile * rows + k) * C + c] =
+// src[(k + (k >= rows / 2 ? ny - rows : 0)) * kp + tile * C + c], zero beyond `width` columns (elem_bytes 4 or 8)
+int pack_tiles(const oa_plan* p, const void* src, void* dst, int rows, int logc, int width, int elem_bytes, hipStream_t st);
+int div_tile_logc(const oa_plan* p, int rows);          // log2 columns per tile of the single-pass divergence launch on `rows` coarse rows
 int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st);
 // windowed simulation front end: hc spectrum -> inverse columns -> fused C2R x window -> R2C rows onto the plan's scratch plane
 // (then qe_map_legs_cols_w with stages = 6, lr = 0)

@@ -375,6 +375,23 @@ __global__ __launch_bounds__(256) void lens_taylor_kernel(const T* __restrict__ 
     out[i] = acc;
 }
 
+// tile-major repack of a full-pitch hc-layout plane onto the coarse grid (common.hpp pack_tiles)
+template <typename E>
+__global__ __launch_bounds__(256) void pack_tiles_kernel(const E* __restrict__ src, E* __restrict__ dst, int rows, int ny, long kp, int logc, int width,
+                                                         long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const int C = 1 << logc;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i & (C - 1));
+        const long r = i >> logc;
+        const int k = (int)(r % rows);
+        const long tile = r / rows;
+        const long col = tile * C + c;
+        const long y = k + (k >= rows / 2 ? ny - rows : 0);
+        dst[i] = col < width ? src[y * kp + col] : (E)0;
+    }
+}
+
 // ---- HBM bandwidth probes (bench.py: the ceiling the roofline fractions are read against, measured in the same run) -----
 // 16-byte accesses, grid-stride, the layout of the guide's float4 copy; the read probe keeps a per-thread checksum so the
 // loads cannot be elided and writes one word per thread at the end.
@@ -636,6 +653,20 @@ int oa_hc_derivs(oa_plan* p, const void* hc_in, int order, void* hc_out_planes, 
     return 0;
 }
 
+}  // extern "C"
+namespace oa {
+int pack_tiles(const oa_plan* p, const void* src, void* dst, int rows, int logc, int width, int elem_bytes, hipStream_t st) {
+    const long tiles = ((long)width + (1 << logc) - 1) >> logc, total = tiles * rows << logc;
+    const int g = flat_grid(total);
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL(pack_tiles_kernel<uint32_t>, dim3(g), dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, p->ny, p->kp, logc, width, total);
+    else
+        hipLaunchKernelGGL(pack_tiles_kernel<uint64_t>, dim3(g), dim3(256), 0, st, (const uint64_t*)src, (uint64_t*)dst, rows, p->ny, p->kp, logc, width, total);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+}  // namespace oa
+extern "C" {
 int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long plane_stride, int order, const int32_t* shift_x,
                    const int32_t* shift_y, const void* dx, const void* dy, void* out, void* stream) {
     OA_REQUIRE(p && src && shift_x && shift_y && dx && dy && out, "oa_lens_taylor: NULL argument");

@@ -400,6 +400,10 @@ struct HipLauncher {
         }
         fuse->gx = gx;
         if (!fuse->store) a.out = nullptr;
+        // tile-major copies of Fn / ids (pipeline.hip) -- valid for THIS tile shape and one Fn for every map of the launch
+        const bool tabs = fuse->tab_logc == a.logC && fuse->tab_rows == a.ny;
+        a.Fn_t = (tabs && a.fn_moff == 0) ? (const T*)fuse->fn_t : nullptr;
+        if (!tabs) fuse->ids_t = nullptr;
         hipLaunchKernelGGL(kern, dim3(gx, 1, gz), dim3(nt), smem, st, a, *fuse);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
@@ -780,6 +784,10 @@ static int lens_derivs_impl(oa_plan* p, int nmaps, const void* real_in, long in_
                    nullptr, na, 0, rp, (const T*)p->lxd, a0, b);
         }
     return q.rc;
+}
+int div_tile_logc(const oa_plan* p, int rows) {
+    const int lt = p->dtype == OA_F32 ? Fft2dPlan<float>::div_lt() : Fft2dPlan<double>::div_lt();
+    return lt - ilog2(rows);
 }
 int lens_chunk_planes(const oa_plan* p) {
     const size_t plane = (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8);

@@ -56,6 +56,10 @@ struct DivBinTail {
 #else
     __device__ __forceinline__ int id_at(unsigned yfull, int col) const { return f.ids[(long)yfull * f.ipitch + col]; }
 #endif
+    // tile-major copy of the ids on the coarse grid ([tile][coarse row][C], DivBinFuse::ids_t): contiguous per tile instead of 16- /
+    // 32-byte row segments of the full-pitch plane (7.3 / 15.3 MB fetched for 3.5 MB: profiles/r04_overfetch.txt)
+    __device__ __forceinline__ bool packed_ids() const { return f.ids_t != nullptr; }
+    __device__ __forceinline__ int id_at_t(long i) const { return f.ids_t[i]; }
     // id < 0: this lane has no value in this step; pw = re^2 + im^2 of kappa
     __device__ __forceinline__ void add(GpuCtx&, int id, T pw, int col) {
         const int m = (col == 0 || col == f.nxh) ? 1 : (col < f.nxh ? 2 : 0);

@@ -1736,6 +1736,10 @@ struct ColDivArgs {
     int yshift;      // COLUMN GRID: output row y of this My-row transform is row y + (y >= ny/2 ? yshift : 0) of Fn, ly, out
     long in_moff, out_moff;   // several maps per launch (grid z = map): map z's A / B planes and its `out` sit z * {in,out}_moff behind
     long fn_moff;             // ... and its Fn plane z * fn_moff behind (0: one Fn for all -- two Monte-Carlo maps; oa_qe_mv: one per estimator)
+    // SINGLE-PASS launches with ONE Fn for all maps: TILE-MAJOR copy of Fn on the coarse grid, [tile][coarse row][C] (made when the
+    // filters are bound: pipeline.hip) -- read instead of the 16- / 32-byte row segments of the full-pitch plane, of which whole 64- /
+    // 128-byte lines travelled (profiles/r04_overfetch.txt: 10.7 / 14.6 MB fetched for 3.5 / 7 MB).  nullptr: the plane itself.
+    const T* Fn_t;
 };
 
 // LOGC: log2 of the tile width.  The default (32 columns) is the two-pass layout; with a WHOLE column in the tile (SEQ = the
@@ -1748,6 +1752,8 @@ struct NoDivTail {
     static constexpr bool active = false;
     template <class Ctx> OA_HD void begin(Ctx&, void*) {}
     OA_HD int id_at(unsigned, int) const { return -1; }
+    OA_HD bool packed_ids() const { return false; }
+    OA_HD int id_at_t(long) const { return -1; }
     template <class Ctx, typename T> OA_HD void add(Ctx&, int, T, int) {}
     template <class Ctx> OA_HD void finish(Ctx&) {}
 };
@@ -1835,14 +1841,17 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
 #ifdef OA_DIV_NOFN           // traffic experiment only (wrong values): no loads of the normalisation plane
                     cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * (T)(1 + (i & 1));
 #else
-                    cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * Fnb[i];
+                    // (tile-major tables: entry [tile][k][c]; single pass: k is the coarse row)
+                    const long ti_ = (((long)tile << logL) + k) * (1 << logC) + c;
+                    const T fn = a.Fn_t ? a.Fn_t[ti_] : Fnb[i];
+                    cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * fn;
 #endif
                     if (a.out) {
                         if (a.accumulate) d = d + outb[i];
                         outb[i] = d;
                     }
                     pw[u * RL + t] = d.x * d.x + d.y * d.y;
-                    idv[u * RL + t] = tail.id_at(y + up, c0 + c);
+                    idv[u * RL + t] = tail.packed_ids() ? tail.id_at_t((((long)tile << logL) + k) * (1 << logC) + c) : tail.id_at(y + up, c0 + c);
                 }
             }
         }

@@ -43,6 +43,12 @@ struct Pipeline {
     int mc_cap = 0;
     void* lens_pool = nullptr;        // oa_lens_maps: transforms + derivative planes (hc and real) of the maps of one call
     size_t lens_bytes = 0;
+    // tile-major copies of Fnorm and of the bin ids on the coarse grid of the fused divergence + binning launch (what they were
+    // made from: rebuilt when the filters / bins / column grid change)
+    void* fn_t = nullptr; int32_t* ids_t = nullptr;
+    size_t fn_t_bytes = 0, ids_t_bytes = 0;
+    const void* tab_fn = nullptr; const void* tab_ids = nullptr;
+    int tab_rows = 0, tab_logc = 0, tab_wk = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
     // oa_plan_set_option (include/orphics_amd.h): which of the equivalent launch sequences the one-call entries run
@@ -75,6 +81,8 @@ void pipeline_release(oa_plan* p) {
     if (q->mc_src) (void)hipFree(q->mc_src);
     if (q->mv_rtab) (void)hipFree(q->mv_rtab);
     if (q->lens_pool) (void)hipFree(q->lens_pool);
+    if (q->fn_t) (void)hipFree(q->fn_t);
+    if (q->ids_t) (void)hipFree(q->ids_t);
     delete q;
     p->pipe = nullptr;
 }
@@ -151,6 +159,8 @@ static int resolve_col_grid(oa_plan* p, Pipeline* q) { return resolve_my(p, q->m
 }  // namespace oa
 
 using namespace oa;
+
+static int ensure_div_tables(oa_plan* p, oa::Pipeline* q, hipStream_t st);
 
 extern "C" {
 
@@ -229,8 +239,9 @@ int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, v
     }
     q->ids = ids_hc; q->nids = nids; q->norm = norm;
     // mode counts per bin over the WHOLE plane (the per-call binning visits only kappa's active region)
-    return oa_bin_power(p->dtype, q->c[0], q->c[0], norm, ids_hc, nullptr, (long)p->ny * p->kp, nids, p->kp, p->nx / 2, q->sums,
-                        q->counts_full, nullptr, q->bin_scratch, 0, 0, stream);
+    if (int rc = oa_bin_power(p->dtype, q->c[0], q->c[0], norm, ids_hc, nullptr, (long)p->ny * p->kp, nids, p->kp, p->nx / 2, q->sums,
+                              q->counts_full, nullptr, q->bin_scratch, 0, 0, stream)) return rc;
+    return ensure_div_tables(p, q, (hipStream_t)stream);
 }
 
 void* oa_plan_kappa(oa_plan* p) { return (p && p->pipe) ? ((Pipeline*)p->pipe)->kk : nullptr; }
@@ -239,8 +250,36 @@ const int64_t* oa_plan_bin_counts(oa_plan* p) { return (p && p->pipe) ? ((Pipeli
 // Binning + moments in the tail of the single-pass divergence launch (fft_divbin.hpp): the request the one-call entries hand to
 // the divergence wrappers.  OA_OPT_DIV_BIN = 0: always the separate histogram launches (the path of the other geometries).
 static bool divbin_enabled(const Pipeline* q) { return q->opt_divbin; }
+// (re)build the tile-major copies of Fnorm / ids for the single-pass divergence launch on this plan's column grid.  Called where the
+// filters, the bins and the grid are known (oa_plan_set_bins, and again by make_fuse_tabs if any of them changed since): the first
+// build of a size allocates (one device synchronisation), later rebuilds are two small stream-ordered launches.
+static int ensure_div_tables(oa_plan* p, Pipeline* q, hipStream_t st) {
+    const int rows = q->my;
+    if (!(q->Fn && q->ids && (rows == 1024 || rows == 2048) && q->wk > 0)) { q->tab_rows = 0; return 0; }
+    const int logc = div_tile_logc(p, rows);
+    if (q->tab_fn == q->Fn && q->tab_ids == q->ids && q->tab_rows == rows && q->tab_logc == logc && q->tab_wk == q->wk) return 0;
+    const size_t rs = p->dtype == OA_F32 ? 4 : 8;
+    const long tiles = ((long)q->wk + (1 << logc) - 1) >> logc, total = (tiles * rows) << logc;
+    if (q->fn_t_bytes < (size_t)total * rs) {
+        if (q->fn_t) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->fn_t); q->fn_t = nullptr; }
+        OA_HIP(hipMalloc(&q->fn_t, (size_t)total * rs));
+        q->fn_t_bytes = (size_t)total * rs;
+    }
+    if (q->ids_t_bytes < (size_t)total * 4) {
+        if (q->ids_t) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->ids_t); q->ids_t = nullptr; }
+        OA_HIP(hipMalloc((void**)&q->ids_t, (size_t)total * 4));
+        q->ids_t_bytes = (size_t)total * 4;
+    }
+    if (int rc = pack_tiles(p, q->Fn, q->fn_t, rows, logc, q->wk, (int)rs, st)) return rc;
+    if (int rc = pack_tiles(p, q->ids, q->ids_t, rows, logc, q->wk, 4, st)) return rc;
+    q->tab_fn = q->Fn; q->tab_ids = q->ids; q->tab_rows = rows; q->tab_logc = logc; q->tab_wk = q->wk;
+    return 0;
+}
 static DivBinFuse make_fuse(const oa_plan* p, const Pipeline* q, int64_t* n, double* S, double* C, int store) {
     DivBinFuse f{};
+    if (q->tab_rows && q->tab_fn == q->Fn && q->tab_ids == q->ids && q->tab_rows == q->my && q->tab_wk == q->wk) {
+        f.ids_t = q->ids_t; f.fn_t = q->fn_t; f.tab_logc = q->tab_logc; f.tab_rows = q->tab_rows;
+    }
     f.ids = q->ids; f.ipitch = p->kp; f.pnorm = q->norm; f.nids = q->nids; f.nxh = p->nx / 2;
     f.part = (double*)q->bin_scratch; f.part_cap = (long)(oa_bin_scratch_bytes(q->nids) / (long)sizeof(double)) * MC_BATCH_MAX;
     f.sums = q->sums; f.ticket = q->ticket; f.mcounts = q->counts_full; f.n = n; f.S = S; f.C = C; f.store = store; f.done = false;
@@ -376,6 +415,7 @@ int oa_qe_tt_moments(oa_plan* p, const void* real_map, int64_t* n, double* S, do
     OA_REQUIRE(p && p->pipe && ((Pipeline*)p->pipe)->FG && ((Pipeline*)p->pipe)->ids, "oa_qe_tt_moments: call oa_plan_set_filters and oa_plan_set_bins first");
     OA_REQUIRE(real_map && n && S && C, "oa_qe_tt_moments: NULL argument");
     Pipeline* q = (Pipeline*)p->pipe;
+    if (int rc = ensure_div_tables(p, q, (hipStream_t)stream)) return rc;
     DivBinFuse f = make_fuse(p, q, n, S, C, 0);
     if (int rc = qe_tt_impl(p, real_map, nullptr, nullptr, nullptr, 0, stream, divbin_enabled(q) ? &f : nullptr)) return rc;
     if (f.done) return 0;                      // binned and accumulated in the divergence launch
@@ -627,6 +667,7 @@ int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, 
     const long pl = work_pitch(p, q->wl), pk = work_pitch(p, q->wk);
     // second kappa plane: the plan-owned input-transform plane (unused on the from-map path); only kappa's active region of
     // it is ever read back (binning)
+    if (int rc = ensure_div_tables(p, q, (hipStream_t)stream)) return rc;
     DivBinFuse f = make_fuse(p, q, n, S, C, 0);
     int rc = qe_tt_pair_w(p, real_map0, real_map1, q->FG, q->FH, q->Fn, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], q->kk, q->kT, q->wl,
                           q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream, divbin_enabled(q) ? &f : nullptr);
@@ -730,6 +771,7 @@ static int mc_batch_tail(oa_plan* p, Pipeline* q, int B, int64_t* n, double* S, 
                          (long)(2 * lb / es), (long)(lb / es), (long)(2 * lbk / es));
     if (rc < 0) { *fallback = 1; return 0; }          // this geometry's row stage takes one map per launch: one-by-one loop
     if (rc) return rc;
+    if ((rc = ensure_div_tables(p, q, st))) return rc;
     DivBinFuse f = make_fuse(p, q, n, S, C, meanfield_acc ? 1 : 0);
     if ((rc = qe_cols_div_batch_w(p, prod, prod + lbk, q->Fn, q->c[0], tmp, B, (long)(2 * lbk / es), 0, (long)(pb / es), q->wk, q->rk, pk, st, my,
                                   divbin_enabled(q) ? &f : nullptr)))
