@@ -457,7 +457,7 @@ OA_HD void c2r_prologue_impl(Ctx& ctx, cx<T>* s, const cx<T>* in, long pitch, lo
             if (dlx) {
                 T fa = (T)1, fb = (T)1;
                 const T la = dlx[kk], lb = dlx[L - kk];
-                for (int i = 0; i < apow; ++i) { fa *= la; fb *= lb; }
+                for (int i = 0; i < apow; ++i) { fa = fa * la; fb = fb * lb; }
                 A = rot_i(A, apow) * fa;
                 B = rot_i(B, apow) * fb;
             }

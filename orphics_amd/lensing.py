@@ -976,7 +976,9 @@ class FlatLenser(object):
     def alpha_from_kappa_hc(self, kk):
         """the same from kappa's (unnormalised) hc transform -- a simulation that drew kappa in harmonic space has it already"""
         e = self.eng
-        gx, gy, _ = e.qe_legs(kk, kk, self._fphi, self._fphi)
+        if getattr(self, "_alpha_work", None) is None:       # the three leg planes of the gradient kernel, allocated once (not zero-filled per call)
+            self._alpha_work = (e.hc(), e.hc(), e.hc())
+        gx, gy, _ = e.qe_legs(kk, kk, self._fphi, self._fphi, out=self._alpha_work)
         return e.irfft(gy), e.irfft(gx)
 
     def kappa_to_phi(self, kappa):

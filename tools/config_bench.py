@@ -61,6 +61,8 @@ def mv(N=8192, res=0.5):
 
 def mcn0(N=4096, res=0.5, nsims=600):
     shape, g, th, ml, beam, noise, q = setup(N, res, False)
+    if "--mc-batch" in sys.argv:          # realisations per launch (plan option; 1 = one by one)
+        q.eng.set_option("mc_batch", int(sys.argv[sys.argv.index("--mc-batch") + 1]))
     nxh = N // 2
     tot = (th.lCl("TT", ml) * beam ** 2 + noise)[:, :nxh + 1]
     edges = np.linspace(20, 3500, 20)

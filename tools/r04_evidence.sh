@@ -4,7 +4,7 @@ TAG=${1:-r04z}; O=gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
 [ -n "$SKIP_TESTS" ] || timeout -k 10 1000 python -m pytest tests -m gpu -x -q --durations=8 > $O/gpu_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 $O/gpu_pytest.log
 timeout -k 10 120 python3 __graft_entry__.py smoke > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
-timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; 
+T0=$(date +%s); timeout -k 10 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall $(( $(date +%s) - T0 )) s"; 
 python3 - $O <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1] + '/bench.json'))
