@@ -43,7 +43,7 @@ typedef struct oa_plan oa_plan;
 const char* oa_last_error(void);
 /* ABI version = 100 x the build round that last changed a signature in this header; bindings must refuse a library
  * that reports less than the version they were written against (OA_ABI_VERSION) */
-#define OA_ABI_VERSION 401
+#define OA_ABI_VERSION 402
 int oa_version(void);
 /* number of HIP devices visible; <0 on error (no compute) */
 int oa_device_count(void);
@@ -345,6 +345,13 @@ int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long p
  * oa_qe_tt_splits / oa_mc_run), the next call reallocates. */
 int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int order, const int32_t* shift_x, const int32_t* shift_y,
                  const void* dx, const void* dy, void* real_out, long out_stride, void* stream);
+/* The same from the maps' hc transforms (a simulation that DREW its fields in harmonic space has them already: MapGen.get_map's
+ * transform, lensing.py:499-512): `hc_in` holds nmaps planes hc_stride complex elements apart, map = scale * C2R(hc_in)
+ * (scale = 1 / sqrt(Ny Nx) for MapGen's unitary draws).  No forward transform is taken and the undisplaced map itself -- the
+ * (a, b) = (0, 0) term -- leaves the same batched row launch as the x-derivatives of the b = 0 column transform: nmaps fewer
+ * R2Cs and nmaps fewer separate C2Rs than oa_lens_maps on the inverse-transformed maps, same results to rounding. */
+int oa_lens_maps_hc(oa_plan* p, int nmaps, const void* hc_in, long hc_stride, double scale, int order, const int32_t* shift_x,
+                    const int32_t* shift_y, const void* dx, const void* dy, void* real_out, long out_stride, void* stream);
 int oa_plan_release_pools(oa_plan* p);
 
 /* ---- radial binning (stats.bin2D, stats.py:782-811) ------------------------
@@ -398,6 +405,16 @@ int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt
  * A Monte-Carlo loop whose estimator reads only its leg band (oa_mc_run does this itself) draws ~1 % of the modes. */
 int oa_grf_hc_band(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, int width, int rband,
                    void* stream);
+/* MapGen.get_map's draw in ONE pass (maps.py:1579-1587: covsqrt * rand_gauss_harm, then harm2map's rotation): ncomp (1..3) white
+ * fields of streams (seed, stream_id0 + j) -- bit-identical to oa_grf_hc's -- mixed by the covariance square root,
+ *     v_i = sum_j covsqrt_hc[i * ncomp + j] * w_j        (hc-real planes; a NULL entry is a zero block),
+ * then, with rotation planes (ncomp == 3: components 1, 2 <- (x1 c - x2 s, x1 s + x2 c), oa_rot2's convention),
+ *     hc_in == NULL : hc_out[i] = scale * rot(v)_i                       (unlensed T, Q, U transforms; kappa)
+ *     hc_in != NULL : hc_out[i] = rot(hc_in * filt_hcreal)_i + scale * v_i   (beam x lensed Q, U -> E, B, + noise: the observed
+ *                                                                          transforms of lensing.py:513-516 in one pass)
+ * filt_hcreal may be NULL (= 1); hc_out[i] may alias hc_in[i]. */
+int oa_grf_mix(oa_plan* p, uint64_t seed, uint64_t stream_id0, int ncomp, const void* const* covsqrt_hc, const void* rot_c, const void* rot_s,
+               const void* const* hc_in, const void* filt_hcreal, double scale, void* const* hc_out, void* stream);
 /* real white noise N(0,1) plane of n elements (enmap.rand_gauss) */
 int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, void* stream);
 

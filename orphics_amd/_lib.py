@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ORPHICS_AMD_LIB", os.path.join(_HERE, "liborphics_amd
 
 OA_F32 = 0
 OA_F64 = 1
-ABI_VERSION = 401     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
+ABI_VERSION = 402     # include/orphics_amd.h OA_ABI_VERSION: the signatures below are those of this version
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -84,6 +84,7 @@ SIGNATURES = {
     "oa_qe_div": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "oa_lens_split": (c_int, [c_int, c_void_p, c_double, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_lens_maps": (c_int, [c_void_p, c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "oa_lens_maps_hc": (c_int, [c_void_p, c_int, c_void_p, c_long, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "oa_plan_release_pools": (c_int, [c_void_p]),
     "oa_lens_gather": (c_int, [c_void_p] * 6 + [c_int, c_int, c_double, c_void_p, c_int, c_void_p]),
     "oa_hc_derivs": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_long, c_void_p]),
@@ -97,6 +98,7 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "oa_grf_hc": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_void_p]),
     "oa_grf_hc_band": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "oa_grf_mix": (c_int, [c_void_p, c_u64, c_u64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
     "oa_randn": (c_int, [c_int, c_u64, c_u64, c_void_p, c_long, c_void_p]),
     "oa_moments_add": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "oa_moments_add_binned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

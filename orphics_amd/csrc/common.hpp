@@ -119,7 +119,8 @@ int lens_chunk_planes(const oa_plan* p);      // derivative planes per launch tr
 // src[(k + (k >= rows / 2 ? ny - rows : 0)) * kp + tile * C + c], zero beyond `width` columns (elem_bytes 4 or 8)
 int pack_tiles(const oa_plan* p, const void* src, void* dst, int rows, int logc, int width, int elem_bytes, hipStream_t st);
 int div_tile_logc(const oa_plan* p, int rows);          // log2 columns per tile of the single-pass divergence launch on `rows` coarse rows
-int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st);
+int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st,
+                     const void* hc_in = nullptr, long hc_stride = 0, double hc_scale = 1.0);
 // windowed simulation front end: hc spectrum -> inverse columns -> fused C2R x window -> R2C rows onto the plan's scratch plane
 // (then qe_map_legs_cols_w with stages = 6, lr = 0)
 int qe_windowed_rows_w(oa_plan* p, const void* hc_in, void* cols_tmp, const void* window, int width, long pl, double scale, hipStream_t st,

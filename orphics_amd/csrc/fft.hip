@@ -92,15 +92,28 @@ template <class SEQ> constexpr int pair_nt() { return (1 << seq_logl<SEQ>()) / E
 // register budget of the two-rows-per-transform row stage: grids up to 2048 points keep h, the leg and the
 // butterfly temporaries in registers only at 2 waves/SIMD (at 3 they spill 17-45 VGPRs: 117 us vs 87 us at 8192^2,
 // profiles/r02e_rowqe_variants.txt); the 4096-point grid fits 3 waves/SIMD without spilling
+// float64 keeps one wave per SIMD: -DOA_PAIR_F64_WAVES=2 (two waves for the instances that then spill at most ~30 registers) makes the
+// 2048-point NZ = 2 kernel 10 % faster alone (54.9 -> 49.3 us) and leaves every line of the bench where it was
+// (gpurun_out r04q: headline 5231 / 5118, kappa_out 5402 / 5534, MV 1210 / 1210): not adopted
+#ifndef OA_PAIR_F64_WAVES
+#define OA_PAIR_F64_WAVES 1
+#endif
+template <class SEQ, int NZ, int LR> constexpr int pair_f64_waves() {
+    constexpr int ll = seq_logl<SEQ>();
+    if (OA_PAIR_F64_WAVES < 2 || SEQ::n > 3) return 1;
+    if (LR == 3) return NZ == 1 ? 2 : 1;
+    if (LR == 2) return ll == 10 ? (NZ == 1 ? 2 : 1) : ll == 11 ? (NZ <= 2 ? 2 : 1) : (NZ <= 4 ? 2 : 1);
+    return 2;
+}
 #ifdef OA_PAIR_WAVES_PER_EU
-template <typename T, class SEQ> constexpr int pair_waves_per_eu() { return sizeof(T) == 8 ? 1 : OA_PAIR_WAVES_PER_EU; }
+template <typename T, class SEQ, int NZ, int LR> constexpr int pair_waves_per_eu() { return sizeof(T) == 8 ? pair_f64_waves<SEQ, NZ, LR>() : OA_PAIR_WAVES_PER_EU; }
 #else
-template <typename T, class SEQ> constexpr int pair_waves_per_eu() {
-    return sizeof(T) == 8 ? 1 : (seq_logl<SEQ>() == 12 ? 3 : 2);
+template <typename T, class SEQ, int NZ, int LR> constexpr int pair_waves_per_eu() {
+    return sizeof(T) == 8 ? pair_f64_waves<SEQ, NZ, LR>() : (seq_logl<SEQ>() == 12 ? 3 : 2);
 }
 #endif
 template <typename T, class SEQ, int NZ, int LR = 0>
-__global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ>())) void row_qe_pair_kernel(RowQeArgs<T> a) {
+__global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ, NZ, LR>())) void row_qe_pair_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_qe_pair_body<T, SEQ, NZ, LR>(c, a);
 }
@@ -759,14 +772,20 @@ int qe_fwd_cols_batch_w(oa_plan* p, const void* in, long pin, void* out, int B, 
 // launch per (map, y-derivative order) (hc_pool: one hc plane at least; real_pool: nmaps * nd real planes, 1 / Npix applied)
 template <typename T>
 static int lens_derivs_impl(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd,
-                            hipStream_t st) {
+                            hipStream_t st, const void* hc_in, long hc_stride, double hc_scale) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, plane)) return rc;
     HipLauncher q{st};
     auto f = view<T>(p);
     const long hcp = (long)p->ny * p->kp, rp = (long)p->ny * (p->nx / 2);       // plane strides in complex elements
-    for (int m = 0; m < nmaps; ++m)
-        f.r2c(q, (const T*)real_in + (long)m * in_stride, (cx<T>*)k0 + (long)m * hcp, (cx<T>*)p->scratch, (T)1);
+    // hc_in: the maps' transforms are the caller's (oa_lens_maps_hc) -- no R2C, and the map itself ((a, b) = (0, 0)) is one more plane
+    // of the b = 0 row launch: a map then owns nd + 1 planes of the real pool, D_00 first
+    const cx<T>* src = hc_in ? (const cx<T>*)hc_in : (const cx<T>*)k0;
+    const long sstride = hc_in ? hc_stride : hcp;
+    const int d00 = hc_in ? 1 : 0;
+    if (!hc_in)
+        for (int m = 0; m < nmaps; ++m)
+            f.r2c(q, (const T*)real_in + (long)m * in_stride, (cx<T>*)k0 + (long)m * hcp, (cx<T>*)p->scratch, (T)1);
     // SEPARABLE derivatives: (i lx)^a (i ly)^b k0 -- the column transform of (i ly)^b k0 does not depend on a, so a map needs `order`
     // column transforms (b = 0 .. order - 1; col_deriv_body, b-only mode) instead of nd = order (order + 1) / 2 - 1, and every
     // x-derivative is a row C2R of that column-transformed plane with (i lx)^a applied at its load (RowArgs::dlx): per b ONE launch
@@ -775,12 +794,13 @@ static int lens_derivs_impl(oa_plan* p, int nmaps, const void* real_in, long in_
     // over one cache-resident float64 plane at 4096^2 takes 49-52 us, over planes streamed from HBM 71-83 us:
     // profiles/r04f_lensloop_kernel_stats_f64_batched.txt, r04_lensloop_step.txt).
     const int order = (int)((std::sqrt(8.0 * (nd + 1) + 1.0) - 1.0) / 2.0 + 0.5);      // nd = order (order + 1) / 2 - 1
+    const double cscale = hc_in ? hc_scale : 1.0 / ((double)p->ny * p->nx);
     for (int m = 0; m < nmaps; ++m)
         for (int b = 0; b < order; ++b) {
-            const int a0 = b == 0 ? 1 : 0, na = order - b - a0;
+            const int a0 = (b == 0 && !d00) ? 1 : 0, na = order - b - a0;
             if (na <= 0) continue;
-            f.cols_derivs(q, (const cx<T>*)k0, hcp, (cx<T>*)hc_pool, hcp, nmaps, order, (const T*)p->lxd, (const T*)p->lyd, m * order + b, 1, 1);
-            f.rows(q, ROW_C2R, hc_pool, p->kp, (cx<T>*)real_pool + (long)m * nd * rp, p->nx / 2, (T)(1.0 / ((double)p->ny * p->nx)), 0x7fffffff,
+            f.cols_derivs(q, src, sstride, (cx<T>*)hc_pool, hcp, nmaps, order, (const T*)p->lxd, (const T*)p->lyd, m * order + b, 1, 1);
+            f.rows(q, ROW_C2R, hc_pool, p->kp, (cx<T>*)real_pool + ((long)m * (nd + d00) + d00) * rp, p->nx / 2, (T)cscale, 0x7fffffff,
                    nullptr, na, 0, rp, (const T*)p->lxd, a0, b);
         }
     return q.rc;
@@ -794,9 +814,10 @@ int lens_chunk_planes(const oa_plan* p) {
     const int G = (int)((size_t)96 * 1024 * 1024 / plane);
     return G < 1 ? 1 : G;
 }
-int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st) {
-    return p->dtype == OA_F32 ? lens_derivs_impl<float>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st)
-                              : lens_derivs_impl<double>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st);
+int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st,
+                     const void* hc_in, long hc_stride, double hc_scale) {
+    return p->dtype == OA_F32 ? lens_derivs_impl<float>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st, hc_in, hc_stride, hc_scale)
+                              : lens_derivs_impl<double>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st, hc_in, hc_stride, hc_scale);
 }
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my) {

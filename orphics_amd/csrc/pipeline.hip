@@ -345,6 +345,39 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
  * planes -- column pass 1 with the factor (i lx)^a (i ly)^b applied at its load (the derivative spectra never exist in HBM),
  * column pass 2, row C2R -- and one gather pass per map.  The planes live in a plan-owned pool (allocated / grown on first use: that call synchronises the device
  * once; oa_plan_release_pools frees it). */
+static int lens_maps_impl(oa_plan* p, int nmaps, const void* real_in, long in_stride, const void* hc_in, long hc_stride, double hc_scale, int order,
+                          const int32_t* shift_x, const int32_t* shift_y, const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
+    const long rplane = (long)p->ny * p->nx;
+    Pipeline* q = pipe_of(p);
+    const size_t rs = p->dtype == OA_F32 ? 4 : 8;
+    const int nd = order * (order + 1) / 2 - 1;
+    const int d00 = hc_in ? 1 : 0;               // transforms in: the undisplaced map is a pool plane too (the first of each map's nd + 1)
+    hipStream_t st = (hipStream_t)stream;
+    char* realp = nullptr;
+    if (nd + d00 > 0) {
+        const size_t hcb = plane_bytes(p), rb = (size_t)rplane * rs;
+        const int chunk = std::min(lens_chunk_planes(p), nmaps * (nd + d00));
+        const size_t nk0 = hc_in ? 0 : (size_t)nmaps;
+        const size_t need = nk0 * hcb + (size_t)chunk * hcb + (size_t)nmaps * (nd + d00) * rb;
+        if (q->lens_bytes < need) {
+            if (q->lens_pool) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->lens_pool); q->lens_pool = nullptr; q->lens_bytes = 0; }
+            OA_HIP(hipMalloc(&q->lens_pool, need));
+            q->lens_bytes = need;
+        }
+        char* k0 = (char*)q->lens_pool;
+        char* hcp = k0 + nk0 * hcb;
+        realp = hcp + (size_t)chunk * hcb;
+        if (int rc = qe_lens_derivs_w(p, nmaps, real_in, in_stride, k0, hcp, realp, nd, st, hc_in, hc_stride, hc_scale)) return rc;
+    }
+    for (int m = 0; m < nmaps; ++m) {
+        const char* pm = realp + (size_t)m * (nd + d00) * rplane * rs;
+        const void* src = hc_in ? (const void*)pm : (const void*)((const char*)real_in + (size_t)m * in_stride * rs);
+        void* dst = (char*)real_out + (size_t)m * out_stride * rs;
+        if (int rc = oa_lens_taylor(p, src, nd > 0 ? pm + (size_t)d00 * rplane * rs : nullptr, rplane, order, shift_x, shift_y, dx, dy, dst, stream)) return rc;
+    }
+    return 0;
+}
+
 int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int order, const int32_t* shift_x, const int32_t* shift_y,
                  const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
     OA_REQUIRE(p && real_in && shift_x && shift_y && dx && dy && real_out && nmaps >= 1, "oa_lens_maps: bad argument");
@@ -354,31 +387,17 @@ int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int
     OA_REQUIRE(real_in != real_out, "oa_lens_maps: in-place not supported");
     const long rplane = (long)p->ny * p->nx;
     OA_REQUIRE(in_stride >= rplane && out_stride >= rplane, "oa_lens_maps: plane stride smaller than a plane");
-    Pipeline* q = pipe_of(p);
-    const size_t rs = p->dtype == OA_F32 ? 4 : 8;
-    const int nd = order * (order + 1) / 2 - 1;
-    hipStream_t st = (hipStream_t)stream;
-    char* realp = nullptr;
-    if (nd > 0) {
-        const size_t hcb = plane_bytes(p), rb = (size_t)rplane * rs;
-        const int chunk = std::min(lens_chunk_planes(p), nmaps * nd);
-        const size_t need = (size_t)nmaps * hcb + (size_t)chunk * hcb + (size_t)nmaps * nd * rb;
-        if (q->lens_bytes < need) {
-            if (q->lens_pool) { OA_HIP(hipDeviceSynchronize()); (void)hipFree(q->lens_pool); q->lens_pool = nullptr; q->lens_bytes = 0; }
-            OA_HIP(hipMalloc(&q->lens_pool, need));
-            q->lens_bytes = need;
-        }
-        char* k0 = (char*)q->lens_pool;
-        char* hcp = k0 + (size_t)nmaps * hcb;
-        realp = hcp + (size_t)chunk * hcb;
-        if (int rc = qe_lens_derivs_w(p, nmaps, real_in, in_stride, k0, hcp, realp, nd, st)) return rc;
-    }
-    for (int m = 0; m < nmaps; ++m) {
-        const void* src = (const char*)real_in + (size_t)m * in_stride * rs;
-        void* dst = (char*)real_out + (size_t)m * out_stride * rs;
-        if (int rc = oa_lens_taylor(p, src, nd > 0 ? realp + (size_t)m * nd * rplane * rs : nullptr, rplane, order, shift_x, shift_y, dx, dy, dst, stream)) return rc;
-    }
-    return 0;
+    return lens_maps_impl(p, nmaps, real_in, in_stride, nullptr, 0, 1.0, order, shift_x, shift_y, dx, dy, real_out, out_stride, stream);
+}
+
+int oa_lens_maps_hc(oa_plan* p, int nmaps, const void* hc_in, long hc_stride, double scale, int order, const int32_t* shift_x,
+                    const int32_t* shift_y, const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
+    OA_REQUIRE(p && hc_in && shift_x && shift_y && dx && dy && real_out && nmaps >= 1, "oa_lens_maps_hc: bad argument");
+    OA_NEED_POW2(p, "oa_lens_maps_hc");
+    OA_REQUIRE(p->have_laxes, "oa_lens_maps_hc: call oa_plan_set_laxes first");
+    OA_REQUIRE(order >= 1 && order <= 8, "oa_lens_maps_hc: order must be 1..8");
+    OA_REQUIRE(hc_stride >= (long)p->ny * p->kp && out_stride >= (long)p->ny * p->nx, "oa_lens_maps_hc: plane stride smaller than a plane");
+    return lens_maps_impl(p, nmaps, nullptr, 0, hc_in, hc_stride, scale, order, shift_x, shift_y, dx, dy, real_out, out_stride, stream);
 }
 
 /* frees the plan-owned pools that the multi-map entries grow on demand (oa_lens_maps, oa_qe_mv / oa_qe_tt_splits, oa_mc_run): they

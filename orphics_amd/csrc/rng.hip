@@ -83,6 +83,92 @@ __global__ __launch_bounds__(256) void grf_hc_kernel(uint64_t seed, uint64_t sid
     }
 }
 
+// MapGen.get_map in one pass (maps.py:1579-1587): up to three white fields of streams (seed, sid0 + j) -- the counters and the
+// Hermitian rules of grf_hc_kernel, so every w_j is bit-identical to a separate oa_grf_hc draw -- mixed by the covariance square
+// root, v_i = sum_j cs[i][j] w_j (terms formed and added in the order of the per-plane path: cmul_real, then +), optionally
+// rotated (E, B <-> Q, U on components 1, 2) and optionally ADDED to filtered input planes:
+//   in == nullptr : out_i = rot(v)_i * scale                          (the unlensed T, Q, U transforms; kappa)
+//   in != nullptr : out_i = rot(in * filt)_i + scale * v_i            (beam x lensed transforms -> E, B, + noise)
+template <typename T>
+struct GrfMixArgs {
+    uint64_t seed, sid0;
+    const T* cs[9];
+    const T* rc;
+    const T* rs;
+    const cx<T>* in[3];
+    const T* filt;
+    cx<T>* out[3];
+    T scale;
+    int ncomp, ny, nx;
+    long kp;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void grf_mix_kernel(GrfMixArgs<T> a) {
+    const int nxh = a.nx / 2, npair = nxh / 2 + 1, ny = a.ny;
+    const int pr = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (2L * pr >= a.kp) return;
+    const T rs2 = (T)0.70710678118654752440;
+    float n[3][4];
+    int cur_ys = -1;
+    for (int j = 0; j < 2; ++j) {
+        const int x = 2 * pr + j;
+        if (x > nxh) {              // the row padding of the outputs (columns nx/2 + 1 .. kp - 1) is written as zero: callers pass torch.empty planes
+            if (x < a.kp) for (int c = 0; c < a.ncomp; ++c) a.out[c][(long)y * a.kp + x] = mk<T>((T)0, (T)0);
+            continue;
+        }
+        const bool edgecol = (x == 0 || x == nxh);
+        int ys = y;
+        bool cj = false;
+        if (edgecol && y > ny / 2) { ys = ny - y; cj = true; }
+        // columns 2p, 2p + 1 share a counter unless one of them is a self-conjugate column read at the mirrored row
+        if (ys != cur_ys) {
+            for (int c = 0; c < a.ncomp; ++c) normals4(a.seed, a.sid0 + c, (uint64_t)ys * (uint64_t)npair + (uint64_t)pr, n[c]);
+            cur_ys = ys;
+        }
+        const long i = (long)y * a.kp + x;
+        cx<T> w[3], v[3];
+        for (int c = 0; c < a.ncomp; ++c) {
+            T re = (T)n[c][2 * j], im = (T)n[c][2 * j + 1];
+            if (edgecol && (ys == 0 || ys == ny / 2)) { im = (T)0; }
+            else { re *= rs2; im *= rs2; }
+            if (cj) im = -im;
+            w[c] = mk<T>(re, im);
+        }
+        for (int c = 0; c < a.ncomp; ++c) {
+            bool any = false;
+            v[c] = mk<T>((T)0, (T)0);
+            for (int k = 0; k < a.ncomp; ++k) {
+                const T* q = a.cs[c * a.ncomp + k];
+                if (!q) continue;
+                const T sv = q[i];
+                const cx<T> term = mk<T>(w[k].x * sv, w[k].y * sv);
+                v[c] = any ? v[c] + term : term;
+                any = true;
+            }
+        }
+        if (a.in[0]) {
+            cx<T> u[3];
+            const T f = a.filt ? a.filt[i] : (T)1;
+            for (int c = 0; c < a.ncomp; ++c) { const cx<T> t = a.in[c][i]; u[c] = a.filt ? mk<T>(t.x * f, t.y * f) : t; }
+            if (a.rc) {
+                const T cc = a.rc[i], ss = a.rs[i];
+                const cx<T> p = u[1], q = u[2];
+                u[1] = p * cc - q * ss;
+                u[2] = p * ss + q * cc;
+            }
+            for (int c = 0; c < a.ncomp; ++c) a.out[c][i] = u[c] + v[c] * a.scale;
+        } else {
+            if (a.rc) {
+                const T cc = a.rc[i], ss = a.rs[i];
+                const cx<T> p = v[1], q = v[2];
+                v[1] = p * cc - q * ss;
+                v[2] = p * ss + q * cc;
+            }
+            for (int c = 0; c < a.ncomp; ++c) a.out[c][i] = a.scale == (T)1 ? v[c] : v[c] * a.scale;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void randn_kernel(uint64_t seed, uint64_t sid, T* __restrict__ out, long n) {
     const long n4 = (n + 3) / 4;
@@ -124,6 +210,23 @@ __global__ __launch_bounds__(256) void moments_add_binned_kernel(const double* _
     if (gid == 0) n[0] += 1;
 }
 
+template <typename T>
+static int grf_mix_launch(oa_plan* p, uint64_t seed, uint64_t sid0, int ncomp, const void* const* cs, const void* rc, const void* rs,
+                          const void* const* in, const void* filt, double scale, void* const* out, hipStream_t st) {
+    GrfMixArgs<T> a;
+    a.seed = seed; a.sid0 = sid0;
+    for (int i = 0; i < 9; ++i) a.cs[i] = i < ncomp * ncomp ? (const T*)cs[i] : nullptr;
+    a.rc = (const T*)rc; a.rs = (const T*)rs;
+    for (int i = 0; i < 3; ++i) { a.in[i] = (in && i < ncomp) ? (const cx<T>*)in[i] : nullptr; a.out[i] = i < ncomp ? (cx<T>*)out[i] : nullptr; }
+    a.filt = (const T*)filt;
+    a.scale = (T)scale;
+    a.ncomp = ncomp; a.ny = p->ny; a.nx = p->nx; a.kp = p->kp;
+    const int npair = (int)((p->kp + 1) / 2), bs = npair >= 256 ? 256 : 64;          // pairs of columns, the row padding included
+    hipLaunchKernelGGL(grf_mix_kernel<T>, dim3((npair + bs - 1) / bs, p->ny), dim3(bs), 0, st, a);
+    OA_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace oa
 
 using namespace oa;
@@ -162,6 +265,20 @@ extern "C" {
 
 int oa_grf_hc(oa_plan* p, uint64_t seed, uint64_t stream_id, const void* covsqrt_hc, void* hc_out, void* stream) {
     return oa_grf_hc_band(p, seed, stream_id, covsqrt_hc, hc_out, 0, 0, stream);
+}
+
+int oa_grf_mix(oa_plan* p, uint64_t seed, uint64_t stream_id0, int ncomp, const void* const* covsqrt_hc, const void* rot_c, const void* rot_s,
+               const void* const* hc_in, const void* filt_hcreal, double scale, void* const* hc_out, void* stream) {
+    OA_REQUIRE(p && covsqrt_hc && hc_out && ncomp >= 1 && ncomp <= 3, "oa_grf_mix: bad argument (1 <= ncomp <= 3)");
+    OA_REQUIRE((rot_c == nullptr) == (rot_s == nullptr), "oa_grf_mix: rotation needs both planes");
+    OA_REQUIRE(!rot_c || ncomp == 3, "oa_grf_mix: the rotation acts on components 1, 2 of three");
+    for (int i = 0; i < ncomp; ++i) {
+        OA_REQUIRE(hc_out[i], "oa_grf_mix: NULL output plane");
+        OA_REQUIRE(!hc_in || hc_in[i], "oa_grf_mix: NULL input plane");
+    }
+    OA_REQUIRE(hc_in || !filt_hcreal, "oa_grf_mix: a filter without input planes");
+    return p->dtype == OA_F32 ? grf_mix_launch<float>(p, seed, stream_id0, ncomp, covsqrt_hc, rot_c, rot_s, hc_in, filt_hcreal, scale, hc_out, (hipStream_t)stream)
+                              : grf_mix_launch<double>(p, seed, stream_id0, ncomp, covsqrt_hc, rot_c, rot_s, hc_in, filt_hcreal, scale, hc_out, (hipStream_t)stream);
 }
 
 int oa_randn(int dtype, uint64_t seed, uint64_t stream_id, void* out, long n, void* stream) {

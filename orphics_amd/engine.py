@@ -524,6 +524,49 @@ class Engine(object):
         check(self.lib.oa_grf_hc_band(self.plan, int(seed), int(stream_id), _ptr(covsqrt_hc), _ptr(out), int(width), int(rband), _stream()))
         return out
 
+    def grf_mix(self, seed, covsqrt_hc, rot=None, inputs=None, filt=None, scale=1.0, out=None, stream_id0=0):
+        """``oa_grf_mix``: the draw of :meth:`grf_hc` for streams stream_id0 .. stream_id0 + n - 1, mixed by the n x n table of
+        hc-real planes ``covsqrt_hc`` (None = zero block), rotated by ``rot`` = (c, s) on components 1, 2 and -- with
+        ``inputs`` (n hc planes) -- added, times ``scale``, to rot(inputs * filt); one pass.  ``out``: n hc planes
+        (may be the inputs); returns them as a list."""
+        import ctypes
+        n = len(covsqrt_hc)
+        if not (1 <= n <= 3) or any(len(r) != n for r in covsqrt_hc):
+            raise ValueError("grf_mix: covsqrt_hc must be an n x n table, 1 <= n <= 3")
+        if rot is not None and n != 3:
+            raise ValueError("grf_mix: the rotation acts on components 1, 2 of three")
+        if filt is not None and inputs is None:
+            raise ValueError("grf_mix: a filter without input planes")
+        for r in covsqrt_hc:
+            for c in r:
+                if c is not None:
+                    self._chk(c, "hcreal")
+        if rot is not None:
+            self._chk(rot[0], "hcreal"); self._chk(rot[1], "hcreal")
+        if filt is not None:
+            self._chk(filt, "hcreal")
+        if inputs is not None:
+            if len(inputs) != n:
+                raise ValueError("grf_mix: %d input planes for %d components" % (len(inputs), n))
+            for k in inputs:
+                self._chk(k, "hc")
+        if out is None:                    # the kernel writes the row padding too: no fill
+            t = torch.empty((n, self.ny, self.kp), dtype=self.cdt, device=self.device)
+            out = [t[i] for i in range(n)]
+        else:
+            if len(out) != n:
+                raise ValueError("grf_mix: %d output planes for %d components" % (len(out), n))
+            for k in out:
+                _dirty(self._chk(k, "hc"))
+        PT = ctypes.c_void_p * (n * n)
+        cs = PT(*[_ptr(covsqrt_hc[i][j]) for i in range(n) for j in range(n)])
+        P3 = ctypes.c_void_p * n
+        outs = P3(*[_ptr(k) for k in out])
+        ins = P3(*[_ptr(k) for k in inputs]) if inputs is not None else None
+        check(self.lib.oa_grf_mix(self.plan, int(seed), int(stream_id0), n, cs, _ptr(rot[0]) if rot is not None else None,
+                                  _ptr(rot[1]) if rot is not None else None, ins, _ptr(filt), float(scale), outs, _stream()))
+        return list(out)
+
     def randn(self, seed, stream_id, shape=None):
         out = torch.empty(shape if shape is not None else (self.ny, self.nx), dtype=self.rdt, device=self.device)
         check(self.lib.oa_randn(self.code, int(seed), int(stream_id), _ptr(out), out.numel(), _stream()))

@@ -1018,6 +1018,25 @@ class FlatLenser(object):
                                  _ptr(out), e.ny * e.nx, _stream()))
         return out
 
+    def lens_many_hc(self, khc, alpha, taylor_order=5, split=None, scale=None, out=None):
+        """:meth:`lens_many` from the maps' hc transforms (``khc``: (n, Ny, kp) complex device tensor; map = scale x C2R(khc),
+        ``scale`` default 1 / sqrt(Ny Nx): MapGen's unitary draws) -- ``oa_lens_maps_hc``: no forward transform, and the
+        undisplaced maps come out of the same batched row launches as their derivatives."""
+        from ._lib import check
+        from .engine import _ptr, _stream
+        e = self.eng
+        torch = _torch()
+        sx, sy, dx, dy = split if split is not None else self.split(alpha)
+        if not (torch.is_tensor(khc) and khc.is_cuda and khc.dtype == e.cdt and khc.ndim == 3 and tuple(khc.shape[-2:]) == (e.ny, e.kp)):
+            raise ValueError("lens_many_hc: expected a (n, %d, %d) %s device tensor" % (e.ny, e.kp, e.cdt))
+        khc = khc.contiguous()
+        if out is None:
+            out = torch.empty((khc.shape[0], e.ny, e.nx), dtype=e.rdt, device=e.device)
+        sc = 1.0 / float(np.sqrt(e.npix)) if scale is None else float(scale)
+        check(e.lib.oa_lens_maps_hc(e.plan, int(khc.shape[0]), _ptr(khc), e.ny * e.kp, sc, int(taylor_order), _ptr(sx), _ptr(sy), _ptr(dx),
+                                    _ptr(dy), _ptr(out), e.ny * e.nx, _stream()))
+        return out
+
     def release(self):
         """free the plan-owned work planes of ``lens`` / ``lens_many`` (they are reallocated by the next call)"""
         self.eng.release_pools()
@@ -1140,16 +1159,30 @@ class FlatLensingSims(object):
         e = self.lenser.eng
         rt = float(np.sqrt(e.npix))                       # MapGen draws are unitary: rfft(map) = sqrt(Npix) x the drawn transform
         assert not self._fixed, "get_sim_teb draws its own kappa"
+        cached = getattr(self, "_kbeam_hc", None)
+        if cached is None or cached[0] is not self.kbeam:
+            self._kbeam_hc = (self.kbeam, e.fullreal_to_hc(e.to_real(self.kbeam)))
+        beam = self._kbeam_hc[1]
+        pol = len(self.shape) > 2 and self.shape[0] == 3
+        if e.pow2 and 1 <= lens_order <= 8 and (pol or len(self.shape) == 2):
+            # device pipeline: one draw-and-mix pass per field set (oa_grf_mix: covsqrt x white, E, B -> Q, U), the lens operation from
+            # the drawn transforms (oa_lens_maps_hc: no transform of the unlensed maps in either direction), and one pass for
+            # beam x lensed -> E, B + noise
+            kunl = self.mgen.draw_hc(seed_cmb, rot="inverse" if pol else None)
+            kin = self.kgen.draw_hc(seed_kappa, scale=rt)[0]
+            self.alpha = self.lenser.alpha_from_kappa_hc(kin)
+            lensed = self.lenser.lens_many_hc(kunl, self.alpha, taylor_order=lens_order, split=self.lenser.split(self.alpha))
+            ks = torch.empty_like(kunl)
+            for i in range(lensed.shape[0]):
+                e.rfft(lensed[i], out=ks[i])
+            teb = self.ngen.draw_hc(seed_noise, rot="forward" if pol else None, inputs=ks, filt=beam, scale=rt, out=ks)
+            return teb, kin
         unl = self.get_unlensed(seed_cmb)
         kin = self.kgen.get_map(seed=seed_kappa, scalar=True, harm=True).t * rt
         self.alpha = self.lenser.alpha_from_kappa_hc(kin)
         lensed = self.lens_maps(unl, self.alpha, lens_order)
         pol = lensed.ndim == 3
         planes = [lensed[i] for i in range(lensed.shape[0])] if pol else [lensed]
-        cached = getattr(self, "_kbeam_hc", None)
-        if cached is None or cached[0] is not self.kbeam:
-            self._kbeam_hc = (self.kbeam, e.fullreal_to_hc(e.to_real(self.kbeam)))
-        beam = self._kbeam_hc[1]
         ks = [e.cmul_real(e.rfft(p.contiguous()), beam) for p in planes]
         if pol:
             if getattr(self, "_fc_half", None) is None:

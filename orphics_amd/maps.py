@@ -599,10 +599,7 @@ class MapGen(object):
         transformed (unitary R2C) instead of being drawn mode by mode -- same statistics, the reference's other path."""
         torch = _torch()
         eng = _engine(self.shape, self.prec)
-        if seed is None:
-            seed = int(np.random.randint(0, 2 ** 31 - 1))
-        elif isinstance(seed, (tuple, list)):
-            seed = int(np.random.SeedSequence(list(seed)).generate_state(1, dtype=np.uint64)[0] >> 1)
+        seed = self._seed_int(seed)
         cs = self._covsqrt_hc(eng)
         nc = self.ncomp
         # a component that couples to no other (its row and column of covsqrt hold the diagonal entry only: white noise, kappa, the
@@ -642,6 +639,41 @@ class MapGen(object):
                 eng.irfft(k, scale=1.0 / np.sqrt(eng.npix), out=out[i])
             return out
         return eng.irfft(ks[0], scale=1.0 / np.sqrt(eng.npix))
+
+    def _seed_int(self, seed):
+        if seed is None:
+            return int(np.random.randint(0, 2 ** 31 - 1))
+        if isinstance(seed, (tuple, list)):
+            return int(np.random.SeedSequence(list(seed)).generate_state(1, dtype=np.uint64)[0] >> 1)
+        return int(seed)
+
+    def draw_hc(self, seed=None, rot=None, inputs=None, filt=None, scale=1.0, out=None, iau=False):
+        """``get_map(seed, harm=True)``'s transforms in ONE device pass (``oa_grf_mix``) -- the same white fields (Philox streams
+        (seed, component)), mixed by covsqrt in the same order of operations -- with what usually follows folded in:
+          rot="inverse" : harm2map's E, B -> Q, U rotation (maps.py:1584-1586) applied to the draw,
+          inputs (+filt): the draw, times ``scale``, is ADDED to rot(inputs * filt) -- rot="forward": Q, U -> E, B
+                          (FourierCalc.iqu2teb's rotation) -- i.e. beam x signal + noise in the T, E, B basis.
+        Returns the (ncomp, Ny, kp) stacked hc tensor (the drawn transforms are unitary: rfft(map) = sqrt(Npix) x them)."""
+        torch = _torch()
+        eng = _engine(self.shape, self.prec)
+        seed = self._seed_int(seed)
+        cs = self._covsqrt_hc(eng)
+        nc = self.ncomp
+        tab = [[cs[i][j] if self._nz[i][j] else None for j in range(nc)] for i in range(nc)]
+        r = None
+        if rot is not None:
+            if rot not in ("inverse", "forward") or nc != 3:
+                raise ValueError("draw_hc: rot is 'inverse' or 'forward' and needs three components")
+            key = (eng.prec, bool(iau), rot)
+            if key not in self._rot_dev:
+                m = queb_rotmat(self.geom.lmap(), inverse=(rot == "inverse"), iau=iau)
+                self._rot_dev[key] = (eng.fullreal_to_hc(eng.to_real(m[0, 0])), eng.fullreal_to_hc(eng.to_real(m[1, 0])))
+            r = self._rot_dev[key]
+        if out is None:
+            out = torch.empty((nc, eng.ny, eng.kp), dtype=eng.cdt, device=eng.device)
+        ins = None if inputs is None else [inputs[i] for i in range(nc)]
+        eng.grf_mix(seed, tab, rot=r, inputs=ins, filt=filt, scale=scale, out=[out[i] for i in range(nc)])
+        return out
 
     def get_map_from_rand(self, rand, scalar=False, iau=False, harm=False):
         """Reference arithmetic (maps.py:1579-1587) on a caller-supplied complex

@@ -341,11 +341,14 @@ static int do_lens_derivs(int ny, int nx, const cx<T>* k0, const T* lxd, const T
     int order = 1;
     while (order * (order + 1) / 2 - 1 < nd) ++order;
     std::vector<cx<T>> plane((size_t)hcp);
+    // separable = 2 (oa_lens_maps_hc): the undisplaced field (a, b) = (0, 0) is one more plane of the b = 0 launch -- out = nd + 1
+    // planes, D_00 first
+    const int d00 = separable == 2 ? 1 : 0;
     for (int b = 0; b < order; ++b) {
-        const int a0 = b == 0 ? 1 : 0, na = order - b - a0;
+        const int a0 = (b == 0 && !d00) ? 1 : 0, na = order - b - a0;
         if (na <= 0) continue;
         h.p.cols_derivs(q, k0, hcp, plane.data(), hcp, 1, order, lxd, lyd, b, 1, 1);
-        h.p.rows(q, ROW_C2R, plane.data(), h.p.kp, out, nx / 2, (T)(1.0 / ((double)ny * nx)), 0x7fffffff, nullptr, na, 0, rp, lxd, a0, b);
+        h.p.rows(q, ROW_C2R, plane.data(), h.p.kp, out + (size_t)d00 * ny * nx, nx / 2, (T)(1.0 / ((double)ny * nx)), 0x7fffffff, nullptr, na, 0, rp, lxd, a0, b);
     }
     return 0;
 }

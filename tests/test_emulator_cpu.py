@@ -719,7 +719,7 @@ def test_fused_windowed_row_pass(emu, ny, nx, wc, prec):
     assert np.all(out[:, wc:] == 7.0)
 
 
-@pytest.mark.parametrize("ny,nx,order,separable", [(64, 128, 5, 1), (256, 64, 3, 1), (64, 128, 5, 0), (32, 256, 6, 1)])
+@pytest.mark.parametrize("ny,nx,order,separable", [(64, 128, 5, 1), (256, 64, 3, 1), (64, 128, 5, 0), (32, 256, 6, 1), (64, 128, 5, 2), (32, 64, 1, 2)])
 def test_batched_derivative_inverse_transforms(emu, ny, nx, order, separable):
     """col_deriv_body + batched row C2R (oa_lens_maps): every Fourier-space derivative (i lx)^a (i ly)^b k, a + b < order, of a
     transform inverse-transformed with the factor applied at the load of the inverse column pass; plane idx(a, b) =
@@ -736,9 +736,13 @@ def test_batched_derivative_inverse_transforms(emu, ny, nx, order, separable):
     lyd[ny // 2] = 0
     lxd[nx // 2] = 0
     nd = order * (order + 1) // 2 - 1
-    out = np.zeros((nd, ny, nx))
+    d00 = 1 if separable == 2 else 0          # oa_lens_maps_hc: the field itself is plane 0 of nd + 1, out of the b = 0 row launch
+    out = np.zeros((nd + d00, ny, nx))
     assert emu.emu_lens_derivs_f64(ny, nx, _p(k0), _p(lxd), _p(lyd), _p(out), nd, separable) == 0
     kf = np.fft.rfft2(x)
+    if d00:
+        assert np.abs(out[0] - x).max() < 1e-12 * np.abs(x).max()
+        out = out[1:]
     for n in range(1, order):
         for b in range(n + 1):
             a = n - b

@@ -1040,3 +1040,74 @@ def test_get_sim_teb_equals_iqu2teb_of_get_sim(prec, tol):
     for i in range(3):
         d = (teb[i] - ref[i])[rows][:, :w].abs().max() / ref[i].abs().max()
         assert float(d) < tol, (i, float(d))
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_draw_hc_is_get_map_harm_in_one_pass(prec):
+    """MapGen.draw_hc (oa_grf_mix: the white fields, the covsqrt mix, the E, B -> Q, U rotation and -- with inputs -- the beam, the
+    Q, U -> E, B rotation and the sum, in ONE kernel) against the plane-by-plane path it replaces (oa_grf_hc + oa_cmul_real + add +
+    oa_rot2): the same Philox streams and the same order of operations, so the draws are BIT-identical; the input mode agrees to
+    rounding (torch's add(alpha=) contracts its multiply-add)."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N = 128
+    shape = (3, N, 2 * N)
+    g = FlatGeometry.from_res(shape, 1.5)
+    th = cosmology.default_theory()
+    sims = lensing.FlatLensingSims(shape, g, th, 1.5, 1.0, pol=True, dtype=prec)
+    e = sims.lenser.eng
+    seed = (7, 1, 3)
+    ref = sims.mgen.get_map(seed=seed, harm=True).t
+    got = sims.mgen.draw_hc(seed)
+    assert torch.equal(got, ref)                                           # T-E correlated: two terms per E mode, same order
+    assert float(ref[1].abs().max()) > 0 and bool((got[..., e.nxh + 1:] == 0).all())
+    mi = maps.queb_rotmat(g.lmap(), inverse=True)
+    c, s = e.fullreal_to_hc(e.to_real(mi[0, 0])), e.fullreal_to_hc(e.to_real(mi[1, 0]))
+    q, u = e.rot2(c, s, ref[1].contiguous(), ref[2].contiguous())
+    rot = sims.mgen.draw_hc(seed, rot="inverse")
+    assert torch.equal(rot[0], ref[0]) and torch.equal(rot[1], q) and torch.equal(rot[2], u)
+    k = sims.kgen.draw_hc((7, 2, 3), scale=3.0)[0]
+    assert torch.equal(k, sims.kgen.get_map(seed=(7, 2, 3), scalar=True, harm=True).t * 3.0)
+    # inputs: rot(in * beam) + scale * noise draw
+    mf = maps.queb_rotmat(g.lmap(), inverse=False)
+    cf, sf = e.fullreal_to_hc(e.to_real(mf[0, 0])), e.fullreal_to_hc(e.to_real(mf[1, 0]))
+    beam = e.fullreal_to_hc(e.to_real(maps.gauss_beam(g.modlmap(), 1.5)))
+    ks = [e.cmul_real(rot[i].contiguous(), beam) for i in range(3)]
+    ks[1], ks[2] = e.rot2(cf, sf, ks[1], ks[2])
+    nk = sims.ngen.get_map(seed=(7, 3, 3), harm=True).t
+    want = torch.stack([ks[i] + 2.5 * nk[i] for i in range(3)])
+    out = sims.ngen.draw_hc((7, 3, 3), rot="forward", inputs=rot.clone(), filt=beam, scale=2.5)
+    tol = 1e-14 if prec == "f64" else 1e-6
+    assert float((out - want).abs().max() / want.abs().max()) < tol
+    inp = rot.clone()                                                      # in place: the outputs may be the inputs
+    sims.ngen.draw_hc((7, 3, 3), rot="forward", inputs=inp, filt=beam, scale=2.5, out=inp)
+    assert torch.equal(inp, out)
+    with pytest.raises(ValueError):
+        sims.kgen.draw_hc(1, rot="inverse")
+    with pytest.raises(ValueError):
+        e.grf_mix(1, [[None]], filt=beam)
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 3e-5)])
+@pytest.mark.parametrize("order", [1, 2, 5])
+def test_lens_many_hc_equals_lens_many_of_the_inverse_transforms(prec, tol, order):
+    """oa_lens_maps_hc (the maps' transforms in: no R2C, the undisplaced map one more plane of the batched row launches) against
+    oa_lens_maps on the inverse-transformed maps: same lensed maps to rounding, for T, Q, U of one realisation."""
+    from orphics_amd import cosmology, lensing
+    from orphics_amd.geometry import FlatGeometry
+    N = 256
+    shape = (3, N, N)
+    g = FlatGeometry.from_res(shape, 1.5)
+    th = cosmology.default_theory()
+    sims = lensing.FlatLensingSims(shape, g, th, 1.5, 1.0, pol=True, dtype=prec)
+    e = sims.lenser.eng
+    khc = sims.mgen.draw_hc((5, 1, 0), rot="inverse")
+    unl = torch.stack([e.irfft(khc[i].contiguous(), scale=1.0 / np.sqrt(e.npix)) for i in range(3)])
+    alpha = sims.lenser.alpha_from_kappa_hc(sims.kgen.draw_hc((5, 2, 0), scale=float(np.sqrt(e.npix)))[0])
+    sp = sims.lenser.split(alpha)
+    ref = sims.lenser.lens_many(unl, alpha, taylor_order=order, split=sp)
+    got = sims.lenser.lens_many_hc(khc, alpha, taylor_order=order, split=sp)
+    assert float((got - ref).abs().max() / ref.abs().max()) < tol
+    assert float((ref - unl).abs().max() / ref.abs().max()) > 1e-3      # the deflection does something
+    with pytest.raises(ValueError):
+        sims.lenser.lens_many_hc(unl, alpha)
