@@ -346,9 +346,12 @@ __global__ __launch_bounds__(256) void hc_derivs_kernel(const cx<T>* __restrict_
 
 // flat_taylens in one gather pass: out = sum_{a + b < order} dx^a dy^b / (a! b!) D_ab[(y + sy) % ny, (x + sx) % nx], D_00 = src
 // and D_ab (n >= 1) = real plane idx(a, b) of `planes` (the C2R of hc_derivs_kernel's output).
-template <typename T>
+// ORDER is compile-time: the term loops unroll, the powers dx^a / a!, dy^b / b! are formed once (the same operations in the same order
+// as the run-time-order loop this replaces -- identical values -- which recomputed dy^b / b! for every total order and indexed
+// dx^a / a! through scratch: 385 us per 4096^2 float32 map against 215 us of traffic) and all gathers of a pixel are in flight together
+template <typename T, int ORDER>
 __global__ __launch_bounds__(256) void lens_taylor_kernel(const T* __restrict__ src, const T* __restrict__ planes, long pstride,
-                                                          int order, const int* __restrict__ sx, const int* __restrict__ sy,
+                                                          const int* __restrict__ sx, const int* __restrict__ sy,
                                                           const T* __restrict__ dx, const T* __restrict__ dy, T* __restrict__ out,
                                                           int ny, int nx) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,17 +363,19 @@ __global__ __launch_bounds__(256) void lens_taylor_kernel(const T* __restrict__ 
     if (ys < 0) ys += ny;
     const long g = (long)ys * nx + xs;
     const T ddx = dx[i], ddy = dy[i];
-    T acc = src[g];
-    T xa[8];                                      // dx^a / a!
-    xa[0] = (T)1;
-    for (int n = 1; n < order; ++n) {
-        xa[n] = xa[n - 1] * ddx / (T)n;
-        T yb = (T)1;                              // dy^b / b!
-        const T* pl = planes + (long)(n * (n + 1) / 2 - 1) * pstride + g;
-        for (int b = 0; b <= n; ++b) {
-            acc += pl[(long)b * pstride] * (xa[n - b] * yb);
-            yb = yb * ddy / (T)(b + 1);
-        }
+    T v[ORDER * (ORDER + 1) / 2];
+    v[0] = src[g];
+#pragma unroll
+    for (int k = 1; k < ORDER * (ORDER + 1) / 2; ++k) v[k] = planes[(long)(k - 1) * pstride + g];
+    T xa[ORDER], ya[ORDER];                       // dx^a / a!, dy^b / b!
+    xa[0] = (T)1; ya[0] = (T)1;
+#pragma unroll
+    for (int n = 1; n < ORDER; ++n) { xa[n] = xa[n - 1] * ddx / (T)n; ya[n] = ya[n - 1] * ddy / (T)n; }
+    T acc = v[0];
+#pragma unroll
+    for (int n = 1; n < ORDER; ++n) {
+#pragma unroll
+        for (int b = 0; b <= n; ++b) acc += v[n * (n + 1) / 2 + b] * (xa[n - b] * ya[b]);
     }
     out[i] = acc;
 }
@@ -674,11 +679,17 @@ int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long p
     OA_REQUIRE(order == 1 || plane_stride >= (long)p->ny * p->nx, "oa_lens_taylor: plane_stride smaller than a plane");
     OA_REQUIRE(src != out, "oa_lens_taylor: in-place not supported");
     hipStream_t st = (hipStream_t)stream;
-    DISPATCH(p->dtype,
-             hipLaunchKernelGGL(lens_taylor_kernel<float>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const float*)src, (const float*)deriv_planes,
-                                plane_stride, order, shift_x, shift_y, (const float*)dx, (const float*)dy, (float*)out, p->ny, p->nx),
-             hipLaunchKernelGGL(lens_taylor_kernel<double>, PLANE_GRID(p, p->nx), dim3(256), 0, st, (const double*)src, (const double*)deriv_planes,
-                                plane_stride, order, shift_x, shift_y, (const double*)dx, (const double*)dy, (double*)out, p->ny, p->nx));
+#define OA_TAYLOR(T, O) \
+    hipLaunchKernelGGL((lens_taylor_kernel<T, O>), PLANE_GRID(p, p->nx), dim3(256), 0, st, (const T*)src, (const T*)deriv_planes, plane_stride, \
+                       shift_x, shift_y, (const T*)dx, (const T*)dy, (T*)out, p->ny, p->nx)
+#define OA_TAYLOR_ORDERS(T) \
+    switch (order) { \
+        case 1: OA_TAYLOR(T, 1); break; case 2: OA_TAYLOR(T, 2); break; case 3: OA_TAYLOR(T, 3); break; case 4: OA_TAYLOR(T, 4); break; \
+        case 5: OA_TAYLOR(T, 5); break; case 6: OA_TAYLOR(T, 6); break; case 7: OA_TAYLOR(T, 7); break; default: OA_TAYLOR(T, 8); break; \
+    }
+    if (p->dtype == OA_F32) { OA_TAYLOR_ORDERS(float) } else { OA_TAYLOR_ORDERS(double) }
+#undef OA_TAYLOR_ORDERS
+#undef OA_TAYLOR
     OA_LAUNCH_CHECK();
     return 0;
 }

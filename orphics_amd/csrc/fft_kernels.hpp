@@ -1907,7 +1907,9 @@ struct ColDerivArgs {
     const T* lxd; const T* lyd;
 };
 
-template <typename T>
+// BONLY (what oa_lens_maps runs: the x-derivatives ride on the row pass): the factor is i^b ly^b -- one LDS read and two multiplies per
+// point, the power of i an exact swap / negation (same values as the general form, whose products with cr, ci in {0, +-1} are exact)
+template <typename T, bool BONLY = false>
 struct ColDerivLoad {
     static constexpr bool reads_lds = false;    // (the factor tables sit behind the tile, filled and synced before the pipeline: no hazard with its writes)
     const cx<T>* base;
@@ -1916,12 +1918,19 @@ struct ColDerivLoad {
     const T* fx;                // LDS: lx^a of the tile's columns
     const T* fy;                // LDS: ly^b of the tile's rows (point n of this group)
     T cr, ci;                   // i^(a + b)
+    int q;                      // (a + b) & 3
     template <typename U> OA_HD cx<U> get(int n, int c) const {
         cx<U> x = mk<U>((U)0, (U)0);
         if (c < ncols) {
             const cx<U> v = base[(unsigned)n * nstride + (unsigned)c];
-            const U f = fx[c] * fy[n];
-            x = mk<U>((v.x * cr - v.y * ci) * f, (v.x * ci + v.y * cr) * f);
+            if constexpr (BONLY) {
+                const U f = fy[n];
+                const cx<U> r = rot_i(v, q);
+                x = mk<U>(r.x * f, r.y * f);
+            } else {
+                const U f = fx[c] * fy[n];
+                x = mk<U>((v.x * cr - v.y * ci) * f, (v.x * ci + v.y * cr) * f);
+            }
         }
         return swp(x);          // inverse transform = forward transform of the swapped data
     }
@@ -1965,10 +1974,15 @@ OA_HD void col_deriv_body(Ctx& ctx, const ColDerivArgs<T>& a) {
     ctx.sync();
     const int q = n & 3;                                     // i^n
     const T cr = (T)((q == 0) - (q == 2)), ci = (T)((q == 1) - (q == 3));
-    const ColDerivLoad<T> ld{a.in + (long)m * a.in_mstride + g * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, fx, fy, cr, ci};
     const ColStore<T> st{a.out + (long)ctx.bid_z() * a.out_pstride + g * a.out_gs * a.pitch + c0, (unsigned)a.pitch, ncols, true, ti, (unsigned)g, (T)1,
                          0, 0, 0, 0};
-    fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
+    if (a.bonly) {
+        const ColDerivLoad<T, true> ld{a.in + (long)m * a.in_mstride + g * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, fx, fy, cr, ci, q};
+        fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
+    } else {
+        const ColDerivLoad<T, false> ld{a.in + (long)m * a.in_mstride + g * a.pitch + c0, (unsigned)(a.in_ns * a.pitch), ncols, fx, fy, cr, ci, q};
+        fft_pipeline<T, false, true, true, SEQ>(ctx, s, tid, CNT, logL, CLC, 0, twl, logL, ld, st);
+    }
 }
 
 template <typename T, class SEQ, class Ctx>

@@ -102,71 +102,103 @@ struct GrfMixArgs {
     int ncomp, ny, nx;
     long kp;
 };
-template <typename T>
+// NC and the input mode are compile-time: every loop unrolls, the pointer tables and the per-component values stay in registers
+// (with run-time indices they went through scratch: 400-660 us per call at 4096^2 float64 instead of 100-250).  A thread owns the
+// column pair (2p, 2p + 1) of one row and moves it with ONE load / store per plane (32 B float64, 16 B float32: kp is a multiple
+// of 16, so pairs are aligned and in bounds, row padding included); all loads are issued before the Philox / Box-Muller arithmetic.
+template <typename T> struct alignas(2 * sizeof(T)) Pair { T a, b; };
+template <typename T, int NC, bool HAS_IN>
 __global__ __launch_bounds__(256) void grf_mix_kernel(GrfMixArgs<T> a) {
     const int nxh = a.nx / 2, npair = nxh / 2 + 1, ny = a.ny;
     const int pr = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (2L * pr >= a.kp) return;
+    const long i0 = (long)y * a.kp + 2 * pr;
+    typedef Pair<T> R2;
+    typedef Pair<cx<T>> C2;
+    // ---- loads ----
+    R2 sv[NC * NC];
+#pragma unroll
+    for (int k = 0; k < NC * NC; ++k) { sv[k].a = (T)0; sv[k].b = (T)0; if (a.cs[k]) sv[k] = *reinterpret_cast<const R2*>(a.cs[k] + i0); }
+    R2 rc{(T)1, (T)1}, rs{(T)0, (T)0}, fl{(T)1, (T)1};
+    if (NC == 3 && a.rc) { rc = *reinterpret_cast<const R2*>(a.rc + i0); rs = *reinterpret_cast<const R2*>(a.rs + i0); }
+    C2 u[NC];
+    if constexpr (HAS_IN) {
+        if (a.filt) fl = *reinterpret_cast<const R2*>(a.filt + i0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) u[c] = *reinterpret_cast<const C2*>(a.in[c] + i0);
+    }
+    // ---- draws: columns 2p, 2p + 1 share a counter unless one of them is a self-conjugate column read at the mirrored row ----
     const T rs2 = (T)0.70710678118654752440;
-    float n[3][4];
+    cx<T> w[2][NC];
+    float n[NC][4];
     int cur_ys = -1;
+#pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int x = 2 * pr + j;
-        if (x > nxh) {              // the row padding of the outputs (columns nx/2 + 1 .. kp - 1) is written as zero: callers pass torch.empty planes
-            if (x < a.kp) for (int c = 0; c < a.ncomp; ++c) a.out[c][(long)y * a.kp + x] = mk<T>((T)0, (T)0);
-            continue;
-        }
         const bool edgecol = (x == 0 || x == nxh);
         int ys = y;
         bool cj = false;
         if (edgecol && y > ny / 2) { ys = ny - y; cj = true; }
-        // columns 2p, 2p + 1 share a counter unless one of them is a self-conjugate column read at the mirrored row
-        if (ys != cur_ys) {
-            for (int c = 0; c < a.ncomp; ++c) normals4(a.seed, a.sid0 + c, (uint64_t)ys * (uint64_t)npair + (uint64_t)pr, n[c]);
+        if (ys != cur_ys && x <= nxh) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) normals4(a.seed, a.sid0 + c, (uint64_t)ys * (uint64_t)npair + (uint64_t)pr, n[c]);
             cur_ys = ys;
         }
-        const long i = (long)y * a.kp + x;
-        cx<T> w[3], v[3];
-        for (int c = 0; c < a.ncomp; ++c) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
             T re = (T)n[c][2 * j], im = (T)n[c][2 * j + 1];
             if (edgecol && (ys == 0 || ys == ny / 2)) { im = (T)0; }
             else { re *= rs2; im *= rs2; }
             if (cj) im = -im;
-            w[c] = mk<T>(re, im);
+            w[j][c] = mk<T>(re, im);
         }
-        for (int c = 0; c < a.ncomp; ++c) {
+    }
+    // ---- mix, rotate, add: per column of the pair ----
+    C2 o[NC];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = 2 * pr + j;
+        cx<T> v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
             bool any = false;
             v[c] = mk<T>((T)0, (T)0);
-            for (int k = 0; k < a.ncomp; ++k) {
-                const T* q = a.cs[c * a.ncomp + k];
-                if (!q) continue;
-                const T sv = q[i];
-                const cx<T> term = mk<T>(w[k].x * sv, w[k].y * sv);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                if (!a.cs[c * NC + k]) continue;
+                const T q = j ? sv[c * NC + k].b : sv[c * NC + k].a;
+                const cx<T> term = mk<T>(w[j][k].x * q, w[j][k].y * q);
                 v[c] = any ? v[c] + term : term;
                 any = true;
             }
         }
-        if (a.in[0]) {
-            cx<T> u[3];
-            const T f = a.filt ? a.filt[i] : (T)1;
-            for (int c = 0; c < a.ncomp; ++c) { const cx<T> t = a.in[c][i]; u[c] = a.filt ? mk<T>(t.x * f, t.y * f) : t; }
-            if (a.rc) {
-                const T cc = a.rc[i], ss = a.rs[i];
-                const cx<T> p = u[1], q = u[2];
-                u[1] = p * cc - q * ss;
-                u[2] = p * ss + q * cc;
+        const T cc = j ? rc.b : rc.a, ss = j ? rs.b : rs.a;
+        cx<T> r[NC];
+        if constexpr (HAS_IN) {
+            const T f = j ? fl.b : fl.a;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const cx<T> t = j ? u[c].b : u[c].a; r[c] = a.filt ? mk<T>(t.x * f, t.y * f) : t; }
+            if constexpr (NC == 3) {
+                if (a.rc) { const cx<T> p = r[1], q = r[2]; r[1] = p * cc - q * ss; r[2] = p * ss + q * cc; }
             }
-            for (int c = 0; c < a.ncomp; ++c) a.out[c][i] = u[c] + v[c] * a.scale;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = r[c] + v[c] * a.scale;
         } else {
-            if (a.rc) {
-                const T cc = a.rc[i], ss = a.rs[i];
-                const cx<T> p = v[1], q = v[2];
-                v[1] = p * cc - q * ss;
-                v[2] = p * ss + q * cc;
+            if constexpr (NC == 3) {
+                if (a.rc) { const cx<T> p = v[1], q = v[2]; v[1] = p * cc - q * ss; v[2] = p * ss + q * cc; }
             }
-            for (int c = 0; c < a.ncomp; ++c) a.out[c][i] = a.scale == (T)1 ? v[c] : v[c] * a.scale;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = a.scale == (T)1 ? v[c] : v[c] * a.scale;
+        }
+        // the row padding of the outputs (columns nx/2 + 1 .. kp - 1) is written as zero: callers pass torch.empty planes
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const cx<T> z = x > nxh ? mk<T>((T)0, (T)0) : r[c];
+            if (j) o[c].b = z; else o[c].a = z;
         }
     }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *reinterpret_cast<C2*>(a.out[c] + i0) = o[c];
 }
 
 template <typename T>
@@ -222,7 +254,16 @@ static int grf_mix_launch(oa_plan* p, uint64_t seed, uint64_t sid0, int ncomp, c
     a.scale = (T)scale;
     a.ncomp = ncomp; a.ny = p->ny; a.nx = p->nx; a.kp = p->kp;
     const int npair = (int)((p->kp + 1) / 2), bs = npair >= 256 ? 256 : 64;          // pairs of columns, the row padding included
-    hipLaunchKernelGGL(grf_mix_kernel<T>, dim3((npair + bs - 1) / bs, p->ny), dim3(bs), 0, st, a);
+    const dim3 grid((npair + bs - 1) / bs, p->ny);
+#define OA_MIX(NC) \
+    do { \
+        if (in) hipLaunchKernelGGL((grf_mix_kernel<T, NC, true>), grid, dim3(bs), 0, st, a); \
+        else hipLaunchKernelGGL((grf_mix_kernel<T, NC, false>), grid, dim3(bs), 0, st, a); \
+    } while (0)
+    if (ncomp == 1) OA_MIX(1);
+    else if (ncomp == 2) OA_MIX(2);
+    else OA_MIX(3);
+#undef OA_MIX
     OA_LAUNCH_CHECK();
     return 0;
 }
