@@ -117,9 +117,12 @@ __global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ, NZ, LR>(
     GpuCtx c{oa_dyn_smem};
     row_qe_pair_body<T, SEQ, NZ, LR>(c, a);
 }
+#ifndef OA_CHAIN_F64_WAVES
+#define OA_CHAIN_F64_WAVES 1
+#endif
 // estimator chains (oa_qe_mv): two more 16-point register sets (the running products of both legs)
 template <typename T, class SEQ, int NZ>
-__global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? 1 : 2)) void row_qe_chain_kernel(RowQeArgs<T> a) {
+__global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? OA_CHAIN_F64_WAVES : 2)) void row_qe_chain_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_qe_pair_body<T, SEQ, NZ, 0, true>(c, a);
 }

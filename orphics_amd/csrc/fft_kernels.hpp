@@ -1908,7 +1908,10 @@ struct ColDerivArgs {
 };
 
 // BONLY (what oa_lens_maps runs: the x-derivatives ride on the row pass): the factor is i^b ly^b -- one LDS read and two multiplies per
-// point, the power of i an exact swap / negation (same values as the general form, whose products with cr, ci in {0, +-1} are exact)
+// point, the power of i an exact swap / sign (same values as the general form, whose products with cr, ci in {0, +-1} are exact).
+// BRANCH-FREE: the column index is clamped and the value zeroed by a select, the power of i is a select + signed factor -- with
+// the load inside an `if (c < ncols)` block next to its arithmetic the compiler waited for every load before issuing the next
+// (16 round trips per thread: 86 us per 4096^2 float64 plane against 59 us for the plain pass 1)
 template <typename T, bool BONLY = false>
 struct ColDerivLoad {
     static constexpr bool reads_lds = false;    // (the factor tables sit behind the tile, filled and synced before the pipeline: no hazard with its writes)
@@ -1920,17 +1923,17 @@ struct ColDerivLoad {
     T cr, ci;                   // i^(a + b)
     int q;                      // (a + b) & 3
     template <typename U> OA_HD cx<U> get(int n, int c) const {
-        cx<U> x = mk<U>((U)0, (U)0);
-        if (c < ncols) {
-            const cx<U> v = base[(unsigned)n * nstride + (unsigned)c];
-            if constexpr (BONLY) {
-                const U f = fy[n];
-                const cx<U> r = rot_i(v, q);
-                x = mk<U>(r.x * f, r.y * f);
-            } else {
-                const U f = fx[c] * fy[n];
-                x = mk<U>((v.x * cr - v.y * ci) * f, (v.x * ci + v.y * cr) * f);
-            }
+        const int cc = c < ncols ? c : ncols - 1;
+        const cx<U> v = base[(unsigned)n * nstride + (unsigned)cc];
+        cx<U> x;
+        if constexpr (BONLY) {
+            const U f = c < ncols ? fy[n] : (U)0;
+            const bool odd = (q & 1) != 0;
+            const U sr = (q == 1 || q == 2) ? -f : f, si = (q >= 2) ? -f : f;     // i^q (x + i y): (x, y), (-y, x), (-x, -y), (y, -x)
+            x = mk<U>((odd ? v.y : v.x) * sr, (odd ? v.x : v.y) * si);
+        } else {
+            const U f = c < ncols ? fx[cc] * fy[n] : (U)0;
+            x = mk<U>((v.x * cr - v.y * ci) * f, (v.x * ci + v.y * cr) * f);
         }
         return swp(x);          // inverse transform = forward transform of the swapped data
     }
