@@ -30,6 +30,9 @@
 namespace oa {
 
 constexpr int EPT = 16;        // complex points per thread per stage
+#ifndef OA_CHAIN_ACC_REGS
+#define OA_CHAIN_ACC_REGS(T) (sizeof(T) == 8)      // estimator chains: running products in registers (float64) or in LDS (float32)
+#endif
 #ifndef OA_COL_LOGC
 #define OA_COL_LOGC 5
 #endif
@@ -1086,9 +1089,14 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     if constexpr (CHAIN) {
         static_assert(LAY == 0, "chains read natural-order leg planes");
         const int first = a.chain[2 * m], count = a.chain[2 * m + 1];        // uniform: scalar loads
-        // the running products of both legs live in LDS behind the twiddle table ([leg][t][thread]: conflict-free), not in 64
-        // more registers (the 256-register build spilled 100 of them: no faster than piece-by-piece launches)
+        // the running products of both legs: float64 keeps them in REGISTERS -- at one wave per SIMD (launch bound) the unified file
+        // has 512 per lane, and the workgroup then needs the transform tile only (35 KB: two workgroups per CU, register-limited) --
+        // behind the twiddle table in LDS ([leg][t][thread]: conflict-free) they made it 100 KB: ONE 128-thread workgroup per CU, half
+        // the SIMDs idle (541 us of the 911 us of an 8192^2 MV reconstruction).  float32 keeps the LDS form (50 KB, three per CU; with
+        // the 256 registers of its two-waves bound the register form spilled 100 of them)
+        constexpr bool ACC_REGS = OA_CHAIN_ACC_REGS(T);
         cx<T>* accl = twl + tw_lds_size(logM) + tid;
+        cx<T> acc[ACC_REGS ? 2 : 1][ACC_REGS ? EPT : 1];
 #pragma unroll 1
         for (int i = 0; i < count; ++i) {
             const RowQeMap<T> e = a.tab[first + i];
@@ -1096,25 +1104,42 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
 #pragma unroll
             for (int t = 0; t < EPT; ++t) hreg[t] = hreg[t] * e.scale;
             ctx.sync();
+#pragma unroll
             for (int leg = 0; leg < 2; ++leg) {
                 const cx<T>* src = leg ? e.gy : e.gx;
                 pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
-                cx<T>* al = accl + leg * EPT * NT;
-                if (i == 0) {
+                if constexpr (ACC_REGS) {
+                    if (i == 0) {
 #pragma unroll
-                    for (int t = 0; t < EPT; ++t) al[t * NT] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                        for (int t = 0; t < EPT; ++t) acc[leg][t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < EPT; ++t) acc[leg][t] = acc[leg][t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                    }
                 } else {
+                    cx<T>* al = accl + leg * EPT * NT;
+                    if (i == 0) {
 #pragma unroll
-                    for (int t = 0; t < EPT; ++t) al[t * NT] = al[t * NT] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                        for (int t = 0; t < EPT; ++t) al[t * NT] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < EPT; ++t) al[t * NT] = al[t * NT] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+                    }
                 }
                 ctx.sync();
             }
         }
         const RowQeMap<T> e0 = a.tab[first];
+#pragma unroll
         for (int leg = 0; leg < 2; ++leg) {
             cx<T>* dst = leg ? e0.py : e0.px;
+            if constexpr (ACC_REGS) {
 #pragma unroll
-            for (int t = 0; t < EPT; ++t) v[t] = accl[(leg * EPT + t) * NT];
+                for (int t = 0; t < EPT; ++t) v[t] = acc[leg][t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < EPT; ++t) v[t] = accl[(leg * EPT + t) * NT];
+            }
 #pragma unroll
             for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
             stage_out<T, R0, true, false>(work, v, tid, NT, logM, 0, RS, 0, NoStore{});

@@ -17,6 +17,9 @@ from orphics_amd import cosmology, lensing, maps, mc
 from orphics_amd.geometry import FlatGeometry
 
 
+PREC = "f64" if "--f64" in sys.argv else "f32"      # --f64: the reference's arithmetic type
+
+
 def setup(N, res, pol, prune=True):
     shape = (N, N)
     g = FlatGeometry.from_res(shape, res)
@@ -27,7 +30,7 @@ def setup(N, res, pol, prune=True):
     tmask = ((ml > 300) & (ml < 2000)).astype(np.int64)
     kmask = ((ml > 20) & (ml < 3500)).astype(np.int64)
     q = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, kmask_P=tmask, noise2d_P=2 * noise, kmask_K=kmask,
-                     pol=pol, unlensed_equals_lensed=True, prune=prune)
+                     pol=pol, unlensed_equals_lensed=True, prune=prune, dtype=PREC)
     return shape, g, th, ml, beam, noise, q
 
 

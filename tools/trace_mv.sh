@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 export TMPDIR=/tmp
 O=gpurun_out/$TAG
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_mv -- python3 tools/config_bench.py mv --no-dense > $O/mv_run.txt 2> $O/mv.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_mv -- python3 tools/config_bench.py mv --no-dense ${MV_FLAGS:-} > $O/mv_run.txt 2> $O/mv.err
 python3 - $O <<'PY'
 import csv, glob, sys
 O = sys.argv[1]
