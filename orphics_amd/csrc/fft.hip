@@ -117,12 +117,10 @@ __global__ __launch_bounds__(pair_nt<SEQ>(), (pair_waves_per_eu<T, SEQ, NZ, LR>(
     GpuCtx c{oa_dyn_smem};
     row_qe_pair_body<T, SEQ, NZ, LR>(c, a);
 }
-#ifndef OA_CHAIN_F64_WAVES
-#define OA_CHAIN_F64_WAVES 1
-#endif
-// estimator chains (oa_qe_mv): two more 16-point register sets (the running products of both legs)
+// estimator chains (oa_qe_mv): two more 16-point register sets (the running products of both legs) -- float64 at one wave per
+// SIMD: 256 VGPRs + ~150 AGPRs, nothing spilled; float32 at two: 238-256 VGPRs (NZ = 4 spills 19)
 template <typename T, class SEQ, int NZ>
-__global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? OA_CHAIN_F64_WAVES : 2)) void row_qe_chain_kernel(RowQeArgs<T> a) {
+__global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? 1 : 2)) void row_qe_chain_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_qe_pair_body<T, SEQ, NZ, 0, true>(c, a);
 }

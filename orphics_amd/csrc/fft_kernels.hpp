@@ -30,9 +30,6 @@
 namespace oa {
 
 constexpr int EPT = 16;        // complex points per thread per stage
-#ifndef OA_CHAIN_ACC_REGS
-#define OA_CHAIN_ACC_REGS(T) (sizeof(T) == 8)      // estimator chains: running products in registers (float64) or in LDS (float32)
-#endif
 #ifndef OA_COL_LOGC
 #define OA_COL_LOGC 5
 #endif
@@ -1089,14 +1086,12 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
     if constexpr (CHAIN) {
         static_assert(LAY == 0, "chains read natural-order leg planes");
         const int first = a.chain[2 * m], count = a.chain[2 * m + 1];        // uniform: scalar loads
-        // the running products of both legs: float64 keeps them in REGISTERS -- at one wave per SIMD (launch bound) the unified file
-        // has 512 per lane, and the workgroup then needs the transform tile only (35 KB: two workgroups per CU, register-limited) --
-        // behind the twiddle table in LDS ([leg][t][thread]: conflict-free) they made it 100 KB: ONE 128-thread workgroup per CU, half
-        // the SIMDs idle (541 us of the 911 us of an 8192^2 MV reconstruction).  float32 keeps the LDS form (50 KB, three per CU; with
-        // the 256 registers of its two-waves bound the register form spilled 100 of them)
-        constexpr bool ACC_REGS = OA_CHAIN_ACC_REGS(T);
-        cx<T>* accl = twl + tw_lds_size(logM) + tid;
-        cx<T> acc[ACC_REGS ? 2 : 1][ACC_REGS ? EPT : 1];
+        // the running products of both legs live in REGISTERS: the workgroup then needs the transform tile only (35 KB at float64: two
+        // workgroups per CU at the one-wave launch bound, whose unified file has 512 registers per lane; 18 KB and four per CU at
+        // float32).  Behind the twiddle table in LDS they made a float64 workgroup 100 KB -- ONE 128-thread workgroup per CU, half the
+        // SIMDs idle: 541 of the 911 us of an 8192^2 MV reconstruction -- and a float32 one 50 KB (three per CU): MV 1207 -> 1565
+        // reconstructions/s at float64, 2790 -> 3065 at float32
+        cx<T> acc[2][EPT];
 #pragma unroll 1
         for (int i = 0; i < count; ++i) {
             const RowQeMap<T> e = a.tab[first + i];
@@ -1108,23 +1103,12 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
             for (int leg = 0; leg < 2; ++leg) {
                 const cx<T>* src = leg ? e.gy : e.gx;
                 pair_inverse_to_regs<T, SEQ, NZ, 0>(ctx, work, v, tid, NT, RS, twl, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
-                if constexpr (ACC_REGS) {
-                    if (i == 0) {
+                if (i == 0) {
 #pragma unroll
-                        for (int t = 0; t < EPT; ++t) acc[leg][t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < EPT; ++t) acc[leg][t] = acc[leg][t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
-                    }
+                    for (int t = 0; t < EPT; ++t) acc[leg][t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
                 } else {
-                    cx<T>* al = accl + leg * EPT * NT;
-                    if (i == 0) {
 #pragma unroll
-                        for (int t = 0; t < EPT; ++t) al[t * NT] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < EPT; ++t) al[t * NT] = al[t * NT] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
-                    }
+                    for (int t = 0; t < EPT; ++t) acc[leg][t] = acc[leg][t] + mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
                 }
                 ctx.sync();
             }
@@ -1133,13 +1117,8 @@ OA_HD void row_qe_pair_body(Ctx& ctx, const RowQeArgs<T>& a) {
 #pragma unroll
         for (int leg = 0; leg < 2; ++leg) {
             cx<T>* dst = leg ? e0.py : e0.px;
-            if constexpr (ACC_REGS) {
 #pragma unroll
-                for (int t = 0; t < EPT; ++t) v[t] = acc[leg][t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < EPT; ++t) v[t] = accl[(leg * EPT + t) * NT];
-            }
+            for (int t = 0; t < EPT; ++t) v[t] = acc[leg][t];
 #pragma unroll
             for (int u = 0; u < EPT / R0; ++u) Dft<T, R0>::run(v + u * R0);
             stage_out<T, R0, true, false>(work, v, tid, NT, logM, 0, RS, 0, NoStore{});

@@ -179,8 +179,7 @@ struct Fft2dPlan {
             if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
             a.tab = tab;
             a.lr = lr; a.nrows = ny; a.chain = chain;
-            const size_t accs = (chain && !OA_CHAIN_ACC_REGS(T)) ? (size_t)2 * EPT * a.NT : 0;     // estimator chains: running products of both legs in LDS (float32)
-            q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM) + accs) * sizeof(cx<T>), a);
+            q.row_qe_pair(ny / 2 * (nmaps > 1 ? nmaps : 1), a.NT, ((size_t)a.rowStride + tw_lds_size(logM)) * sizeof(cx<T>), a);
             return;
         }
         if (lr) { q.fail_rlayout(); return; }                 // (callers check rows_qe_is_pair first)
