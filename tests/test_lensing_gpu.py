@@ -1144,3 +1144,24 @@ def test_lensed_sims_loop_fast_path_equals_the_notebook_sequence():
     # kappa_hat x kappa_in tracks the input power where the TT estimator has signal (three realisations: loose bound)
     r = np.asarray(fast.acc.mean("cross_TT")) / np.asarray(fast.acc.mean("input"))
     assert np.all(np.abs(r[1:5] - 1.0) < 0.3), r
+
+
+def test_get_sim_teb_temperature_only():
+    """the device-pipeline simulator without polarisation (one component, no rotation): T's observed transform and kappa's equal the
+    transforms of get_sim's maps on the same seeds"""
+    from orphics_amd import cosmology, lensing
+    from orphics_amd.geometry import FlatGeometry
+    N = 256
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, 1.5)
+    sims = lensing.FlatLensingSims(shape, g, cosmology.default_theory(), 1.5, 1.0, pol=False, dtype="f64")
+    e = sims.lenser.eng
+    teb, kin = sims.get_sim_teb(seed_cmb=(4, 1, 0), seed_kappa=(4, 2, 0), seed_noise=(4, 3, 0), lens_order=5)
+    assert tuple(teb.shape) == (1, N, e.kp)
+    parts = sims.get_sim(seed_cmb=(4, 1, 0), seed_kappa=(4, 2, 0), seed_noise=(4, 3, 0), lens_order=5, return_intermediate=True)
+    ref = e.rfft(parts[5].contiguous())
+    kref = e.rfft(parts[1].contiguous())
+    rows = torch.arange(N, device=e.device) != N // 2
+    w = N // 2
+    assert float((kin - kref)[rows][:, :w].abs().max() / kref.abs().max()) < 1e-10
+    assert float((teb[0] - ref)[rows][:, :w].abs().max() / ref.abs().max()) < 1e-10
