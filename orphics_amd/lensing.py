@@ -1014,6 +1014,7 @@ class FlatLenser(object):
             raise ValueError("lens_many: expected (n, %d, %d) maps" % (e.ny, e.nx))
         if out is None:
             out = torch.empty_like(src)
+        e._ordered()                                   # the work planes belong to the plan: calls from another stream queue behind
         check(e.lib.oa_lens_maps(e.plan, int(src.shape[0]), _ptr(src), e.ny * e.nx, int(taylor_order), _ptr(sx), _ptr(sy), _ptr(dx), _ptr(dy),
                                  _ptr(out), e.ny * e.nx, _stream()))
         return out
@@ -1033,6 +1034,7 @@ class FlatLenser(object):
         if out is None:
             out = torch.empty((khc.shape[0], e.ny, e.nx), dtype=e.rdt, device=e.device)
         sc = 1.0 / float(np.sqrt(e.npix)) if scale is None else float(scale)
+        e._ordered()
         check(e.lib.oa_lens_maps_hc(e.plan, int(khc.shape[0]), _ptr(khc), e.ny * e.kp, sc, int(taylor_order), _ptr(sx), _ptr(sy), _ptr(dx),
                                     _ptr(dy), _ptr(out), e.ny * e.nx, _stream()))
         return out
