@@ -28,11 +28,18 @@ OA_D U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
 OA_D void box_muller(uint32_t a, uint32_t b, float& n0, float& n1) {
     const float u1 = ((float)a + 0.5f) * 2.3283064365386963e-10f;  // (0,1]
     const float u2 = ((float)b + 0.5f) * 2.3283064365386963e-10f;
+#ifdef OA_FAST_BOXMULLER     // experiment: hardware log2 / sqrt / sin / cos (v_log_f32, v_sqrt_f32, v_sin_f32, v_cos_f32 take revolutions)
+    const float l2 = __builtin_amdgcn_logf(u1);                    // log2(u1) <= 0
+    const float r = __builtin_amdgcn_sqrtf(fmaxf(-1.3862943611198906f * l2, 0.0f));
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
+#else
     const float r = sqrtf(-2.0f * logf(u1));
     float s, c;
     sincospif(2.0f * u2, &s, &c);
     n0 = r * c;
     n1 = r * s;
+#endif
 }
 
 // 4 normals for counter index `idx` of stream (seed, sid)
