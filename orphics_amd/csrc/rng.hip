@@ -10,8 +10,11 @@ OA_D U4 philox4x32_10(U4 ctr, uint32_t k0, uint32_t k1) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-        const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low one: the quarter-rate integer
+        // multiplies are what the draw kernels spend their time on
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)ctr.x, p1 = (uint64_t)M1 * (uint64_t)ctr.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         U4 n;
         n.x = hi1 ^ ctr.y ^ k0;
         n.y = lo1;
@@ -69,6 +72,8 @@ __global__ __launch_bounds__(256) void grf_hc_kernel(uint64_t seed, uint64_t sid
     if (rband > 0 && y >= rband) y += ny - (2 * rband - 1);
     if (pr >= (wpairs > 0 ? wpairs : npair)) return;
     const T rs2 = (T)0.70710678118654752440;
+    float n[4];
+    int cur_ys = -1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int x = 2 * pr + j;
@@ -78,8 +83,9 @@ __global__ __launch_bounds__(256) void grf_hc_kernel(uint64_t seed, uint64_t sid
         int ys = y;
         bool cj = false;
         if (edgecol && y > ny / 2) { ys = ny - y; cj = true; }
-        float n[4];
-        normals4(seed, sid, (uint64_t)ys * (uint64_t)npair + (uint64_t)pr, n);
+        // columns 2p, 2p + 1 share a counter (and its four normals) unless one of them is a self-conjugate column read at the
+        // mirrored row: ONE Philox evaluation per thread, not one per column
+        if (ys != cur_ys) { normals4(seed, sid, (uint64_t)ys * (uint64_t)npair + (uint64_t)pr, n); cur_ys = ys; }
         T re = (T)n[2 * j], im = (T)n[2 * j + 1];
         if (edgecol && (ys == 0 || ys == ny / 2)) { im = (T)0; }  // real mode, variance 1
         else { re *= rs2; im *= rs2; }
