@@ -1165,3 +1165,24 @@ def test_get_sim_teb_temperature_only():
     w = N // 2
     assert float((kin - kref)[rows][:, :w].abs().max() / kref.abs().max()) < 1e-10
     assert float((teb[0] - ref)[rows][:, :w].abs().max() / ref.abs().max()) < 1e-10
+
+
+def test_draw_hc_two_correlated_components():
+    """oa_grf_mix with two components (a 2 x 2 covariance with an off-diagonal block): bit-identical to the plane-by-plane draw"""
+    from orphics_amd import maps
+    from orphics_amd.geometry import FlatGeometry
+    N = 128
+    shape = (2, N, N)
+    g = FlatGeometry.from_res(shape, 2.0)
+    ml = g.modlmap()
+    p11 = 1.0 / (1.0 + (ml / 500.0) ** 2)
+    p22 = 0.5 / (1.0 + (ml / 800.0) ** 2)
+    p12 = 0.4 * np.sqrt(p11 * p22)
+    cov = np.array([[p11, p12], [p12, p22]])
+    for prec in ("f64", "f32"):
+        mg = maps.MapGen(shape, g, cov, dtype=prec)
+        ref = mg.get_map(seed=(2, 5), harm=True).t
+        got = mg.draw_hc((2, 5))
+        assert torch.equal(got, ref) and float(ref[1].abs().max()) > 0
+        with pytest.raises(ValueError):
+            mg.draw_hc((2, 5), rot="inverse")
