@@ -86,6 +86,7 @@ struct oa_plan {
     void* cz_bhat; void* cz_a; void* cz_f;   // cx<T>[My*Mx]: chirp-kernel transform, two work planes
     void* cz_full;                           // cx<T>[ny*nx]
     void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
+    void* rq8c[4];                           // per-thread constants of the fused row stage's grids of 1024, 1536, 2048, 4096 points (fft_rowqe8.hpp)
     void* tw_y_small[16];                    // COLUMN GRID: cx<T>[my] = W_my^k for my = 2^i (made on first use, kept: estimators
                                              // with different row bands may alternate on one plan)
 };

@@ -94,6 +94,18 @@ __device__ __forceinline__ cx<double> operator*(cx<double> a, cx<double> b) {
 }
 #endif
 
+// load through a pointer the compiler cannot prove global (read from a device table, selected at run time): a generic pointer becomes
+// a flat_load, which also counts in lgkmcnt -- every LDS-only barrier (GpuCtx::sync) and wave-level wait would then wait for it.
+// All such pointers in these kernels are device-memory planes.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class U> __device__ __forceinline__ U ldg(const U* p) {
+    typedef const __attribute__((address_space(1))) U* gp;
+    return *(gp)(unsigned long long)p;
+}
+#else
+template <class U> inline U ldg(const U* p) { return *p; }
+#endif
+
 OA_HD int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

@@ -125,6 +125,19 @@ __global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? 1 : 2)) void row_
     row_qe_pair_body<T, SEQ, NZ, 0, true>(c, a);
 }
 
+// eight points per thread, M / 512 waves per row pair (fft_rowqe8.hpp): four waves per SIMD
+#ifndef OA_RQ8_WAVES_F64
+#define OA_RQ8_WAVES_F64 4
+#endif
+#ifndef OA_RQ8_WAVES_F32
+#define OA_RQ8_WAVES_F32 4
+#endif
+template <typename T, int A, int NZ, int LAY, bool CHAIN>
+__global__ __launch_bounds__(64 * A, (sizeof(T) == 8 ? OA_RQ8_WAVES_F64 : OA_RQ8_WAVES_F32)) void row_qe8_kernel(RowQeArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_qe8_body<T, A, NZ, LAY, CHAIN>(c, a);
+}
+
 template <typename T, class SEQ>
 __global__ __launch_bounds__(col_maxnt<SEQ>(), fused_col_waves_per_eu<T>()) void col_div_kernel(ColDivArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -351,6 +364,16 @@ struct HipLauncher {
         if (!ok && !rc) rc = fail("fft: unsupported row length");
     }
     template <typename T>
+    void row_qe_pair8(int grid, int M, const RowQeArgs<T>& a) {
+        const bool ok = dispatch_rq8(M, a.win, a.lr, a.chain != nullptr, [&](auto ac, auto nzc, auto lay, auto ch) {
+            constexpr int A = decltype(ac)::value;
+            if (ch.value && !a.tab) { if (!rc) rc = fail("fft: estimator chains need a table"); return; }
+            if (!a.rq8c) { if (!rc) rc = fail("fft: the 8-point row stage needs the constants of its grid"); return; }
+            go(row_qe8_kernel<T, A, decltype(nzc)::value, decltype(lay)::value, decltype(ch)::value>, dim3(grid), 64 * A, rq8_lds_bytes<T, A>(), a);
+        });
+        if (!ok && !rc) rc = fail("fft: unsupported row grid / layout for the 8-point row stage");
+    }
+    template <typename T>
     void row_qe_pair(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         const bool ok = dispatch_seq(a.logL, [&](auto seq) {
             using S = decltype(seq);
@@ -474,7 +497,7 @@ template <typename T>
 static Fft2dPlan<T> view(const oa_plan* p) {
     Fft2dPlan<T> f;
     f.ny = p->ny; f.nx = p->nx; f.logNy = p->logNy; f.logNx = p->logNx; f.kp = p->kp;
-    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y;
+    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y; for (int i = 0; i < 4; ++i) f.rq8c[i] = (const cx<T>*)p->rq8c[i];
     return f;
 }
 // COLUMN GRID view: the same map transformed on my < ny rows (plan_ensure_col_grid made the W_my table)
@@ -558,7 +581,8 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
         if (2L * wi + wo > mrow) mrow = 0;                                  // no band limit to exploit: full-length path
     } else if (mrow > 0) {
         if (mrow > p->nx) mrow = p->nx;
-        if (!is_pow2(mrow) || mrow < 64) return fail("oa_qe_rows: mrow must be a power of two >= 64");
+        if (!(is_pow2(mrow) && mrow >= 64) && !(rq8_is_m3(mrow) && f.rows_qe_is_pair(wi, wo, mrow)))
+            return fail("oa_qe_rows: mrow must be a power of two >= 64 (or 1536 for band limits that fit it)");
         if (2L * wi + wo > mrow) return fail("oa_qe_rows: mrow < 2*win + wout would alias the leg products into the kept columns");
     }
     if (lr && !f.rows_qe_is_pair(wi, wo, mrow)) return fail("oa_qe_rows: leg planes in the R-layout need the two-rows-per-transform row stage");

@@ -6,6 +6,7 @@
 #include <vector>
 #include "fft_kernels.hpp"
 #include "fft_fband.hpp"
+#include "fft_rowqe8.hpp"
 
 namespace oa {
 
@@ -32,6 +33,9 @@ struct Fft2dPlan {
     long kp = 0;                 // half-complex pitch (complex elements)
     const cx<T>* tw_x = nullptr; // W_nx^k, k < nx
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
+    const cx<T>* rq8c[4] = {nullptr, nullptr, nullptr, nullptr};   // constants of the 8-point row stage's grids 1024, 1536, 2048, 4096 (nullptr: not offered)
+    static int rq8_slot(int m) { return m == 1024 ? 0 : m == 1536 ? 1 : m == 2048 ? 2 : m == 4096 ? 3 : -1; }
+    bool rq8_ready(int m) const { const int i = rq8_slot(m); return rowqe8_on() && i >= 0 && rq8c[i] != nullptr; }
     // COLUMN GRID view (fft.hip coarse_view): this plan describes ny = My rows of a map with ny_full rows; filters, ly
     // axis and caller-owned planes are addressed at the full-resolution rows (ColLegsArgs::yshift).  0 = own grid.
     int ny_full = 0;
@@ -138,14 +142,25 @@ struct Fft2dPlan {
     // scale here.  The real-space planes exist only in LDS, so the sampling grid is not observable.
     // factor rows_qe puts on the caller's scale when the products are formed on an mrow-point grid
     double row_grid_scale(int mrow) const { return (mrow > 0 && mrow < nx) ? (double)nx / (double)mrow : 1.0; }
-    // does rows_qe run the two-rows-per-transform kernel (the only row stage that takes two maps per launch)?
+    // does rows_qe run a two-rows-per-transform kernel (the only row stage that takes two maps per launch)?
+    // mrow: a power of two in [1024, 8192], or 1536 (= 3 x 512, eight-points-per-thread body only)
     bool rows_qe_is_pair(int win, int wout, int mrow) const {
-        const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
-        return mrow > 0 && logM >= 10 && logM <= 13 && 2L * win + wout <= (1L << logM) && ny % 2 == 0;
+        if (mrow <= 0 || ny % 2) return false;
+        const int M = mrow < nx ? mrow : nx;
+        if (rq8_is_m3(M)) return rq8_ready(M) && rq8_covers(M, win, wout);
+        return is_pow2(M) && M >= 1024 && M <= 8192 && 2L * win + wout <= M;
     }
+    // which body runs the two-rows-per-transform row stage on 1024- to 4096-point grids: 8 points per thread (default) or 16
+    // (experiment builds: OA_NO_ROWQE8=1; the emulator tests run both)
+    static bool& rowqe8_on() {
+        static bool on = exp_env("OA_NO_ROWQE8") == nullptr;
+        return on;
+    }
+    // smallest row grid the two-rows-per-transform kernels are built for that holds 2 win + wout points without aliasing
     static int row_grid_min(int nx, int win, int wout) {
         long need = 2L * win + wout;
-        int m = 1024;                                   // shortest grid the two-rows-per-transform kernel is built for
+        if (rowqe8_on() && need > 1024 && need <= 1536 && win <= 512 && nx >= 2048) return 1536;
+        int m = 1024;
         while (m < need && m < nx) m <<= 1;
         return m >= nx ? nx : m;
     }
@@ -166,15 +181,27 @@ struct Fft2dPlan {
         RowQeArgs<T> a{};
         // mrow > 0 ("grid mode", mrow <= nx): band-limited legs declared by the caller; mrow == 0: legacy full-length
         // transforms with no assumption beyond win / wout
-        const int logM = (mrow > 0 && mrow < nx) ? ilog2(mrow) : logNx;
-        if (logM < logNx) scale = scale * (T)((double)nx / (double)(1 << logM));
+        const int Mg = (mrow > 0 && mrow < nx) ? mrow : nx;          // the row grid
+        const int logM = ilog2(Mg);
+        if (Mg < nx) scale = scale * (T)((double)nx / (double)Mg);
         a.tw = tw_x; a.logTw = logNx; a.scale = scale;
         a.pitch = pin > 0 ? pin : kp; a.opitch = pout > 0 ? pout : kp;
         a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
         a.win = win; a.wout = wout;
-        if (mrow > 0 && logM >= 10 && logM <= 13 && 2L * win + wout <= (1L << logM) && ny % 2 == 0) {
-            // alias-free row grid: two rows per complex transform of length M (row_qe_pair_body)
-            const int M = 1 << logM;
+        if (mrow > 0 && rows_qe_is_pair(win, wout, mrow)) {
+            // alias-free row grid: two rows per complex transform of length M
+            const int M = Mg;
+            if (rq8_ready(M) && rq8_covers(M, win, wout) && (lr == 0 || lr == 2 || lr == 3)) {
+                // eight points per thread, M / 512 waves per row pair (row_qe8_body, fft_rowqe8.hpp)
+                a.logL = logM; a.logC = 0; a.NT = M / 8; a.rowStride = M;
+                a.rq8c = rq8c[rq8_slot(M)];
+                if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
+                a.tab = tab;
+                a.lr = lr; a.nrows = ny; a.chain = chain;
+                q.row_qe_pair8(ny / 2 * (nmaps > 1 ? nmaps : 1), M, a);
+                return;
+            }
+            // 16 points per thread, M / 16 threads per row pair (row_qe_pair_body): 8192-point grids
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
             if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
             a.tab = tab;

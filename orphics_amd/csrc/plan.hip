@@ -30,6 +30,13 @@ static int upload_tables(oa_plan* p) {
     OA_HIP(hipMalloc(&p->tw_y, ty.size() * sizeof(cx<T>)));
     OA_HIP(hipMemcpy(p->tw_x, tx.data(), tx.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     OA_HIP(hipMemcpy(p->tw_y, ty.data(), ty.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    const int waves[4] = {2, 3, 4, 8};         // row grids of the fused row stage (512 points per wave) shorter than or equal to the rows
+    for (int i = 0; i < 4; ++i) {
+        if (512 * waves[i] > p->nx) continue;
+        auto t = rq8_make_consts<T>(waves[i]);
+        OA_HIP(hipMalloc(&p->rq8c[i], t.size() * sizeof(cx<T>)));
+        OA_HIP(hipMemcpy(p->rq8c[i], t.data(), t.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 }  // namespace oa
@@ -85,6 +92,7 @@ int oa_plan_destroy(oa_plan* p) {
     czt_release(p);
     if (p->tw_x) (void)hipFree(p->tw_x);
     if (p->tw_y) (void)hipFree(p->tw_y);
+    for (void* t : p->rq8c) if (t) (void)hipFree(t);
     for (void* t : p->tw_y_small) if (t) (void)hipFree(t);
     if (p->scratch) (void)hipFree(p->scratch);
     if (p->ly) (void)hipFree(p->ly);

@@ -84,6 +84,13 @@ struct EmuLauncher {
                 });
         });
     }
+    template <typename T> void row_qe_pair8(int grid, int M, const RowQeArgs<T>& a) {
+        dispatch_rq8(M, a.win, a.lr, a.chain != nullptr, [&](auto ac, auto nzc, auto lay, auto ch) {
+            constexpr int A = decltype(ac)::value;
+            run(grid, 1, 64 * A, rq8_lds_bytes<T, A>(),
+                [&](EmuCtx& c) { row_qe8_body<T, A, decltype(nzc)::value, decltype(lay)::value, decltype(ch)::value>(c, a); });
+        });
+    }
     void fail_rlayout() {}
     template <typename T> void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
         if (a.lr != 2) return;
@@ -158,13 +165,15 @@ struct EmuLauncher {
 
 template <typename T>
 struct Holder {
-    std::vector<cx<T>> twx, twy;
+    std::vector<cx<T>> twx, twy, rq8t[4];
     Fft2dPlan<T> p;
     Holder(int ny, int nx) {
         twx = make_twiddles<T>(nx);
         twy = make_twiddles<T>(ny);
         p.ny = ny; p.nx = nx; p.logNy = ilog2(ny); p.logNx = ilog2(nx);
         p.kp = kpitch_for(nx); p.tw_x = twx.data(); p.tw_y = twy.data();
+        const int waves[4] = {2, 3, 4, 8};
+        for (int i = 0; i < 4; ++i) if (512 * waves[i] <= nx) { rq8t[i] = rq8_make_consts<T>(waves[i]); p.rq8c[i] = rq8t[i].data(); }
     }
 };
 
@@ -547,6 +556,8 @@ int emu_cols_div_w_f64(int ny, int nx, const void* pa, const void* pb, const dou
     return do_cols_div<double>(ny, nx, (const cx<double>*)pa, (const cx<double>*)pb, Fn, lxd, lyd, (cx<double>*)out, width, rband);
 }
 void emu_set_stockham_qe(int on) { stockham_qe = on != 0; }
+// which two-rows-per-transform row stage the plan launches: 8 points per thread (fft_rowqe8.hpp, default) or 16
+void emu_set_rowqe8(int on) { Fft2dPlan<float>::rowqe8_on() = on != 0; Fft2dPlan<double>::rowqe8_on() = on != 0; }
 long emu_kpitch(int nx) { return kpitch_for(nx); }
 int emu_r2c_f32(int ny, int nx, const float* in, void* out, double s) { return do_r2c<float>(ny, nx, in, (cx<float>*)out, s); }
 int emu_r2c_f64(int ny, int nx, const double* in, void* out, double s) { return do_r2c<double>(ny, nx, in, (cx<double>*)out, s); }

@@ -18,7 +18,7 @@ def emu():
     so = os.path.join(EMUL, "libemul_fft.so")
     src = os.path.join(EMUL, "emul_fft.cpp")
     csrc = os.path.join(HERE, "..", "orphics_amd", "csrc")
-    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "cx.hpp")]
+    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "fft_rowqe8.hpp", "cx.hpp")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -136,14 +136,27 @@ def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
             assert np.all(got[:, wo:W] == 5.0)                    # untouched
 
 
-@pytest.mark.parametrize("ny,nx,win,wout,mrow,expect", [(32, 8192, 380, 664, -1, 2048), (32, 8192, 1139, 664, -1, 4096),
+@pytest.fixture(params=[8, 16], ids=["8pt", "16pt"])
+def body(emu, request):
+    """which two-rows-per-transform row stage Fft2dPlan::rows_qe launches: 8 points per thread (fft_rowqe8.hpp, the default; also the
+    only one with the 3 x 512-point grid) or 16 (row_qe_pair_body)"""
+    emu.emu_set_rowqe8(1 if request.param == 8 else 0)
+    yield request.param
+    emu.emu_set_rowqe8(1)
+
+
+@pytest.mark.parametrize("ny,nx,win,wout,mrow,expect", [(32, 8192, 380, 664, -1, (1536, 2048)), (32, 8192, 1139, 664, -1, 4096),
                                                          (32, 2048, 100, 150, -1, 1024), (32, 1024, 60, 100, 512, 512),
                                                          (32, 512, 100, 150, -1, 512), (32, 4096, 190, 332, -1, 1024),
-                                                         (16, 16384, 380, 664, -1, 2048)])
-def test_fused_row_stage_on_alias_free_row_grid(emu, ny, nx, win, wout, mrow, expect):
+                                                         (16, 16384, 380, 664, -1, (1536, 2048)), (8, 8192, 380, 664, 2048, 2048),
+                                                         (8, 4096, 512, 512, -1, (1536, 2048)), (8, 8192, 513, 400, -1, 2048)])
+def test_fused_row_stage_on_alias_free_row_grid(emu, body, ny, nx, win, wout, mrow, expect):
     """ROW GRID (include/orphics_amd.h): band-limited legs (columns >= win vanish) -> the row stage on a grid of
     mrow >= 2 win + wout points returns the same product columns k < wout as the full-length transform
-    (through the actual kernel body, here at a shorter compile-time row length)."""
+    (through the actual kernel body, here at a shorter compile-time row length).  Both bodies; the 8-point one also on
+    the 1536-point grid (radix-3 cross-wave stage)."""
+    if isinstance(expect, tuple):
+        expect = expect[0] if body == 8 else expect[1]
     emu.emu_set_stockham_qe(1)
     rng = np.random.default_rng(7 + nx + win)
     W = nx // 2 + 1
@@ -170,11 +183,14 @@ def test_fused_row_stage_on_alias_free_row_grid(emu, ny, nx, win, wout, mrow, ex
         assert np.all(got[:, wout:W] == 5.0)
 
 
-def test_row_stage_of_several_maps_per_launch(emu):
+@pytest.mark.parametrize("mrow", [1024, 1536])
+def test_row_stage_of_several_maps_per_launch(emu, body, mrow):
     """row_qe_pair_body with workgroup ranges = maps: evenly spaced planes (oa_mc_run, oa_qe_tt_moments2; the h planes may
     have their own spacing) and a table of per-map planes and scales (oa_qe_mv) give, map by map, bit for bit what one
     launch per map gives -- also when accumulating."""
-    ny, nx, win, wout, mrow = 8, 4096, 100, 150, 1024
+    if body == 16 and mrow == 1536:
+        pytest.skip("the 3 x 512-point grid exists in the 8-point body only")
+    ny, nx, win, wout = 8, 4096, 100, 150
     rng = np.random.default_rng(77)
     kp = emu.emu_kpitch(nx)
     nm = 3
@@ -213,11 +229,14 @@ def test_row_stage_of_several_maps_per_launch(emu):
     assert np.array_equal(tab, one)
 
 
-def test_row_stage_estimator_chains(emu):
+@pytest.mark.parametrize("mrow", [1024, 1536])
+def test_row_stage_estimator_chains(emu, body, mrow):
     """row_qe_pair_body<.., CHAIN>: every estimator's pieces in ONE launch -- per piece three inverse transforms and the real-space
     product, summed over the pieces in registers, one forward pair per estimator -- against piece-by-piece launches that
     accumulate in the product planes (the linear forward transform commutes with the sum)."""
-    ny, nx, win, wout, mrow = 8, 4096, 100, 150, 1024
+    if body == 16 and mrow == 1536:
+        pytest.skip("the 3 x 512-point grid exists in the 8-point body only")
+    ny, nx, win, wout = 8, 4096, 100, 150
     rng = np.random.default_rng(78)
     kp = emu.emu_kpitch(nx)
     counts = [1, 3, 2]
@@ -665,11 +684,14 @@ def test_rsplit_single_pass_column_stage(emu, prec, nmaps, ny, my):
 
 
 @pytest.mark.parametrize("prec,R,M,win,wout", [("f64", 4, 1024, 20, 30), ("f32", 4, 1024, 20, 30), ("f64", 8, 2048, 20, 30), ("f32", 8, 2048, 20, 30),
-                                               ("f64", 8, 2048, 380, 664), ("f64", 4, 2048, 380, 664)])
-def test_row_stage_on_r_layout_planes(emu, prec, R, M, win, wout):
+                                               ("f64", 8, 2048, 380, 664), ("f64", 4, 2048, 380, 664), ("f64", 4, 1536, 380, 664),
+                                               ("f32", 4, 1536, 380, 664), ("f64", 8, 1536, 380, 664), ("f64", 4, 4096, 1139, 664)])
+def test_row_stage_on_r_layout_planes(emu, body, prec, R, M, win, wout):
     """row_qe_pair_body<.., LAY = 2 / 3>: the same products from leg planes in the R-LAYOUT (R = 4, R = 8) as from natural-order planes
     (380 / 664 columns: the headline's band limits -- four live taps per side of the first inverse stage)"""
-    my, nx = 64, 4096
+    if body == 16 and M == 1536:
+        pytest.skip("the 3 x 512-point grid exists in the 8-point body only")
+    my, nx = 64, (8192 if M == 4096 else 4096)
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 2e-5)
     rng = np.random.default_rng(12)
     kp = emu.emu_kpitch(nx)
