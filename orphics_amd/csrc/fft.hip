@@ -132,8 +132,13 @@ __global__ __launch_bounds__(pair_nt<SEQ>(), (sizeof(T) == 8 ? 1 : 2)) void row_
 #ifndef OA_RQ8_WAVES_F32
 #define OA_RQ8_WAVES_F32 4
 #endif
+// estimator chains carry two more register sets (the running products of both legs): three waves per SIMD in float32 (168
+// registers: 12 waves = four 3-wave workgroups per CU), two in float64
+template <typename T, bool CHAIN> constexpr int rq8_waves_per_eu() {
+    return CHAIN ? (sizeof(T) == 8 ? 2 : 3) : (sizeof(T) == 8 ? OA_RQ8_WAVES_F64 : OA_RQ8_WAVES_F32);
+}
 template <typename T, int A, int NZ, int LAY, bool CHAIN>
-__global__ __launch_bounds__(64 * A, (sizeof(T) == 8 ? OA_RQ8_WAVES_F64 : OA_RQ8_WAVES_F32)) void row_qe8_kernel(RowQeArgs<T> a) {
+__global__ __launch_bounds__(64 * A, (rq8_waves_per_eu<T, CHAIN>())) void row_qe8_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_qe8_body<T, A, NZ, LAY, CHAIN>(c, a);
 }
@@ -364,12 +369,12 @@ struct HipLauncher {
         if (!ok && !rc) rc = fail("fft: unsupported row length");
     }
     template <typename T>
-    void row_qe_pair8(int grid, int M, const RowQeArgs<T>& a) {
+    void row_qe_pair8(int pairs, int M, const RowQeArgs<T>& a) {
         const bool ok = dispatch_rq8(M, a.win, a.lr, a.chain != nullptr, [&](auto ac, auto nzc, auto lay, auto ch) {
             constexpr int A = decltype(ac)::value;
             if (ch.value && !a.tab) { if (!rc) rc = fail("fft: estimator chains need a table"); return; }
             if (!a.rq8c) { if (!rc) rc = fail("fft: the 8-point row stage needs the constants of its grid"); return; }
-            go(row_qe8_kernel<T, A, decltype(nzc)::value, decltype(lay)::value, decltype(ch)::value>, dim3(grid), 64 * A, rq8_lds_bytes<T, A>(), a);
+            go(row_qe8_kernel<T, A, decltype(nzc)::value, decltype(lay)::value, decltype(ch)::value>, dim3(pairs), 64 * A, rq8_lds_bytes<T, A, decltype(ch)::value>(), a);
         });
         if (!ok && !rc) rc = fail("fft: unsupported row grid / layout for the 8-point row stage");
     }

@@ -952,11 +952,12 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
 template <typename T, int LAY>
 OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, int idx, cx<T>& a0, cx<T>& a1, int p = 0) {
     static_assert(LAY == 0 || LAY == 2 || LAY == 3, "pair_rows_at: natural layout, R = 4 or R = 8");
-    if (LAY == 0) { a0 = ldg(row0 + idx); a1 = ldg(row1 + idx); return; }
+    auto rd = [](const cx<T>* q) { return ldg(q); };
+    if (LAY == 0) { a0 = rd(row0 + idx); a1 = rd(row1 + idx); return; }
     if (LAY == 3) {
         cx<T> b[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) b[k] = ldg(row0 + k * pitch + idx);
+        for (int k = 0; k < 8; ++k) b[k] = rd(row0 + k * pitch + idx);
         const cx<T> s0 = b[0] + b[4], s1 = b[1] + b[5], s2 = b[2] + b[6], s3 = b[3] + b[7];
         const cx<T> d0 = b[0] - b[4], d1 = b[1] - b[5], d2 = b[2] - b[6], d3 = b[3] - b[7];
         a0 = (s0 + rot_i(s2, 2 * p)) + rot_i(s1 + rot_i(s3, 2 * p), p);
@@ -965,7 +966,7 @@ OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, 
         a1 = (d0 + rot_i(d2, 2 * p + 1)) + th * (d1 + rot_i(d3, 2 * p + 1));
         return;
     }
-    const cx<T> b0 = ldg(row0 + idx), b1 = ldg(row0 + pitch + idx), b2 = ldg(row0 + 2 * pitch + idx), b3 = ldg(row0 + 3 * pitch + idx);
+    const cx<T> b0 = rd(row0 + idx), b1 = rd(row0 + pitch + idx), b2 = rd(row0 + 2 * pitch + idx), b3 = rd(row0 + 3 * pitch + idx);
     const cx<T> s02 = b0 + b2, d02 = b0 - b2, s13 = (b1 + b3) * sg, d13 = (b1 - b3) * sg;
     a0 = s02 + s13;
     a1 = add_pi(d02, d13);

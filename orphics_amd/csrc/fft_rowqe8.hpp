@@ -48,9 +48,6 @@ template <int A_> struct Rq8Geom {
 // LDS entries behind the A regions: float64 keeps the 64-point stage's factors W_64^(lo c), [c - 1][lo], there
 constexpr int RQ8_TAB = 7 * 8;
 template <typename T> constexpr bool rq8_tw_in_regs() { return sizeof(T) == 4; }
-template <typename T, int A> constexpr size_t rq8_lds_bytes() {
-    return ((size_t)A * Rq8Geom<A>::RS + (rq8_tw_in_regs<T>() ? 0 : RQ8_TAB)) * sizeof(cx<T>);
-}
 
 // in-register DFT over the waves' blocks
 template <typename T, int A> OA_HD void rq8_dft(cx<T>* z) {
@@ -229,26 +226,25 @@ OA_HD void rq8_sub_dit(Ctx& ctx, cx<T>* Dk, int l, const TW& tw, cx<T>* v) {
 // ---- inverse transform of a row pair's packed spectrum, pruned input: Z[n] = X0[n] + i X1[n] (n < win), Z[M - n] = conj X0[n] + i conj X1[n],
 // zero elsewhere (2 win <= M).  NZ = live taps per side of the cross-wave butterfly (win <= 512 NZ).  The inverse runs as the forward
 // transform of the swapped data: v = swapped result, (x1, x0).
-template <typename T, int A, int NZ, int LAY, class TW, class Ctx>
+// SEQ: one position at a time, the barrier that frees D first (float64: 16 to 32 operands of 16 bytes per position do not fit next to
+// h and the butterfly in 128 registers); otherwise every load of the thread is in flight before that barrier.
+// (Measured and dropped, tools/probes/rq8_probe.hip + profiles/r05_rowqe_probe.txt: the gradient legs' rows requested a transform ahead by
+// LDS-DMA into a staging buffer, two row pairs of an R-layout group per workgroup sharing it -- the load phases shrink, every other
+// phase grows by as much: 26.3 vs 24.7 us float32, 43.7 vs 36.2 us float64.)
+template <typename T, int A, int NZ, int LAY, bool SEQ, class TW, class Ctx>
 OA_HD void rq8_inverse(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, const cx<T>* row0, const cx<T>* row1, int win,
                        long pitch = 0, T sg = (T)1, int p = 0, int sb = 0) {
     using G = Rq8Geom<A>;
     constexpr int S = G::S, M = G::M, JPT = G::JPT;
     static_assert(NZ >= 1 && 2 * NZ <= A, "rowqe8: live taps per side");
-    // float32: every load of the thread in flight before the barrier that frees D (the wait for the slowest wave of the previous
-    // transform hides their latency).  float64: one position at a time, stored as soon as its butterfly is done -- 16 to 32 operands
-    // of 16 bytes per position would not fit next to h and the butterfly in 128 registers
-    constexpr bool SEQ = sizeof(T) == 8;
     cx<T> z[SEQ ? 1 : JPT][A];
-    cx<T> wa[JPT];
-#pragma unroll
-    for (int u = 0; u < JPT; ++u) wa[u] = tw.wa(u);
     if (SEQ) ctx.sync();                                    // whoever still reads D (previous transform) is done
 #pragma unroll
     for (int u = 0; u < JPT; ++u) {
         cx<T>* zu = z[SEQ ? 0 : u];
         const int j = tid + G::NT * u;
         const bool own = G::FULLJ || j < S;
+        const cx<T> wa = tw.wa(u);
 #pragma unroll
         for (int t = 0; t < A; ++t) {
             const int n = j + S * t;
@@ -268,7 +264,7 @@ OA_HD void rq8_inverse(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cons
             }
         }
         rq8_dft<T, A>(zu);
-        tw.mula(zu, u, wa[u]);
+        tw.mula(zu, u, wa);
         if (SEQ) {
             if (own) {
 #pragma unroll
@@ -293,8 +289,6 @@ OA_HD void rq8_inverse(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cons
     }
     ctx.sync();
     RQ8_STAMP(sb + 1);
-    rq8_sub_dif<T>(ctx, D + G::RS * (tid >> 6), tid & 63, tw, v);
-    RQ8_STAMP(sb + 2);
 }
 
 // ---- forward transform of the product in registers, kept columns k < wout of both rows unpacked and stored:
@@ -303,9 +297,6 @@ template <typename T, int A, class TW, class Ctx>
 OA_HD void rq8_forward(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cx<T>* o0, cx<T>* o1, int wout, int accumulate, int sb = 0) {
     using G = Rq8Geom<A>;
     constexpr int S = G::S, M = G::M, JPT = G::JPT;
-    cx<T> wa[JPT];
-#pragma unroll
-    for (int u = 0; u < JPT; ++u) wa[u] = tw.wa(u);         // (in flight across the sub-transform)
     rq8_sub_dit<T>(ctx, D + G::RS * (tid >> 6), tid & 63, tw, v);
     RQ8_STAMP(sb);
     ctx.sync();
@@ -313,9 +304,10 @@ OA_HD void rq8_forward(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cx<T
 #pragma unroll
     for (int u = 0; u < JPT; ++u) {
         const int q = (tid + G::NT * u) & (S - 1);          // (A = 3: the unused slot reads a valid entry)
+        const cx<T> wa = tw.wa(u);
 #pragma unroll
         for (int k = 0; k < A; ++k) a[u][k] = D[G::RS * k + q];
-        tw.mula(a[u], u, wa[u]);
+        tw.mula(a[u], u, wa);
         rq8_dft<T, A>(a[u]);
     }
     RQ8_STAMP(sb + 1);
@@ -363,12 +355,24 @@ OA_HD bool rq8_covers(int m, int win, int wout) {
     return A == 3 ? win <= 512 : 2 * win <= m;
 }
 
+// LDS of one workgroup: the transform regions, the float64 factor table, the park area
+// float64 at four waves per SIMD has 128 registers for h (32), the transform in flight (32), its factors and the butterfly: the
+// compiler spilled half of h to scratch and reloaded it one dword pair at a time behind vmcnt(0) -- each reload also waiting for the
+// previous transform's stores (stamps: 8 k of a 3.5 k-cycle phase, twice per row pair).  Where the LDS of four workgroups per CU has
+// room (M = 1024 and 1536) the upper half of h is PARKED in LDS instead: 4 entries per thread, [t - 4][tid]
+template <typename T, int A, bool CHAIN> constexpr bool rq8_park() { return sizeof(T) == 8 && !CHAIN && (A == 2 || A == 3); }
+template <typename T, int A, bool CHAIN> constexpr size_t rq8_lds_bytes() {
+    return ((size_t)A * Rq8Geom<A>::RS + (rq8_tw_in_regs<T>() ? 0 : RQ8_TAB) + (rq8_park<T, A, CHAIN>() ? 4 * Rq8Geom<A>::NT : 0)) * sizeof(cx<T>);
+}
+
 template <typename T, int A, int NZ, int LAY = 0, bool CHAIN = false, class Ctx>
 OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
     using G = Rq8Geom<A>;
     constexpr bool FULL = rq8_tw_in_regs<T>();
     cx<T>* D = reinterpret_cast<cx<T>*>(ctx.smem());
     const int tid = ctx.tid();
+    cx<T>* TAB = D + A * G::RS;
+    cx<T>* PKB = TAB + (FULL ? 0 : RQ8_TAB);
     long wg = ctx.bid_x();
     long imo = 0, omo = 0, hmo = 0;
     int m = 0;
@@ -380,7 +384,7 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
         const RowQeMap<T> e = a.tab[m];
         gxp = e.gx; gyp = e.gy; hp = e.h; pxp = e.px; pyp = e.py; scale = e.scale;
     }
-    // row addressing exactly as row_qe_pair_body: natural pairs, or the R-layouts of col_fband_body (LAY = 2: R = 4, LAY = 3: R = 8)
+    // row addressing as row_qe_pair_body: natural pairs, or the R-layouts of col_fband_body (LAY = 2: R = 4, LAY = 3: R = 8)
     long r0 = wg * 2, ra = wg * 2, rb = wg * 2 + 1;
     T sg = (T)1;
     int pp = 0;
@@ -393,6 +397,7 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
         ra = ylo + mq * (2 * pp);
         rb = ra + mq;
     } else if (LAY > 0) {
+        // the two workgroups of a group read the same four rows: workgroups b and b + 8 of a block of 16 (same XCD under the round-robin dispatch)
         const long blk = wg & ~15L;
         const int r = (int)(wg & 15), p = r >> 3;
         const long ylo = (blk >> 1) + (r & 7), mq = a.nrows >> LAY;
@@ -403,9 +408,10 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
     }
     RQ8_STAMP(0);
     Rq8Tw<T, A, FULL> tw;
-    rq8_tw_init<T, A, FULL>(ctx, tw, D + A * G::RS, a.rq8c, tid);
+    rq8_tw_init<T, A, FULL>(ctx, tw, TAB, a.rq8c, tid);
     RQ8_STAMP(1);
     cx<T> hreg[8], v[8];
+    cx<T>* Dk = D + G::RS * (tid >> 6);
     if constexpr (CHAIN) {
         static_assert(LAY == 0, "chains read natural-order leg planes");
         const int first = a.chain[2 * m], count = a.chain[2 * m + 1];
@@ -413,13 +419,15 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
 #pragma unroll 1
         for (int i = 0; i < count; ++i) {
             const RowQeMap<T> e = a.tab[first + i];
-            rq8_inverse<T, A, NZ, 0>(ctx, D, hreg, tid, tw, e.h + r0 * a.pitch, e.h + (r0 + 1) * a.pitch, a.win);
+            rq8_inverse<T, A, NZ, 0, !FULL>(ctx, D, hreg, tid, tw, e.h + r0 * a.pitch, e.h + (r0 + 1) * a.pitch, a.win);
+            rq8_sub_dif<T>(ctx, Dk, tid & 63, tw, hreg);
 #pragma unroll
             for (int t = 0; t < 8; ++t) hreg[t] = hreg[t] * e.scale;
 #pragma unroll
             for (int leg = 0; leg < 2; ++leg) {
                 const cx<T>* src = leg ? e.gy : e.gx;
-                rq8_inverse<T, A, NZ, 0>(ctx, D, v, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
+                rq8_inverse<T, A, NZ, 0, !FULL>(ctx, D, v, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win);
+                rq8_sub_dif<T>(ctx, Dk, tid & 63, tw, v);
                 if (i == 0) {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) acc[leg][t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
@@ -438,56 +446,52 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
         }
         return;
     }
-#ifdef RQ8_TOUCH
-    // experiment: one 4-byte read per 128-byte line of the rows the two gradient legs will load later (brings them into the XCD's L2
-    // while the H leg is transformed)
-    T sink = (T)0;
-    {
-        constexpr int NR = LAY == 0 ? 2 : (LAY == 2 ? 4 : 8);
-        const int lpr = (int)((a.win * sizeof(cx<T>) + 127) / 128), tot = 2 * NR * lpr;
-        for (int i = tid; i < tot; i += G::NT) {
-            const int leg = i / (NR * lpr), rr = (i / lpr) % NR, ln = i % lpr;
-            const T* q = reinterpret_cast<const T*>((leg ? gyp : gxp) + (r0 + rr) * a.pitch) + ln * (128 / sizeof(T));
-            sink += ldg(q);
-        }
-    }
-#endif
-    rq8_inverse<T, A, NZ, LAY>(ctx, D, hreg, tid, tw, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 2);
+    rq8_inverse<T, A, NZ, LAY, !FULL>(ctx, D, hreg, tid, tw, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 2);
+    rq8_sub_dif<T>(ctx, Dk, tid & 63, tw, hreg);
+    RQ8_STAMP(4);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
 #pragma unroll
     for (int t = 0; t < 8; ++t) hreg[t] = hreg[t] * scale;
+    constexpr bool PARK = rq8_park<T, A, CHAIN>();
+    cx<T>* const PK = PKB + tid;
+    if constexpr (PARK) {
+#pragma unroll
+        for (int t = 4; t < 8; ++t) PK[(t - 4) * G::NT] = hreg[t];
+    }
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? gyp : gxp;
         cx<T>* dst = leg ? pyp : pxp;
-        rq8_inverse<T, A, NZ, LAY>(ctx, D, v, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 5 + 7 * leg);
+        rq8_inverse<T, A, NZ, LAY, !FULL>(ctx, D, v, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 5 + 7 * leg);
+        rq8_sub_dif<T>(ctx, Dk, tid & 63, tw, v);
+        RQ8_STAMP(7 + 7 * leg);
         // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = mk<T>(v[t].y * hreg[t].y, v[t].x * hreg[t].x);
+        for (int t = 0; t < 8; ++t) {
+            const cx<T> hh = (PARK && t >= 4) ? PK[(t - 4) * G::NT] : hreg[t];
+            v[t] = mk<T>(v[t].y * hh.y, v[t].x * hh.x);
+        }
         rq8_forward<T, A>(ctx, D, v, tid, tw, dst + ra * a.opitch, dst + rb * a.opitch, a.wout, a.accumulate, 8 + 7 * leg);
     }
-#ifdef RQ8_TOUCH
-    if (sink == (T)1.2345e30) pxp[tid] = mk<T>(sink, sink);       // (never true: keeps the reads alive)
-#endif
 }
 
 // host-side dispatch: f(A, NZ, LAY, CHAIN as integral constants) for the instantiated variant; false: not built
 template <class F>
 inline bool dispatch_rq8(int M, int win, int lr, bool chain, F&& f) {
     const int nz = rq8_nz(M, win);
+    using std::integral_constant;
     auto with_lay = [&](auto ac, auto nzc) -> bool {
         if (chain) {
             if (lr != 0) return false;
-            f(ac, nzc, std::integral_constant<int, 0>{}, std::true_type{});
+            f(ac, nzc, integral_constant<int, 0>{}, std::true_type{});
             return true;
         }
         switch (lr) {
-            case 0: f(ac, nzc, std::integral_constant<int, 0>{}, std::false_type{}); return true;
-            case 2: f(ac, nzc, std::integral_constant<int, 2>{}, std::false_type{}); return true;
-            case 3: f(ac, nzc, std::integral_constant<int, 3>{}, std::false_type{}); return true;
+            case 0: f(ac, nzc, integral_constant<int, 0>{}, std::false_type{}); return true;
+            case 2: f(ac, nzc, integral_constant<int, 2>{}, std::false_type{}); return true;
+            case 3: f(ac, nzc, integral_constant<int, 3>{}, std::false_type{}); return true;
             default: return false;
         }
     };
-    using std::integral_constant;
     switch (M) {
         case 1024: return with_lay(integral_constant<int, 2>{}, integral_constant<int, 1>{});
         case 1536: return with_lay(integral_constant<int, 3>{}, integral_constant<int, 1>{});

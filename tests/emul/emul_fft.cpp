@@ -84,10 +84,10 @@ struct EmuLauncher {
                 });
         });
     }
-    template <typename T> void row_qe_pair8(int grid, int M, const RowQeArgs<T>& a) {
+    template <typename T> void row_qe_pair8(int pairs, int M, const RowQeArgs<T>& a) {
         dispatch_rq8(M, a.win, a.lr, a.chain != nullptr, [&](auto ac, auto nzc, auto lay, auto ch) {
             constexpr int A = decltype(ac)::value;
-            run(grid, 1, 64 * A, rq8_lds_bytes<T, A>(),
+            run(pairs, 1, 64 * A, rq8_lds_bytes<T, A, decltype(ch)::value>(),
                 [&](EmuCtx& c) { row_qe8_body<T, A, decltype(nzc)::value, decltype(lay)::value, decltype(ch)::value>(c, a); });
         });
     }

@@ -31,7 +31,9 @@ using namespace oa;
 #define LAYQ 2
 #endif
 typedef PREC T;
-__global__ __launch_bounds__(64 * GA, WAVES) void probe_kernel(RowQeArgs<T> a) {
+constexpr int NPQ = 1;
+#define STAGED 0
+__global__ __launch_bounds__(64 * GA * NPQ, WAVES) void probe_kernel(RowQeArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
     row_qe8_body<T, GA, 1, LAYQ, false>(c, a);
 }
@@ -48,6 +50,7 @@ int main(int argc, char** argv) {
     srand(1);
     for (auto& v : h) { v.x = (T)(rand() / (double)RAND_MAX - 0.5); v.y = (T)(rand() / (double)RAND_MAX - 0.5); }
     CK(hipMemcpy(legs, h.data(), h.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
+    cx<T>* legs2; CK(hipMalloc(&legs2, 3 * nmaps * legn * sizeof(cx<T>))); CK(hipMemcpy(legs2, legs, 3 * nmaps * legn * sizeof(cx<T>), hipMemcpyDeviceToDevice));
     auto t1 = make_twiddles<T>(nx);
     auto t3 = rq8_make_consts<T>(GA);
     CK(hipMalloc(&tw, t1.size() * sizeof(cx<T>))); CK(hipMemcpy(tw, t1.data(), t1.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
@@ -57,25 +60,29 @@ int main(int argc, char** argv) {
     a.pitch = pl; a.opitch = pk; a.logL = ilog2(M); a.NT = 64 * GA; a.rowStride = M; a.tw = tw; a.logTw = ilog2(nx); a.scale = (T)1e-3;
     a.win = win; a.wout = wout; a.lr = LAYQ; a.nrows = my; a.rq8c = twm;
     if (nmaps > 1) { a.npairs = my / 2; a.in_moff = 3 * legn; a.h_moff = 3 * legn; a.out_moff = 2 * prodn; }
-    const size_t smem = rq8_lds_bytes<T, GA>();
+    const size_t smem = rq8_lds_bytes<T, GA, false>();
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    const int grid = my / 2 * nmaps;
+    const int grid = my / 2 * nmaps / NPQ;
     // a big unrelated buffer written between repetitions: the leg planes are then read from HBM / MALL as inside the step
     char* junk; const size_t jb = (size_t)600 << 20;
     CK(hipMalloc(&junk, jb));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> ts;
     for (int r = 0; r < reps + 3; ++r) {
+#ifdef FLUSH
         CK(hipMemsetAsync(junk, r, jb, 0));
+#else
+        CK(hipMemcpyAsync(legs, legs2, 3 * nmaps * legn * sizeof(cx<T>), hipMemcpyDeviceToDevice, 0));   // the producer kernel's writes: the planes sit in the infinity cache as inside the step
+#endif
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(64 * GA), smem, 0, a);
+        hipLaunchKernelGGL(probe_kernel, dim3(grid), dim3(64 * GA * NPQ), smem, 0, a);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         if (r >= 3) ts.push_back(ms * 1e3f);
     }
     std::sort(ts.begin(), ts.end());
-    printf("rq8 probe %s A=%d waves=%d lay=%d maps=%d lds=%zu : median %.1f us  min %.1f us\n", sizeof(T) == 4 ? "f32" : "f64", GA, WAVES, LAYQ, nmaps, smem,
+    printf("rq8 probe %s A=%d waves=%d lay=%d staged=%d maps=%d lds=%zu : median %.1f us  min %.1f us\n", sizeof(T) == 4 ? "f32" : "f64", GA, WAVES, LAYQ, STAGED, nmaps, smem,
            ts[ts.size() / 2], ts[0]);
 #ifdef STAMPS
     std::vector<unsigned long long> st((size_t)8192 * NSTAMP);
