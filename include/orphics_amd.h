@@ -157,7 +157,10 @@ int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const v
  *  oa_mc_run           : the Gaussian N0 / mean-field Monte-Carlo shard [sim_lo, sim_hi) of
  *                        tutorials/tt_verification.ipynb cell 4: Philox GRF (key = (base_seed, sim)) with per-mode
  *                        amplitude covsqrt_hc -> TT estimator -> bandpower moments (+ mean-field stack of kappa_hat,
- *                        interleaved re/im doubles, if meanfield_acc != NULL).  No host synchronisation. */
+ *                        interleaved re/im doubles, if meanfield_acc != NULL).  No host synchronisation.
+ *  BINDING: the plan keeps the POINTERS handed to oa_plan_set_filters / oa_plan_set_bins and may keep derived copies of what they
+ *  point to (tile-major Fnorm / ids of the fused divergence launch).  Every call of either entry invalidates those copies -- also
+ *  when the addresses are the ones bound before -- so a caller that changes the contents of a bound plane calls the entry again. */
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
                         int leg_rows, int kappa_rows, int mrow);
 /* COLUMN GRID of the one-call TT path (the y-axis counterpart of the ROW GRID above).  Legs confined to the rows
@@ -336,11 +339,11 @@ int oa_lens_taylor(oa_plan* p, const void* src, const void* deriv_planes, long p
                    const int32_t* shift_y, const void* dx, const void* dy, void* out, void* stream);
 /* flat_taylens (lensing.py:395-440) of nmaps real maps (in_stride / out_stride elements apart) by ONE deflection field, given as
  * its nearest-pixel shifts and sub-pixel remainders (oa_lens_split; shared by all maps: T, Q, U of a realisation): nmaps R2Cs, then
- * the inverse transforms of all nmaps * nd derivative fields (nd = order (order + 1) / 2 - 1), three launches per chunk of planes
- * -- inverse column pass 1 with the factor (i lx)^a (i ly)^b applied at its load (the derivative spectra never exist in HBM),
- * column pass 2, row C2R; a chunk is sized for the 256 MB infinity cache, so its intermediates never travel to HBM -- and one
+ * the inverse transforms of all nmaps * nd derivative fields (nd = order (order + 1) / 2 - 1), SEPARABLY: per map and y-derivative
+ * order b one column transform of (i ly)^b k (passes 1 and 2 on ONE plan-owned hc plane, which stays in the infinity cache) and one
+ * row launch that takes every x-derivative (i lx)^a at its load (the derivative spectra never exist in HBM) -- and one
  * gather pass per map (oa_lens_taylor).  Same results as oa_hc_derivs + C2R per term + oa_lens_taylor.  The planes live in a
- * plan-owned pool allocated / grown on first use (that call synchronises the device once): nmaps * (1 + nd) planes + one chunk,
+ * plan-owned pool allocated / grown on first use (that call synchronises the device once): nmaps * (1 + nd) planes + one hc plane,
  * e.g. 6.2 GB for T, Q, U at 4096^2 float64 and order 5; oa_plan_release_pools frees it (and the pools of oa_qe_mv /
  * oa_qe_tt_splits / oa_mc_run), the next call reallocates. */
 int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int order, const int32_t* shift_x, const int32_t* shift_y,

@@ -132,9 +132,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     got = lib.oa_version()
-    if got < ABI_VERSION:       # (a later library with additive changes is fine: include/orphics_amd.h)
-        raise OrphicsAmdError("orphics_amd: %s reports C-ABI version %d, older than the %d this binding was written against "
-                              "(stale build? run __graft_entry__.build())" % (LIB_PATH, got, ABI_VERSION))
+    # version = 100 x MAJOR + minor: MAJOR changes whenever an entry is removed or a signature changes, the minor number when entries
+    # are added.  A library of another MAJOR could be called with the wrong argument types; an older minor lacks entries.
+    if got // 100 != ABI_VERSION // 100 or got < ABI_VERSION:
+        raise OrphicsAmdError("orphics_amd: %s reports C-ABI version %d; this binding was written against %d and accepts %d..%d "
+                              "(stale build? run __graft_entry__.build())" % (LIB_PATH, got, ABI_VERSION, ABI_VERSION, ABI_VERSION // 100 * 100 + 99))
     _lib = lib
     return lib
 

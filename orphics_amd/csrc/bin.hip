@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void bin_final_kernel(const double* __restrict
     if (!tail.ticket) return;
     if (t == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through store of sums[i] has been acknowledged
-        s_last = (__hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) ? 1 : 0;
+        s_last = (__hip_atomic_fetch_add(tail.ticket, 1u, OA_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;

@@ -115,7 +115,6 @@ int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* 
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my = 0);
 // flat-sky Taylor lensing, FFT part: R2C of nmaps maps, then all nmaps * nd derivative fields inverse-transformed in three launches
-int lens_chunk_planes(const oa_plan* p);      // derivative planes per launch triple (a chunk that fits the infinity cache)
 // tile-major copy of a full-pitch real / int32 hc-layout plane on the coarse grid of `rows` rows: dst[(tile * rows + k) * C + c] =
 // src[(k + (k >= rows / 2 ? ny - rows : 0)) * kp + tile * C + c], zero beyond `width` columns (elem_bytes 4 or 8)
 int pack_tiles(const oa_plan* p, const void* src, void* dst, int rows, int logc, int width, int elem_bytes, hipStream_t st);

@@ -106,6 +106,17 @@ template <class U> __device__ __forceinline__ U ldg(const U* p) {
 template <class U> inline U ldg(const U* p) { return *p; }
 #endif
 
+// Memory order of the last-workgroup TICKET of the fused binning tails (fft_divbin.hpp, bin.hip).  The hand-over is the write-through
+// form of /opt/skills/guides/MI355X_MICROARCH.md ("Valid forms"): every partial sum is stored with an agent-scope atomic store (sc1),
+// every storing wave waits for vmcnt(0), a workgroup barrier, ONE lane's agent-scope add; the workgroup whose add came last reads
+// the partials with agent-scope atomic loads (sc1) behind a barrier that lane joins -- so the add itself can stay relaxed.
+// -DOA_TICKET_ACQ_REL builds the release/acquire form for comparison (profiles/r05_ticket_order.txt: what the L2 write-back costs).
+#ifdef OA_TICKET_ACQ_REL
+#define OA_TICKET_ORDER __ATOMIC_ACQ_REL
+#else
+#define OA_TICKET_ORDER __ATOMIC_RELAXED
+#endif
+
 OA_HD int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;

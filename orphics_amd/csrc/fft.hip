@@ -839,11 +839,6 @@ int div_tile_logc(const oa_plan* p, int rows) {
     const int lt = p->dtype == OA_F32 ? Fft2dPlan<float>::div_lt() : Fft2dPlan<double>::div_lt();
     return lt - ilog2(rows);
 }
-int lens_chunk_planes(const oa_plan* p) {
-    const size_t plane = (size_t)p->ny * p->kp * 2 * (p->dtype == OA_F32 ? 4 : 8);
-    const int G = (int)((size_t)96 * 1024 * 1024 / plane);
-    return G < 1 ? 1 : G;
-}
 int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st,
                      const void* hc_in, long hc_stride, double hc_scale) {
     return p->dtype == OA_F32 ? lens_derivs_impl<float>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st, hc_in, hc_stride, hc_scale)

@@ -67,10 +67,6 @@ struct DivBinTail {
         const double v = ok ? (double)(pw * (T)f.pnorm) * (double)m : 0.0;
         const int lane = threadIdx.x & 63;
         double* row = rows + (threadIdx.x >> 6) * f.nids;
-#ifdef OA_DIVBIN_NOACC       // timing experiment only: no accumulation
-        if (v == 1.2345e300) row[0] = v;
-        return;
-#endif
         unsigned long long act = __ballot(ok);
         while (act) {
             const int leader = __ffsll((long long)act) - 1;
@@ -95,13 +91,9 @@ struct DivBinTail {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partials have been acknowledged
         __syncthreads();
         if (t == 0)
-            s_last = (__hip_atomic_fetch_add(f.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.z - 1) ? 1 : 0;
+            s_last = (__hip_atomic_fetch_add(f.ticket, 1u, OA_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.z - 1) ? 1 : 0;
         __syncthreads();
         if (!s_last) return;
-#ifdef OA_DIVBIN_NOLAST      // timing experiment only: the last workgroup does nothing but reset the ticket
-        if (t == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-#endif
         // last workgroup: per map, in map order: sums[i] = the workgroups' partials in a fixed two-level order -- thread (g, i),
         // i = t mod NI, g = t / NI, adds the partials of workgroups b = g, g + G, ... (four loads in flight), then the G group sums
         // are added in group order; b = sums[1 .. nids-2] / mode counts; moments.  (One thread per id walking all workgroups was

@@ -545,11 +545,6 @@ OA_HD void r2c_epilogue(Ctx& ctx, const cx<T>* s, cx<T>* out, long pitch, long r
     else r2c_epilogue_impl<T, true>(ctx, s, out, pitch, r0, logL, logC, NT, RS, tw, logTw, scale, accumulate, wout);
 }
 
-struct SynLoad {   // OA_R2C_NOLOAD experiment
-    static constexpr bool reads_lds = false;
-    float f;
-    template <typename U> OA_HD cx<U> get(int n, int c) const { return mk<U>((U)(n * f), (U)(c + f)); }
-};
 template <typename T, int MODE, class SEQ, class Ctx>
 OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
     cx<T>* s = reinterpret_cast<cx<T>*>(ctx.smem());
@@ -579,18 +574,8 @@ OA_HD void row_fft_body(Ctx& ctx, const RowArgs<T>& a) {
                                                RowLoad<T, true>{in + r0 * a.in_pitch, (unsigned)a.in_pitch},
                                                RowStore<T, true>{out + r0 * a.out_pitch, (unsigned)a.out_pitch, a.scale});
     } else if constexpr (MODE == ROW_R2C) {
-#if defined(OA_R2C_NOLOAD)      // experiment: arithmetic + LDS only (inputs synthesised in registers)
-        fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL, SynLoad{(float)a.scale}, NoStore{});
-#elif defined(OA_R2C_NOCOMP)    // experiment: global loads + one LDS write only
-        {
-            const RowLoad<T, false> ld{in + r0 * a.in_pitch, (unsigned)a.in_pitch};
-            for (int t = 0; t < EPT; ++t) { const int n = tid + t * NT; s[lds_addr<true>(n & ((1 << logL) - 1), n >> logL, a.logC, RS)] = ld.template get<T>(n & ((1 << logL) - 1), n >> logL); }
-            ctx.sync();
-        }
-#else
         fft_pipeline<T, true, true, false, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL,
                                                 RowLoadOnce<T>{in + r0 * a.in_pitch, (unsigned)a.in_pitch}, NoStore{});
-#endif
         r2c_epilogue<T>(ctx, s, out, a.out_pitch, r0, logL, a.logC, NT, RS, a.tw, a.logTw, a.scale, false, a.wcols);
     } else if constexpr (MODE == ROW_WIN) {
         // inverse packed transform with its result left in LDS (natural order, swapped: the inverse runs as a forward transform of
@@ -662,11 +647,7 @@ OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
     const int ngroups = a.my >> a.logC, gstep = ctx.grid_x();
     cx<T> v[EPT];
     auto taps = [&](long grp, int n) {
-#if defined(OA_RSPLIT_NOLOAD)      // experiment: arithmetic + LDS only (inputs synthesised in registers)
-        rsplit_first_taps<T, R0>(v, tid, NT, logL, SynLoad{(float)a.scale + (float)(grp + n)});
-#else
         rsplit_first_taps<T, R0>(v, tid, NT, logL, RowLoadOnce<T>{in + (grp * C + (long)n * a.my) * a.in_pitch, (unsigned)a.in_pitch});
-#endif
     };
     // untangle factors W_2L^kk of this thread's columns: row-invariant, loaded once (inside the loop they would queue behind the
     // prefetch in vmcnt order and the untangle would wait for the whole next row)
@@ -699,9 +680,7 @@ OA_HD void row_r2c_rsplit_body(Ctx& ctx, const RowArgs<T>& a) {
                 else if (grp + gstep < ngroups) taps(grp + gstep, 0);
             }
             ctx.sync();
-#if !defined(OA_RSPLIT_NOCOMP)     // experiment (NOCOMP): global loads + first stage + untangle of whatever is in LDS
             fft_pipeline_rest<T, true, SEQ>(ctx, s, tid, NT, logL, a.logC, RS, twl, logL);
-#endif
             if (c < C) {
                 const cx<T>* sr = s + c * RS;
 #pragma unroll

@@ -104,18 +104,10 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
     for (int r = 0; r < NCOL; ++r) TWK[tid + NT * r] = a.tw[(unsigned)(tid + NT * r) << (a.logTw - (LOGL + 1))];
     cx<T> v[16];
     auto taps = [&](long grp, int n, int t0 = 0, int t1 = 16) {
-#ifdef OA_RS4096_SEQROWS      // timing experiment only (wrong rows): the group's rows adjacent instead of my apart
-        const cx<T>* src = in + (grp * R + n) * a.in_pitch + tid;
-#else
         const cx<T>* src = in + (grp + (long)n * a.my) * a.in_pitch + tid;
-#endif
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-#ifdef OA_RS4096_NOLOAD       // timing experiment only: arithmetic + LDS without the global loads
-            if (t >= t0 && t < t1) v[t] = mk<T>((T)(grp + t), (T)(n + tid));
-#else
             if (t >= t0 && t < t1) v[t] = RowLoadOnce<T>{src, 0u}.template get<T>(S * t, 0);
-#endif
     };
     // row of the group taken at step `step`: R = 4: n = 0, 2, 1, 3 (two radix-2 levels, below); R = 8: natural order
     auto row_of = [](int step) { return R == 4 ? (((step & 1) << 1) | (step >> 1)) : step; };
@@ -144,16 +136,6 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
         for (int step = 0; step < R; ++step) {
             const int n = row_of(step);
             if (!PF) taps(grp, n);
-#ifdef OA_RS4096_LOADONLY     // timing experiment only: the launch shape and load pattern of this kernel as a pure streaming read
-            {
-                cx<T> sacc = v[0];
-#pragma unroll
-                for (int t = 1; t < 16; ++t) sacc = sacc + v[t];
-                if (PF) next_taps(grp, step, 0, 16);
-                if (sacc.x == (T)1.2345e30) out[tid] = sacc;       // (never true: keeps the loads alive)
-                continue;
-            }
-#endif
             // ---- stage 0: residues k0 = t of the 16-point butterfly over x[tid + S t], twiddled, to D[k0][tid]
             Dft<T, 16>::run(v);
             apply_twiddles<T, 16>(v, TW, tid, 0, tw_lds_h(LOGL));

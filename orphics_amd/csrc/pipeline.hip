@@ -47,7 +47,9 @@ struct Pipeline {
     // made from: rebuilt when the filters / bins / column grid change)
     void* fn_t = nullptr; int32_t* ids_t = nullptr;
     size_t fn_t_bytes = 0, ids_t_bytes = 0;
-    const void* tab_fn = nullptr; const void* tab_ids = nullptr;
+    // keyed on a GENERATION bumped by every oa_plan_set_filters / oa_plan_set_bins call, not on the planes' addresses: a caching
+    // allocator hands a new estimator the addresses of a freed one, and a caller may refill Fnorm or the ids in place
+    unsigned long bind_gen = 1, tab_gen = 0;
     int tab_rows = 0, tab_logc = 0, tab_wk = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
@@ -213,6 +215,7 @@ int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* 
     OA_REQUIRE(p->have_laxes, "oa_plan_set_filters: call oa_plan_set_laxes first");
     Pipeline* q = pipe_of(p);
     q->FG = FG; q->FH = FH; q->Fn = Fnorm;
+    ++q->bind_gen;                             // the tile-major copy of Fnorm is repacked by the next call that uses it
     q->wl = leg_cols; q->wk = kappa_cols; q->rl = leg_rows; q->rk = kappa_rows; q->mrow = mrow;
     q->mcol = mrow == 0 ? 0 : -1;             // the map's own grid in x means the map's own grid in y too
     if (int rc = ensure_work(p, q)) return rc;
@@ -238,6 +241,7 @@ int oa_plan_set_bins(oa_plan* p, const int32_t* ids_hc, int nids, double norm, v
         OA_HIP(hipMemset(q->ticket, 0, sizeof(unsigned)));
     }
     q->ids = ids_hc; q->nids = nids; q->norm = norm;
+    ++q->bind_gen;
     // mode counts per bin over the WHOLE plane (the per-call binning visits only kappa's active region)
     if (int rc = oa_bin_power(p->dtype, q->c[0], q->c[0], norm, ids_hc, nullptr, (long)p->ny * p->kp, nids, p->kp, p->nx / 2, q->sums,
                               q->counts_full, nullptr, q->bin_scratch, 0, 0, stream)) return rc;
@@ -257,7 +261,7 @@ static int ensure_div_tables(oa_plan* p, Pipeline* q, hipStream_t st) {
     const int rows = q->my;
     if (!(q->Fn && q->ids && (rows == 1024 || rows == 2048) && q->wk > 0)) { q->tab_rows = 0; return 0; }
     const int logc = div_tile_logc(p, rows);
-    if (q->tab_fn == q->Fn && q->tab_ids == q->ids && q->tab_rows == rows && q->tab_logc == logc && q->tab_wk == q->wk) return 0;
+    if (q->tab_gen == q->bind_gen && q->tab_rows == rows && q->tab_logc == logc && q->tab_wk == q->wk) return 0;
     const size_t rs = p->dtype == OA_F32 ? 4 : 8;
     const long tiles = ((long)q->wk + (1 << logc) - 1) >> logc, total = (tiles * rows) << logc;
     if (q->fn_t_bytes < (size_t)total * rs) {
@@ -272,12 +276,12 @@ static int ensure_div_tables(oa_plan* p, Pipeline* q, hipStream_t st) {
     }
     if (int rc = pack_tiles(p, q->Fn, q->fn_t, rows, logc, q->wk, (int)rs, st)) return rc;
     if (int rc = pack_tiles(p, q->ids, q->ids_t, rows, logc, q->wk, 4, st)) return rc;
-    q->tab_fn = q->Fn; q->tab_ids = q->ids; q->tab_rows = rows; q->tab_logc = logc; q->tab_wk = q->wk;
+    q->tab_gen = q->bind_gen; q->tab_rows = rows; q->tab_logc = logc; q->tab_wk = q->wk;
     return 0;
 }
 static DivBinFuse make_fuse(const oa_plan* p, const Pipeline* q, int64_t* n, double* S, double* C, int store) {
     DivBinFuse f{};
-    if (q->tab_rows && q->tab_fn == q->Fn && q->tab_ids == q->ids && q->tab_rows == q->my && q->tab_wk == q->wk) {
+    if (q->tab_rows && q->tab_gen == q->bind_gen && q->tab_rows == q->my && q->tab_wk == q->wk) {
         f.ids_t = q->ids_t; f.fn_t = q->fn_t; f.tab_logc = q->tab_logc; f.tab_rows = q->tab_rows;
     }
     f.ids = q->ids; f.ipitch = p->kp; f.pnorm = q->norm; f.nids = q->nids; f.nxh = p->nx / 2;
@@ -341,10 +345,10 @@ int oa_qe_pol(oa_plan* p, int npieces, const double* host_signs, const void* con
 
 /* flat_taylens (lensing.py:395-440) of nmaps real maps by ONE deflection field, given as its nearest-pixel shifts and sub-pixel
  * remainders (oa_lens_split): out_m(x) = sum_{a + b < order} dx^a dy^b / (a! b!) D_ab[m](x + shift).  Per call: nmaps R2Cs, then the
- * inverse transforms of all nmaps * nd derivative fields (nd = order (order + 1) / 2 - 1), three launches per cache-sized chunk of
- * planes -- column pass 1 with the factor (i lx)^a (i ly)^b applied at its load (the derivative spectra never exist in HBM),
- * column pass 2, row C2R -- and one gather pass per map.  The planes live in a plan-owned pool (allocated / grown on first use: that call synchronises the device
- * once; oa_plan_release_pools frees it). */
+ * inverse transforms of all nmaps * nd derivative fields (nd = order (order + 1) / 2 - 1), separably (lens_derivs_impl, fft.hip): per
+ * (map, y-derivative order b) the column transform of (i ly)^b k on ONE hc plane and a row launch that takes every x-derivative at
+ * its load -- and one gather pass per map.  The planes live in a plan-owned pool (allocated / grown on first use: that call
+ * synchronises the device once; oa_plan_release_pools frees it). */
 static int lens_maps_impl(oa_plan* p, int nmaps, const void* real_in, long in_stride, const void* hc_in, long hc_stride, double hc_scale, int order,
                           const int32_t* shift_x, const int32_t* shift_y, const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
     const long rplane = (long)p->ny * p->nx;
@@ -356,7 +360,7 @@ static int lens_maps_impl(oa_plan* p, int nmaps, const void* real_in, long in_st
     char* realp = nullptr;
     if (nd + d00 > 0) {
         const size_t hcb = plane_bytes(p), rb = (size_t)rplane * rs;
-        const int chunk = std::min(lens_chunk_planes(p), nmaps * (nd + d00));
+        const int chunk = 1;                      // ONE hc plane: the column-transformed field of the current (map, y-derivative order)
         const size_t nk0 = hc_in ? 0 : (size_t)nmaps;
         const size_t need = nk0 * hcb + (size_t)chunk * hcb + (size_t)nmaps * (nd + d00) * rb;
         if (q->lens_bytes < need) {

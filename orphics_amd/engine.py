@@ -441,6 +441,12 @@ class Engine(object):
         if name not in self.OPTIONS:
             raise ValueError("unknown plan option %r (one of %s)" % (name, sorted(self.OPTIONS)))
         check(self.lib.oa_plan_set_option(self.plan, self.OPTIONS[name], int(value)))
+        # remembered: options belong to the plan, and Estimator.fork() builds new plans for the lanes of a multi-stream run
+        self._options = dict(getattr(self, "_options", {}), **{name: int(value)})
+
+    def copy_options_to(self, other):
+        for name, value in getattr(self, "_options", {}).items():
+            other.set_option(name, value)
 
     def release_pools(self):
         """free the plan-owned pools of the multi-map entries (oa_lens_maps, oa_qe_mv, oa_qe_tt_splits, oa_mc_run)"""

@@ -234,6 +234,7 @@ class Estimator(object):
         other._token = object()
         other.eng = Engine(self.eng.ny, self.eng.nx, self.prec)
         other.eng.set_laxes(*self.geom.laxes())
+        self.eng.copy_options_to(other.eng)      # plan options (Engine.set_option) follow the estimator onto its lanes' plans
         other._work = None
         other._rwork = None
         other._acc = None

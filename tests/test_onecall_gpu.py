@@ -504,3 +504,52 @@ def test_windowed_mc_fused_row_pass_equals_the_two_pass_flow(N, res, prec):
     tol = 1e-10 if prec == "f64" else 3e-5
     np.testing.assert_allclose(m1, m0, rtol=tol)
     assert np.abs(s1 - s0).max() < tol * np.abs(s0).max()
+
+def test_rebinding_filters_at_the_same_addresses_repacks_the_divergence_tables():
+    """the tile-major copies of Fnorm and of the bin ids that the fused divergence + binning launch reads were cached
+    by the planes' ADDRESSES.  A second estimator of the same shape built after the first was freed gets the same addresses from the
+    caching allocator (here forced: the new filters are written INTO the old planes and bound again), and the fused path then used the
+    previous estimator's normalisation.  The cache is keyed on a bind generation now: every oa_plan_set_filters / oa_plan_set_bins
+    repacks.  Fused (div_bin = 1) against the separate histogram (div_bin = 0) after the re-bind."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    N, res = 4096, 0.5
+    shape = (N, N)
+    g = FlatGeometry.from_res(shape, res)
+    th = cosmology.default_theory()
+    ml = g.modlmap()
+
+    def make(noise_uk):
+        return lensing.qest(shape, g, th, noise2d=np.full(shape, cosmology.white_noise_power(noise_uk)), beam2d=maps.gauss_beam(ml, 1.5),
+                            kmask=maps.mask_kspace(shape, g, lmin=300, lmax=2000), kmask_K=maps.mask_kspace(shape, g, lmin=20, lmax=3500),
+                            unlensed_equals_lensed=True, dtype="f32")
+    q = make(1.0)
+    e = q.eng
+    edges = torch.as_tensor(np.linspace(20, 3500, 20), device=e.device)
+    ids = e.modl_digitize(edges, half=True)
+    q.bind_bins(ids, 21, g.area / float(N * N) ** 2)
+    eb = q._bind_bins()
+    assert eb.lib.oa_plan_div_fused(eb.plan) == 1
+    m = e.irfft(e.grf_hc(9, 0), scale=1.0 / N)
+
+    def run():
+        acc = (torch.zeros(1, dtype=torch.int64, device=e.device), torch.zeros(19, dtype=torch.float64, device=e.device),
+               torch.zeros(19, 19, dtype=torch.float64, device=e.device))
+        q.tt_moments(m, *acc)
+        torch.cuda.synchronize()
+        return acc[1].cpu().numpy().copy()
+    first = run()
+    # a different estimator's filters, written into the SAME device planes and bound again (what a caching allocator produces when the
+    # first estimator is freed and a second one of the same shape is built)
+    q2 = make(6.0)
+    for a, b in zip(q._F["TT"], q2._F["TT"]):
+        a.copy_(b)
+    e._pipe_owner = None                                     # the host mirror re-binds (same pointers, new contents)
+    second = run()
+    assert np.abs(second / first - 1).max() > 1e-2          # the new noise level changes the normalisation
+    eb.set_option("div_bin", 0)
+    try:
+        sep = run()
+    finally:
+        eb.set_option("div_bin", 1)
+    np.testing.assert_allclose(second, sep, rtol=1e-12)
