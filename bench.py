@@ -436,15 +436,31 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(N_gpu, res_arcmin, reps=5):
-    """NumPy/SciPy oracle (float64, full-plane C2C like the reference) on a bounded sample, scaled N^2 log N."""
+class _Sections:
+    """wall time of every section of a bench run (reported as `sections_s`: what the driver's 10 minute limit is spent on)"""
+    def __init__(self):
+        self.t = {}
+        self._t0 = time.perf_counter()
+
+    def mark(self, name):
+        now = time.perf_counter()
+        self.t[name] = round(self.t.get(name, 0.0) + now - self._t0, 2)
+        self._t0 = now
+
+
+SECTIONS = _Sections()
+
+
+def cpu_baseline(N_gpu, res_arcmin, reps=3):
+    """NumPy/SciPy oracle (float64, full-plane C2C like the reference): on every host core AT THE WORKLOAD'S SIZE (no scaling: about
+    5 s per 8192^2 reconstruction on the GPU box's 256 cores), and on one core on a bounded 2048^2 sample scaled by N^2 log N."""
     from oracle import maps_oracle as mo
     from oracle import qe_oracle as qo
     from oracle import stats_oracle as so
     cores = os.cpu_count() or 1
     res = res_arcmin * np.pi / 180. / 60.
 
-    def one(Ns, workers):
+    def one(Ns, workers, reps=reps):
         mo.set_workers(workers)
         shape = (Ns, Ns)
         rng = np.random.default_rng(0)
@@ -469,15 +485,15 @@ def cpu_baseline(N_gpu, res_arcmin, reps=5):
         scale = (N_gpu / Ns) ** 2 * (np.log2(float(N_gpu)) / np.log2(float(Ns)))
         return {"sample_side": Ns, "median_s": float(np.median(ts)), "min_s": float(np.min(ts)), "runs": reps,
                 "scale_to_workload": scale, "reconstructions_per_s": 1.0 / (float(np.median(ts)) * scale)}
-    n_all = min(N_gpu, 4096 if cores >= 32 else 2048)
+    n_all = N_gpu if (cores >= 32 and N_gpu <= 8192) else min(N_gpu, 4096 if cores >= 32 else 2048)
     n_one = min(N_gpu, 2048 if cores >= 32 else 1024)
-    all_c = one(n_all, cores)
-    one_c = one(n_one, 1)
+    all_c = one(n_all, cores, 3)
+    one_c = one(n_one, 1, 2)
     import scipy
     return {"value": all_c["reconstructions_per_s"], "unit": "reconstructions/s", "cores": cores, "kind": "port",
             "sample": "oracle (float64 full-plane C2C) TT reconstruction + binned auto-power: %dx%d on %d scipy.fft workers, "
-                      "%dx%d on 1 worker; one warm-up then median of %d runs; scaled by N^2 log N to %dx%d"
-                      % (n_all, n_all, cores, n_one, n_one, reps, N_gpu, N_gpu),
+                      "%dx%d on 1 worker; one warm-up then the median of 3 / 2 runs; scaled by N^2 log N to %dx%d where the sample is smaller (scale %.2f / %.2f)"
+                      % (n_all, n_all, cores, n_one, n_one, N_gpu, N_gpu, all_c["scale_to_workload"], one_c["scale_to_workload"]),
             "workers_all": all_c, "workers_1": one_c, "value_workers_1": one_c["reconstructions_per_s"],
             "cpu_model": cpu_model(), "numpy": np.__version__, "scipy": scipy.__version__}
 
@@ -1043,7 +1059,9 @@ def main():
     other = {"auto": "f32" if args.prec == "f64" else "f64", "none": None}.get(args.also, args.also)
     if other == args.prec:
         other = None
+    SECTIONS.mark("startup")
     head = measure(args, torch, dist, world, rank, args.prec)
+    SECTIONS.mark("headline_" + args.prec)
     out = None
     if rank == 0:
         blk = block_of(args, head, world, dist)
@@ -1073,6 +1091,7 @@ def main():
                 extra["fullres_rows"] = leg
                 del Pf, Rf, perf
                 torch.cuda.empty_cache()
+                SECTIONS.mark("fullres_rows")
             if "dense" in want:
                 leg, _, _, _ = side_leg(torch, args, "dense", ref_p1d, seed, prune=False, tlmax=args.tlmax)
                 rd = leg["reconstructions_per_s"]
@@ -1087,7 +1106,7 @@ def main():
                 extra["dense"] = leg
                 hbm["dense_pipeline"] = {k: leg[k] for k in leg if k.startswith("pipeline_") or k == "pmc_bytes_per_recon"}
                 torch.cuda.empty_cache()
-                torch.cuda.empty_cache()
+                SECTIONS.mark("dense")
             if "wideband" in want and args.tlmax < 6000.0:
                 leg, p_w, Pw, Rw = side_leg(torch, args, "wideband", None, seed, tlmax=6000.0)
                 leg["active_columns"] = {"legs": Pw["q"].leg_cols or W, "kappa": Pw["q"].kappa_cols or W, "of": W}
@@ -1103,12 +1122,14 @@ def main():
                     leg["%s_reconstructions_per_s" % other] = leg2["reconstructions_per_s"]
                 extra["wideband"] = leg
                 torch.cuda.empty_cache()
+                SECTIONS.mark("wideband")
             if "lensed_loop" in want:
                 try:
                     extra["lensed_loop"] = lensed_loop_leg(torch, args)
                 except Exception as ex:      # a side leg never takes the headline down
                     extra["lensed_loop"] = {"error": repr(ex)}
                 torch.cuda.empty_cache()
+                SECTIONS.mark("lensed_loop")
             extra["kappa_out"] = blk.get("kappa_out")
             out["extra"] = extra
         out["hbm"] = hbm
@@ -1123,6 +1144,7 @@ def main():
                            "region of K steps, roofline and per-kernel table" % other
             out[other] = blk2
         release(sec, torch)
+        SECTIONS.mark("second_block_" + other)
     if rank == 0:
         if world == 1 and not args.no_extras and not args.no_prune:
             want = [w for w in args.extras.split(",") if w]
@@ -1135,10 +1157,13 @@ def main():
                     import gc
                     gc.collect()
                     torch.cuda.empty_cache()
+                    SECTIONS.mark(name)
             if other and other in out and "extra" in out:
                 out["extra"]["kappa_out_" + other] = out[other].get("kappa_out")
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(N, args.res)
+            SECTIONS.mark("cpu_baseline")
+        out["sections_s"] = SECTIONS.t
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

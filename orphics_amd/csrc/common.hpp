@@ -85,6 +85,8 @@ struct oa_plan {
     void* chirp_y; void* chirp_x;            // cx<T>[ny], cx<T>[nx]
     void* cz_bhat; void* cz_a; void* cz_f;   // cx<T>[My*Mx]: chirp-kernel transform, two work planes
     void* cz_full;                           // cx<T>[ny*nx]
+    bool mixed;                              // sides 2^a 3^b 5^c: mixed-radix transforms (mixed.hip) instead of the chirp-z path
+    void* mr_twx; void* mr_twxh; void* mr_twy;   // cx<T>[nx + 1], [nx / 2], [ny]
     void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
     void* rq8c[4];                           // per-thread constants of the fused row stage's grids of 1024, 1536, 2048, 4096 points (fft_rowqe8.hpp)
     void* tw_y_small[16];                    // COLUMN GRID: cx<T>[my] = W_my^k for my = 2^i (made on first use, kept: estimators
@@ -98,6 +100,12 @@ void czt_release(oa_plan* p);
 int czt_c2c(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st);
 int czt_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, hipStream_t st);
 int czt_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStream_t st);
+bool mixed_sides_ok(int ny, int nx);
+int mixed_setup(oa_plan* p);
+void mixed_release(oa_plan* p);
+int mixed_c2c(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st);
+int mixed_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, hipStream_t st);
+int mixed_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStream_t st);
 void pipeline_release(oa_plan* p);
 // fused estimator passes on the plan's compact work planes (fft.hip)
 long work_pitch(const oa_plan* p, int w);

@@ -106,15 +106,17 @@ template <class U> __device__ __forceinline__ U ldg(const U* p) {
 template <class U> inline U ldg(const U* p) { return *p; }
 #endif
 
-// Memory order of the last-workgroup TICKET of the fused binning tails (fft_divbin.hpp, bin.hip).  The hand-over is the write-through
-// form of /opt/skills/guides/MI355X_MICROARCH.md ("Valid forms"): every partial sum is stored with an agent-scope atomic store (sc1),
-// every storing wave waits for vmcnt(0), a workgroup barrier, ONE lane's agent-scope add; the workgroup whose add came last reads
-// the partials with agent-scope atomic loads (sc1) behind a barrier that lane joins -- so the add itself can stay relaxed.
-// -DOA_TICKET_ACQ_REL builds the release/acquire form for comparison (profiles/r05_ticket_order.txt: what the L2 write-back costs).
-#ifdef OA_TICKET_ACQ_REL
-#define OA_TICKET_ORDER __ATOMIC_ACQ_REL
-#else
+// Memory order of the last-workgroup TICKET of the fused binning tails (fft_divbin.hpp, bin.hip): acquire-release at agent scope.
+// The partial sums are stored with agent-scope atomic stores (write-through), every storing wave waits for vmcnt(0), the workgroup
+// meets at a barrier and ONE lane adds to the ticket: the release of that add (cumulative over the barrier) publishes the workgroup's
+// partials, the acquire of the add that came last -- followed by the barrier the other lanes of that workgroup join -- lets it read
+// everybody's (with agent-scope atomic loads).  Rounds 2-4 ran the add RELAXED, which is the write-through hand-over
+// /opt/skills/guides/MI355X_MICROARCH.md lists as valid by measurement ("not an architectural guarantee"); the fence costs 1.0 us per
+// float64 and 2.6 us per float32 reconstruction (profiles/r05_ticket_order.txt).  -DOA_TICKET_RELAXED: the old form, for A/B.
+#ifdef OA_TICKET_RELAXED
 #define OA_TICKET_ORDER __ATOMIC_RELAXED
+#else
+#define OA_TICKET_ORDER __ATOMIC_ACQ_REL
 #endif
 
 OA_HD int ilog2(int v) {

@@ -1049,7 +1049,8 @@ int oa_fft_pass(oa_plan* p, int pass_id, const void* in, void* out, int width, v
 int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int width, int rband, void* stream) {
     OA_REQUIRE(p && real_in && hc_out, "oa_fft_r2c: NULL argument");
     OA_REQUIRE(real_in != hc_out, "oa_fft_r2c: in-place not supported");
-    if (!p->pow2) return czt_r2c(p, real_in, hc_out, scale, (hipStream_t)stream);   // width / rband hints do not apply
+    if (p->mixed) return mixed_r2c(p, real_in, hc_out, scale, (hipStream_t)stream);     // width / rband hints do not apply
+    if (!p->pow2) return czt_r2c(p, real_in, hc_out, scale, (hipStream_t)stream);
     return p->dtype == OA_F32 ? r2c_impl<float>(p, real_in, hc_out, scale, width, rband, (hipStream_t)stream)
                               : r2c_impl<double>(p, real_in, hc_out, scale, width, rband, (hipStream_t)stream);
 }
@@ -1057,6 +1058,7 @@ int oa_fft_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, int 
 int oa_fft_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, int width, void* stream) {
     OA_REQUIRE(p && hc_in && real_out, "oa_fft_c2r: NULL argument");
     OA_REQUIRE(hc_in != real_out, "oa_fft_c2r: in-place not supported");
+    if (p->mixed) return mixed_c2r(p, hc_in, real_out, scale, (hipStream_t)stream);
     if (!p->pow2) return czt_c2r(p, hc_in, real_out, scale, (hipStream_t)stream);
     return p->dtype == OA_F32 ? c2r_impl<float>(p, hc_in, real_out, scale, width, (hipStream_t)stream)
                               : c2r_impl<double>(p, hc_in, real_out, scale, width, (hipStream_t)stream);
@@ -1073,6 +1075,7 @@ int oa_fft_c2r_windowed(oa_plan* p, const void* hc_in, void* real_out, double sc
 int oa_fft_c2c(oa_plan* p, const void* full_in, void* full_out, int inverse, double scale, void* stream) {
     OA_REQUIRE(p && full_in && full_out, "oa_fft_c2c: NULL argument");
     OA_REQUIRE(full_in != full_out, "oa_fft_c2c: in-place not supported");
+    if (p->mixed) return mixed_c2c(p, full_in, full_out, inverse, scale, (hipStream_t)stream);
     if (!p->pow2) return czt_c2c(p, full_in, full_out, inverse, scale, (hipStream_t)stream);
     return p->dtype == OA_F32 ? c2c_impl<float>(p, full_in, full_out, inverse, scale, (hipStream_t)stream)
                               : c2c_impl<double>(p, full_in, full_out, inverse, scale, (hipStream_t)stream);

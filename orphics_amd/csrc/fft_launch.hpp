@@ -9,6 +9,7 @@ namespace oa {
 struct GpuCtx {
     char* sm;
     OA_D int tid() const { return threadIdx.x; }
+    OA_D int nthreads() const { return blockDim.x; }
     OA_D int bid_x() const { return blockIdx.x; }
     OA_D int bid_y() const { return blockIdx.y; }
     OA_D int bid_z() const { return blockIdx.z; }

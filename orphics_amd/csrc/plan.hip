@@ -75,7 +75,8 @@ int oa_plan_create(int ny, int nx, int dtype, oa_plan** out) {
     p->ny = ny; p->nx = nx; p->logNy = ilog2(ny); p->logNx = ilog2(nx);
     p->dtype = dtype; p->kp = kpitch_for(nx); p->pow2 = pow2;
     if (hipGetDevice(&p->device) != hipSuccess) { delete p; return fail("hipGetDevice failed"); }
-    int rc = pow2 ? ((dtype == OA_F32) ? upload_tables<float>(p) : upload_tables<double>(p)) : czt_setup(p);
+    p->mixed = !pow2 && mixed_sides_ok(ny, nx);
+    int rc = pow2 ? ((dtype == OA_F32) ? upload_tables<float>(p) : upload_tables<double>(p)) : (p->mixed ? mixed_setup(p) : czt_setup(p));
     // scratch for every transform of a power-of-two plan (two hc planes >= one full complex plane) is taken HERE, so
     // that no stream-ordered entry point ever synchronises the device or frees memory (plan_ensure_scratch grows it
     // only for the chirp-z work planes, at set-up time)
@@ -90,6 +91,7 @@ int oa_plan_destroy(oa_plan* p) {
     (void)hipDeviceSynchronize();
     pipeline_release(p);
     czt_release(p);
+    mixed_release(p);
     if (p->tw_x) (void)hipFree(p->tw_x);
     if (p->tw_y) (void)hipFree(p->tw_y);
     for (void* t : p->rq8c) if (t) (void)hipFree(t);

@@ -552,14 +552,14 @@ class Estimator(object):
             self._P, self._ct = P, ct
         return self._P
 
-    def _real_of(self, U_herm, cache, key):
-        """irfft (f64 kernels) of a Hermitian half-plane host array, cached by description."""
-        torch = _torch()
+    def _real_of(self, build, cache, key):
+        """irfft (f64 kernels) of a Hermitian half-plane DEVICE array ``build()``, cached by description (the array is only built
+        when the description is new: most of the ~400 factors of a five-estimator set-up repeat)."""
         if key in cache:
             return cache[key]
         e = self.eng64
         k = e.hc()
-        k[:, :self.nxh + 1] = torch.as_tensor(np.ascontiguousarray(U_herm), dtype=e.cdt, device=e.device)
+        k[:, :self.nxh + 1] = build()
         r = e.irfft(k)
         cache[key] = r
         return r
@@ -567,32 +567,50 @@ class Estimator(object):
     def _sum_gf(self, gterms, fterms):
         """(1/Area) sum_l1 g(l1,l2) f(l1,l2) on the half plane via real-space products (f64 kernels).
         Every factor carries exactly two l-components in total, each written as (i l_j) so all planes are
-        Hermitian: conv = i^-2 DFT[u v]/a = -DFT[u v]/a; products accumulate per (j,k) class."""
+        Hermitian: conv = i^-2 DFT[u v]/a = -DFT[u v]/a; products accumulate per (j,k) class.
+        The factor planes (filter products x (i l_j) x cos / sin(m angle)) are formed ON THE DEVICE in complex128: in NumPy on the
+        host they were 150 of the 180 s of an 8192^2 five-estimator set-up (tools/profile_setup.py)."""
         torch = _torch()
         e = self.eng64
+        dev = e.device
         P = self._planes()
         lyd, lxd = self.ly.copy(), self.lxh.copy()
         lyd[e.ny // 2] = 0.0
         if self.nxh < lxd.size:
             lxd[self.nxh] = 0.0
-        comp = (lxd[None, :] * np.ones((e.ny, 1)), lyd[:, None] * np.ones((1, self.nxh + 1)))
-        cache = {}
+        # i l_x, i l_y as complex device planes (broadcast views)
+        comp = (1j * torch.as_tensor(lxd, dtype=torch.float64, device=dev)[None, :],
+                1j * torch.as_tensor(lyd, dtype=torch.float64, device=dev)[:, None])
+        ang = torch.as_tensor(self.ang_h, dtype=torch.float64, device=dev) if hasattr(self, "ang_h") else None
+        cache, dplane, dprod, dtrig = {}, {}, {}, {}
         S = {"xx": None, "yy": None, "xy": None}
-
-        def plane(name_or_arr):
-            return P[name_or_arr] if isinstance(name_or_arr, str) else name_or_arr
 
         def tag(x):
             return x if isinstance(x, str) else ("arr", id(x))
 
+        def plane(x):                                   # host plane (by name or array) -> float64 device plane, once per call
+            t = tag(x)
+            if t not in dplane:
+                dplane[t] = torch.as_tensor(np.ascontiguousarray(P[x] if isinstance(x, str) else x), dtype=torch.float64, device=dev)
+            return dplane[t]
+
+        def prod(a, b):
+            t = (tag(a), tag(b))
+            if t not in dprod:
+                dprod[t] = plane(a) * plane(b)
+            return dprod[t]
+
+        def trig(kind, mh):
+            if (kind, mh) not in dtrig:
+                dtrig[(kind, mh)] = torch.cos(mh * ang) if kind == "c" else torch.sin(mh * ang)
+            return dtrig[(kind, mh)]
+
         def add(cls, coef, u, v):
-            prod = e.mul_real(u, v)
-            S[cls] = e.axpby(prod, prod, coef, 0.0) if S[cls] is None else e.axpby(S[cls], prod, 1.0, coef)
+            pr = e.mul_real(u, v)
+            S[cls] = e.axpby(pr, pr, coef, 0.0) if S[cls] is None else e.axpby(S[cls], pr, 1.0, coef)
 
         for (cg, p, Ag, Bg, tg) in gterms:
             for (cf, q, Af, Bf, tf) in fterms:
-                A = plane(Ag) * plane(Af)
-                B = plane(Bg) * plane(Bf)
                 kA, kB = (tag(Ag), tag(Af)), (tag(Bg), tag(Bf))
                 for (ct_, mh, kind) in self._trig_product(tg, tf):
                     for j in range(2):
@@ -602,28 +620,31 @@ class Estimator(object):
                             (fu if p == 1 else fv).append(j)
                             (fu if q == 1 else fv).append(k)
 
-                            def build(base, comps, trig, which):
-                                arr = base.astype(np.complex128)
-                                for cidx in comps:
-                                    arr = arr * (1j * comp[cidx])
-                                if trig is not None:
-                                    arr = arr * (np.cos(mh * self.ang_h) if trig == "c" else np.sin(mh * self.ang_h))
-                                return arr
+                            def build(x, y, comps, tr):
+                                def go():
+                                    arr = prod(x, y).to(torch.complex128)
+                                    for cidx in comps:
+                                        arr = arr * comp[cidx]
+                                    if tr is not None:
+                                        arr = arr * trig(tr, mh)
+                                    return arr
+                                return go
 
                             coef = -cg * cf * ct_   # i^-2
                             if kind == "1":
-                                u = self._real_of(build(A, fu, None, 0), cache, (kA, tuple(fu), None, 0))
-                                v = self._real_of(build(B, fv, None, 1), cache, (kB, tuple(fv), None, 0))
+                                u = self._real_of(build(Ag, Af, fu, None), cache, (kA, tuple(fu), None, 0))
+                                v = self._real_of(build(Bg, Bf, fv, None), cache, (kB, tuple(fv), None, 0))
                                 add(cls, coef, u, v)
                             else:
-                                uc = self._real_of(build(A, fu, "c", 0), cache, (kA, tuple(fu), "c", mh))
-                                us = self._real_of(build(A, fu, "s", 0), cache, (kA, tuple(fu), "s", mh))
-                                vc = self._real_of(build(B, fv, "c", 1), cache, (kB, tuple(fv), "c", mh))
-                                vs = self._real_of(build(B, fv, "s", 1), cache, (kB, tuple(fv), "s", mh))
+                                uc = self._real_of(build(Ag, Af, fu, "c"), cache, (kA, tuple(fu), "c", mh))
+                                us = self._real_of(build(Ag, Af, fu, "s"), cache, (kA, tuple(fu), "s", mh))
+                                vc = self._real_of(build(Bg, Bf, fv, "c"), cache, (kB, tuple(fv), "c", mh))
+                                vs = self._real_of(build(Bg, Bf, fv, "s"), cache, (kB, tuple(fv), "s", mh))
                                 if kind == "cos":      # cos(m(a2-a1)) = c1 c2 + s1 s2
                                     add(cls, coef, uc, vc); add(cls, coef, us, vs)
                                 else:                  # sin(m(a2-a1)) = s2 c1 - c2 s1
                                     add(cls, coef, uc, vs); add(cls, -coef, us, vc)
+        del dplane, dprod, dtrig
         zero = torch.zeros((e.ny, e.nx), dtype=e.rdt, device=e.device)
         A_, B_, C_ = [e.rfft(S[c] if S[c] is not None else zero) for c in ("xx", "yy", "xy")]
         C2 = e.hc()
@@ -1303,10 +1324,11 @@ class NlGenerator(object):
         for j in range(2):
             for k in range(j, 2):
                 mult = 1.0 if j == k else 2.0
-                v = q._real_of(-comp[j] * comp[k] * clpp_h + 0j, cache, ("v", j, k))       # (i l_j)(i l_k) C^pp
+                dev_c128 = lambda a: _torch().as_tensor(np.ascontiguousarray(a + 0j), dtype=e.cdt, device=e.device)     # noqa: E731
+                v = q._real_of(lambda: dev_c128(-comp[j] * comp[k] * clpp_h), cache, ("v", j, k))       # (i l_j)(i l_k) C^pp
                 for key, trig in (("1", None), ("c", np.cos(2 * ang)), ("s", np.sin(2 * ang))):
                     base = -comp[j] * comp[k] * clee_h * (1.0 if trig is None else trig)
-                    u = q._real_of(base + 0j, cache, ("u", j, k, key))
+                    u = q._real_of(lambda: dev_c128(base), cache, ("u", j, k, key))
                     prod = e.mul_real(u, v)
                     acc[key] = e.axpby(prod, prod, mult, 0.0) if acc[key] is None else e.axpby(acc[key], prod, 1.0, mult)
         out = {}

@@ -10,11 +10,13 @@
 #include "../../orphics_amd/csrc/fft_plan.hpp"
 #include "../../orphics_amd/csrc/fft_r2c_w64.hpp"
 #include "../../orphics_amd/csrc/fft_r2c_rs4096.hpp"
+#include "../../orphics_amd/csrc/fft_mixed.hpp"
 
 using namespace oa;
 
 struct EmuCtx {
-    int tid_, bx_, by_, bz_, gx_ = 1;
+    int tid_, bx_, by_, bz_, gx_ = 1, nt_ = 0;
+    int nthreads() const { return nt_; }
     std::barrier<>* bar;
     char* sm;
     int tid() const { return tid_; }
@@ -41,7 +43,7 @@ struct EmuLauncher {
                 for (int bz = 0; bz < gz; ++bz)
                   for (int by = 0; by < gy; ++by)
                     for (int bx = 0; bx < gx; ++bx) {
-                        EmuCtx c{t, bx, by, bz, gx, &bar, sm.data()};
+                        EmuCtx c{t, bx, by, bz, gx, nt, &bar, sm.data()};
                         body(c);
                         bar.arrive_and_wait();
                     }
@@ -361,7 +363,43 @@ static int do_lens_derivs(int ny, int nx, const cx<T>* k0, const T* lxd, const T
     }
     return 0;
 }
+// ---- mixed-radix passes (fft_mixed.hpp): sides 2^a 3^b 5^c.  what = 0: r2c (real (ny, nx) -> hc (ny, nx/2 + 1), contiguous),
+// 1: c2r (the inverse, unnormalised), 2 / 3: c2c forward / inverse on a full (ny, nx) complex plane
+template <typename T>
+static int do_mixed(int ny, int nx, int what, const void* in, void* out) {
+    if (!mixed_ok(ny) || !mixed_ok(nx) || !mixed_ok(nx / 2) || (nx & 1)) return 1;
+    auto tab = [](int N, int extra) {
+        std::vector<cx<T>> t((size_t)N + extra);
+        const long double tau = 6.283185307179586476925286766559005768L;
+        for (int k = 0; k < N + extra; ++k) { const long double x = tau * k / (long double)N; t[(size_t)k] = mk<T>((T)cosl(x), (T)(-sinl(x))); }
+        return t;
+    };
+    const auto twx = tab(nx, 1), twxh = tab(nx / 2, 0), twy = tab(ny, 0);
+    const long kp = nx / 2 + 1;
+    EmuLauncher q;
+    auto rows = [&](int mode, const void* i, long ip, void* o, long op, int N, const cx<T>* tw) {
+        MrRowArgs<T> a{};
+        a.in = i; a.out = o; a.in_pitch = ip; a.out_pitch = op; a.N = N; a.f = mixed_factor(N); a.tw = tw; a.tw2 = twx.data(); a.scale = (T)1; a.mode = mode;
+        q.run(ny, 1, 64, 2 * ((size_t)N + 1) * sizeof(cx<T>), [&](EmuCtx& c) { mr_row_body<T>(c, a); });
+    };
+    auto cols = [&](const cx<T>* i, long ip, cx<T>* o, long op, int width, bool inv) {
+        MrColArgs<T> a{};
+        a.in = i; a.out = o; a.in_pitch = ip; a.out_pitch = op; a.N = ny; a.width = width; a.logC = 2; a.f = mixed_factor(ny); a.tw = twy.data(); a.scale = (T)1;
+        a.inverse = inv ? 1 : 0;
+        q.run((width + 3) / 4, 1, 64, 2 * ((size_t)ny << 2) * sizeof(cx<T>), [&](EmuCtx& c) { mr_col_body<T>(c, a); });
+    };
+    if (what == 0) { rows(MR_R2C, in, nx, out, kp, nx / 2, twxh.data()); cols((const cx<T>*)out, kp, (cx<T>*)out, kp, (int)kp, false); }
+    else if (what == 1) {
+        std::vector<cx<T>> tmp((size_t)ny * kp);
+        cols((const cx<T>*)in, kp, tmp.data(), kp, (int)kp, true);
+        rows(MR_C2R, tmp.data(), kp, out, nx, nx / 2, twxh.data());
+    } else { rows(what == 3 ? MR_C2C_I : MR_C2C_F, in, nx, out, nx, nx, twx.data()); cols((const cx<T>*)out, nx, (cx<T>*)out, nx, nx, what == 3); }
+    return 0;
+}
+
 extern "C" {
+int emu_mixed_f64(int ny, int nx, int what, const void* in, void* out) { return do_mixed<double>(ny, nx, what, in, out); }
+int emu_mixed_f32(int ny, int nx, int what, const void* in, void* out) { return do_mixed<float>(ny, nx, what, in, out); }
 int emu_lens_derivs_f64(int ny, int nx, const void* k0, const double* lxd, const double* lyd, double* out, int nd, int separable) { return do_lens_derivs<double>(ny, nx, (const cx<double>*)k0, lxd, lyd, out, nd, separable); }
 int emu_rows_win_f64(int ny, int nx, const void* in, const double* w, void* out, long opitch, double s, int wcols) { return do_rows_win<double>(ny, nx, (const cx<double>*)in, w, (cx<double>*)out, opitch, s, wcols); }
 int emu_rows_win_f32(int ny, int nx, const void* in, const float* w, void* out, long opitch, double s, int wcols) { return do_rows_win<float>(ny, nx, (const cx<float>*)in, w, (cx<float>*)out, opitch, s, wcols); }

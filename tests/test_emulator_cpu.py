@@ -18,7 +18,7 @@ def emu():
     so = os.path.join(EMUL, "libemul_fft.so")
     src = os.path.join(EMUL, "emul_fft.cpp")
     csrc = os.path.join(HERE, "..", "orphics_amd", "csrc")
-    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "fft_rowqe8.hpp", "cx.hpp")]
+    hdrs = [os.path.join(csrc, h) for h in ("fft_kernels.hpp", "fft_plan.hpp", "fft_r2c_w64.hpp", "fft_r2c_rs4096.hpp", "fft_fband.hpp", "fft_rowqe8.hpp", "fft_mixed.hpp", "cx.hpp")]
     if (not os.path.exists(so)) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++20", "-fPIC", "-shared", "-pthread", "-o", so, src])
     lib = ctypes.CDLL(so)
@@ -790,4 +790,40 @@ def test_c2r_drops_the_non_hermitian_part_of_the_self_conjugate_columns(emu):
     back = np.fft.rfft2(out)
     herm0 = 0.5 * (hc[:, 0] + np.conj(hc[(-np.arange(ny)) % ny, 0]))
     assert np.abs(back[:, 0] - herm0).max() < 1e-12 * np.abs(herm0).max()      # kx = 0 holds ITS OWN Hermitian part only
+
+
+@pytest.mark.parametrize("ny,nx", [(12, 20), (30, 50), (60, 36), (40, 600), (150, 24), (16, 1200), (90, 120)])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_mixed_radix_passes_match_numpy(emu, ny, nx, prec):
+    """fft_mixed.hpp (sides 2^a 3^b 5^c that are not powers of two -- the reference notebooks' 600 / 1200 / 2400-pixel patches): the
+    radix-2/3/4/5 Stockham stages, the packed real-row transform with its (un)tangle and the column tiles, against numpy.fft."""
+    rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
+    fn = emu.emu_mixed_f64 if prec == "f64" else emu.emu_mixed_f32
+    rng = np.random.default_rng(ny * 131 + nx)
+    x = rng.standard_normal((ny, nx)).astype(rdt)
+    k = np.zeros((ny, nx // 2 + 1), dtype=cdt)
+    assert fn(ny, nx, 0, _p(x), _p(k)) == 0
+    ref = np.fft.rfft2(x.astype(np.float64))
+    assert np.abs(k - ref).max() < tol * np.abs(ref).max() * np.log2(ny * nx)
+    back = np.zeros((ny, nx), dtype=rdt)
+    kin = np.ascontiguousarray(ref.astype(cdt))
+    kin[:, 0] += 0.5j * rng.standard_normal(ny).astype(rdt)          # a non-Hermitian k_x = 0 column: its imaginary part is dropped, as ifft(...).real drops it
+    assert fn(ny, nx, 1, _p(kin), _p(back)) == 0
+    full = np.zeros((ny, nx), dtype=np.complex128)
+    full[:, :nx // 2 + 1] = kin
+    full[:, nx // 2 + 1:] = np.conj(np.roll(kin[::-1], 1, axis=0)[:, 1:nx // 2][:, ::-1])
+    want = np.fft.ifft2(full).real * ny * nx
+    # (the packed C2R keeps the Hermitian part of the self-conjugate columns only: compare with the same symmetrisation)
+    sym = full.copy()
+    for c in (0, nx // 2):
+        col = full[:, c]
+        sym[:, c] = 0.5 * (col + np.conj(np.roll(col[::-1], 1)))
+    want = np.fft.ifft2(sym).real * ny * nx
+    assert np.abs(back - want).max() < tol * np.abs(want).max() * np.log2(ny * nx)
+    z = (rng.standard_normal((ny, nx)) + 1j * rng.standard_normal((ny, nx))).astype(cdt)
+    o = np.zeros_like(z)
+    assert fn(ny, nx, 2, _p(z), _p(o)) == 0
+    assert np.abs(o - np.fft.fft2(z.astype(np.complex128))).max() < tol * np.abs(o).max() * np.log2(ny * nx)
+    assert fn(ny, nx, 3, _p(z), _p(o)) == 0
+    assert np.abs(o - np.fft.ifft2(z.astype(np.complex128)) * ny * nx).max() < tol * np.abs(o).max() * np.log2(ny * nx)
 

@@ -284,9 +284,10 @@ def test_error_behaviour_is_loud():
         e2.qe_legs(e2.hc(), e2.hc(), e2.hcreal(), e2.hcreal())
 
 
-@pytest.mark.parametrize("ny,nx", [(96, 160), (600, 750), (250, 36)])
-def test_non_power_of_two_sides_chirp_z(ny, nx):
-    """Even sides that are not powers of two (reference notebooks: 600, 750, 2400) go through the chirp-z path:
+@pytest.mark.parametrize("ny,nx", [(96, 160), (600, 750), (250, 36), (1200, 1200), (112, 154), (66, 98)])
+def test_non_power_of_two_sides(ny, nx):
+    """Even sides that are not powers of two: 2^a 3^b 5^c (the reference notebooks' 600, 750, 1200, 2400) are mixed-radix transforms
+    (csrc/fft_mixed.hpp), sides with another prime factor (112 = 2^4 7, 154 = 2 7 11, 66, 98) the chirp-z path (csrc/czt.hip):
     rfft / irfft / cfft equal NumPy; the fused estimator entry points refuse loudly."""
     from orphics_amd.engine import Engine
     from orphics_amd._lib import OrphicsAmdError

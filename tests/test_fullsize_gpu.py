@@ -1,5 +1,7 @@
 """GPU, BASELINE.json full sizes: size-independent properties (round trips, Parseval, linearity, checksums of
 the bit-exact bin ids, f32-vs-f64 agreement) where the NumPy oracle would take minutes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -232,31 +234,44 @@ def _pol_inputs(N, res, th, beam_h, noise_T, seed=21):
     return out
 
 
+_POL_CACHE = {}
+
+
+def _pol_qest(N, res=0.5):
+    """The five-estimator float64 set-up at (N, N) 0.5' with the reference's band limits -- filters, A_L of TT, TE, EE, EB, TB, MV
+    weights: by far the longest part of the two config-3 tests at 8192^2 (minutes of host-side NumPy on 67 M-mode planes), built ONCE
+    for both."""
+    from orphics_amd import cosmology, lensing, maps
+    from orphics_amd.geometry import FlatGeometry
+    if N not in _POL_CACHE:
+        shape = (N, N)
+        g = FlatGeometry.from_res(shape, res)
+        th = cosmology.default_theory()
+        beam = maps.gauss_beam(g.modlmap(), 1.5)
+        nT = cosmology.white_noise_power(1.0)
+        noise = np.full(shape, nT)
+        tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
+        kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+        q64 = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, noise2d_P=2 * noise, kmask_P=tmask, kmask_K=kmask,
+                           pol=True, unlensed_equals_lensed=True, dtype="f64")
+        _POL_CACHE.clear()                   # (one size at a time: the 8192^2 set-up holds gigabytes of filter planes)
+        _POL_CACHE[N] = dict(q=q64, g=g, th=th, beam=beam, nT=nT, noise=noise, tmask=tmask, kmask=kmask)
+    return _POL_CACHE[N]
+
+
 @pytest.mark.parametrize("N", [2048, 8192])
 def test_config3_mv_f32_vs_f64_and_fused_vs_modular(N):
     """BASELINE config 3: minimum-variance combination of TT, TE, EE, EB, TB on 0.5' maps (8192^2 = the configured
     size).  f32 kernels vs f64 kernels on the kappa bandpowers (< 1e-5, the north-star tolerance), every single
     estimator's bandpowers likewise, and -- at the smaller size -- the fused one-call path vs the modular chain of
     public calls (3 C2R, 2 products, 2 R2C per piece)."""
-    from orphics_amd import cosmology, lensing, maps
-    from orphics_amd.geometry import FlatGeometry
     res = 0.5
-    shape = (N, N)
-    g = FlatGeometry.from_res(shape, res)
-    th = cosmology.default_theory()
-    ml = g.modlmap()
-    beam = maps.gauss_beam(ml, 1.5)
-    nT = cosmology.white_noise_power(1.0)
-    noise = np.full(shape, nT)
-    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
-    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
-    del ml
+    c = _pol_qest(N, res)
+    g, th, beam, nT, q64 = c["g"], c["th"], c["beam"], c["nT"], c["q"]
     k64 = _pol_inputs(N, res, th, beam[:, :N // 2 + 1], nT)
     edges = np.linspace(20, 3500, 20)
     ests = ("TT", "TE", "EE", "EB", "TB")
     res_p = {}
-    q64 = lensing.qest(shape, g, th, noise2d=noise, beam2d=beam, kmask=tmask, noise2d_P=2 * noise, kmask_P=tmask, kmask_K=kmask,
-                       pol=True, unlensed_equals_lensed=True, dtype="f64")
     for prec in ("f64", "f32"):
         q = q64.astype(prec)             # one set-up (f64 kernels), two sets of per-map kernels
         e = q.eng
@@ -407,24 +422,17 @@ def test_config3_mv_8192_f64_matches_numpy_oracle_per_map_arithmetic():
     estimator, combined with the device estimator's per-mode weight x normalisation planes (geometry-generic float64 FFT
     convolutions, pinned against the oracle's A_L / N_L at 128..2048^2 in test_lensing_gpu.py): kappa bandpowers within 1e-9,
     per estimator and for the MV sum."""
-    from orphics_amd import cosmology, lensing, maps
-    from orphics_amd.geometry import FlatGeometry
     from oracle import maps_oracle as mo
     from oracle import qe_oracle as qo
     from oracle import stats_oracle as so
     N, res = 8192, 0.5
     shape = (N, N)
-    g = FlatGeometry.from_res(shape, res)
-    th = cosmology.default_theory()
-    ml = g.modlmap()
-    beam = maps.gauss_beam(ml, 1.5)
-    nT = np.full(shape, cosmology.white_noise_power(1.0))
+    c = _pol_qest(N, res)                  # (shared with test_config3_mv_f32_vs_f64_and_fused_vs_modular[8192])
+    g, th, beam, tmask, kmask, q = c["g"], c["th"], c["beam"], c["tmask"], c["kmask"], c["q"]
+    nT = c["noise"]
     nP = 2 * nT
-    tmask = maps.mask_kspace(shape, g, lmin=300, lmax=2000)
-    kmask = maps.mask_kspace(shape, g, lmin=20, lmax=3500)
+    ml = g.modlmap()
     ests = ("TT", "TE", "EE", "EB", "TB")
-    q = lensing.qest(shape, g, th, noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask, pol=True,
-                     unlensed_equals_lensed=True, dtype="f64")
     e = q.eng
     k64 = _pol_inputs(N, res, th, beam[:, :N // 2 + 1], float(nT[0, 0]))
     kmv = q.reconstruct_mv_hc(*k64, estimators=ests).clone()
@@ -443,9 +451,10 @@ def test_config3_mv_8192_f64_matches_numpy_oracle_per_map_arithmetic():
     fn_mv = {XY: _full_from_half(-(L * (L + 1.) / 2.) * q.AL[XY] * q.mask_K * w[XY], N) for XY in ests}
     fn_one = {XY: _full_from_half(-(L * (L + 1.) / 2.) * q.AL[XY] * q.mask_K, N) for XY in ("TE", "EB")}
     kfull = {X: e.hc_to_full(k64[i]).cpu().numpy() for i, X in enumerate("TEB")}
-    del kmv, kone, k64, q
+    del kmv, kone, k64, q, c
+    _POL_CACHE.clear()
     torch.cuda.empty_cache()
-    mo.set_workers(16)
+    mo.set_workers(min(64, os.cpu_count() or 16))
     try:
         cl = {k: th.lCl(k, ml) for k in ("TT", "EE", "BB", "TE")}
         qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)

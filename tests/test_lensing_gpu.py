@@ -936,7 +936,7 @@ def test_reconstruct_from_map_fused_forward_legs(N, res):
 
 
 def test_tt_estimator_on_non_power_of_two_map():
-    """A 480 x 600 patch (chirp-z FFTs, modular estimator chain): kappa bandpowers == NumPy oracle."""
+    """A 480 x 600 patch (mixed-radix FFTs, modular estimator chain): kappa bandpowers == NumPy oracle."""
     from orphics_amd import cosmology, lensing, maps, stats
     from orphics_amd.geometry import FlatGeometry
     from oracle import maps_oracle as mo
@@ -967,7 +967,8 @@ def test_tt_estimator_on_non_power_of_two_map():
 @pytest.mark.parametrize("XY", ["EB", "TE", "EE"])
 def test_pol_estimators_on_non_power_of_two_map(XY):
     """The reference's verification notebook runs pol=True estimators on a 1200 x 1200 patch: on sides that are
-    not powers of two the general estimators go through the modular chain (chirp-z FFTs) and match the oracle."""
+    not powers of two the general estimators go through the modular chain (mixed-radix FFTs; the patch itself:
+    test_notebook_patch_1200_estimators_match_oracle) and match the oracle."""
     from orphics_amd import lensing
     shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup((96, 160), 2.0, seed=5)
     qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)
@@ -980,6 +981,32 @@ def test_pol_estimators_on_non_power_of_two_map(XY):
     sel = (ml > 40) & (ml < 2900) & (qr.R[XY] != 0)
     assert np.max(np.abs(q.N_kappa(XY)[sel] / qr.Nlkk[XY][sel] - 1)) < 1e-7
     assert np.abs(got - kref)[sel].max() / np.abs(kref[sel]).max() < 1e-8
+
+
+@pytest.mark.parametrize("XY", ["TT", "EB"])
+def test_notebook_patch_1200_estimators_match_oracle(XY):
+    """The reference's verification loop runs on a 10 degree patch at 0.5' = 1200 x 1200 pixels (tutorials/tt_verification.ipynb
+    cells 1-4): 1200 = 2^4 3 5^2, so every transform of the modular estimator chain is a mixed-radix transform (csrc/fft_mixed.hpp;
+    until round 4: a chirp-z convolution on an inner 4096^2 plan).  qest.kappa_from_map("TT" / "EB") against oracle.QEOracle, float64
+    1e-8 on the DFT of kappa_hat, float32 1e-5 on its bandpowers."""
+    from orphics_amd import lensing, maps, stats
+    shape, g, th, ml, beam, nT, nP, tmask, kmask, cl, k = pol_setup(1200, 0.5, seed=11)
+    qr = qo.QEOracle(shape, g.step_y, g.step_x, cl, dict(T=nT, P=nP), beam, dict(T=tmask, P=tmask), kmask_K=kmask)
+    qr.setup(XY)
+    kref = qr.kappa_ft(XY, k[XY[0]], k[XY[1]])
+    kw = dict(noise2d=nT, beam2d=beam, kmask=tmask, noise2d_P=nP, kmask_P=tmask, kmask_K=kmask, pol=True, unlensed_equals_lensed=True)
+    args = dict(T2DData=k["T"], E2DData=k["E"], B2DData=k["B"], alreadyFTed=True, returnFt=True)
+    q = lensing.qest(shape, g, th, dtype="f64", **kw)
+    assert not q.eng.pow2
+    got = q.kappa_from_map(XY, **args)
+    sel = (ml > 40) & (ml < 2900) & (qr.R[XY] != 0)
+    assert np.abs(got - kref)[sel].max() / np.abs(kref[sel]).max() < 1e-8
+    edges = np.linspace(20, 3000, 20)
+    binner = stats.bin2D(ml, edges)
+    ref_b = binner.bin(np.abs(kref) ** 2)[1]
+    got32 = q.astype("f32").kappa_from_map(XY, **args)
+    b32 = binner.bin(np.abs(np.asarray(got32, dtype=np.complex128)) ** 2)[1]
+    assert np.max(np.abs(b32 / ref_b - 1)) < 1e-5
 
 
 @pytest.mark.parametrize("ny,nx", [(512, 2048), (2048, 512), (1024, 4096)])
