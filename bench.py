@@ -302,6 +302,8 @@ def row_qe_flops(N, win, wout, mrow=0):
         M = 64
         while M < 2 * win + wout and M < N:
             M *= 2
+        if 1024 < 2 * win + wout <= 1536 and win <= 512 and N >= 2048:
+            M = 1536
     elif mrow > 0:
         M = mrow
     L = M // 2
@@ -927,7 +929,8 @@ def measure(args, torch, dist, world, rank, prec):
                                          "row_r2c_w64x2_kernel" if (w64 and N == 16384 and wl_ <= 768) else "row_fft_kernel<%s, R2C>" % tn)
     roofline["active_columns"] = {"legs": G["wl"] or W, "kappa": G["wk"] or W, "of": W}
     roofline["row_grid"] = {"points": G["mrow"], "of": N, "note": "band-limited legs: the real-space products are formed on the smallest "
-                            "alias-free power-of-two row grid >= 2 leg_cols + kappa_cols (exact; include/orphics_amd.h ROW GRID)"}
+                            "alias-free row grid >= 2 leg_cols + kappa_cols the row stage is built for -- 1024, 1536 (= 3 x 512), 2048, 4096, 8192 "
+                            "points (exact; include/orphics_amd.h ROW GRID)"}
     roofline["col_grid"] = {"rows": G["mcol"] or N, "of": N, "note": "the same argument along y: inverse column transforms of the legs, row stage "
                             "and forward column transforms of the products run on the smallest alias-free power-of-two number of rows "
                             ">= max(2 leg_rows + kappa_rows, 2 kappa_rows) (exact; include/orphics_amd.h COLUMN GRID); extra.fullres_rows "

@@ -108,10 +108,12 @@ int oa_fft_cols(oa_plan* p, const void* hc_in, void* hc_out, int inverse, double
  * the existing px, py (estimators whose weight is a sum of separable terms: cos/sin spin-2 pieces;
  * `scale` carries the sign).
  * ROW GRID (`mrow`): legs that vanish beyond column `win` have real-space products band-limited to 2 (win - 1), so
- * the row transforms may run on any grid of mrow >= 2 win + wout points (power of two <= nx): no aliased product
- * frequency reaches the kept columns k < wout, which therefore equal the full-length result (the grid-size factor
- * is folded into the scale; rounding differs at the 1e-7 level in f32).  The real-space planes live in LDS only.
- * mrow = 0: full length nx;  mrow < 0: the smallest alias-free power of two;  otherwise checked against the bound. */
+ * the row transforms may run on any grid of mrow >= 2 win + wout points (a power of two <= nx, or 1536 = 3 x 512 when
+ * win <= 512 and nx >= 2048): no aliased product frequency reaches the kept columns k < wout, which therefore equal the
+ * full-length result (the grid-size factor is folded into the scale; rounding differs at the 1e-7 level in f32).  The
+ * real-space planes live in LDS only.
+ * mrow = 0: full length nx;  mrow < 0: the smallest alias-free grid of 1024, 1536, 2048, 4096, 8192, ... points;  otherwise
+ * checked against the bound. */
 int oa_qe_rows(oa_plan* p, const void* gx, const void* gy, const void* h, void* px, void* py, double scale,
                int accumulate, int win, int wout, int mrow, void* stream);
 

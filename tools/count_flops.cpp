@@ -83,6 +83,7 @@ struct EmuCtx {
     int bid_y() const { return 0; }
     int bid_z() const { return 0; }
     void sync() const { bar->arrive_and_wait(); }
+    void wsync() const { bar->arrive_and_wait(); }
     void* smem() const { return sm; }
 };
 
@@ -92,6 +93,26 @@ struct CountLauncher {
     int nz_used = -1;
     int rows_per_wg = 1;
     void fail_rlayout() {}
+    // eight points per thread (fft_rowqe8.hpp): ONE workgroup = one row pair
+    template <typename T> void row_qe_pair8(int pairs, int M, const RowQeArgs<T>& a) {
+        rows_per_wg = 2;
+        dispatch_rq8(M, a.win, a.lr, a.chain != nullptr, [&](auto ac, auto nzc, auto lay, auto ch) {
+            constexpr int A = decltype(ac)::value;
+            nz_used = decltype(nzc)::value;
+            const int nt = 64 * A;
+            std::vector<char> sm(rq8_lds_bytes<T, A, decltype(ch)::value>() + 64);
+            std::barrier<> bar(nt);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t)
+                th.emplace_back([&, t]() {
+                    t_flops = 0;
+                    EmuCtx c{t, 0, &bar, sm.data()};
+                    row_qe8_body<T, A, decltype(nzc)::value, decltype(lay)::value, decltype(ch)::value>(c, a);
+                    g_flops += t_flops;
+                });
+            for (auto& x : th) x.join();
+        });
+    }
     template <typename T> void row_qe_pair(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
         rows_per_wg = 2;
         dispatch_seq(a.logL, [&](auto seq) {
@@ -152,13 +173,23 @@ int main(int argc, char** argv) {
     std::vector<cx<CF>> twx((size_t)N);
     for (int i = 0; i < N; ++i) twx[i] = mk<CF>(CF::run(tw[i].x), CF::run(tw[i].y));
     p.ny = N; p.nx = N; p.logNy = ilog2(N); p.logNx = ilog2(N); p.kp = kpitch_for(N); p.tw_x = twx.data(); p.tw_y = twx.data();
+    // per-thread constants of the 8-point row stage's grids, as run-time (non-foldable) values
+    std::vector<cx<CF>> rq8t[4];
+    const int waves[4] = {2, 3, 4, 8};
+    for (int i = 0; i < 4; ++i)
+        if (512 * waves[i] <= N) {
+            const auto tf = rq8_make_consts<float>(waves[i]);
+            rq8t[i].resize(tf.size());
+            for (size_t k = 0; k < tf.size(); ++k) rq8t[i][k] = mk<CF>(CF::run(tf[k].x), CF::run(tf[k].y));
+            p.rq8c[i] = rq8t[i].data();
+        }
     if (mrow < 0) {
         mrow = Fft2dPlan<CF>::row_grid_min(N, p.clampw(win), p.clampw(wout));
         if (2L * p.clampw(win) + p.clampw(wout) > mrow) mrow = 0;
     }
     if (mrow > N) mrow = N;
     const int grid = mrow == 0 ? N : mrow;
-    const int L = grid / 2;
+    const int L = grid / 2;         // (nominal count below: packed transforms of L points; the 1536 grid has no power-of-two L -- the ratio is informative only)
     int C = 4096 / L; if (C < 2) C = 2;
     const size_t rows = (size_t)C;
     std::vector<cx<CF>> gx(rows * p.kp), gy(rows * p.kp), h(rows * p.kp), px(rows * p.kp), py(rows * p.kp);
