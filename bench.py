@@ -801,6 +801,10 @@ def measure(args, torch, dist, world, rank, prec):
     # room: 16384^2 f64 maps are 2.1 GB each)
     nmaps = max(2, min(B, int(32e9 // (float(es) * N * N))))
     tmaps = make_maps(P, torch, seed, nmaps)
+    if getattr(args, "auto_streams", False):
+        # auto: three streams below 8192^2 and for the float64 kernels at 8192^2 and above, two for float32 there (A/B on one box,
+        # profiles/r05_streams.txt: f64 5.25 / 5.39 / 5.22 k recon/s on 2 / 3 / 4 streams, f32 10.6 / 10.2 / 9.8 k)
+        args.streams = 3 if (args.n < 8192 or prec == "f64") else 2
     R = Runner(P, torch, tmaps, args.streams, pair=not args.no_pair)
     ns = R.ns
 
@@ -1026,6 +1030,7 @@ def main():
     ap.add_argument("--mc-sims", type=int, default=1000)
     ap.add_argument("--mc-windowed", action="store_true", help="--config mc with the reference's apodisation taper (oa_mc_run_windowed)")
     args = ap.parse_args()
+    args.auto_streams = args.streams <= 0
     if args.streams <= 0:
         args.streams = 2 if args.n >= 8192 else 3
 
