@@ -106,6 +106,8 @@ void mixed_release(oa_plan* p);
 int mixed_c2c(oa_plan* p, const void* in, void* out, int inverse, double scale, hipStream_t st);
 int mixed_r2c(oa_plan* p, const void* real_in, void* hc_out, double scale, hipStream_t st);
 int mixed_c2r(oa_plan* p, const void* hc_in, void* real_out, double scale, hipStream_t st);
+int mixed_lens_derivs(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st,
+                      const void* hc_in, long hc_stride, double hc_scale);
 void pipeline_release(oa_plan* p);
 // fused estimator passes on the plan's compact work planes (fft.hip)
 long work_pitch(const oa_plan* p, int w);

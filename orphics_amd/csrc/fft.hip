@@ -841,6 +841,7 @@ int div_tile_logc(const oa_plan* p, int rows) {
 }
 int qe_lens_derivs_w(oa_plan* p, int nmaps, const void* real_in, long in_stride, void* k0, void* hc_pool, void* real_pool, int nd, hipStream_t st,
                      const void* hc_in, long hc_stride, double hc_scale) {
+    if (p->mixed) return mixed_lens_derivs(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st, hc_in, hc_stride, hc_scale);
     return p->dtype == OA_F32 ? lens_derivs_impl<float>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st, hc_in, hc_stride, hc_scale)
                               : lens_derivs_impl<double>(p, nmaps, real_in, in_stride, k0, hc_pool, real_pool, nd, st, hc_in, hc_stride, hc_scale);
 }

@@ -35,6 +35,16 @@ inline MrFactors mixed_factor(int N) {
 }
 inline bool mixed_ok(int N) { return N >= 2 && mixed_factor(N).n > 0; }
 
+// multiply by i^q
+template <typename T> OA_HD cx<T> mr_rot_i(cx<T> x, int q) {
+    switch (q & 3) {
+        case 0: return x;
+        case 1: return mk<T>(-x.y, x.x);
+        case 2: return mk<T>(-x.x, -x.y);
+        default: return mk<T>(x.y, -x.x);
+    }
+}
+
 template <typename T, int R> struct MrDft;
 template <typename T> struct MrDft<T, 2> {
     static OA_HD void run(cx<T>* v) { const cx<T> a = v[0] + v[1], b = v[0] - v[1]; v[0] = a; v[1] = b; }
@@ -120,6 +130,12 @@ struct MrRowArgs {
     const cx<T>* tw2;                // real modes: W_(2N)^e, e <= N (the (un)tangle factors)
     T scale;
     int mode;
+    // X-DERIVATIVE C2R (oa_lens_maps on these sides; RowArgs::dlx of fft_kernels.hpp): dlx != nullptr -> launch plane z (grid y) is the
+    // C2R of (i lx)^(dpow0 + z) x the SAME input (a column-transformed field that already carries (i ly)^dcol_b) and goes to output
+    // plane n (n + 1) / 2 - 1 + dcol_b, n = dpow0 + z + dcol_b (the order lens_taylor_kernel reads), out_zoff reals per plane
+    const T* dlx;
+    int dpow0, dcol_b;
+    long out_zoff;
 };
 
 // one row per workgroup
@@ -153,9 +169,23 @@ OA_HD void mr_row_body(Ctx& ctx, const MrRowArgs<T>& a) {
         // C2R: Z'[k] = (X[k] + conj X[N - k]) + i conj(W_2N^k) (X[k] - conj X[N - k]), k < N; inverse of the packed transform; the
         // self-conjugate columns k = 0 and k = N keep their Hermitian (real) part only, as ifft(...).real does
         const cx<T>* src = reinterpret_cast<const cx<T>*>(a.in) + row * a.in_pitch;
-        cx<T>* dst = reinterpret_cast<cx<T>*>(reinterpret_cast<T*>(a.out) + row * a.out_pitch);
+        T* outp = reinterpret_cast<T*>(a.out);
+        int apow = 0;
+        if (a.dlx) {
+            apow = a.dpow0 + ctx.bid_y();
+            const int nn = apow + a.dcol_b;
+            outp += (long)(nn * (nn + 1) / 2 - 1 + a.dcol_b) * a.out_zoff;
+        }
+        cx<T>* dst = reinterpret_cast<cx<T>*>(outp + row * a.out_pitch);
         for (int k = tid; k < N; k += NT) {
             cx<T> A = src[k], B = src[N - k];
+            if (a.dlx) {                                    // (i lx)^apow at the load; lx = 0 at the self-conjugate Nyquist column
+                T fa = (T)1, fb = (T)1;
+                const T la = a.dlx[k], lb = a.dlx[N - k];
+                for (int i = 0; i < apow; ++i) { fa = fa * la; fb = fb * lb; }
+                A = mr_rot_i(A, apow) * fa;
+                B = mr_rot_i(B, apow) * fb;
+            }
             if (k == 0) { A.y = (T)0; B.y = (T)0; }
             const cx<T> z = (A + conj(B)) + mul_pi(conj(a.tw2[k]) * (A - conj(B)));
             b0[k] = swp(z);
@@ -176,6 +206,8 @@ struct MrColArgs {
     const cx<T>* tw;
     T scale;
     int inverse;
+    const T* dly;                    // != nullptr: the input is multiplied by (i ly[n])^dpow at the load (y-derivative of a field's transform)
+    int dpow;
 };
 
 // a tile of C adjacent columns per workgroup, transformed along y
@@ -193,6 +225,12 @@ OA_HD void mr_col_body(Ctx& ctx, const MrColArgs<T>& a) {
         const int c = i & (C - 1), n = i >> a.logC;
         cx<T> v = mk<T>((T)0, (T)0);
         if (c < ncols) v = a.in[(long)n * a.in_pitch + c0 + c];
+        if (a.dly) {
+            T f = (T)1;
+            const T l = a.dly[n];
+            for (int q = 0; q < a.dpow; ++q) f = f * l;
+            v = mr_rot_i(v, a.dpow) * f;
+        }
         b0[i] = inv ? swp(v) : v;
     }
     ctx.sync();

@@ -385,7 +385,7 @@ static int lens_maps_impl(oa_plan* p, int nmaps, const void* real_in, long in_st
 int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int order, const int32_t* shift_x, const int32_t* shift_y,
                  const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
     OA_REQUIRE(p && real_in && shift_x && shift_y && dx && dy && real_out && nmaps >= 1, "oa_lens_maps: bad argument");
-    OA_NEED_POW2(p, "oa_lens_maps");
+    OA_REQUIRE(p->pow2 || p->mixed, "oa_lens_maps: needs map sides of the form 2^a 3^b 5^c");
     OA_REQUIRE(p->have_laxes, "oa_lens_maps: call oa_plan_set_laxes first");
     OA_REQUIRE(order >= 1 && order <= 8, "oa_lens_maps: order must be 1..8");
     OA_REQUIRE(real_in != real_out, "oa_lens_maps: in-place not supported");
@@ -397,7 +397,7 @@ int oa_lens_maps(oa_plan* p, int nmaps, const void* real_in, long in_stride, int
 int oa_lens_maps_hc(oa_plan* p, int nmaps, const void* hc_in, long hc_stride, double scale, int order, const int32_t* shift_x,
                     const int32_t* shift_y, const void* dx, const void* dy, void* real_out, long out_stride, void* stream) {
     OA_REQUIRE(p && hc_in && shift_x && shift_y && dx && dy && real_out && nmaps >= 1, "oa_lens_maps_hc: bad argument");
-    OA_NEED_POW2(p, "oa_lens_maps_hc");
+    OA_REQUIRE(p->pow2 || p->mixed, "oa_lens_maps_hc: needs map sides of the form 2^a 3^b 5^c");
     OA_REQUIRE(p->have_laxes, "oa_lens_maps_hc: call oa_plan_set_laxes first");
     OA_REQUIRE(order >= 1 && order <= 8, "oa_lens_maps_hc: order must be 1..8");
     OA_REQUIRE(hc_stride >= (long)p->ny * p->kp && out_stride >= (long)p->ny * p->nx, "oa_lens_maps_hc: plane stride smaller than a plane");

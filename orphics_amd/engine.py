@@ -191,6 +191,15 @@ class Engine(object):
         self.npix = self.ny * self.nx
         # power-of-two sides: LDS FFT kernels + fused estimator kernels; other even sides: chirp-z FFTs only
         self.pow2 = (self.ny & (self.ny - 1)) == 0 and (self.nx & (self.nx - 1)) == 0
+
+        def smooth(n):
+            for r in (2, 3, 5):
+                while n % r == 0:
+                    n //= r
+            return n == 1
+        # sides 2^a 3^b 5^c that are not powers of two: mixed-radix transforms (csrc/fft_mixed.hpp) and the one-call lensing op;
+        # other even sides: chirp-z transforms, modular calls only
+        self.mixed = (not self.pow2) and self.ny % 2 == 0 and self.nx % 2 == 0 and smooth(self.ny) and smooth(self.nx)
         self._laxes = None
         self._bin_scratch = None
         self._last_stream = None          # the plan's scratch planes are single-buffered: see _ordered()

@@ -1073,7 +1073,7 @@ class FlatLenser(object):
         e = self.eng
         sx, sy, dx, dy = split if split is not None else self.split(alpha)
         src = e.to_real(imap)
-        if fused and 1 <= taylor_order <= 8 and e.pow2:
+        if fused and 1 <= taylor_order <= 8 and (e.pow2 or e.mixed):
             return self.lens_many(src[None], alpha, taylor_order=taylor_order, split=(sx, sy, dx, dy))[0]
         out = e.real()
         e.lens_gather(src, sx, sy, dx, dy, 0, 0, 1.0, out, False)
@@ -1150,7 +1150,7 @@ class FlatLensingSims(object):
         sp = self.lenser.split(alpha)                       # once per deflection, shared by every component
         if unlensed.ndim == 2:
             return self.lenser.lens(unlensed, alpha, taylor_order=lens_order, split=sp)
-        if self.lenser.eng.pow2 and 1 <= lens_order <= 8:   # all components in ONE oa_lens_maps call
+        if (self.lenser.eng.pow2 or self.lenser.eng.mixed) and 1 <= lens_order <= 8:   # all components in ONE oa_lens_maps call
             return self.lenser.lens_many(unlensed, alpha, taylor_order=lens_order, split=sp)
         return torch.stack([self.lenser.lens(unlensed[i].contiguous(), alpha, taylor_order=lens_order, split=sp) for i in range(unlensed.shape[0])])
 
@@ -1188,7 +1188,7 @@ class FlatLensingSims(object):
             self._kbeam_hc = (self.kbeam, e.fullreal_to_hc(e.to_real(self.kbeam)))
         beam = self._kbeam_hc[1]
         pol = len(self.shape) > 2 and self.shape[0] == 3
-        if e.pow2 and 1 <= lens_order <= 8 and (pol or len(self.shape) == 2):
+        if (e.pow2 or e.mixed) and 1 <= lens_order <= 8 and (pol or len(self.shape) == 2):
             # device pipeline: one draw-and-mix pass per field set (oa_grf_mix: covsqrt x white, E, B -> Q, U), the lens operation from
             # the drawn transforms (oa_lens_maps_hc: no transform of the unlensed maps in either direction), and one pass for
             # beam x lensed -> E, B + noise

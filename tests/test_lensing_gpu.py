@@ -1140,6 +1140,38 @@ def test_lens_many_hc_equals_lens_many_of_the_inverse_transforms(prec, tol, orde
         sims.lenser.lens_many_hc(unl, alpha)
 
 
+@pytest.mark.parametrize("shape", [(120, 150), (96, 160)])
+def test_flat_lensing_op_on_mixed_radix_sides(shape):
+    """oa_lens_maps / oa_lens_maps_hc on sides 2^a 3^b 5^c (the notebooks' patches; csrc/mixed.hip lens_derivs_t: per y-derivative
+    order one inverse column transform with (i ly)^b at its load, one row launch that takes every (i lx)^a at its load): the lensed map
+    against the NumPy Taylens, against the term-by-term chain of public calls, and from the map's own transform."""
+    from orphics_amd import lensing
+    from orphics_amd.geometry import FlatGeometry
+    ny, nx = shape
+    g = FlatGeometry.from_res(shape, 2.0)
+    rng = np.random.default_rng(ny + nx)
+    ml = g.modlmap()
+    kap = np.fft.ifft2(np.fft.fft2(rng.standard_normal(shape)) * 1.5 / (1 + (ml / 200.) ** 2)).real
+    T = np.fft.ifft2(np.fft.fft2(rng.standard_normal(shape)) / (1 + (ml / 400.) ** 2)).real
+    for prec, tol in (("f64", 1e-10), ("f32", 3e-5)):
+        L = lensing.FlatLenser(shape, g, dtype=prec)
+        e = L.eng
+        assert e.mixed and not e.pow2
+        ay, ax = L.alpha_from_kappa(kap)
+        ray, rax = qo.alpha_from_kappa(kap, g.step_y, g.step_x)
+        for order in (5, 3):
+            ref = qo.flat_taylens((ray, rax), T, g.step_y, g.step_x, taylor_order=order)
+            lensed = L.lens(T, (ay, ax), taylor_order=order)
+            assert np.abs(lensed.cpu().numpy() - ref).max() / np.abs(ref).max() < tol
+            per_term = L.lens(T, (ay, ax), taylor_order=order, fused=False)
+            assert float((lensed - per_term).abs().max()) / np.abs(ref).max() < tol
+            # from the transform (oa_lens_maps_hc): unnormalised rfft in, scale 1 / Npix
+            src = e.to_real(T)
+            k = e.rfft(src)
+            hc = L.lens_many_hc(k[None].contiguous(), (ay, ax), taylor_order=order, scale=1.0 / e.npix)[0]
+            assert float((hc - lensed).abs().max()) / np.abs(ref).max() < tol
+
+
 def test_lensed_sims_loop_fast_path_equals_the_notebook_sequence():
     """mc.LensedSimsMonteCarlo (tutorials/tt_verification.ipynb's loop): the device pipeline (get_sim_teb: oa_grf_mix,
     oa_lens_maps_hc; estimator-owned output planes; binning over the bins' support only) against the notebook's sequence
