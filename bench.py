@@ -49,7 +49,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 VALU_PEAK_TFLOPS = 157.3   # f32 vector peak (MI355X_MICROARCH.md chip table)
-PROFILE_TAG = "r04"        # profiles/traffic_<tag>_<prec>[_dense|_fullrows].json (tools/collect_profiles.sh)
+PROFILE_TAG = "r05"        # profiles/traffic_<tag>_<prec>[_dense|_fullrows].json (tools/collect_profiles.sh)
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ struct oa_plan {
     bool mixed;                              // sides 2^a 3^b 5^c: mixed-radix transforms (mixed.hip) instead of the chirp-z path
     void* mr_twx; void* mr_twxh; void* mr_twy;   // cx<T>[nx + 1], [nx / 2], [ny]
     void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
-    void* rq8c[4];                           // per-thread constants of the fused row stage's grids of 1024, 1536, 2048, 4096 points (fft_rowqe8.hpp)
+    void* rq8c[5];                           // per-thread constants of the fused row stage's grids of 1024, 1536, 2048, 4096, 8192 points (fft_rowqe8.hpp)
     void* tw_y_small[16];                    // COLUMN GRID: cx<T>[my] = W_my^k for my = 2^i (made on first use, kept: estimators
                                              // with different row bands may alternate on one plan)
 };

@@ -502,7 +502,7 @@ template <typename T>
 static Fft2dPlan<T> view(const oa_plan* p) {
     Fft2dPlan<T> f;
     f.ny = p->ny; f.nx = p->nx; f.logNy = p->logNy; f.logNx = p->logNx; f.kp = p->kp;
-    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y; for (int i = 0; i < 4; ++i) f.rq8c[i] = (const cx<T>*)p->rq8c[i];
+    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y; for (int i = 0; i < 5; ++i) f.rq8c[i] = (const cx<T>*)p->rq8c[i];
     return f;
 }
 // COLUMN GRID view: the same map transformed on my < ny rows (plan_ensure_col_grid made the W_my table)

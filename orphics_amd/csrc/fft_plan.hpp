@@ -33,8 +33,8 @@ struct Fft2dPlan {
     long kp = 0;                 // half-complex pitch (complex elements)
     const cx<T>* tw_x = nullptr; // W_nx^k, k < nx
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
-    const cx<T>* rq8c[4] = {nullptr, nullptr, nullptr, nullptr};   // constants of the 8-point row stage's grids 1024, 1536, 2048, 4096 (nullptr: not offered)
-    static int rq8_slot(int m) { return m == 1024 ? 0 : m == 1536 ? 1 : m == 2048 ? 2 : m == 4096 ? 3 : -1; }
+    const cx<T>* rq8c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // constants of the 8-point row stage's grids 1024, 1536, 2048, 4096, 8192 (nullptr: not offered)
+    static int rq8_slot(int m) { return m == 1024 ? 0 : m == 1536 ? 1 : m == 2048 ? 2 : m == 4096 ? 3 : m == 8192 ? 4 : -1; }
     bool rq8_ready(int m) const { const int i = rq8_slot(m); return rowqe8_on() && i >= 0 && rq8c[i] != nullptr; }
     // COLUMN GRID view (fft.hip coarse_view): this plan describes ny = My rows of a map with ny_full rows; filters, ly
     // axis and caller-owned planes are addressed at the full-resolution rows (ColLegsArgs::yshift).  0 = own grid.
@@ -188,9 +188,22 @@ struct Fft2dPlan {
         a.pitch = pin > 0 ? pin : kp; a.opitch = pout > 0 ? pout : kp;
         a.gx = gx; a.gy = gy; a.h = h; a.px = px; a.py = py; a.accumulate = accumulate;
         a.win = win; a.wout = wout;
-        if (mrow > 0 && rows_qe_is_pair(win, wout, mrow)) {
+        // the map's own 8192-point rows (mrow = 0 / mrow = nx) with band-limited legs: the two-rows-per-transform stage on the radix-16
+        // cross stage of row_qe8_body, one map per launch, natural layout (1327 against 1101 reconstructions/s with both grids off;
+        // with every column live the packed kernel below stays faster: 340 against 290 /s -- profiles/r05_fullrows_a16.txt)
+        const bool full8 = Mg == nx && nx == 8192 && ny % 2 == 0 && nmaps <= 1 && !tab && !chain && lr == 0 && rq8_ready(Mg) && win <= 2048 &&
+                           rq8_covers_full(Mg, win, wout < nx ? wout : nx / 2 + 1);
+        if (full8 || (mrow > 0 && rows_qe_is_pair(win, wout, mrow))) {
             // alias-free row grid: two rows per complex transform of length M
             const int M = Mg;
+            if (full8) {
+                a.wout = wout < nx ? wout : nx / 2 + 1;
+                a.logL = logM; a.logC = 0; a.NT = M / 8; a.rowStride = M;
+                a.rq8c = rq8c[rq8_slot(M)];
+                a.tab = nullptr; a.lr = 0; a.nrows = ny; a.chain = nullptr;
+                q.row_qe_pair8(ny / 2, M, a);
+                return;
+            }
             if (rq8_ready(M) && rq8_covers(M, win, wout) && (lr == 0 || lr == 2 || lr == 3)) {
                 // eight points per thread, M / 512 waves per row pair (row_qe8_body, fft_rowqe8.hpp)
                 a.logL = logM; a.logC = 0; a.NT = M / 8; a.rowStride = M;

@@ -42,7 +42,12 @@ namespace oa {
 template <int A_> struct Rq8Geom {
     static constexpr int A = A_, NT = 64 * A, S = 512, RS = 576, M = A * S, JPT = (S + NT - 1) / NT;
     static constexpr bool FULLJ = JPT * NT == S;            // A = 3: the third position of a thread exists for tid < 128 only
-    static_assert(A == 2 || A == 3 || A == 4 || A == 8, "rowqe8: row grids of 1024, 1536, 2048 or 4096 points");
+    // A = 16 (8192-point grids): TWO threads per cross-stage position j = tid mod 512 -- thread half p = tid / 512 takes the outputs
+    // k = 2 k0 + p of the radix-16 butterfly (k even: DFT_8 of x_t + x_(t+8); k odd: DFT_8 of (x_t - x_(t+8)) W_16^t)
+    static constexpr bool HALVES = A == 16;
+    static constexpr int AR = HALVES ? 8 : A;               // radix of a thread's cross-stage butterfly
+    static constexpr int NTW = HALVES ? 8 : A - 1;          // cross-stage factors per position of a thread
+    static_assert(A == 2 || A == 3 || A == 4 || A == 8 || A == 16, "rowqe8: row grids of 1024, 1536, 2048, 4096 or 8192 points");
 };
 
 // LDS entries behind the A regions: float64 keeps the 64-point stage's factors W_64^(lo c), [c - 1][lo], there
@@ -74,9 +79,9 @@ struct Rq8Tw {
     static constexpr int JPT = Rq8Geom<A>::JPT, NT = Rq8Geom<A>::NT;
     cx<T> r1[FULL ? 7 : 3], r2[FULL ? 7 : 1];
     const cx<T>* s2;                                        // COMPACT: LDS table + lo
-    cx<T> ra[FULL ? JPT : 1][FULL ? A - 1 : 1];
+    cx<T> ra[FULL ? JPT : 1][FULL ? Rq8Geom<A>::NTW : 1];
     const cx<T>* ga;                                        // COMPACT: this thread's W_M^(j_0) in the constants table
-    int gs;                                                 // ... and the distance to W_M^(j_(u+1))
+    int gs;                                                 // ... and the distance to W_M^(j_(u+1)) (A = 16: one table row)
     // v[c] *= W_512^(l c)
     OA_HD void mul1(cx<T>* v) const {
         if constexpr (FULL) {
@@ -96,19 +101,20 @@ struct Rq8Tw {
             else v[c] = v[c] * s2[8 * (c - 1)];
         }
     }
-    // W_M^(j_u): issued early by the callers (COMPACT; FULL: unused)
-    OA_HD cx<T> wa(int u) const {
-        if constexpr (FULL) return ra[u][0];
-        else return ldg(ga + u * gs);
-    }
-    // z[k] *= W_M^(j_u k); w1 = wa(u)
-    OA_HD void mula(cx<T>* z, int u, cx<T> w1) const {
+    // z[k] *= W_M^(j_u k), k = 1 .. A - 1   (A = 16, thread half p: z[k0] *= W_M^(j (2 k0 + p)), k0 = 0 .. 7)
+    OA_HD void cross(cx<T>* z, int u) const {
+        constexpr int NTW = Rq8Geom<A>::NTW;
         if constexpr (FULL) {
 #pragma unroll
-            for (int k = 1; k < A; ++k) z[k] = z[k] * ra[u][k - 1];
+            for (int k = 0; k < NTW; ++k) z[k + (A == 16 ? 0 : 1)] = z[k + (A == 16 ? 0 : 1)] * ra[u][k];
+        } else if constexpr (A == 16) {
+            cx<T> c = ldg(ga);                              // W_M^(j p)
+            const cx<T> st = ldg(ga + 8 * gs);              // W_M^(2 j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { z[k] = z[k] * c; if (k < 7) c = c * st; }
         } else {
             cx<T> w[A];
-            w[1] = w1;
+            w[1] = ldg(ga + u * gs);
 #pragma unroll
             for (int k = 2; k < A; ++k) w[k] = w[k / 2] * w[k - k / 2];
 #pragma unroll
@@ -122,18 +128,22 @@ struct Rq8Tw {
 //   [c - 1][l]            W_512^(l c),  c = 1 .. 7, l < 64
 //   [c - 1][lo]           W_64^(lo c),  c = 1 .. 7, lo < 8
 //   [u][k - 1][tid]       W_M^(j k),    j = (tid + NT u) mod 512, k = 1 .. A - 1
+//   A = 16:  [k0][tid]    W_M^(j (2 k0 + p)), k0 < 8, p = tid / 512, j = tid mod 512;  then  [8][tid] = W_M^(2 j)
 // Built on the host (plan creation / the emulator's Holder), one table per grid.
-template <int A> constexpr int rq8_const_entries() { return 7 * 64 + 7 * 8 + Rq8Geom<A>::JPT * (A - 1) * Rq8Geom<A>::NT; }
-inline int rq8_const_entries_rt(int A) { return A == 2 ? rq8_const_entries<2>() : A == 3 ? rq8_const_entries<3>() : A == 4 ? rq8_const_entries<4>() : rq8_const_entries<8>(); }
 template <typename T>
 inline std::vector<cx<T>> rq8_make_consts(int A) {
     const int NT = 64 * A, M = 512 * A, JPT = (512 + NT - 1) / NT;
-    std::vector<cx<T>> t((size_t)(7 * 64 + 7 * 8 + JPT * (A - 1) * NT));
+    std::vector<cx<T>> t((size_t)(7 * 64 + 7 * 8 + (A == 16 ? 9 : JPT * (A - 1)) * NT));
     const long double tau = 6.283185307179586476925286766559005768L;
     auto w = [&](long e, long n) { const long double x = tau * (long double)(e % n) / (long double)n; return mk<T>((T)cosl(x), (T)(-sinl(x))); };
     size_t o = 0;
     for (int c = 1; c < 8; ++c) for (int l = 0; l < 64; ++l) t[o++] = w((long)l * c, 512);
     for (int c = 1; c < 8; ++c) for (int lo = 0; lo < 8; ++lo) t[o++] = w((long)lo * c, 64);
+    if (A == 16) {
+        for (int k0 = 0; k0 < 8; ++k0) for (int tid = 0; tid < NT; ++tid) t[o++] = w((long)(tid & 511) * (2 * k0 + (tid >> 9)), M);
+        for (int tid = 0; tid < NT; ++tid) t[o++] = w((long)(tid & 511) * 2, M);
+        return t;
+    }
     for (int u = 0; u < JPT; ++u) for (int k = 1; k < A; ++k) for (int tid = 0; tid < NT; ++tid) t[o++] = w((long)((tid + NT * u) & 511) * k, M);
     return t;
 }
@@ -155,15 +165,15 @@ OA_HD void rq8_tw_init(Ctx& ctx, Rq8Tw<T, A, FULL>& tw, cx<T>* tab, const cx<T>*
 #pragma unroll
         for (int u = 0; u < G::JPT; ++u)
 #pragma unroll
-            for (int k = 1; k < A; ++k) tw.ra[u][k - 1] = ta[(u * (A - 1) + (k - 1)) * G::NT + tid];
+            for (int k = 0; k < G::NTW; ++k) tw.ra[u][k] = ta[(u * G::NTW + k) * G::NT + tid];
     } else {
         tw.r1[0] = tc[l];
         tw.r1[1] = tc[64 + l];
         tw.r1[2] = tc[3 * 64 + l];
         for (int e = tid; e < RQ8_TAB; e += G::NT) tab[e] = t2[e];
         tw.s2 = tab + lo;
-        tw.ga = ta + tid;                                   // W_M^(j_u): entry (u, k = 1)
-        tw.gs = (A - 1) * G::NT;
+        tw.ga = ta + tid;                                   // W_M^(j_u): entry (u, k = 1); A = 16: entry k0 = 0, the step W_M^(2 j) 8 rows on
+        tw.gs = A == 16 ? G::NT : (A - 1) * G::NT;
     }
 }
 
@@ -244,7 +254,6 @@ OA_HD void rq8_inverse(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cons
         cx<T>* zu = z[SEQ ? 0 : u];
         const int j = tid + G::NT * u;
         const bool own = G::FULLJ || j < S;
-        const cx<T> wa = tw.wa(u);
 #pragma unroll
         for (int t = 0; t < A; ++t) {
             const int n = j + S * t;
@@ -264,7 +273,7 @@ OA_HD void rq8_inverse(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cons
             }
         }
         rq8_dft<T, A>(zu);
-        tw.mula(zu, u, wa);
+        tw.cross(zu, u);
         if (SEQ) {
             if (own) {
 #pragma unroll
@@ -304,10 +313,9 @@ OA_HD void rq8_forward(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cx<T
 #pragma unroll
     for (int u = 0; u < JPT; ++u) {
         const int q = (tid + G::NT * u) & (S - 1);          // (A = 3: the unused slot reads a valid entry)
-        const cx<T> wa = tw.wa(u);
 #pragma unroll
         for (int k = 0; k < A; ++k) a[u][k] = D[G::RS * k + q];
-        tw.mula(a[u], u, wa);
+        tw.cross(a[u], u);
         rq8_dft<T, A>(a[u]);
     }
     RQ8_STAMP(sb + 1);
@@ -338,9 +346,100 @@ OA_HD void rq8_forward(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cx<T
     RQ8_STAMP(sb + 3);
 }
 
+// ---- A = 16 (8192-point grids: the map's own row length at 8192^2): the radix-16 cross-wave stage on two threads per position ------
+// inverse, as rq8_inverse: thread (p, j) loads the 16 taps x[j + 512 tt] (pruned: tt < NZ low, tt >= 16 - NZ high), forms
+// u_t = x_t + x_(t+8) (p = 0) or (x_t - x_(t+8)) W_16^t (p = 1), a radix-8 butterfly, the factors W_M^(j (2 k0 + p)), and stores
+// region 2 k0 + p.  M == nx is allowed: the Nyquist column n = M / 2 is its own mirror image (taken once, on the high side).
+template <typename T, int NZ, int LAY, class TW, class Ctx>
+OA_HD void rq8_inverse16(Ctx& ctx, cx<T>* D, int tid, const TW& tw, const cx<T>* row0, const cx<T>* row1, int win, long pitch, T sg, int pp) {
+    using G = Rq8Geom<16>;
+    constexpr int S = G::S, M = G::M;
+    static_assert(NZ >= 1 && NZ <= 8, "rowqe8: live taps per side");
+    const int p = tid >> 9, j = tid & 511;
+    auto tap = [&](int tt) -> cx<T> {                       // swapped packed operand Z[j + 512 tt], zero outside the band
+        const int n = j + S * tt;
+        if (tt < NZ) {
+            const bool ok = n < win && 2 * n < M;           // (n = M / 2 belongs to the high side)
+            cx<T> a0, a1;
+            pair_rows_at<T, LAY>(row0, row1, pitch, sg, ok ? n : 0, a0, a1, pp);
+            return ok ? swp(add_pi(a0, a1)) : mk<T>((T)0, (T)0);
+        } else if (tt >= 16 - NZ) {
+            const int m = M - n;
+            const bool ok = m < win;
+            cx<T> a0, a1;
+            pair_rows_at<T, LAY>(row0, row1, pitch, sg, ok ? m : 0, a0, a1, pp);
+            return ok ? mk<T>(a1.x - a0.y, a0.x + a1.y) : mk<T>((T)0, (T)0);
+        }
+        return mk<T>((T)-0.0, (T)-0.0);
+    };
+    cx<T> z[8];
+    ctx.sync();                                             // whoever still reads D (previous transform) is done
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const cx<T> lo = tap(t), hi = tap(t + 8);
+        z[t] = p ? (lo - hi) : (lo + hi);
+    }
+    if (p) {
+#pragma unroll
+        for (int t = 1; t < 8; ++t) {
+            if (t == 4) z[t] = mul_mi(z[t]);                // W_16^4 = -i
+            else z[t] = z[t] * w16<T>(t);
+        }
+    }
+    Dft<T, 8>::run(z);
+    tw.cross(z, 0);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) D[G::RS * (2 * k0) + G::RS * p + j] = z[k0];
+    ctx.sync();
+}
+
+// forward: thread (p, q): E_p[r'] = DFT_8 over k0 of W_M^(q (2 k0 + p)) U_(2 k0 + p)[q], times W_16^r' for p = 1;
+// P[q + 512 r'] = E_0 + E_1', P[q + 512 (r' + 8)] = E_0 - E_1' are formed by the unpack from the two stored halves
+template <typename T, class TW, class Ctx>
+OA_HD void rq8_forward16(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cx<T>* o0, cx<T>* o1, int wout, int accumulate) {
+    using G = Rq8Geom<16>;
+    constexpr int S = G::S, M = G::M;
+    rq8_sub_dit<T>(ctx, D + G::RS * (tid >> 6), tid & 63, tw, v);
+    ctx.sync();
+    const int p = tid >> 9, q = tid & 511;
+    cx<T> a[8];
+#pragma unroll
+    for (int k0 = 0; k0 < 8; ++k0) a[k0] = D[G::RS * (2 * k0) + G::RS * p + q];
+    tw.cross(a, 0);
+    Dft<T, 8>::run(a);
+    if (p) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+            if (r == 4) a[r] = mul_mi(a[r]);
+            else a[r] = a[r] * w16<T>(r);
+        }
+    }
+    ctx.sync();                                             // all cross-stage reads precede the writes
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = q + S * r;                             // the bins this half contributes to: k and k + M / 2
+        if (k < wout || k > M - wout || k + M / 2 < wout || k + M / 2 > M - wout) D[G::RS * (r + 8 * p) + q] = a[r];
+    }
+    ctx.sync();
+    auto bin = [&](int k) -> cx<T> {                        // P[k] from the two halves
+        const int r = k >> 9, qq = k & 511;
+        const cx<T> e0 = D[G::RS * (r & 7) + qq], e1 = D[G::RS * ((r & 7) + 8) + qq];
+        return (r & 8) ? e0 - e1 : e0 + e1;
+    };
+    for (int k = tid; k < wout; k += G::NT) {
+        const cx<T> Pk = bin(k);
+        const cx<T> Pm = conj(bin(k ? M - k : 0));
+        cx<T> p0 = (Pk + Pm) * (T)0.5;
+        cx<T> p1 = mul_mi(Pk - Pm) * (T)0.5;
+        if (accumulate) { p0 = p0 + o0[k]; p1 = p1 + o1[k]; }
+        o0[k] = p0;
+        o1[k] = p1;
+    }
+}
+
 // ---- which grids this body runs -------------------------------------------------------------------------------------------------
 OA_HD bool rq8_is_m3(int m) { return m == 1536; }
-OA_HD int rq8_waves(int m) { return m == 1024 ? 2 : m == 1536 ? 3 : m == 2048 ? 4 : m == 4096 ? 8 : 0; }
+OA_HD int rq8_waves(int m) { return m == 1024 ? 2 : m == 1536 ? 3 : m == 2048 ? 4 : m == 4096 ? 8 : m == 8192 ? 16 : 0; }
 // live taps per side of the cross-wave butterfly for `win` active columns: ceil(win / 512) rounded up to a power of two (<= A / 2)
 OA_HD int rq8_nz(int m, int win) {
     const int A = rq8_waves(m);
@@ -354,6 +453,8 @@ OA_HD bool rq8_covers(int m, int win, int wout) {
     if (!A || 2L * win + wout > m || wout > m) return false;
     return A == 3 ? win <= 512 : 2 * win <= m;
 }
+// the map's OWN row length (no alias argument needed: the products are then formed on the grid the reference forms them on): any band
+OA_HD bool rq8_covers_full(int m, int win, int wout) { return rq8_waves(m) == 16 && win <= m / 2 + 1 && wout <= m / 2 + 1; }
 
 // LDS of one workgroup: the transform regions, the float64 factor table, the park area
 // float64 at four waves per SIMD has 128 registers for h (32), the transform in flight (32), its factors and the butterfly: the
@@ -413,7 +514,7 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
     cx<T> hreg[8], v[8];
     cx<T>* Dk = D + G::RS * (tid >> 6);
     if constexpr (CHAIN) {
-        static_assert(LAY == 0, "chains read natural-order leg planes");
+        static_assert(LAY == 0 && A != 16, "chains read natural-order leg planes on grids of up to 4096 points");
         const int first = a.chain[2 * m], count = a.chain[2 * m + 1];
         cx<T> acc[2][8];
 #pragma unroll 1
@@ -446,7 +547,8 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
         }
         return;
     }
-    rq8_inverse<T, A, NZ, LAY, !FULL>(ctx, D, hreg, tid, tw, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 2);
+    if constexpr (A == 16) rq8_inverse16<T, NZ, LAY>(ctx, D, tid, tw, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp);
+    else rq8_inverse<T, A, NZ, LAY, !FULL>(ctx, D, hreg, tid, tw, hp + r0 * a.pitch, hp + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 2);
     rq8_sub_dif<T>(ctx, Dk, tid & 63, tw, hreg);
     RQ8_STAMP(4);
     // hreg holds the swapped inverse: (h1, h0); the product scale rides on it
@@ -461,7 +563,8 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
     for (int leg = 0; leg < 2; ++leg) {
         const cx<T>* src = leg ? gyp : gxp;
         cx<T>* dst = leg ? pyp : pxp;
-        rq8_inverse<T, A, NZ, LAY, !FULL>(ctx, D, v, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 5 + 7 * leg);
+        if constexpr (A == 16) rq8_inverse16<T, NZ, LAY>(ctx, D, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp);
+        else rq8_inverse<T, A, NZ, LAY, !FULL>(ctx, D, v, tid, tw, src + r0 * a.pitch, src + (r0 + 1) * a.pitch, a.win, a.pitch, sg, pp, 5 + 7 * leg);
         rq8_sub_dif<T>(ctx, Dk, tid & 63, tw, v);
         RQ8_STAMP(7 + 7 * leg);
         // v = (g1, g0) swapped; p = g0 h0 + i g1 h1
@@ -470,7 +573,8 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
             const cx<T> hh = (PARK && t >= 4) ? PK[(t - 4) * G::NT] : hreg[t];
             v[t] = mk<T>(v[t].y * hh.y, v[t].x * hh.x);
         }
-        rq8_forward<T, A>(ctx, D, v, tid, tw, dst + ra * a.opitch, dst + rb * a.opitch, a.wout, a.accumulate, 8 + 7 * leg);
+        if constexpr (A == 16) rq8_forward16<T>(ctx, D, v, tid, tw, dst + ra * a.opitch, dst + rb * a.opitch, a.wout, a.accumulate);
+        else rq8_forward<T, A>(ctx, D, v, tid, tw, dst + ra * a.opitch, dst + rb * a.opitch, a.wout, a.accumulate, 8 + 7 * leg);
     }
 }
 
@@ -502,6 +606,12 @@ inline bool dispatch_rq8(int M, int win, int lr, bool chain, F&& f) {
             if (nz == 1) return with_lay(integral_constant<int, 8>{}, integral_constant<int, 1>{});
             if (nz == 2) return with_lay(integral_constant<int, 8>{}, integral_constant<int, 2>{});
             return with_lay(integral_constant<int, 8>{}, integral_constant<int, 4>{});
+        case 8192:                                          // natural layout, no chains: the map's own rows at 8192^2 (fullres / dense)
+            if (chain || lr != 0) return false;
+            if (nz == 1) f(integral_constant<int, 16>{}, integral_constant<int, 1>{}, integral_constant<int, 0>{}, std::false_type{});
+            else if (nz <= 4) f(integral_constant<int, 16>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{}, std::false_type{});
+            else return false;                              // every column live: the packed full-row kernel (row_qe_body) is faster
+            return true;
         default: return false;
     }
 }

@@ -167,15 +167,15 @@ struct EmuLauncher {
 
 template <typename T>
 struct Holder {
-    std::vector<cx<T>> twx, twy, rq8t[4];
+    std::vector<cx<T>> twx, twy, rq8t[5];
     Fft2dPlan<T> p;
     Holder(int ny, int nx) {
         twx = make_twiddles<T>(nx);
         twy = make_twiddles<T>(ny);
         p.ny = ny; p.nx = nx; p.logNy = ilog2(ny); p.logNx = ilog2(nx);
         p.kp = kpitch_for(nx); p.tw_x = twx.data(); p.tw_y = twy.data();
-        const int waves[4] = {2, 3, 4, 8};
-        for (int i = 0; i < 4; ++i) if (512 * waves[i] <= nx) { rq8t[i] = rq8_make_consts<T>(waves[i]); p.rq8c[i] = rq8t[i].data(); }
+        const int waves[5] = {2, 3, 4, 8, 16};
+        for (int i = 0; i < 5; ++i) if (512 * waves[i] <= nx) { rq8t[i] = rq8_make_consts<T>(waves[i]); p.rq8c[i] = rq8t[i].data(); }
     }
 };
 

@@ -105,8 +105,23 @@ def _col_ifft(k, ny):
 def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
     """row_qe: P = R2C(C2R(G) * C2R(H)) row by row, with and without active-column limits; both kernel bodies
     (Stockham = the product kernel, in-place DIF/DIT = the -DOA_QE_INPLACE variant with 18 instead of 30 barriers).
-    The 8192 and 512 cases with small win run the active-column first stage (NZ = 2, 1, 2 live taps per side)."""
+    The 8192 and 512 cases with small win run the active-column first stage (NZ = 2, 1, 2 live taps per side).
+    full8: 8192-point rows through the two-rows-per-transform stage with the radix-16 cross stage (row_qe8_body, A = 16: what
+    Fft2dPlan::rows_qe launches for the map's own row length at 8192^2)."""
+    _run_fused_row_stage(emu, ny, nx, win, wout, stockham, False)
+
+
+@pytest.mark.parametrize("ny,win,wout", [(8, 380, 664), (4, 1139, 664), (4, 2048, 4097)])
+def test_fused_row_stage_on_8192_point_rows_two_rows_per_transform(emu, ny, win, wout):
+    """The map's own row length at 8192^2 (row_grid = "full" and the dense pipeline): row_qe8_body with A = 16 -- two threads per
+    position of the radix-16 cross-wave stage, the Nyquist column taken once, products on the grid the reference forms them on (no
+    alias argument) -- against NumPy, with 1 and 4 live 512-point blocks per side (wider bands keep the packed kernel)."""
+    _run_fused_row_stage(emu, ny, 8192, win, wout, 1, True)
+
+
+def _run_fused_row_stage(emu, ny, nx, win, wout, stockham, full8):
     emu.emu_set_stockham_qe(stockham)
+    emu.emu_set_rowqe8(1 if full8 else 0)
     rng = np.random.default_rng(100 + nx + win)
     W = nx // 2 + 1
     wi = win if win else W
@@ -134,6 +149,7 @@ def test_fused_row_stage(emu, ny, nx, win, wout, stockham):
         assert np.abs(got[:, :wo] - want[:, :wo]).max() < 1e-11 * np.abs(want).max()
         if wout:
             assert np.all(got[:, wo:W] == 5.0)                    # untouched
+    emu.emu_set_rowqe8(1)
 
 
 @pytest.fixture(params=[8, 16], ids=["8pt", "16pt"])
