@@ -88,7 +88,7 @@ struct oa_plan {
     bool mixed;                              // sides 2^a 3^b 5^c: mixed-radix transforms (mixed.hip) instead of the chirp-z path
     void* mr_twx; void* mr_twxh; void* mr_twy;   // cx<T>[nx + 1], [nx / 2], [ny]
     void* pipe;                              // oa::Pipeline* (pipeline.hip): filters, bins, work planes of the one-call entries
-    void* rq8c[5];                           // per-thread constants of the fused row stage's grids of 1024, 1536, 2048, 4096, 8192 points (fft_rowqe8.hpp)
+    void* rq8c[5];                           // per-thread constants of the fused row stage's grids of 1024, 1536, 2048, 4096, 8192 points (fft_rowqe8.hpp: RQ8_NGRIDS)
     void* tw_y_small[16];                    // COLUMN GRID: cx<T>[my] = W_my^k for my = 2^i (made on first use, kept: estimators
                                              // with different row bands may alternate on one plan)
 };
@@ -120,8 +120,12 @@ int plan_ensure_col_grid(oa_plan* p, int my);
 // lr > 0 (qe_rsplit_lr): R-SPLIT path -- row R2C with the first radix-R column butterfly, then one single-pass column kernel;
 // the leg planes are then in the R-LAYOUT and qe_rows_w must be told so (same lr)
 int qe_rsplit_lr(const oa_plan* p, int my, int width, int wout, int mrow);
+// fgh (lr > 0 only): the packed (FG, FH) table of this binding made by qe_fband_pack_w (qe_fband_table_entries complex entries), or
+// nullptr: the column kernel reads the filter planes
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
-                       int rband, long pl, hipStream_t st, int stages = 7, int my = 0, int lr = 0);
+                       int rband, long pl, hipStream_t st, int stages = 7, int my = 0, int lr = 0, const void* fgh = nullptr);
+long qe_fband_table_entries(const oa_plan* p, int width, int my);
+int qe_fband_pack_w(oa_plan* p, const void* FG, const void* FH, void* out, int width, int rband, int my, hipStream_t st);
 int qe_legs_cols_w(oa_plan* p, const void* kX, const void* kY, const void* FG, const void* FH, void* gx, void* gy, void* h,
                    int width, int rband, long pl, hipStream_t st, int my = 0);
 // flat-sky Taylor lensing, FFT part: R2C of nmaps maps, then all nmaps * nd derivative fields inverse-transformed in three launches
@@ -169,7 +173,7 @@ int qe_cols_div_w(oa_plan* p, const void* pa, const void* pb, const void* Fn, vo
 // two maps at once (fft.hip); -1 = not available for this geometry
 int qe_tt_pair_w(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0, void* c1,
                  void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow, int my, long pl, long pk,
-                 hipStream_t st, DivBinFuse* fuse = nullptr);
+                 hipStream_t st, DivBinFuse* fuse = nullptr, const void* fgh = nullptr);
 }
 #define OA_NEED_POW2(p, what) \
     OA_REQUIRE((p)->pow2, what ": needs power-of-two map sides (other sizes: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and the modular oa_qe_legs / oa_mul_real / oa_qe_div calls)")

@@ -39,6 +39,12 @@ __global__ __launch_bounds__(RS4096_NT, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)
     row_r2c_rs4096_body<T, 2, PF>(c, a);
 }
 // 4096-point rows (4096^2 maps), <= 256 columns kept: the same body on 128 threads per row
+// the wide band (<= 1280 kept columns), radix-2 column butterfly: 8192^2 maps on the 4096-row column grid
+template <typename T, bool PF>
+__global__ __launch_bounds__(RS4096_NT, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)) void row_r2c_rs4096w_kernel(RowArgs<T> a) {
+    GpuCtx c{oa_dyn_smem};
+    row_r2c_rs_body<T, 12, 1, PF, 5>(c, a);
+}
 template <typename T, bool PF>
 __global__ __launch_bounds__(128, (sizeof(T) == 8 ? 2 : OA_RS4096_F32_OCC)) void row_r2c_rs2048_kernel(RowArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -57,6 +63,11 @@ __global__ __launch_bounds__(512, (sizeof(T) == 8 ? 2 : OA_RS8192_F32_OCC)) void
 }
 
 // single-pass column stage of the R-split path: [My][C] tile, all threads forward, R groups inverse (fft_fband.hpp)
+template <typename T, class SEQF, int LR, int LOGC>
+__global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024)) void col_fband_pack_kernel(ColFBandArgs<T> a, cx<T>* out) {
+    GpuCtx c{nullptr};
+    col_fband_pack_body<T, SEQF, LR, LOGC>(c, a, out);
+}
 template <typename T, class SEQF, int LR, int LOGC>
 __global__ __launch_bounds__((sizeof(T) == 8 ? 512 : 1024), (sizeof(T) == 8 ? 2 : 4)) void col_fband_kernel(ColFBandArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
@@ -291,15 +302,17 @@ struct HipLauncher {
         static const int pfenv = [] { const char* e = exp_env("OA_RS4096_PF"); return e ? atoi(e) : -1; }();
         const bool l12 = a.lr == 2 && a.logL == 12 && a.wcols <= 512 && a.logTw >= 13, l11 = a.lr == 2 && a.logL == 11 && a.wcols <= 256 && a.logTw >= 12;
         const bool l13 = sizeof(T) == 8 && a.lr == 3 && a.logL == 13 && a.wcols <= 512 && a.logTw >= 14;      // 16384-point rows, R = 8 (float64)
-        if (off || rc || !(l12 || l11 || l13)) return false;
-        const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && l12);     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
-        const size_t smem = l13 ? rs_lds_bytes<T, 13>() : (l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>());
-        const int NTr = l13 ? 512 : (l12 ? RS4096_NT : 128);
+        const bool l12w = a.lr == 1 && a.logL == 12 && a.wcols <= 1280 && a.logTw >= 13;                       // the wide band, R = 2
+        if (rc || !(l12w || (!off && (l12 || l11 || l13)))) return false;
+        const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && (l12 || l12w));     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
+        const size_t smem = l13 ? rs_lds_bytes<T, 13>() : (l12w ? rs_lds_bytes<T, 12, 5>() : (l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>()));
+        const int NTr = l13 ? 512 : ((l12 || l12w) ? RS4096_NT : 128);
         void (*kern)(RowArgs<T>) = l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)
                                        : (nopf ? row_r2c_rs2048_kernel<T, false> : row_r2c_rs2048_kernel<T, true>);
         // (float at 16384^2 keeps the two-waves-per-row kernel + multi-pass columns: measured 274 us / 2743 recon/s against 306 us /
         //  2698 for the float build of this body -- 194 registers leave one 512-thread workgroup per CU; profiles/r04e_16384_f32_variants.txt)
         if constexpr (sizeof(T) == 8) { if (l13) kern = nopf ? row_r2c_rs8192_kernel<T, false> : row_r2c_rs8192_kernel<T, true>; }
+        if (l12w) kern = nopf ? row_r2c_rs4096w_kernel<T, false> : row_r2c_rs4096w_kernel<T, true>;
         static const int cus = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
         std::string err;
         const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), NTr, smem, &err);
@@ -331,19 +344,43 @@ struct HipLauncher {
         }
         if (!ok && !rc) rc = fail("fft: unsupported R-split row pass");
     }
+    // f(SEQF, LR, LOGC as integral constants) for the col_fband variant of this grid; false: not built
+    template <typename T, class F>
+    static bool dispatch_fband(int gy, int logMy, bool narrow, F&& f) {
+        using std::integral_constant;
+        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
+        if (gy == 4 && logMy == 11 && !narrow) f(Seq<16, 16, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc11>{});
+        else if (gy == 4 && logMy == 10 && !narrow) f(Seq<16, 8, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc10>{});
+        else if (gy == 4 && logMy == 11) f(Seq<16, 16, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc11 - 1>{});
+        else if (gy == 4 && logMy == 10) f(Seq<16, 8, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc10 - 1>{});
+        else if (sizeof(T) == 8 && gy == 8 && logMy == 11 && !narrow) {        // 16384 rows on the 2048-row grid (float64 only: see row_rs4096)
+            if constexpr (sizeof(T) == 8) f(Seq<16, 8, 16>{}, integral_constant<int, 3>{}, integral_constant<int, lc11>{});
+        } else if (gy == 2 && logMy == 12 && !narrow) {                          // the wide band: 8192 rows on the 4096-row grid
+            f(Seq<16, 16, 4, 4>{}, integral_constant<int, 1>{}, integral_constant<int, lc11 - 1>{});
+        } else return false;
+        return true;
+    }
     template <typename T>
     void col_fband(int gx, int gy, int gz, size_t smem, int logMy, const ColFBandArgs<T>& a) {
         if (rc) return;
         const int lt = Fft2dPlan<T>::fband_lt(), nt = (1 << lt) / EPT;
-        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
         const bool narrow = lt < (sizeof(T) == 4 ? 14 : 13);
-        if (gy == 4 && logMy == 11 && !narrow) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11>, dim3(gx, gy, gz), nt, smem, a);
-        else if (gy == 4 && logMy == 10 && !narrow) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10>, dim3(gx, gy, gz), nt, smem, a);
-        else if (gy == 4 && logMy == 11) go(col_fband_kernel<T, Seq<16, 16, 8>, 2, lc11 - 1>, dim3(gx, gy, gz), nt, smem, a);
-        else if (gy == 4 && logMy == 10) go(col_fband_kernel<T, Seq<16, 8, 8>, 2, lc10 - 1>, dim3(gx, gy, gz), nt, smem, a);
-        else if (sizeof(T) == 8 && gy == 8 && logMy == 11 && !narrow) {        // 16384 rows on the 2048-row grid (float64 only: see row_rs4096)
-            if constexpr (sizeof(T) == 8) go(col_fband_kernel<T, Seq<16, 8, 16>, 3, lc11>, dim3(gx, gy, gz), nt, smem, a);
-        } else rc = fail("fft: unsupported R-split column stage");
+        const bool ok = dispatch_fband<T>(gy, logMy, narrow, [&](auto seq, auto lrc, auto lcc) {
+            go(col_fband_kernel<T, decltype(seq), decltype(lrc)::value, decltype(lcc)::value>, dim3(gx, gy, gz), nt, smem, a);
+        });
+        if (!ok) rc = fail("fft: unsupported R-split column stage");
+    }
+    template <typename T>
+    void col_fband_pack(int gx, int gy, int logMy, const ColFBandArgs<T>& a, cx<T>* out) {
+        if (rc) return;
+        const int lt = Fft2dPlan<T>::fband_lt(), nt = (1 << lt) / EPT;
+        const bool narrow = lt < (sizeof(T) == 4 ? 14 : 13);
+        const bool ok = dispatch_fband<T>(gy, logMy, narrow, [&](auto seq, auto lrc, auto lcc) {
+            hipLaunchKernelGGL((col_fband_pack_kernel<T, decltype(seq), decltype(lrc)::value, decltype(lcc)::value>), dim3(gx, gy), dim3(nt), 0, st, a, out);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = fail(std::string("fft launch: ") + hipGetErrorString(e));
+        });
+        if (!ok) rc = fail("fft: unsupported R-split column stage");
     }
     template <typename T>
     void row_qe(int grid, int nt, size_t smem, const RowQeArgs<T>& a) {
@@ -502,7 +539,7 @@ template <typename T>
 static Fft2dPlan<T> view(const oa_plan* p) {
     Fft2dPlan<T> f;
     f.ny = p->ny; f.nx = p->nx; f.logNy = p->logNy; f.logNx = p->logNx; f.kp = p->kp;
-    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y; for (int i = 0; i < 5; ++i) f.rq8c[i] = (const cx<T>*)p->rq8c[i];
+    f.tw_x = (const cx<T>*)p->tw_x; f.tw_y = (const cx<T>*)p->tw_y; for (int i = 0; i < RQ8_NGRIDS; ++i) f.rq8c[i] = (const cx<T>*)p->rq8c[i];
     return f;
 }
 // COLUMN GRID view: the same map transformed on my < ny rows (plan_ensure_col_grid made the W_my table)
@@ -590,7 +627,8 @@ static int qe_rows_impl(oa_plan* p, const void* gx, const void* gy, const void* 
             return fail("oa_qe_rows: mrow must be a power of two >= 64 (or 1536 for band limits that fit it)");
         if (2L * wi + wo > mrow) return fail("oa_qe_rows: mrow < 2*win + wout would alias the leg products into the kept columns");
     }
-    if (lr && !f.rows_qe_is_pair(wi, wo, mrow)) return fail("oa_qe_rows: leg planes in the R-layout need the two-rows-per-transform row stage");
+    if (lr && (!f.rows_qe_is_pair(wi, wo, mrow) || (lr == 1 && !f.rows_qe_lr1(wi, wo, mrow))))
+        return fail("oa_qe_rows: leg planes in the R-layout need the two-rows-per-transform row stage");
     f.rows_qe(q, (const cx<T>*)gx, (const cx<T>*)gy, (const cx<T>*)h, (cx<T>*)px, (cx<T>*)py, (T)scale, accumulate, wi, wo, mrow,
               pin, pout, 1, 0, 0, -1, nullptr, lr);
     return q.rc;
@@ -602,7 +640,10 @@ static int rsplit_lr(const oa_plan* p, int my, int width, int wout, int mrow) {
     const int w = f.clampw(width), wo = f.clampw(wout);
     if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !Fft2dPlan<T>::has_rsplit(p->logNy, p->logNx, my, w)) return 0;
     if (mrow < 0) { mrow = Fft2dPlan<T>::row_grid_min(p->nx, w, wo); if (2L * w + wo > mrow) mrow = 0; }
-    return coarse_view<T>(p, my).rows_qe_is_pair(w, wo, mrow) ? p->logNy - ilog2(my) : 0;
+    const auto cv = coarse_view<T>(p, my);
+    const int lr = p->logNy - ilog2(my);
+    if (lr == 1 && !cv.rows_qe_lr1(w, wo, mrow)) return 0;
+    return cv.rows_qe_is_pair(w, wo, mrow) ? lr : 0;
 }
 int qe_rsplit_lr(const oa_plan* p, int my, int width, int wout, int mrow) {
     return p->dtype == OA_F32 ? rsplit_lr<float>(p, my, width, wout, mrow) : rsplit_lr<double>(p, my, width, wout, mrow);
@@ -619,7 +660,8 @@ static int legs_cols_impl(oa_plan* p, const void* kX, const void* kY, const void
 // real map -> the three column-transformed leg planes (both legs from this one map)
 template <typename T>
 static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h,
-                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7, int my = 0, int lr = 0) {
+                              int width, int rband, hipStream_t st, long pwork = 0, long pout = 0, int stages = 7, int my = 0, int lr = 0,
+                              const void* fgh = nullptr) {
     const size_t plane = (size_t)p->ny * p->kp * sizeof(cx<T>);
     if (int rc = plan_ensure_scratch(p, 2 * plane)) return rc;
     HipLauncher q{st};
@@ -635,7 +677,7 @@ static int map_legs_cols_impl(oa_plan* p, const void* map, const void* FG, const
         const long kplane = (long)my * pw;
         if (stages & 1) f.rows_rsplit(q, map, tA, pw, kplane, w, my);
         if (stages & 4) f.legs_fband(q, cv, tA, kplane, pw, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)gx, (cx<T>*)gy,
-                                     (cx<T>*)h, width, rband, pout > 0 ? pout : p->kp);
+                                     (cx<T>*)h, width, rband, pout > 0 ? pout : p->kp, 1, 0, 0, (const cx<T>*)fgh);
         return q.rc;
     }
     if (stages & 1) f.rows(q, ROW_R2C, map, p->nx / 2, tA, pw, (T)1, w);
@@ -704,7 +746,7 @@ static int cols_div_batch_impl(oa_plan* p, const void* pa, const void* pb, const
 template <typename T>
 static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0,
                            void* c1, void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow,
-                           int my, long pl, long pk, hipStream_t st, DivBinFuse* fuse) {
+                           int my, long pl, long pk, hipStream_t st, DivBinFuse* fuse, const void* fgh) {
     auto f = view<T>(p);
     const int lr = rsplit_lr<T>(p, my, wl, wk, mrow);
     if (!(my > 0 && my < p->ny && is_pow2(my) && p->tw_y_small[ilog2(my)]) || !(lr || Fft2dPlan<T>::has_fwdlegs_cg(p->logNy, my))) return -1;
@@ -727,7 +769,7 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
         f.rows_rsplit(q, map0, tA, pl, kplane, wi, my);
         f.rows_rsplit(q, map1, tA + ms, pl, kplane, wi, my);
         f.legs_fband(q, cv, tA, kplane, pl, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)c0, (cx<T>*)c1, (cx<T>*)c2, wl, rl,
-                     pl, 2, ms, cms);
+                     pl, 2, ms, cms, (const cx<T>*)fgh);
         cv.rows_qe(q, (const cx<T>*)c0, (const cx<T>*)c1, (const cx<T>*)c2, (cx<T>*)g0, (cx<T>*)g1, (T)(s * s * sy), 0, wi, wo, mrow, pl, pk, 2, cms, gms,
                    -1, nullptr, lr);
         cv.cols_div(q, (const cx<T>*)g0, (const cx<T>*)g1, (const T*)Fn, (const T*)p->lxd, (const T*)p->lyd, (cx<T>*)out0, tA, tB, 0, wk, rk, pk, 2,
@@ -749,9 +791,26 @@ static int qe_tt_pair_impl(oa_plan* p, const void* map0, const void* map1, const
 }
 int qe_tt_pair_w(oa_plan* p, const void* map0, const void* map1, const void* FG, const void* FH, const void* Fn, void* c0, void* c1,
                  void* c2, void* g0, void* g1, void* out0, void* out1, int wl, int wk, int rl, int rk, int mrow, int my, long pl, long pk,
-                 hipStream_t st, DivBinFuse* fuse) {
-    return p->dtype == OA_F32 ? qe_tt_pair_impl<float>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st, fuse)
-                              : qe_tt_pair_impl<double>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st, fuse);
+                 hipStream_t st, DivBinFuse* fuse, const void* fgh) {
+    return p->dtype == OA_F32 ? qe_tt_pair_impl<float>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st, fuse, fgh)
+                              : qe_tt_pair_impl<double>(p, map0, map1, FG, FH, Fn, c0, c1, c2, g0, g1, out0, out1, wl, wk, rl, rk, mrow, my, pl, pk, st, fuse, fgh);
+}
+// the packed filter table of the R-split column stage (ColFBandArgs::fgh) for this binding: entries of it, and the launch that fills it
+template <typename T>
+static int fband_pack_impl(oa_plan* p, const void* FG, const void* FH, void* out, int width, int rband, int my, hipStream_t st) {
+    HipLauncher q{st};
+    auto f = view<T>(p);
+    const auto cv = coarse_view<T>(p, my);
+    f.legs_fband(q, cv, nullptr, 0, 0, (const T*)FG, (const T*)FH, (const T*)p->lxd, (const T*)p->lyd, nullptr, nullptr, nullptr, width, rband, 0, 1, 0, 0,
+                 nullptr, (cx<T>*)out);
+    return q.rc;
+}
+long qe_fband_table_entries(const oa_plan* p, int width, int my) {
+    return p->dtype == OA_F32 ? view<float>(p).fband_table_entries(coarse_view<float>(p, my), width)
+                              : view<double>(p).fband_table_entries(coarse_view<double>(p, my), width);
+}
+int qe_fband_pack_w(oa_plan* p, const void* FG, const void* FH, void* out, int width, int rband, int my, hipStream_t st) {
+    return p->dtype == OA_F32 ? fband_pack_impl<float>(p, FG, FH, out, width, rband, my, st) : fband_pack_impl<double>(p, FG, FH, out, width, rband, my, st);
 }
 
 // ---- the same passes on the plan's COMPACT work planes (pipeline.hip): pl = pitch of the leg planes and of the
@@ -760,9 +819,9 @@ long work_pitch(const oa_plan* p, int w) {
     return p->dtype == OA_F32 ? view<float>(p).work_pitch(w) : view<double>(p).work_pitch(w);
 }
 int qe_map_legs_cols_w(oa_plan* p, const void* map, const void* FG, const void* FH, void* gx, void* gy, void* h, int width,
-                       int rband, long pl, hipStream_t st, int stages, int my, int lr) {
-    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr)
-                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr);
+                       int rband, long pl, hipStream_t st, int stages, int my, int lr, const void* fgh) {
+    return p->dtype == OA_F32 ? map_legs_cols_impl<float>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr, fgh)
+                              : map_legs_cols_impl<double>(p, map, FG, FH, gx, gy, h, width, rband, st, pl, pl, stages, my, lr, fgh);
 }
 // Windowed simulation front end (oa_mc_run_windowed): full-plane hc spectrum -> inverse column transform (into `cols_tmp`, a full
 // hc plane) -> ONE fused row pass C2R x window -> R2C (ROW_WIN) that leaves the row-transformed windowed map on the plan's first

@@ -18,8 +18,14 @@
 // reads the row pass's output once and writes the leg planes once.
 // LDS: the [My][C] forward tile (128 KB: C = 8 f32 / 4 f64 columns at My = 2048) is reused as R buffers of [Mq][C]: three
 // legs + idle groups that only keep the barriers company.
+// R = 2 (the wide band: 8192^2 maps on the 4096-row column grid, tiles of 4 f32 / 2 f64 columns): two buffers for three legs -- H and Gx
+// are transformed first, Gy waits in registers (two values per butterfly) and takes buffer 0 in a second round; W_My^(k1 y_lo) is 1
+// (k1 = 0) or taken from the forward transform's two-level table at the store (k1 = 1: 2048 entries would not fit next to the tile).
 #pragma once
 #include "fft_kernels.hpp"
+#ifndef FB_STAMP
+#define FB_STAMP(i)           // (tools/probes/fband_probe.hip records the cycle counter at the phase boundaries)
+#endif
 
 namespace oa {
 
@@ -29,6 +35,10 @@ struct ColFBandArgs {
     long kplane, pitch;
     const T* FG; const T* FH;   // full-resolution filter planes (row pitch fpitch)
     long fpitch;
+    // fgh != nullptr: (FG, FH) of every kept bin in the order the threads read them -- col_fband_pack_body, made once per binding:
+    // [k1][tile][2 u + side][tid], dead bins (beyond the band or the width) zero.  From the planes a wave's read of 64 bins touches
+    // 32 rows x 16 bytes; the probe (tools/probes/fband_probe.hip) put a fifth of the R = 2 kernel's time there
+    const cx<T>* fgh;
     const T* lxd; const T* lyd;
     cx<T>* gx; cx<T>* gy; cx<T>* h;   // My-row leg planes in the R-LAYOUT, row pitch opitch
     long opitch;
@@ -36,6 +46,22 @@ struct ColFBandArgs {
     const cx<T>* tw;            // W_My^k
     int ny_full, rband;         // rband > 0: the filters vanish on rows rband <= y <= ny_full - rband (not read)
     long in_moff, out_moff;     // several maps per launch (grid z = map)
+};
+
+// R = 2: ColStore with the factor W_My^(k1 y_lo) taken from the forward transform's two-level LDS table (a global table read between the
+// stores of ColStore::put would wait for each of them in turn)
+template <typename T>
+struct FBandStore2 {
+    cx<T>* base;
+    unsigned kstride;
+    int ncols;
+    const cx<T>* twl;
+    int h, k1;
+    template <typename U> OA_HD void put(int k, int c, cx<U> v) const {
+        if (c >= ncols) return;
+        if (k1) v = v * tw_lds(twl, h, k);
+        base[(unsigned)k * kstride + (unsigned)c] = swp(v);
+    }
 };
 
 template <typename T, class SEQF, int LR, int LOGC, class Ctx>
@@ -53,10 +79,11 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     const int tid = ctx.tid();
     int tile = ctx.bid_x();
     if ((sizeof(cx<T>) << LOGC) < 128) {
-        // 64-byte row segments: tiles 2m and 2m+1 share every 128-byte line -> give them to workgroups b and b + 8 of a group
-        // of 16 (same XCD under the round-robin dispatch; see col_div_body)
-        const int nt = ctx.grid_x(), base = tile & ~15, r = tile & 15;
-        if (base + 16 <= nt) tile = base + 2 * (r & 7) + (r >> 3);
+        // row segments of 64 (32) bytes: G = 2 (4) neighbouring tiles share every 128-byte line -> give them to workgroups b, b + 8, ..
+        // of a group of 8 G (same XCD under the round-robin dispatch, resident together; see col_div_body)
+        constexpr int G = 128 / (int)(sizeof(cx<T>) << LOGC), GW = 8 * G;
+        const int nt = ctx.grid_x(), base = tile & ~(GW - 1), r = tile & (GW - 1);
+        if (base + GW <= nt) tile = base + G * (r & 7) + (r >> 3);
     }
     const int c0 = tile << LOGC;
     const int k1 = ctx.bid_y();
@@ -66,50 +93,126 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     cx<T>* twl = s + (1 << (logL + LOGC));                   // forward stage twiddles (W_My)
     cx<T>* twq = twl + tw_lds_size(logL);                    // inverse stage twiddles (W_Mq)
     cx<T>* ti = twq + tw_lds_size(logMq);                    // W_My^(k1 y_lo), y_lo < Mq
+    FB_STAMP(0);
     tw_lds_fill<T>(ctx, twl, a.tw, logL, logL, NT);
     tw_lds_fill<T>(ctx, twq, a.tw, logL, logMq, NT);
-    for (int i = tid; i < Mq; i += NT) ti[i] = a.tw[((unsigned)k1 * (unsigned)i) & (unsigned)(L - 1)];
+    if constexpr (LR != 1)
+        for (int i = tid; i < Mq; i += NT) ti[i] = a.tw[((unsigned)k1 * (unsigned)i) & (unsigned)(L - 1)];
     ctx.sync();
+    FB_STAMP(1);
     const long zmap = ctx.bid_z();
-    const ColLoad<T> ld{a.in + zmap * a.in_moff + (long)k1 * a.kplane + c0, (unsigned)a.pitch, ncols, false};
-    col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, LOGC, twl, logL, ld);
-    ctx.sync();                                              // every LDS read of the forward precedes the leg buffers' writes
-    cx<T>* bh = s;
-    cx<T>* bx = s + (Mq << LOGC);
-    cx<T>* by = s + 2 * (Mq << LOGC);
+    // the filter values of this thread's 2 NB kept bins, requested together, ahead of the forward transform, from valid addresses (dead bins: element 0, value unused) --
+    // inside per-bin `if` blocks the compiler issued one read, waited, used it, issued the next (tools/isa_loads.py)
+    T fgv[2 * NB], fhv[2 * NB], lyv[2 * NB], lxv[NB];
+    bool lv[2 * NB];
+    const cx<T>* fq = a.fgh ? a.fgh + (((long)k1 * ctx.grid_x() + tile) * (2 * NB)) * NT + tid : nullptr;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
         const int c = b & (C - 1), j = b >> LOGC;            // j < Ns = Mq / 2
         const bool ok = c < ncols;
-        const T lx = ok ? a.lxd[c0 + c] : (T)0;
+        lxv[u] = ldg(a.lxd + (ok ? c0 + c : 0));
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
-            const cx<T> x = side ? gv[u * RL + RL - 1] : gv[u * RL];
             const int k2 = side ? j + (RL - 1) * Ns : j;     // bin of the My-point forward transform
-            const int k2p = side ? j + Ns : j;               // its place in the Mq-point coarse spectrum of this k1
             const int yf = k1 + R * k2;                      // row of the full-resolution grid
             bool live = ok;
             if (a.rband) live = ok && !(yf >= a.rband && yf <= a.ny_full - a.rband);
-            T fg = 0, fh = 0, ly = 0;
-            if (live) {
-                const long fi = (long)yf * a.fpitch + (c0 + c);
-                fg = a.FG[fi]; fh = a.FH[fi]; ly = a.lyd[yf];
+            if (fq) {
+                const cx<T> f = ldg(fq + (2 * u + side) * NT);
+                fgv[2 * u + side] = f.x; fhv[2 * u + side] = f.y;
+            } else {
+                const long fi = live ? (long)yf * a.fpitch + (c0 + c) : 0;
+                fgv[2 * u + side] = ldg(a.FG + fi);
+                fhv[2 * u + side] = ldg(a.FH + fi);
             }
+            lyv[2 * u + side] = ldg(a.lyd + (live ? yf : 0));
+            lv[2 * u + side] = live;
+        }
+    }
+    FB_STAMP(2);
+    const ColLoad<T> ld{a.in + zmap * a.in_moff + (long)k1 * a.kplane + c0, (unsigned)a.pitch, ncols, false};
+    col_pipeline_to_regs<T, SEQF>(ctx, s, gv, tid, NT, LOGC, twl, logL, ld);
+    ctx.sync();
+    FB_STAMP(3);                                              // every LDS read of the forward precedes the leg buffers' writes
+    cx<T>* bh = s;
+    cx<T>* bx = s + (Mq << LOGC);
+    cx<T>* by = s + 2 * (Mq << LOGC);
+    cx<T> gyv[LR == 1 ? 2 * NB : 1];                         // R = 2: Gy's spectrum until buffer 0 is free
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b & (C - 1), j = b >> LOGC;
+        const T lx = (c < ncols) ? lxv[u] : (T)0;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const cx<T> x = side ? gv[u * RL + RL - 1] : gv[u * RL];
+            const int k2p = side ? j + Ns : j;               // the bin's place in the Mq-point coarse spectrum of this k1
+            const bool live = lv[2 * u + side];
+            const T fg = live ? fgv[2 * u + side] : (T)0, fh = live ? fhv[2 * u + side] : (T)0, ly = live ? lyv[2 * u + side] : (T)0;
             const cx<T> g = mul_pi(x * fg);
             const int at = (k2p << LOGC) + c;
             bh[at] = swp(x * fh);                            // inverse transform = forward transform of the swapped data
             bx[at] = swp(g * lx);
-            by[at] = swp(g * ly);
+            if constexpr (LR == 1) gyv[2 * u + side] = swp(g * ly);
+            else by[at] = swp(g * ly);
         }
     }
     ctx.sync();
+    FB_STAMP(4);
     const int grp = tid / NTQ, tq = tid - grp * NTQ;         // groups 0..2: H, Gx, Gy; the others idle along
     cx<T>* outp = grp == 0 ? a.h : (grp == 1 ? a.gx : a.gy);
-    const ColStore<T> st{outp + zmap * a.out_moff + (long)k1 * a.opitch + c0, (unsigned)(R * a.opitch), grp < 3 ? ncols : 0, true, ti, 0u, (T)1,
-                         0, 0, 0, 0};
     using SI = typename SeqOf<logMq>::type;
-    fft_pipeline<T, false, false, true, SI>(ctx, s + grp * (Mq << LOGC), tq, NTQ, logMq, LOGC, 0, twq, logMq, NoLoad{}, st);
+    if constexpr (LR != 1) {
+        const ColStore<T> st{outp + zmap * a.out_moff + (long)k1 * a.opitch + c0, (unsigned)(R * a.opitch), grp < 3 ? ncols : 0, true, ti, 0u, (T)1,
+                             0, 0, 0, 0};
+        fft_pipeline<T, false, false, true, SI>(ctx, s + grp * (Mq << LOGC), tq, NTQ, logMq, LOGC, 0, twq, logMq, NoLoad{}, st);
+    } else {
+        const FBandStore2<T> st{outp + zmap * a.out_moff + (long)k1 * a.opitch + c0, (unsigned)(R * a.opitch), ncols, twl, tw_lds_h(logL), k1};
+        fft_pipeline<T, false, false, true, SI>(ctx, s + grp * (Mq << LOGC), tq, NTQ, logMq, LOGC, 0, twq, logMq, NoLoad{}, st);
+    }
+    FB_STAMP(5);
+    if constexpr (LR == 1) {
+        ctx.sync();                                          // round 1 has left buffer 0
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int b = tid + u * NT;
+            const int c = b & (C - 1), j = b >> LOGC;
+            bh[(j << LOGC) + c] = gyv[2 * u];
+            bh[((j + Ns) << LOGC) + c] = gyv[2 * u + 1];
+        }
+        ctx.sync();
+        FB_STAMP(6);
+        const FBandStore2<T> st2{a.gy + zmap * a.out_moff + (long)k1 * a.opitch + c0, (unsigned)(R * a.opitch), grp == 0 ? ncols : 0, twl, tw_lds_h(logL), k1};
+        fft_pipeline<T, false, false, true, SI>(ctx, s + grp * (Mq << LOGC), tq, NTQ, logMq, LOGC, 0, twq, logMq, NoLoad{}, st2);      // (group 1 keeps the barriers company)
+        FB_STAMP(7);
+    }
+}
+
+// the packed filter table of ColFBandArgs::fgh: same grid and workgroup size as col_fband_body (grid z unused)
+template <typename T, class SEQF, int LR, int LOGC, class Ctx>
+OA_HD void col_fband_pack_body(Ctx& ctx, const ColFBandArgs<T>& a, cx<T>* out) {
+    constexpr int logL = seq_total_log<SEQF>();
+    constexpr int L = 1 << logL, R = 1 << LR;
+    constexpr int RL = SEQF::get(SEQF::n - 1), NB = EPT / RL, Ns = L / RL, C = 1 << LOGC;
+    constexpr int NT = (1 << (logL + LOGC)) / EPT;
+    const int tid = ctx.tid(), tile = ctx.bid_x(), k1 = ctx.bid_y(), c0 = tile << LOGC;
+    cx<T>* o = out + (((long)k1 * ctx.grid_x() + tile) * (2 * NB)) * NT + tid;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int b = tid + u * NT;
+        const int c = b & (C - 1), j = b >> LOGC;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int k2 = side ? j + (RL - 1) * Ns : j;
+            const int yf = k1 + R * k2;
+            bool live = c0 + c < a.width;
+            if (a.rband) live = live && !(yf >= a.rband && yf <= a.ny_full - a.rband);
+            cx<T> f = mk<T>((T)0, (T)0);
+            if (live) { const long fi = (long)yf * a.fpitch + (c0 + c); f = mk<T>(a.FG[fi], a.FH[fi]); }
+            o[(2 * u + side) * NT] = f;
+        }
+    }
 }
 
 }  // namespace oa

@@ -924,15 +924,22 @@ OA_HD void row_qe_body(Ctx& ctx, const RowQeArgs<T>& a) {
 // sum_k1 W_R^(-k1 y_hi) B[k1][y_lo] -- the last radix-R butterfly of the inverse column transform, taken here at the load;
 // the pair (y_hi = 2 p, 2 p + 1) of group y_lo: with s02 = B0 + B2, d02 = B0 - B2, s13 = B1 + B3, d13 = B1 - B3 and
 // sg = +1 (p = 0) / -1 (p = 1):  a0 = s02 + sg s13,  a1 = d02 + sg i d13.
+// LAY = 1 (R = 2, the wide band of 8192^2 maps on the 4096-row column grid; 8-point row stage only): rows 2 y_lo, 2 y_lo + 1 of the
+// plane hold B0, B1 and the one workgroup of group y_lo forms the rows y_lo, y_lo + Mq:  a0 = B0 + B1,  a1 = B0 - B1.
 // LAY = 3 (R = 8: 16384-row maps on the 2048-row column grid): the plane holds B[k1][y_lo] at row 8 y_lo + k1; workgroup p < 4 of
 // group y_lo forms the rows y_hi = 2 p and 2 p + 1:  a0 = sum_k W_8^(-2 p k) b_k,  a1 = sum_k W_8^(-(2 p + 1) k) b_k.  With
 // s_k = b_k + b_(k+4), d_k = b_k - b_(k+4) (k < 4):  a0 = (s0 + i^(2p) s2) + i^p (s1 + i^(2p) s3),
 // a1 = (d0 + i^(2p+1) d2) + th (d1 + i^(2p+1) d3),  th = exp(+i pi (2 p + 1) / 4): one complex product per tap and row pair.
 template <typename T, int LAY>
 OA_HD void pair_rows_at(const cx<T>* row0, const cx<T>* row1, long pitch, T sg, int idx, cx<T>& a0, cx<T>& a1, int p = 0) {
-    static_assert(LAY == 0 || LAY == 2 || LAY == 3, "pair_rows_at: natural layout, R = 4 or R = 8");
+    static_assert(LAY >= 0 && LAY <= 3, "pair_rows_at: natural layout, R = 2, R = 4 or R = 8");
     auto rd = [](const cx<T>* q) { return ldg(q); };
     if (LAY == 0) { a0 = rd(row0 + idx); a1 = rd(row1 + idx); return; }
+    if (LAY == 1) {                                          // R = 2: rows y_lo and y_lo + Mq of the field are B0 + B1 and B0 - B1
+        const cx<T> b0 = rd(row0 + idx), b1 = rd(row1 + idx);
+        a0 = b0 + b1; a1 = b0 - b1;
+        return;
+    }
     if (LAY == 3) {
         cx<T> b[8];
 #pragma unroll

@@ -33,8 +33,7 @@ struct Fft2dPlan {
     long kp = 0;                 // half-complex pitch (complex elements)
     const cx<T>* tw_x = nullptr; // W_nx^k, k < nx
     const cx<T>* tw_y = nullptr; // W_ny^k, k < ny
-    const cx<T>* rq8c[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // constants of the 8-point row stage's grids 1024, 1536, 2048, 4096, 8192 (nullptr: not offered)
-    static int rq8_slot(int m) { return m == 1024 ? 0 : m == 1536 ? 1 : m == 2048 ? 2 : m == 4096 ? 3 : m == 8192 ? 4 : -1; }
+    const cx<T>* rq8c[RQ8_NGRIDS] = {};   // constants of the 8-point row stage's grids (slot = rq8_slot(M): 1024, 1536, 2048, 4096, 8192; nullptr: not offered)
     bool rq8_ready(int m) const { const int i = rq8_slot(m); return rowqe8_on() && i >= 0 && rq8c[i] != nullptr; }
     // COLUMN GRID view (fft.hip coarse_view): this plan describes ny = My rows of a map with ny_full rows; filters, ly
     // axis and caller-owned planes are addressed at the full-resolution rows (ColLegsArgs::yshift).  0 = own grid.
@@ -87,7 +86,8 @@ struct Fft2dPlan {
 
     // ---- R-SPLIT: row R2C with the first radix-R butterfly of the column transform on top (RowArgs::lr), then ONE
     //      single-pass column kernel to the leg planes (fft_fband.hpp).  THIS plan is the full-resolution one; my = the
-    //      column grid.  Available for R = ny / my = 4, my = 1024 or 2048, leg widths up to a quarter of the packed row.
+    //      column grid.  Available for R = ny / my = 4, my = 1024 or 2048, leg widths up to a quarter of the packed row; R = 8 (16384^2,
+    //      float64) and R = 2 (8192^2 on 4096 rows, <= 1280 kept columns).
     static bool has_rsplit(int logNy, int logNx, int my, int wl) {
         if (my <= 0) return false;
         static const bool off = exp_env("OA_NO_RSPLIT") != nullptr;        // A/B switch
@@ -96,6 +96,8 @@ struct Fft2dPlan {
         // R = 8: 16384^2 maps on the 2048-row column grid (row_r2c_rs_body<T, 13, 3>: 16384-point rows, <= 512 kept columns)
         // (float64: the float build measured slower than the two-waves-per-row kernel + multi-pass columns, which float keeps)
         if (logNy - logMy == 3) return sizeof(T) == 8 && logMy == 11 && logNx == 14 && wl <= 512;
+        // R = 2: the wide band of 8192^2 maps on the 4096-row column grid (row_r2c_rs_body<T, 12, 1, .., 5>: <= 1280 kept columns)
+        if (logNy - logMy == 1) return logMy == 12 && logNx == 13 && wl <= 1280;
         return logNy - logMy == 2 && (logMy == 10 || logMy == 11) && logNx >= 11 && logNx <= 14 && wl <= L / 4 && wl <= RS_MAXS * (L / EPT);
     }
     template <class Launcher>
@@ -124,15 +126,23 @@ struct Fft2dPlan {
     template <class Launcher>
     void legs_fband(Launcher& q, const Fft2dPlan<T>& cv, const cx<T>* Y, long kplane, long pin, const T* FG, const T* FH, const T* lxd,
                     const T* lyd, cx<T>* gx, cx<T>* gy, cx<T>* h, int wmax, int rband, long pout, int nmaps = 1, long in_moff = 0,
-                    long out_moff = 0) const {
+                    long out_moff = 0, const cx<T>* fgh = nullptr, cx<T>* pack_out = nullptr) const {
+        // fgh: the packed filter table of this (FG, FH, wmax, rband, grid) -- pack_out != nullptr: MAKE it (nothing else runs)
         ColFBandArgs<T> a{};
-        a.in = Y; a.kplane = kplane; a.pitch = pin; a.FG = FG; a.FH = FH; a.fpitch = kp; a.lxd = lxd; a.lyd = lyd;
+        a.in = Y; a.kplane = kplane; a.pitch = pin; a.FG = FG; a.FH = FH; a.fpitch = kp; a.lxd = lxd; a.lyd = lyd; a.fgh = fgh;
         a.gx = gx; a.gy = gy; a.h = h; a.opitch = pout; a.width = clampw(wmax); a.tw = cv.tw_y; a.ny_full = ny; a.rband = clampr(rband);
         a.in_moff = in_moff; a.out_moff = out_moff;
         const int lt = fband_lt(), lc = lt - cv.logNy, Cs = 1 << lc;
         const int logMq = cv.logNy - (logNy - cv.logNy);
-        const size_t smem = ((size_t)(1 << lt) + tw_lds_size(cv.logNy) + tw_lds_size(logMq) + (1 << logMq)) * sizeof(cx<T>);
-        q.col_fband((a.width + Cs - 1) / Cs, 1 << (logNy - cv.logNy), nmaps, smem, cv.logNy, a);
+        // (R = 2: no LDS table of W_My^(k1 y_lo) -- col_fband_body)
+        const size_t smem = ((size_t)(1 << lt) + tw_lds_size(cv.logNy) + tw_lds_size(logMq) + (logNy - cv.logNy == 1 ? 0 : (1 << logMq))) * sizeof(cx<T>);
+        if (pack_out) q.col_fband_pack((a.width + Cs - 1) / Cs, 1 << (logNy - cv.logNy), cv.logNy, a, pack_out);
+        else q.col_fband((a.width + Cs - 1) / Cs, 1 << (logNy - cv.logNy), nmaps, smem, cv.logNy, a);
+    }
+    // entries (cx<T>) of the packed filter table for `wmax` leg columns on the column grid `cv`
+    long fband_table_entries(const Fft2dPlan<T>& cv, int wmax) const {
+        const int lc = fband_lt() - cv.logNy, Cs = 1 << lc;
+        return (long)((clampw(wmax) + Cs - 1) / Cs) * Cs * cv.ny;          // tiles x C x My
     }
 
     // ---- fused QE row stage: 3 hc planes (column-transformed legs) -> 2 hc planes -------------
@@ -150,6 +160,8 @@ struct Fft2dPlan {
         if (rq8_is_m3(M)) return rq8_ready(M) && rq8_covers(M, win, wout);
         return is_pow2(M) && M >= 1024 && M <= 8192 && 2L * win + wout <= M;
     }
+    // can the row stage read R = 2 planes (LAY = 1) of this band on grid mrow?
+    bool rows_qe_lr1(int win, int wout, int mrow) const { return mrow == 4096 && mrow <= nx && rq8_ready(mrow) && rq8_covers(mrow, win, wout); }
     // which body runs the two-rows-per-transform row stage on 1024- to 4096-point grids: 8 points per thread (default) or 16
     // (experiment builds: OA_NO_ROWQE8=1; the emulator tests run both)
     static bool& rowqe8_on() {
@@ -204,7 +216,7 @@ struct Fft2dPlan {
                 q.row_qe_pair8(ny / 2, M, a);
                 return;
             }
-            if (rq8_ready(M) && rq8_covers(M, win, wout) && (lr == 0 || lr == 2 || lr == 3)) {
+            if (rq8_ready(M) && rq8_covers(M, win, wout) && (lr == 0 || lr == 2 || lr == 3 || (lr == 1 && M == 4096))) {
                 // eight points per thread, M / 512 waves per row pair (row_qe8_body, fft_rowqe8.hpp)
                 a.logL = logM; a.logC = 0; a.NT = M / 8; a.rowStride = M;
                 a.rq8c = rq8c[rq8_slot(M)];
@@ -215,6 +227,7 @@ struct Fft2dPlan {
                 return;
             }
             // 16 points per thread, M / 16 threads per row pair (row_qe_pair_body): 8192-point grids
+            if (lr == 1) { q.fail_rlayout(); return; }        // (R = 2 exists in the 8-point body only; callers check rows_qe_lr1)
             a.logL = logM; a.logC = 0; a.NT = M / EPT; a.rowStride = M + (M >> 4) + 2;
             if (nmaps > 1 || tab) { a.npairs = ny / 2; a.in_moff = in_moff; a.out_moff = out_moff; a.h_moff = h_moff < 0 ? in_moff : h_moff; }
             a.tab = tab;

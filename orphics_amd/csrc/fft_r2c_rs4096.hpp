@@ -28,6 +28,9 @@ namespace oa {
 // at the untangle; <= 512 columns kept, one per thread).  S = L / 16 = threads per row = points per sub-transform.
 // Column butterfly on top: R = 4 (LR = 2: two radix-2 levels, three live values per column) or R = 8 (LR = 3, 16384^2 maps on the
 // 2048-row column grid: eight running sums per column -- one column per thread there).
+// WIDE BAND (RKW = 5, LOGL = 12, R = 2: SURVEY section 8(d)'s T filter up to ell = 6000 -- 1138 kept columns of an 8192^2 map on the
+// 4096-row column grid): the last stage keeps 5 of its 16 bins per side (columns < 1280 and their mirror images), a thread
+// untangles five columns tid + 256 r, one running value per column (A = X0, then Y0 = A + X1, Y1 = (A - X1) W_ny^g).
 constexpr int RS4096_NT = 256;
 template <int LOGL> constexpr int rs_nt() { return (1 << LOGL) / 16; }
 template <int LOGL> constexpr int rs_ncol() { return LOGL == 13 ? 1 : 2; }          // kept columns per thread
@@ -43,9 +46,10 @@ template <int LOGL> constexpr int rs_twn() { return LOGL == 13 ? 192 : 128; }   
 // lane group never spans two sub-transforms (32 lanes each): no pad
 template <typename T, int LOGL> constexpr int rs_sub() { return LOGL == 13 ? 512 : (LOGL == 12 ? (sizeof(T) == 4 ? 272 : 256) : 136); }
 template <typename T> constexpr int rs4096_sub() { return rs_sub<T, 12>(); }
-template <typename T, int LOGL> constexpr size_t rs_lds_bytes() {
-    // data + two-level W_L table + W_S table [m][i] + the untangle factors of the kept columns
-    return (size_t)(16 * rs_sub<T, LOGL>() + rs_twn<LOGL>() + rs_nt<LOGL>() + rs_ncol<LOGL>() * rs_nt<LOGL>()) * sizeof(cx<T>);
+template <typename T, int LOGL, int RKW = 0> constexpr size_t rs_lds_bytes() {
+    // data + two-level W_L table + W_S table [m][i] + the untangle factors of the kept columns (wide band: of the first NT, the
+    // others are those times W_32^r -- five columns' worth would cost the second workgroup of a CU its LDS)
+    return (size_t)(16 * rs_sub<T, LOGL>() + rs_twn<LOGL>() + rs_nt<LOGL>() + (RKW ? 1 : rs_ncol<LOGL>()) * rs_nt<LOGL>()) * sizeof(cx<T>);
 }
 template <typename T> constexpr size_t rs4096_lds_bytes() { return rs_lds_bytes<T, 12>(); }
 
@@ -76,13 +80,27 @@ OA_HD cx<T> w8(int e) {
     }
 }
 
-template <typename T, int LOGL, int LR, bool PF = true, class Ctx>
+// W_32^r = exp(-2 pi i r / 32), r < 5
+template <typename T>
+OA_HD cx<T> w32(int r) {
+    switch (r) {
+        case 0: return mk<T>((T)1, (T)0);
+        case 1: return mk<T>((T)0.98078528040323044913L, (T)-0.19509032201612826785L);
+        case 2: return mk<T>((T)0.92387953251128675613L, (T)-0.38268343236508977173L);
+        case 3: return mk<T>((T)0.83146961230254523708L, (T)-0.55557023301960222474L);
+        default: return mk<T>((T)0.70710678118654752440L, (T)-0.70710678118654752440L);
+    }
+}
+
+template <typename T, int LOGL, int LR, bool PF = true, int RKW = 0, class Ctx>
 OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
     constexpr int L = 1 << LOGL, R = 1 << LR, NT = rs_nt<LOGL>(), S = NT, SUB = rs_sub<T, LOGL>();
-    constexpr int LPS = S / 16, NSW = 64 / LPS, RK = LOGL >= 12 ? 2 : 1;      // lanes per sub-transform, sub-transforms per wave, kept bins per side
-    constexpr int NCOL = rs_ncol<LOGL>();
+    constexpr int LPS = S / 16, NSW = 64 / LPS, RK = RKW ? RKW : (LOGL >= 12 ? 2 : 1);      // lanes per sub-transform, sub-transforms per wave, kept bins per side
+    constexpr int NCOL = RKW ? RKW : rs_ncol<LOGL>();
     static_assert(LOGL == 13 || LOGL == 12 || LOGL == 11, "row_r2c_rs_body: 16384-, 8192- or 4096-point rows");
-    static_assert(R == 4 || (R == 8 && NCOL == 1), "column butterfly: R = 4, or R = 8 with one column per thread");
+    static_assert(R == 4 || (R == 8 && NCOL == 1) || (R == 2 && RKW == 5 && LOGL == 12),
+                  "column butterfly: R = 4, R = 8 with one column per thread, or R = 2 on the wide band of 8192-point rows");
+    static_assert(RKW == 0 || (LPS == 16 && RKW <= 5), "wide band: 16 x 16-point sub-transforms (the exchange area holds 2 RK x 64 entries per wave)");
     cx<T>* D = reinterpret_cast<cx<T>*>(ctx.smem());          // [k0][j0]: 16 x S
     cx<T>* TW = D + 16 * SUB;                                 // two-level W_L table
     cx<T>* TS = TW + rs_twn<LOGL>();                          // [m][i] = W_S^(i m), m < 16, i < LPS
@@ -101,7 +119,7 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
     // up to 8 VGPRs across the whole row; loaded from global inside the loop they would queue behind the prefetch)
     cx<T>* TWK = TS + NT;
 #pragma unroll
-    for (int r = 0; r < NCOL; ++r) TWK[tid + NT * r] = a.tw[(unsigned)(tid + NT * r) << (a.logTw - (LOGL + 1))];
+    for (int r = 0; r < (RKW ? 1 : NCOL); ++r) TWK[tid + NT * r] = a.tw[(unsigned)(tid + NT * r) << (a.logTw - (LOGL + 1))];
     cx<T> v[16];
     auto taps = [&](long grp, int n, int t0 = 0, int t1 = 16) {
         const cx<T>* src = in + (grp + (long)n * a.my) * a.in_pitch + tid;
@@ -189,10 +207,11 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
                 for (int t = 0; t < 16; ++t) u[t] = Dk[16 * i + rs_swz<16>(t, i)];   // V[m = i][t]
                 Dft<T, 16>::run(u);                            // u[r] = Z[k0 + 16 i + 256 r]; r = 0, 1, 14, 15 used (the rest is dead code)
                 ctx.wsync();                                   // the reads above precede the exchange writes (same part of D)
-                D[rs_epos<SUB, NSW>(0, k0, i)] = u[0];
-                D[rs_epos<SUB, NSW>(1, k0, i)] = u[1];
-                D[rs_epos<SUB, NSW>(2, k0, i)] = u[14];
-                D[rs_epos<SUB, NSW>(3, k0, i)] = u[15];
+#pragma unroll
+                for (int r = 0; r < RK; ++r) {                 // RK = 2: r = 0, 1, 14, 15;  wide band: 0 .. 4 and 11 .. 15
+                    D[rs_epos<SUB, NSW>(r, k0, i)] = u[r];
+                    D[rs_epos<SUB, NSW>(RK + r, k0, i)] = u[16 - RK + r];
+                }
             } else {
                 // lane i finishes m = 2 i and 2 i + 1: two 8-point butterflies over the lanes' values V[m][t], t < 8
 #pragma unroll
@@ -218,8 +237,16 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
                     const cx<T> Zm = kept(P ? (P >> 8) - (LPS - 2 * RK) : 0, P & 15, (P >> 4) & 15);
                     const cx<T> E = (Zk + conj(Zm)) * (T)0.5;
                     const cx<T> O = mul_mi(Zk - conj(Zm)) * (T)0.5;
-                    const cx<T> X = (E + TWK[kk] * O) * a.scale;
-                    if constexpr (R == 8) {
+                    const cx<T> wk = RKW ? TWK[tid] * w32<T>(r) : TWK[kk];      // W_2L^kk  (wide band: W_2L^tid W_32^r)
+                    const cx<T> X = (E + wk * O) * a.scale;
+                    if constexpr (R == 2) {
+                        if (step == 0) A[r] = X;
+                        else {
+                            cx<T>* dst = out + grp * a.out_pitch + kk;
+                            dst[0] = A[r] + X;
+                            dst[a.kplane] = (A[r] - X) * wy1;
+                        }
+                    } else if constexpr (R == 8) {
                         if (step == 0) {
 #pragma unroll
                             for (int k1 = 0; k1 < 8; ++k1) acc[k1] = X;

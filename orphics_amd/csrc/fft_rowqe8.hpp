@@ -49,6 +49,15 @@ template <int A_> struct Rq8Geom {
     static constexpr int NTW = HALVES ? 8 : A - 1;          // cross-stage factors per position of a thread
     static_assert(A == 2 || A == 3 || A == 4 || A == 8 || A == 16, "rowqe8: row grids of 1024, 1536, 2048, 4096 or 8192 points");
 };
+// the grids a plan carries constants for (slot order).  (3072 = 6 x 512 -- the wide band's 2 x 1138 + 665 points -- was built and
+// measured, radix-6 cross stage, two 6-wave workgroups per CU: 169 us float64 and 92 us float32 against 169 / 77 us on the 4096-point
+// grid, whose eight waves fill the SIMDs evenly; not kept.  profiles/r05_wideband.txt)
+constexpr int RQ8_NGRIDS = 5;
+constexpr int RQ8_WAVES[RQ8_NGRIDS] = {2, 3, 4, 8, 16};
+OA_HD int rq8_slot(int m) {
+    for (int i = 0; i < RQ8_NGRIDS; ++i) if (m == 512 * RQ8_WAVES[i]) return i;
+    return -1;
+}
 
 // LDS entries behind the A regions: float64 keeps the 64-point stage's factors W_64^(lo c), [c - 1][lo], there
 constexpr int RQ8_TAB = 7 * 8;
@@ -439,7 +448,7 @@ OA_HD void rq8_forward16(Ctx& ctx, cx<T>* D, cx<T>* v, int tid, const TW& tw, cx
 
 // ---- which grids this body runs -------------------------------------------------------------------------------------------------
 OA_HD bool rq8_is_m3(int m) { return m == 1536; }
-OA_HD int rq8_waves(int m) { return m == 1024 ? 2 : m == 1536 ? 3 : m == 2048 ? 4 : m == 4096 ? 8 : m == 8192 ? 16 : 0; }
+OA_HD int rq8_waves(int m) { return rq8_slot(m) >= 0 ? m / 512 : 0; }
 // live taps per side of the cross-wave butterfly for `win` active columns: ceil(win / 512) rounded up to a power of two (<= A / 2)
 OA_HD int rq8_nz(int m, int win) {
     const int A = rq8_waves(m);
@@ -485,7 +494,7 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
         const RowQeMap<T> e = a.tab[m];
         gxp = e.gx; gyp = e.gy; hp = e.h; pxp = e.px; pyp = e.py; scale = e.scale;
     }
-    // row addressing as row_qe_pair_body: natural pairs, or the R-layouts of col_fband_body (LAY = 2: R = 4, LAY = 3: R = 8)
+    // row addressing as row_qe_pair_body: natural pairs, or the R-layouts of col_fband_body (LAY = 1: R = 2, LAY = 2: R = 4, LAY = 3: R = 8)
     long r0 = wg * 2, ra = wg * 2, rb = wg * 2 + 1;
     T sg = (T)1;
     int pp = 0;
@@ -497,6 +506,10 @@ OA_HD void row_qe8_body(Ctx& ctx, const RowQeArgs<T>& a) {
         r0 = ylo << 3;
         ra = ylo + mq * (2 * pp);
         rb = ra + mq;
+    } else if (LAY == 1) {
+        const long mq = a.nrows >> 1;                        // group y_lo = wg: plane rows 2 wg, 2 wg + 1 -> field rows wg, wg + Mq
+        ra = wg;
+        rb = wg + mq;
     } else if (LAY > 0) {
         // the two workgroups of a group read the same four rows: workgroups b and b + 8 of a block of 16 (same XCD under the round-robin dispatch)
         const long blk = wg & ~15L;
@@ -591,6 +604,9 @@ inline bool dispatch_rq8(int M, int win, int lr, bool chain, F&& f) {
         }
         switch (lr) {
             case 0: f(ac, nzc, integral_constant<int, 0>{}, std::false_type{}); return true;
+            case 1:                                         // R = 2: the wide band's 4096-point grid only
+                if constexpr (decltype(ac)::value == 8) { f(ac, nzc, integral_constant<int, 1>{}, std::false_type{}); return true; }
+                else return false;
             case 2: f(ac, nzc, integral_constant<int, 2>{}, std::false_type{}); return true;
             case 3: f(ac, nzc, integral_constant<int, 3>{}, std::false_type{}); return true;
             default: return false;

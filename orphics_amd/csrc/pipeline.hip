@@ -51,6 +51,11 @@ struct Pipeline {
     // allocator hands a new estimator the addresses of a freed one, and a caller may refill Fnorm or the ids in place
     unsigned long bind_gen = 1, tab_gen = 0;
     int tab_rows = 0, tab_logc = 0, tab_wk = 0;
+    // the packed (FG, FH) table of the R-split column stage (ColFBandArgs::fgh), same generation key
+    void* fb_t = nullptr;
+    size_t fb_t_bytes = 0;
+    unsigned long fb_gen = 0;
+    int fb_my = 0, fb_wl = 0, fb_rl = 0;
     void** mv_ftab = nullptr;         // oa_qe_mv: device table of the distinct filter planes (gradient fields, then H fields)
     std::vector<const void*> mv_fkey; // what the table holds
     // oa_plan_set_option (include/orphics_amd.h): which of the equivalent launch sequences the one-call entries run
@@ -84,6 +89,7 @@ void pipeline_release(oa_plan* p) {
     if (q->mv_rtab) (void)hipFree(q->mv_rtab);
     if (q->lens_pool) (void)hipFree(q->lens_pool);
     if (q->fn_t) (void)hipFree(q->fn_t);
+    if (q->fb_t) (void)hipFree(q->fb_t);
     if (q->ids_t) (void)hipFree(q->ids_t);
     delete q;
     p->pipe = nullptr;
@@ -279,6 +285,22 @@ static int ensure_div_tables(oa_plan* p, Pipeline* q, hipStream_t st) {
     q->tab_gen = q->bind_gen; q->tab_rows = rows; q->tab_logc = logc; q->tab_wk = q->wk;
     return 0;
 }
+// the packed filter table of the R-split column stage for the bound filters on this plan's column grid, (re)made when the filters, the
+// band or the grid changed: nullptr when this geometry does not take the R-split path (or on failure: the kernel then reads the planes)
+static const void* fband_table(oa_plan* p, Pipeline* q, hipStream_t st) {
+    static const bool off = exp_env("OA_NO_FBAND_TABLE") != nullptr;        // A/B switch
+    if (off || !q->FG || q->my <= 0 || !qe_rsplit_lr(p, q->my, q->wl, q->wk, q->mrow)) return nullptr;
+    if (q->fb_t && q->fb_gen == q->bind_gen && q->fb_my == q->my && q->fb_wl == q->wl && q->fb_rl == q->rl) return q->fb_t;
+    const size_t need = (size_t)qe_fband_table_entries(p, q->wl, q->my) * 2 * (p->dtype == OA_F32 ? 4 : 8);
+    if (q->fb_t_bytes < need) {
+        if (q->fb_t) { if (hipDeviceSynchronize() != hipSuccess) return nullptr; (void)hipFree(q->fb_t); q->fb_t = nullptr; q->fb_t_bytes = 0; }
+        if (hipMalloc(&q->fb_t, need) != hipSuccess) { q->fb_t = nullptr; (void)hipGetLastError(); return nullptr; }
+        q->fb_t_bytes = need;
+    }
+    if (qe_fband_pack_w(p, q->FG, q->FH, q->fb_t, q->wl, q->rl, q->my, st)) return nullptr;
+    q->fb_gen = q->bind_gen; q->fb_my = q->my; q->fb_wl = q->wl; q->fb_rl = q->rl;
+    return q->fb_t;
+}
 static DivBinFuse make_fuse(const oa_plan* p, const Pipeline* q, int64_t* n, double* S, double* C, int store) {
     DivBinFuse f{};
     if (q->tab_rows && q->tab_gen == q->bind_gen && q->tab_rows == q->my && q->tab_wk == q->wk) {
@@ -311,7 +333,8 @@ static int qe_tt_impl(oa_plan* p, const void* real_map, const void* kX, const vo
     int rc;
     const int my = q->my;
     const int lr = (real_map && !rows_done) ? qe_rsplit_lr(p, my, q->wl, q->wk, q->mrow) : 0;     // from a map: R-split row pass + one column kernel
-    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, rows_done ? 6 : 7, my, lr);
+    if (real_map) rc = qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, rows_done ? 6 : 7, my, lr,
+                                          lr ? fband_table(p, q, st) : nullptr);
     else rc = qe_legs_cols_w(p, kX, kY ? kY : kX, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, my);
     if (rc) return rc;
     const double s = 1.0 / ((double)p->ny * p->nx), sy = my ? (double)p->ny / my : 1.0;   // DFT on my rows = my/ny x the full one
@@ -693,7 +716,8 @@ int oa_qe_tt_moments2(oa_plan* p, const void* real_map0, const void* real_map1, 
     if (int rc = ensure_div_tables(p, q, (hipStream_t)stream)) return rc;
     DivBinFuse f = make_fuse(p, q, n, S, C, 0);
     int rc = qe_tt_pair_w(p, real_map0, real_map1, q->FG, q->FH, q->Fn, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], q->kk, q->kT, q->wl,
-                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream, divbin_enabled(q) ? &f : nullptr);
+                          q->wk, q->rl, q->rk, q->mrow, q->my, pl, pk, (hipStream_t)stream, divbin_enabled(q) ? &f : nullptr,
+                          fband_table(p, q, (hipStream_t)stream));
     if (rc > 0) return rc;
     if (rc == 0 && f.done) return 0;           // both maps binned and accumulated (map order) in the divergence launch
     if (rc < 0) {
@@ -723,7 +747,8 @@ int oa_qe_tt_stage(oa_plan* p, int stage, const void* real_map, void* stream) {
     switch (stage) {
         case 0: case 1: case 2:
             OA_REQUIRE(real_map, "oa_qe_tt_stage: stages 0-2 need the map");
-            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my, lr);
+            return qe_map_legs_cols_w(p, real_map, q->FG, q->FH, q->c[0], q->c[1], q->c[2], q->wl, q->rl, pl, st, 1 << stage, my, lr,
+                                      lr ? fband_table(p, q, st) : nullptr);
         case 3: return qe_rows_w(p, q->c[0], q->c[1], q->c[2], q->g[0], q->g[1], s * s * sy, 0, q->wl, q->wk, q->mrow, pl, pk, st, my, lr);
         case 4: {
             if (q->ids && divbin_enabled(q)) {      // as the one-call entries: binning + moments (into dummies) in the divergence launch

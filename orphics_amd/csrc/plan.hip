@@ -30,10 +30,9 @@ static int upload_tables(oa_plan* p) {
     OA_HIP(hipMalloc(&p->tw_y, ty.size() * sizeof(cx<T>)));
     OA_HIP(hipMemcpy(p->tw_x, tx.data(), tx.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     OA_HIP(hipMemcpy(p->tw_y, ty.data(), ty.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
-    const int waves[5] = {2, 3, 4, 8, 16};     // row grids of the fused row stage (512 points per wave) shorter than or equal to the rows
-    for (int i = 0; i < 5; ++i) {
-        if (512 * waves[i] > p->nx) continue;
-        auto t = rq8_make_consts<T>(waves[i]);
+    for (int i = 0; i < RQ8_NGRIDS; ++i) {       // row grids of the fused row stage (512 points per wave) shorter than or equal to the rows
+        if (512 * RQ8_WAVES[i] > p->nx) continue;
+        auto t = rq8_make_consts<T>(RQ8_WAVES[i]);
         OA_HIP(hipMalloc(&p->rq8c[i], t.size() * sizeof(cx<T>)));
         OA_HIP(hipMemcpy(p->rq8c[i], t.data(), t.size() * sizeof(cx<T>), hipMemcpyHostToDevice));
     }

@@ -30,6 +30,7 @@ struct EmuCtx {
 };
 
 static bool stockham_qe = false;
+static bool emu_fband_packed = false;     // do_rsplit_legs: the filters through the packed table (emu_set_fband_packed)
 static bool rsplit_pf = false;     // general R-split row pass: persistent workgroups with prefetch order (emu_set_rsplit_pf)   // which fused-row-stage body the emulator runs (both are tested)
 
 struct EmuLauncher {
@@ -95,6 +96,10 @@ struct EmuLauncher {
     }
     void fail_rlayout() {}
     template <typename T> void row_rsplit(int grid, int nt, size_t smem, const RowArgs<T>& a) {
+        if (a.lr == 1 && a.logL == 12 && a.wcols <= 1280) {     // the wide band (fft.hip row_rs4096: persistent workgroups; here 3 walk the groups)
+            run(a.my < 3 ? a.my : 3, 1, RS4096_NT, rs_lds_bytes<T, 12, 5>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 1, false, 5>(c, a); });
+            return;
+        }
         if (a.lr != 2) return;
         if (rsplit_pf) {
             grid = grid > 2 ? (grid + 2) / 3 : grid;     // persistent workgroups: each walks ~3 groups (prefetch across group boundaries)
@@ -113,6 +118,15 @@ struct EmuLauncher {
         if (gy == 4 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 8>, 2, lc11>(c, a); }, gz);
         else if (gy == 4 && logMy == 10) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 8>, 2, lc10>(c, a); }, gz);
         else if (gy == 8 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 16>, 3, lc11>(c, a); }, gz);
+        else if (gy == 2 && logMy == 12) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 4, 4>, 1, lc11 - 1>(c, a); }, gz);
+    }
+    template <typename T> void col_fband_pack(int gx, int gy, int logMy, const ColFBandArgs<T>& a, cx<T>* out) {
+        constexpr int nt = sizeof(T) == 4 ? 1024 : 512;
+        constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
+        if (gy == 4 && logMy == 11) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 16, 8>, 2, lc11>(c, a, out); });
+        else if (gy == 4 && logMy == 10) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 8, 8>, 2, lc10>(c, a, out); });
+        else if (gy == 8 && logMy == 11) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 8, 16>, 3, lc11>(c, a, out); });
+        else if (gy == 2 && logMy == 12) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 16, 4, 4>, 1, lc11 - 1>(c, a, out); });
     }
     template <typename T> void col_deriv(int gx, int gy, int nt, size_t smem, const ColDerivArgs<T>& a, int nz) {
         dispatch_seq(a.logL, [&](auto seq) {
@@ -167,15 +181,14 @@ struct EmuLauncher {
 
 template <typename T>
 struct Holder {
-    std::vector<cx<T>> twx, twy, rq8t[5];
+    std::vector<cx<T>> twx, twy, rq8t[RQ8_NGRIDS];
     Fft2dPlan<T> p;
     Holder(int ny, int nx) {
         twx = make_twiddles<T>(nx);
         twy = make_twiddles<T>(ny);
         p.ny = ny; p.nx = nx; p.logNy = ilog2(ny); p.logNx = ilog2(nx);
         p.kp = kpitch_for(nx); p.tw_x = twx.data(); p.tw_y = twy.data();
-        const int waves[5] = {2, 3, 4, 8, 16};
-        for (int i = 0; i < 5; ++i) if (512 * waves[i] <= nx) { rq8t[i] = rq8_make_consts<T>(waves[i]); p.rq8c[i] = rq8t[i].data(); }
+        for (int i = 0; i < RQ8_NGRIDS; ++i) if (512 * RQ8_WAVES[i] <= nx) { rq8t[i] = rq8_make_consts<T>(RQ8_WAVES[i]); p.rq8c[i] = rq8t[i].data(); }
     }
 };
 
@@ -297,6 +310,13 @@ static int do_rsplit_legs(int ny, int my, int nx, const cx<T>* Y, long pitch, co
     Holder<T> hd(ny, nx);
     CoarseHolder<T> cv(ny, my, nx);
     EmuLauncher q;
+    if (emu_fband_packed) {
+        // the filters through the packed table (what the one-call entries of pipeline.hip do); the planes themselves are then not read
+        std::vector<cx<T>> tab((size_t)hd.p.fband_table_entries(cv.p, width));
+        hd.p.legs_fband(q, cv.p, (const cx<T>*)nullptr, 0, 0, FG, FH, lxd, lyd, (cx<T>*)nullptr, (cx<T>*)nullptr, (cx<T>*)nullptr, width, rband, 0, 1, 0, 0, (const cx<T>*)nullptr, tab.data());
+        hd.p.legs_fband(q, cv.p, Y, (long)my * pitch, pitch, (const T*)nullptr, (const T*)nullptr, lxd, lyd, gx, gy, h, width, rband, opitch, nmaps, in_moff, out_moff, tab.data());
+        return 0;
+    }
     hd.p.legs_fband(q, cv.p, Y, (long)my * pitch, pitch, FG, FH, lxd, lyd, gx, gy, h, width, rband, opitch, nmaps, in_moff, out_moff);
     return 0;
 }
@@ -314,18 +334,22 @@ static int do_qe_rows_rlayout(int my, int nx, const cx<T>* gx, const cx<T>* gy, 
 // (R = 8), either precision
 template <typename T>
 static int do_rs4096(int ny, int nx, const T* in, void* out, long pitch, int width, int nwg, int pf) {
-    const int R = nx == 16384 ? 8 : 4;
-    if (!((nx == 16384 && width <= 512) || (nx == 8192 && width <= 512) || (nx == 4096 && width <= 256)) || (ny % R)) return 1;
+    const bool wide = nx == 8192 && width > 512 && width <= 1280;      // the wide band: R = 2, five kept bins per side
+    const int R = nx == 16384 ? 8 : (wide ? 2 : 4);
+    if (!((nx == 16384 && width <= 512) || (nx == 8192 && (width <= 512 || wide)) || (nx == 4096 && width <= 256)) || (ny % R)) return 1;
     auto tw = make_twiddles<T>(nx);
     auto twy = make_twiddles<T>(ny);
     RowArgs<T> a{};
     a.in = in; a.out = out; a.in_pitch = nx / 2; a.out_pitch = pitch; a.logL = ilog2(nx) - 1; a.logC = 0; a.NT = nx / 32;
-    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (T)1; a.mode = ROW_R2C; a.wcols = width; a.lr = R == 8 ? 3 : 2; a.my = ny / R;
+    a.tw = tw.data(); a.logTw = ilog2(nx); a.scale = (T)1; a.mode = ROW_R2C; a.wcols = width; a.lr = R == 8 ? 3 : (R == 2 ? 1 : 2); a.my = ny / R;
     a.kplane = (long)(ny / R) * pitch; a.twy = twy.data();
     EmuLauncher q;
     if (nx == 16384) {
         if (pf) q.run(nwg, 1, 512, rs_lds_bytes<T, 13>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 13, 3, true>(c, a); });
         else q.run(nwg, 1, 512, rs_lds_bytes<T, 13>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 13, 3, false>(c, a); });
+    } else if (wide) {
+        if (pf) q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12, 5>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 1, true, 5>(c, a); });
+        else q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12, 5>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 1, false, 5>(c, a); });
     } else if (nx == 8192) {
         if (pf) q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 2, true>(c, a); });
         else q.run(nwg, 1, RS4096_NT, rs_lds_bytes<T, 12>(), [&](EmuCtx& c) { row_r2c_rs_body<T, 12, 2, false>(c, a); });
@@ -404,6 +428,7 @@ int emu_lens_derivs_f64(int ny, int nx, const void* k0, const double* lxd, const
 int emu_rows_win_f64(int ny, int nx, const void* in, const double* w, void* out, long opitch, double s, int wcols) { return do_rows_win<double>(ny, nx, (const cx<double>*)in, w, (cx<double>*)out, opitch, s, wcols); }
 int emu_rows_win_f32(int ny, int nx, const void* in, const float* w, void* out, long opitch, double s, int wcols) { return do_rows_win<float>(ny, nx, (const cx<float>*)in, w, (cx<float>*)out, opitch, s, wcols); }
 void emu_set_rsplit_pf(int on) { rsplit_pf = on != 0; }
+void emu_set_fband_packed(int on) { emu_fband_packed = on != 0; }
 int emu_rsplit_rows_f32(int ny, int my, int nx, const float* map, void* Y, long pitch, int width) { return do_rsplit_rows<float>(ny, my, nx, map, (cx<float>*)Y, pitch, width); }
 int emu_rsplit_rows_f64(int ny, int my, int nx, const double* map, void* Y, long pitch, int width) { return do_rsplit_rows<double>(ny, my, nx, map, (cx<double>*)Y, pitch, width); }
 int emu_rsplit_legs_f32(int ny, int my, int nx, const void* Y, long pitch, const float* FG, const float* FH, const float* lxd, const float* lyd, void* gx,

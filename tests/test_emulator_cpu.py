@@ -621,19 +621,21 @@ def test_rsplit_row_pass(emu, prec, pf):
 
 @pytest.mark.parametrize("nx,prec,w,pf", [(8192, "f64", 380, 1), (8192, "f64", 512, 0), (8192, "f32", 380, 1), (8192, "f64", 1, 1),
                                           (4096, "f64", 190, 0), (4096, "f32", 256, 1), (4096, "f64", 256, 1), (4096, "f32", 3, 0),
-                                          (16384, "f64", 380, 1), (16384, "f64", 512, 0), (16384, "f32", 380, 1), (16384, "f32", 2, 0)])
+                                          (16384, "f64", 380, 1), (16384, "f64", 512, 0), (16384, "f32", 380, 1), (16384, "f32", 2, 0),
+                                          (8192, "f64", 1138, 0), (8192, "f32", 1138, 1), (8192, "f64", 1280, 1), (8192, "f32", 513, 0)])
 def test_rsplit_row_pass_one_crosswave_exchange(emu, nx, prec, w, pf):
     """row_r2c_rs_body: L = 16 x S with the sub-transforms (S = 256 = 16 x 16 points for 8192-point rows, 128 = 16 x 8 for
     4096-point rows, 512 = 16 x 32 for 16384-point rows: lane pairs share a 32-point butterfly) inside one wave's part of the
     buffer, pruned last stage, persistent workgroups (3 walk 8 groups) with and without the prefetch order; the column butterfly
-    on top is R = 4, for 16384-point rows R = 8"""
-    R = 8 if nx == 16384 else 4
+    on top is R = 4, for 16384-point rows R = 8; more than 512 kept columns of 8192-point rows: the wide band (five kept bins per side
+    of the last stage, five columns per thread) with R = 2"""
+    R = 8 if nx == 16384 else (2 if w > 512 else 4)
     ny = 8 * R
     my = ny // R
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 3e-6)
     rng = np.random.default_rng(11)
     x = rng.standard_normal((ny, nx)).astype(rdt)
-    pitch = 520
+    pitch = 520 if w <= 512 else 1296
     Y = np.full((R, my, pitch), 7.0 + 0j, dtype=cdt)
     fn = emu.emu_rsplit_rows_rs4096_f64 if prec == "f64" else emu.emu_rsplit_rows_rs4096_f32
     assert fn(ny, nx, _p(x), _p(Y), ctypes.c_long(pitch), w, 3, pf) == 0
@@ -663,9 +665,13 @@ def _fband_reference(Y, my, FG, FH, lxd, lyd, w, ny):
     return outs, fields
 
 
-@pytest.mark.parametrize("prec,nmaps,ny,my", [("f64", 1, 4096, 1024), ("f32", 2, 4096, 1024), ("f64", 1, 16384, 2048), ("f32", 1, 16384, 2048)])
-def test_rsplit_single_pass_column_stage(emu, prec, nmaps, ny, my):
-    nx, w, rb = 2048, 21, 150
+@pytest.mark.parametrize("packed", [0, 1], ids=["planes", "packed"])
+@pytest.mark.parametrize("prec,nmaps,ny,my", [("f64", 1, 4096, 1024), ("f32", 2, 4096, 1024), ("f64", 1, 16384, 2048), ("f32", 1, 16384, 2048),
+                                              ("f64", 1, 8192, 4096), ("f32", 2, 8192, 4096)])
+def test_rsplit_single_pass_column_stage(emu, prec, nmaps, ny, my, packed):
+    """col_fband_body (R = 4, 8, 2) against NumPy; packed: the filters through the per-binding table of col_fband_pack_body (what the
+    one-call entries run) instead of the filter planes"""
+    nx, w, rb = 2048, 21, (150 if my < 4096 else 1139)
     R = ny // my
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 4e-6)
     rng = np.random.default_rng(9)
@@ -685,8 +691,10 @@ def test_rsplit_single_pass_column_stage(emu, prec, nmaps, ny, my):
     outs = [np.full((nmaps, my, opitch), 5.0 + 0j, dtype=cdt) for _ in range(3)]           # gx, gy, h
     fn = emu.emu_rsplit_legs_f64 if prec == "f64" else emu.emu_rsplit_legs_f32
     args = [a.astype(rdt) for a in (FG, FH, lxd, lyd)]
+    emu.emu_set_fband_packed(packed)
     assert fn(ny, my, nx, _p(Y), ctypes.c_long(pitch), _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(outs[0]), _p(outs[1]), _p(outs[2]),
               ctypes.c_long(opitch), w, rb, nmaps, ctypes.c_long(R * my * pitch), ctypes.c_long(my * opitch)) == 0
+    emu.emu_set_fband_packed(0)
     for m in range(nmaps):
         (rh, rgx, rgy), fields = _fband_reference(Y[m].astype(np.complex128), my, FG, FH, lxd, lyd, w, ny)
         for got, want in ((outs[2][m], rh), (outs[0][m], rgx), (outs[1][m], rgy)):
@@ -701,12 +709,13 @@ def test_rsplit_single_pass_column_stage(emu, prec, nmaps, ny, my):
 
 @pytest.mark.parametrize("prec,R,M,win,wout", [("f64", 4, 1024, 20, 30), ("f32", 4, 1024, 20, 30), ("f64", 8, 2048, 20, 30), ("f32", 8, 2048, 20, 30),
                                                ("f64", 8, 2048, 380, 664), ("f64", 4, 2048, 380, 664), ("f64", 4, 1536, 380, 664),
-                                               ("f32", 4, 1536, 380, 664), ("f64", 8, 1536, 380, 664), ("f64", 4, 4096, 1139, 664)])
+                                               ("f32", 4, 1536, 380, 664), ("f64", 8, 1536, 380, 664), ("f64", 4, 4096, 1139, 664),
+                                               ("f64", 2, 4096, 1139, 664), ("f32", 2, 4096, 1139, 664), ("f64", 2, 4096, 600, 664)])
 def test_row_stage_on_r_layout_planes(emu, body, prec, R, M, win, wout):
     """row_qe_pair_body<.., LAY = 2 / 3>: the same products from leg planes in the R-LAYOUT (R = 4, R = 8) as from natural-order planes
     (380 / 664 columns: the headline's band limits -- four live taps per side of the first inverse stage)"""
-    if body == 16 and M == 1536:
-        pytest.skip("the 3 x 512-point grid exists in the 8-point body only")
+    if body == 16 and (M == 1536 or R == 2):
+        pytest.skip("the 3 x 512-point grid and the R = 2 layout exist in the 8-point body only")
     my, nx = 64, (8192 if M == 4096 else 4096)
     rdt, cdt, tol = (np.float64, np.complex128, 1e-12) if prec == "f64" else (np.float32, np.complex64, 2e-5)
     rng = np.random.default_rng(12)
@@ -727,7 +736,7 @@ def test_row_stage_on_r_layout_planes(emu, body, prec, R, M, win, wout):
         return out
     fn = emu.emu_qe_rows_rlayout_f64 if prec == "f64" else emu.emu_qe_rows_rlayout_f32
     res = []
-    for lr, planes in ((0, nat), (2 if R == 4 else 3, [to_r(a) for a in nat])):
+    for lr, planes in ((0, nat), ({2: 1, 4: 2, 8: 3}[R], [to_r(a) for a in nat])):
         pl = [np.ascontiguousarray(a.astype(cdt)) for a in planes]
         px = np.full((my, kp), 3.0 + 0j, dtype=cdt); py = np.full((my, kp), 3.0 + 0j, dtype=cdt)
         assert fn(my, nx, _p(pl[0]), _p(pl[1]), _p(pl[2]), _p(px), _p(py), ctypes.c_double(1.0 / nx ** 2), win, wout, M, lr) == 0

@@ -174,9 +174,9 @@ int main(int argc, char** argv) {
     for (int i = 0; i < N; ++i) twx[i] = mk<CF>(CF::run(tw[i].x), CF::run(tw[i].y));
     p.ny = N; p.nx = N; p.logNy = ilog2(N); p.logNx = ilog2(N); p.kp = kpitch_for(N); p.tw_x = twx.data(); p.tw_y = twx.data();
     // per-thread constants of the 8-point row stage's grids, as run-time (non-foldable) values
-    std::vector<cx<CF>> rq8t[5];
-    const int waves[5] = {2, 3, 4, 8, 16};
-    for (int i = 0; i < 5; ++i)
+    std::vector<cx<CF>> rq8t[RQ8_NGRIDS];
+    const int* waves = RQ8_WAVES;
+    for (int i = 0; i < RQ8_NGRIDS; ++i)
         if (512 * waves[i] <= N) {
             const auto tf = rq8_make_consts<float>(waves[i]);
             rq8t[i].resize(tf.size());
