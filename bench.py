@@ -924,8 +924,9 @@ def measure(args, torch, dist, world, rank, prec):
         w64 = prec == "f32"
         tn = "float" if prec == "f32" else "double"
         if G.get("rsplit"):
-            rs = (N == 16384 and wl_ <= 512 and prec == "f64") or (N == 8192 and wl_ <= 512) or (N == 4096 and wl_ <= 256)
-            roofline["kernel_symbol"] = ("row_r2c_rs%d_kernel<%s, ...>" % (N // 2, tn) if rs else "row_r2c_rsplit_kernel<%s, ...>" % tn)
+            rs = (N == 16384 and wl_ <= 512 and prec == "f64") or (N == 8192 and wl_ <= 1280) or (N == 4096 and wl_ <= 256)
+            wide = "w" if (N == 8192 and wl_ > 512) else ""       # the wide band (R = 2): row_r2c_rs4096w_kernel
+            roofline["kernel_symbol"] = ("row_r2c_rs%d%s_kernel<%s, ...>" % (N // 2, wide, tn) if rs else "row_r2c_rsplit_kernel<%s, ...>" % tn)
             roofline["rsplit"] = {"R": G["rsplit"], "note": "the row pass also takes the first radix-R butterfly of the column transform (rows g + my n, n < R, "
                                   "per workgroup) and writes R planes Y[k1][g]; one single-pass column kernel follows (include/orphics_amd.h oa_plan_rsplit)"}
         else:

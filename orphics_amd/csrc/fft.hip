@@ -353,11 +353,11 @@ struct HipLauncher {
         else if (gy == 4 && logMy == 10 && !narrow) f(Seq<16, 8, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc10>{});
         else if (gy == 4 && logMy == 11) f(Seq<16, 16, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc11 - 1>{});
         else if (gy == 4 && logMy == 10) f(Seq<16, 8, 8>{}, integral_constant<int, 2>{}, integral_constant<int, lc10 - 1>{});
-        else if (sizeof(T) == 8 && gy == 8 && logMy == 11 && !narrow) {        // 16384 rows on the 2048-row grid (float64 only: see row_rs4096)
+        else if (sizeof(T) == 8 && gy == 8 && logMy == 11 && !narrow) {      // 16384 rows on the 2048-row grid (float64 only: see row_rs4096)
             if constexpr (sizeof(T) == 8) f(Seq<16, 8, 16>{}, integral_constant<int, 3>{}, integral_constant<int, lc11>{});
-        } else if (gy == 2 && logMy == 12 && !narrow) {                          // the wide band: 8192 rows on the 4096-row grid
-            f(Seq<16, 16, 4, 4>{}, integral_constant<int, 1>{}, integral_constant<int, lc11 - 1>{});
-        } else return false;
+        }
+        else if (gy == 2 && logMy == 12 && !narrow) f(Seq<16, 16, 4, 4>{}, integral_constant<int, 1>{}, integral_constant<int, lc11 - 1>{});     // the wide band: 8192 rows on the 4096-row grid
+        else return false;
         return true;
     }
     template <typename T>

@@ -95,6 +95,8 @@ struct Fft2dPlan {
         if (off || !is_pow2(my)) return false;
         // R = 8: 16384^2 maps on the 2048-row column grid (row_r2c_rs_body<T, 13, 3>: 16384-point rows, <= 512 kept columns)
         // (float64: the float build measured slower than the two-waves-per-row kernel + multi-pass columns, which float keeps)
+        // (round 5 re-measured it at two workgroups per CU -- 128 registers, 42 of them spilled, no prefetch: R2C 364 us against 263 us, 2288
+        //  against 2932 reconstructions/s, profiles/r05_16384_f32_rs8.txt)
         if (logNy - logMy == 3) return sizeof(T) == 8 && logMy == 11 && logNx == 14 && wl <= 512;
         // R = 2: the wide band of 8192^2 maps on the 4096-row column grid (row_r2c_rs_body<T, 12, 1, .., 5>: <= 1280 kept columns)
         if (logNy - logMy == 1) return logMy == 12 && logNx == 13 && wl <= 1280;
