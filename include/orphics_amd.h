@@ -51,8 +51,9 @@ int oa_device_count(void);
 /* ---- plan --------------------------------------------------------------
  * Replaces the per-geometry precomputation of FourierCalc.__init__
  * (maps.py:1600-1607).  ny, nx >= 32.  Powers of two run the LDS-staged FFT kernels and every fused
- * estimator kernel.  Other EVEN sides (<= 8192; the reference notebooks use 600, 750, 2400) are served exactly by a
- * chirp-z (Bluestein) evaluation on an inner power-of-two plan: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c and all
+ * estimator kernel.  Other EVEN sides (<= 8192): sides whose only prime factors are 2, 3 and 5 (the reference notebooks
+ * use 600, 750, 1200, 2400) run mixed-radix Stockham transforms (mixed.hip), any other side a chirp-z (Bluestein)
+ * evaluation on an inner power-of-two plan -- both exact: oa_fft_r2c / oa_fft_c2r / oa_fft_c2c, oa_lens_maps(_hc) and all
  * per-mode / binning / RNG kernels work, `width` / `rband` hints are ignored, and the fused oa_qe_rows /
  * oa_qe_*_cols / oa_fft_cols / oa_fft_pass calls return an error (use the modular oa_qe_legs .. oa_qe_div chain,
  * as orphics_amd/lensing.py:_reconstruct_hc_modular does). */
@@ -161,7 +162,7 @@ int oa_qe_cols_div(oa_plan* p, const void* px_rows, const void* py_rows, const v
  *                        amplitude covsqrt_hc -> TT estimator -> bandpower moments (+ mean-field stack of kappa_hat,
  *                        interleaved re/im doubles, if meanfield_acc != NULL).  No host synchronisation.
  *  BINDING: the plan keeps the POINTERS handed to oa_plan_set_filters / oa_plan_set_bins and may keep derived copies of what they
- *  point to (tile-major Fnorm / ids of the fused divergence launch).  Every call of either entry invalidates those copies -- also
+ *  point to (tile-major Fnorm / ids of the fused divergence launch; the (FG, FH) values of the R-split column stage in thread order).  Every call of either entry invalidates those copies -- also
  *  when the addresses are the ones bound before -- so a caller that changes the contents of a bound plane calls the entry again. */
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
                         int leg_rows, int kappa_rows, int mrow);
@@ -179,7 +180,8 @@ int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* 
  * with the row bands of each call (mrow == 0 switches it off there too). */
 int oa_plan_set_col_grid(oa_plan* p, int mcol);
 int oa_plan_col_grid(const oa_plan* p);
-/* R of the R-SPLIT from-map path this plan's one-call TT entries run (0 = not this geometry): the row R2C carries the first
+/* R of the R-SPLIT from-map path this plan's one-call TT entries run (0 = not this geometry; 4: 8192^2 / 4096^2 maps at the reference's
+ * band limits, 8: 16384^2 float64, 2: 8192^2 with up to 1280 leg columns -- the T filter to ell = 6000): the row R2C carries the first
  * radix-R butterfly of the column transform (R = ny / column grid) and ONE single-pass column kernel goes from its output to
  * the three leg planes -- instead of forward pass 1, [forward pass 2 + filters + inverse pass 1] and inverse pass 2.
  * Same arithmetic up to the order of the column butterflies; results agree with the multi-pass path to rounding. */

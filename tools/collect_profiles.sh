@@ -24,6 +24,7 @@ for PREC in ${PRECS:-f64 f32}; do
   if [ -z "${ONLY_DEFAULT:-}" ]; then
     prof _${PREC}_fullrows --prec $PREC --row-grid full "$@"
     prof _${PREC}_dense --prec $PREC --no-prune "$@"
+    prof _${PREC}_wideband --prec $PREC --tlmax 6000 "$@"      # SURVEY 8(d)'s T filter to ell = 6000: the R = 2 split
   fi
   cat $O/summary/${TAG}_step_$PREC.txt
 done

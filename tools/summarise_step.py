@@ -105,7 +105,7 @@ def bench_keys(table):
                 return i
         return None
     keys = {}
-    r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_w64x2_kernel", "row_r2c_w64r_kernel", "row_r2c_rsplit_kernel", "row_r2c_rs4096_kernel", "row_r2c_rs2048_kernel")
+    r0 = first("row_fft_kernel", "row_r2c_w64_kernel", "row_r2c_w64x2_kernel", "row_r2c_w64r_kernel", "row_r2c_rsplit_kernel", "row_r2c_rs4096_kernel", "row_r2c_rs4096w_kernel", "row_r2c_rs8192_kernel", "row_r2c_rs2048_kernel")
     c0 = first("col_fft_kernel")
     q = first("row_qe8_kernel", "row_qe_pair_kernel", "row_qe_kernel")
     d = first("col_div_kernel", "col_div_sp_kernel", "col_div_sp_bin_kernel")
