@@ -139,7 +139,7 @@ def test_config5_16384_tt_qe_runs_and_matches_knox_scatter():
     assert abs(mean.mean() / nl[sel].mean() - 1) < 0.25    # N0 level
 
 
-@pytest.mark.parametrize("N,tlmax", [(2048, 2000), (4096, 2000), (8192, 2000), (4096, 6000), (8192, 6000), (16384, 2000)])
+@pytest.mark.parametrize("N,tlmax", [(2048, 2000), (4096, 2000), (8192, 2000), (4096, 6000), (8192, 6000), (8192, 4000), (16384, 2000)])
 def test_tt_bandpowers_match_numpy_oracle_at_full_size(N, tlmax):
     """The north-star parity statement checked directly at BASELINE config-2 size: the default (pruned, f32) device
     path -- R2C of the map, fused estimator, |kappa_hat|^2 bandpowers -- against the float64 full-plane NumPy
@@ -147,7 +147,8 @@ def test_tt_bandpowers_match_numpy_oracle_at_full_size(N, tlmax):
     size the headline metric is quoted on.  tlmax = 6000: SURVEY 8(d)'s high-resolution variant (T filter ell in (300, 6000):
     569 leg columns at 4096^2, column grid 2048 = ny / 2, row grid 2048) -- the geometry class that runs other kernels than
     the headline's (R = 2); at 8192^2 (1138 leg columns, column grid 4096, row grid 4096) it is the R = 2 split: the wide-band row R2C
-    (row_r2c_rs_body<T, 12, 1, .., 5>), col_fband<LR = 1> and the R = 2 layout of the row stage.  16384 (0.25', BASELINE config 5; 45 s of NumPy on 64 host threads): the R = 8 row R2C, col_fband<LR = 3> and the
+    (row_r2c_rs_body<T, 12, 1, .., 5>), col_fband<LR = 1> and the R = 2 layout of the row stage; tlmax = 4000 (759 leg columns) is the same
+    path with two live 512-column blocks per side in the row stage instead of four.  16384 (0.25', BASELINE config 5; 45 s of NumPy on 64 host threads): the R = 8 row R2C, col_fband<LR = 3> and the
     R = 8 layout of the row stage against NumPy on a real 16384^2 map (first run: profiles/r05_16384_oracle.txt)."""
     import time
     from orphics_amd import cosmology, lensing, maps
