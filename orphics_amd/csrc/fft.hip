@@ -495,14 +495,16 @@ struct HipLauncher {
         const bool narrow = lt < (sizeof(T) == 4 ? 14 : 13);
         constexpr int lc11 = sizeof(T) == 4 ? 3 : 2, lc10 = lc11 + 1;
         // (the wave-private histogram rows of the tail live in the column tile: waves x nids doubles must fit it)
-        if (fuse && !a.accumulate && (long)gx * gz * fuse->nids <= fuse->part_cap && (logL == 10 || logL == 11) &&
+        if (fuse && !a.accumulate && (long)gx * gz * fuse->nids <= fuse->part_cap && (logL == 10 || logL == 11 || (logL == 12 && !narrow)) &&
             (size_t)(nt / 64) * fuse->nids * sizeof(double) <= ((size_t)1 << lt) * sizeof(cx<T>)) {
-            if (logL == 11 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11>, gx, gz, nt, smem, a);
+            if (logL == 12) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 16>, lc11 - 1>, gx, gz, nt, smem, a);      // 4096-row column grids (the wide band at 8192^2)
+            else if (logL == 11 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11>, gx, gz, nt, smem, a);
             else if (logL == 10 && !narrow) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, lc10>, gx, gz, nt, smem, a);
             else if (logL == 11) go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 8>, lc11 - 1>, gx, gz, nt, smem, a);
             else go_fused(col_div_sp_bin_kernel<T, Seq<16, 16, 4>, lc10 - 1>, gx, gz, nt, smem, a);
             return true;
         }
+        if (logL == 12 && !narrow) { go(col_div_sp_kernel<T, Seq<16, 16, 16>, lc11 - 1>, dim3(gx, 1, gz), nt, smem, a); return true; }
         if (logL == 11 && !narrow) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, lc11>, dim3(gx, 1, gz), nt, smem, a); return true; }
         if (logL == 10 && !narrow) { go(col_div_sp_kernel<T, Seq<16, 16, 4>, lc10>, dim3(gx, 1, gz), nt, smem, a); return true; }
         if (logL == 11) { go(col_div_sp_kernel<T, Seq<16, 16, 8>, lc11 - 1>, dim3(gx, 1, gz), nt, smem, a); return true; }

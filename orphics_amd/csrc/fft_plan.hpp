@@ -464,8 +464,8 @@ struct Fft2dPlan {
                   cx<T>* tmpA, cx<T>* tmpB, int accumulate, int wmax = 0x7fffffff, int rband = 0, long pin = 0, int nmaps = 1,
                   long in_moff = 0, long tmp_moff = 0, long out_moff = 0, long fn_moff = 0) const {
         const long pi = pin > 0 ? pin : kp;     // pitch of pa, pb AND of the two scratch planes
-        if (single_pass_div() && (logNy == 10 || logNy == 11)) {
-            // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column (f64: 4- / 8-column) tile in LDS --
+        if (single_pass_div() && (logNy == 10 || logNy == 11 || logNy == 12)) {
+            // SINGLE PASS (short coarse-grid columns): a whole column of an 8- / 16-column (f64: 4- / 8-column; 4096 rows: 4 / 2) tile in LDS --
             // 128 KB --, the product planes are read once and nothing is written back but kappa's band rows
             const int lt = div_lt();
             const int lc = lt - logNy, Cs = 1 << lc;

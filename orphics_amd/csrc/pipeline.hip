@@ -210,8 +210,8 @@ int oa_plan_div_fused(const oa_plan* p) {
     if (!q->FG || !q->ids || !q->opt_divbin) return 0;
     const int rows = q->my ? q->my : p->ny;            // rows of the grid the divergence runs on
     const bool sp = p->dtype == OA_F32 ? Fft2dPlan<float>::single_pass_div() : Fft2dPlan<double>::single_pass_div();
-    const long tiles = ((q->wk > 0 ? q->wk : p->nx / 2 + 1) + 3) / 4;        // (float64: 4-column tiles; float: 8 or 16)
-    return (sp && (rows == 1024 || rows == 2048) && tiles * MC_BATCH_MAX * q->nids <= (long)(oa_bin_scratch_bytes(q->nids) / 8) * MC_BATCH_MAX) ? 1 : 0;
+    const long tiles = ((q->wk > 0 ? q->wk : p->nx / 2 + 1) + (rows == 4096 ? 1 : 3)) / (rows == 4096 ? 2 : 4);        // (float64: 4-column tiles, 2 on 4096 rows; float: twice that)
+    return (sp && (rows == 1024 || rows == 2048 || rows == 4096) && tiles * MC_BATCH_MAX * q->nids <= (long)(oa_bin_scratch_bytes(q->nids) / 8) * MC_BATCH_MAX) ? 1 : 0;
 }
 
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
@@ -265,7 +265,7 @@ static bool divbin_enabled(const Pipeline* q) { return q->opt_divbin; }
 // build of a size allocates (one device synchronisation), later rebuilds are two small stream-ordered launches.
 static int ensure_div_tables(oa_plan* p, Pipeline* q, hipStream_t st) {
     const int rows = q->my;
-    if (!(q->Fn && q->ids && (rows == 1024 || rows == 2048) && q->wk > 0)) { q->tab_rows = 0; return 0; }
+    if (!(q->Fn && q->ids && (rows == 1024 || rows == 2048 || rows == 4096) && q->wk > 0)) { q->tab_rows = 0; return 0; }
     const int logc = div_tile_logc(p, rows);
     if (q->tab_gen == q->bind_gen && q->tab_rows == rows && q->tab_logc == logc && q->tab_wk == q->wk) return 0;
     const size_t rs = p->dtype == OA_F32 ? 4 : 8;

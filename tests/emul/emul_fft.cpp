@@ -165,9 +165,11 @@ struct EmuLauncher {
         if constexpr (sizeof(T) == 4) {
             if (logL == 11) { run(gx, 1, 1024, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 8>, EmuCtx, 3>(c, a); }, gz); return true; }
             if (logL == 10) { run(gx, 1, 1024, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 4>, EmuCtx, 4>(c, a); }, gz); return true; }
+            if (logL == 12) { run(gx, 1, 1024, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 16>, EmuCtx, 2>(c, a); }, gz); return true; }
         } else {
             if (logL == 11) { run(gx, 1, 512, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 8>, EmuCtx, 2>(c, a); }, gz); return true; }
             if (logL == 10) { run(gx, 1, 512, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 4>, EmuCtx, 3>(c, a); }, gz); return true; }
+            if (logL == 12) { run(gx, 1, 512, smem, [&](EmuCtx& c) { col_div_body<T, Seq<16, 16, 16>, EmuCtx, 1>(c, a); }, gz); return true; }
         }
         return false;
     }

@@ -545,10 +545,10 @@ def test_fused_forward_pass2_legs_on_the_column_grid(emu, ny, my, w, rb):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f64"])
-@pytest.mark.parametrize("ny_full,my,w,rb,nx", [(4096, 1024, 20, 150, 64), (8192, 2048, 0, 300, 64), (8192, 2048, 200, 300, 512)])
+@pytest.mark.parametrize("ny_full,my,w,rb,nx", [(4096, 1024, 20, 150, 64), (8192, 2048, 0, 300, 64), (8192, 2048, 200, 300, 512), (8192, 4096, 70, 700, 256)])
 def test_single_pass_forward_columns_and_divergence(emu, ny_full, my, w, rb, nx, prec):
-    """col_div_body with a whole 1024- / 2048-point column in the tile (f32: 16 / 8 columns, 1024 threads; f64: 8 / 4
-    columns, 512 threads -- 128 KB of LDS either way): forward column transform + divergence in ONE pass, with the
+    """col_div_body with a whole 1024- / 2048- / 4096-point column in the tile (f32: 16 / 8 / 4 columns, 1024 threads; f64: 8 / 4 / 2
+    columns, 512 threads -- 128 KB of LDS either way; 4096 rows: the wide band's column grid at 8192^2): forward column transform + divergence in ONE pass, with the
     column-grid row mapping of Fn, ly and the output; the 512-column case has more than 16 tiles, i.e. exercises the
     XCD-pairing tile order of the 64-byte-segment tiles."""
     rdt, cdt = (np.float32, np.complex64) if prec == "f32" else (np.float64, np.complex128)
