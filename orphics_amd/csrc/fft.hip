@@ -356,7 +356,7 @@ struct HipLauncher {
         else if (sizeof(T) == 8 && gy == 8 && logMy == 11 && !narrow) {      // 16384 rows on the 2048-row grid (float64 only: see row_rs4096)
             if constexpr (sizeof(T) == 8) f(Seq<16, 8, 16>{}, integral_constant<int, 3>{}, integral_constant<int, lc11>{});
         }
-        else if (gy == 2 && logMy == 12 && !narrow) f(Seq<16, 16, 4, 4>{}, integral_constant<int, 1>{}, integral_constant<int, lc11 - 1>{});     // the wide band: 8192 rows on the 4096-row grid
+        else if (gy == 2 && logMy == 12 && !narrow) f(Seq<16, 16, 16>{}, integral_constant<int, 1>{}, integral_constant<int, lc11 - 1>{});     // the wide band: 8192 rows on the 4096-row grid
         else return false;
         return true;
     }

@@ -9,7 +9,8 @@
 //     k2' = k2 (k2 < Mq / 2),   k2' = k2 - (My - Mq) (k2 >= My - Mq / 2),   Mq = My / R.
 // The last forward radix is 2 R, so a thread's butterfly u holds bins j + t Mq / 2 (t < 2 R): exactly one low-band bin
 // (t = 0 -> k2' = j) and one high-band bin (t = 2 R - 1 -> k2' = j + Mq / 2) -- every k2' of the coarse spectrum exactly once,
-// no zero-fill.  The inverse on the My-row grid splits y' = y_lo + Mq y_hi:
+// no zero-fill.  (Round 5: any last radix RL that is a multiple of 2 R -- the RL / 2R lowest and highest outputs of a butterfly are kept;
+// the wide band runs its 4096-point forward as 16 x 16 x 16 with 8 of the last stage's 16 outputs.)  The inverse on the My-row grid splits y' = y_lo + Mq y_hi:
 //     x[y_lo + Mq y_hi] = sum_k1 W_R^(-k1 y_hi) { W_My^(-k1 y_lo) sum_k2' X'[k1 + R k2'] W_Mq^(-k2' y_lo) }
 // The braces -- an Mq-point inverse transform over k2' and a twiddle, for the three filtered legs -- are computed here
 // (B[k1][y_lo], stored at row y_lo R + k1: the R-LAYOUT); the radix-R butterfly over k1 is taken by the row stage at its
@@ -36,7 +37,7 @@ struct ColFBandArgs {
     const T* FG; const T* FH;   // full-resolution filter planes (row pitch fpitch)
     long fpitch;
     // fgh != nullptr: (FG, FH) of every kept bin in the order the threads read them -- col_fband_pack_body, made once per binding:
-    // [k1][tile][2 u + side][tid], dead bins (beyond the band or the width) zero.  From the planes a wave's read of 64 bins touches
+    // [k1][tile][KQ u + q][tid], dead bins (beyond the band or the width) zero.  From the planes a wave's read of 64 bins touches
     // 32 rows x 16 bytes; the probe (tools/probes/fband_probe.hip) put a fifth of the R = 2 kernel's time there
     const cx<T>* fgh;
     const T* lxd; const T* lyd;
@@ -70,8 +71,11 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     constexpr int logL = seq_total_log<SEQF>();
     constexpr int L = 1 << logL, R = 1 << LR, logMq = logL - LR, Mq = 1 << logMq;
     constexpr int RL = SEQF::get(SEQF::n - 1), NB = EPT / RL, Ns = L / RL;
-    static_assert(RL == 2 * R, "col_fband: the last forward radix must be 2 R (one low and one high band bin per butterfly)");
-    static_assert(Ns == Mq / 2, "col_fband: band layout");
+    // a last-stage butterfly holds bins j + t Ns, t < RL: the coarse spectrum keeps the KQ / 2 lowest (t < KQ / 2: k2' = k2) and the KQ / 2
+    // highest (t >= RL - KQ / 2: k2' = k2 - (L - Mq)) -- KQ = RL / R; RL = 2 R: one of each (t = 0, t = RL - 1)
+    constexpr int KQ = RL / R, NK = KQ * NB;                 // kept bins per butterfly / per thread
+    static_assert(RL % (2 * R) == 0 && KQ >= 2, "col_fband: the last forward radix must be a multiple of 2 R");
+    static_assert(Ns * KQ == Mq, "col_fband: band layout");
     constexpr int C = 1 << LOGC;
     constexpr int NT = (1 << (logL + LOGC)) / EPT;          // forward: all threads
     constexpr int NTQ = NT / R;                              // inverse: threads per leg buffer
@@ -103,9 +107,9 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     const long zmap = ctx.bid_z();
     // the filter values of this thread's 2 NB kept bins, requested together, ahead of the forward transform, from valid addresses (dead bins: element 0, value unused) --
     // inside per-bin `if` blocks the compiler issued one read, waited, used it, issued the next (tools/isa_loads.py)
-    T fgv[2 * NB], fhv[2 * NB], lyv[2 * NB], lxv[NB];
-    bool lv[2 * NB];
-    const cx<T>* fq = a.fgh ? a.fgh + (((long)k1 * ctx.grid_x() + tile) * (2 * NB)) * NT + tid : nullptr;
+    T fgv[NK], fhv[NK], lyv[NK], lxv[NB];
+    bool lv[NK];
+    const cx<T>* fq = a.fgh ? a.fgh + (((long)k1 * ctx.grid_x() + tile) * NK) * NT + tid : nullptr;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
@@ -113,21 +117,22 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
         const bool ok = c < ncols;
         lxv[u] = ldg(a.lxd + (ok ? c0 + c : 0));
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int k2 = side ? j + (RL - 1) * Ns : j;     // bin of the My-point forward transform
+        for (int q = 0; q < KQ; ++q) {
+            const int t = q < KQ / 2 ? q : RL - KQ + q;
+            const int k2 = j + t * Ns;                       // bin of the My-point forward transform
             const int yf = k1 + R * k2;                      // row of the full-resolution grid
             bool live = ok;
             if (a.rband) live = ok && !(yf >= a.rband && yf <= a.ny_full - a.rband);
             if (fq) {
-                const cx<T> f = ldg(fq + (2 * u + side) * NT);
-                fgv[2 * u + side] = f.x; fhv[2 * u + side] = f.y;
+                const cx<T> f = ldg(fq + (KQ * u + q) * NT);
+                fgv[KQ * u + q] = f.x; fhv[KQ * u + q] = f.y;
             } else {
                 const long fi = live ? (long)yf * a.fpitch + (c0 + c) : 0;
-                fgv[2 * u + side] = ldg(a.FG + fi);
-                fhv[2 * u + side] = ldg(a.FH + fi);
+                fgv[KQ * u + q] = ldg(a.FG + fi);
+                fhv[KQ * u + q] = ldg(a.FH + fi);
             }
-            lyv[2 * u + side] = ldg(a.lyd + (live ? yf : 0));
-            lv[2 * u + side] = live;
+            lyv[KQ * u + q] = ldg(a.lyd + (live ? yf : 0));
+            lv[KQ * u + q] = live;
         }
     }
     FB_STAMP(2);
@@ -138,23 +143,24 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
     cx<T>* bh = s;
     cx<T>* bx = s + (Mq << LOGC);
     cx<T>* by = s + 2 * (Mq << LOGC);
-    cx<T> gyv[LR == 1 ? 2 * NB : 1];                         // R = 2: Gy's spectrum until buffer 0 is free
+    cx<T> gyv[LR == 1 ? NK : 1];                             // R = 2: Gy's spectrum until buffer 0 is free
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
         const int c = b & (C - 1), j = b >> LOGC;
         const T lx = (c < ncols) ? lxv[u] : (T)0;
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const cx<T> x = side ? gv[u * RL + RL - 1] : gv[u * RL];
-            const int k2p = side ? j + Ns : j;               // the bin's place in the Mq-point coarse spectrum of this k1
-            const bool live = lv[2 * u + side];
-            const T fg = live ? fgv[2 * u + side] : (T)0, fh = live ? fhv[2 * u + side] : (T)0, ly = live ? lyv[2 * u + side] : (T)0;
+        for (int q = 0; q < KQ; ++q) {
+            const int t = q < KQ / 2 ? q : RL - KQ + q;
+            const cx<T> x = gv[u * RL + t];
+            const int k2p = j + q * Ns;                      // the bin's place in the Mq-point coarse spectrum of this k1
+            const bool live = lv[KQ * u + q];
+            const T fg = live ? fgv[KQ * u + q] : (T)0, fh = live ? fhv[KQ * u + q] : (T)0, ly = live ? lyv[KQ * u + q] : (T)0;
             const cx<T> g = mul_pi(x * fg);
             const int at = (k2p << LOGC) + c;
             bh[at] = swp(x * fh);                            // inverse transform = forward transform of the swapped data
             bx[at] = swp(g * lx);
-            if constexpr (LR == 1) gyv[2 * u + side] = swp(g * ly);
+            if constexpr (LR == 1) gyv[KQ * u + q] = swp(g * ly);
             else by[at] = swp(g * ly);
         }
     }
@@ -178,8 +184,8 @@ OA_HD void col_fband_body(Ctx& ctx, const ColFBandArgs<T>& a) {
         for (int u = 0; u < NB; ++u) {
             const int b = tid + u * NT;
             const int c = b & (C - 1), j = b >> LOGC;
-            bh[(j << LOGC) + c] = gyv[2 * u];
-            bh[((j + Ns) << LOGC) + c] = gyv[2 * u + 1];
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) bh[((j + q * Ns) << LOGC) + c] = gyv[KQ * u + q];
         }
         ctx.sync();
         FB_STAMP(6);
@@ -194,23 +200,24 @@ template <typename T, class SEQF, int LR, int LOGC, class Ctx>
 OA_HD void col_fband_pack_body(Ctx& ctx, const ColFBandArgs<T>& a, cx<T>* out) {
     constexpr int logL = seq_total_log<SEQF>();
     constexpr int L = 1 << logL, R = 1 << LR;
-    constexpr int RL = SEQF::get(SEQF::n - 1), NB = EPT / RL, Ns = L / RL, C = 1 << LOGC;
+    constexpr int RL = SEQF::get(SEQF::n - 1), NB = EPT / RL, Ns = L / RL, C = 1 << LOGC, KQ = RL / R, NK = KQ * NB;
     constexpr int NT = (1 << (logL + LOGC)) / EPT;
     const int tid = ctx.tid(), tile = ctx.bid_x(), k1 = ctx.bid_y(), c0 = tile << LOGC;
-    cx<T>* o = out + (((long)k1 * ctx.grid_x() + tile) * (2 * NB)) * NT + tid;
+    cx<T>* o = out + (((long)k1 * ctx.grid_x() + tile) * NK) * NT + tid;
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
         const int b = tid + u * NT;
         const int c = b & (C - 1), j = b >> LOGC;
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int k2 = side ? j + (RL - 1) * Ns : j;
+        for (int q = 0; q < KQ; ++q) {
+            const int t = q < KQ / 2 ? q : RL - KQ + q;
+            const int k2 = j + t * Ns;
             const int yf = k1 + R * k2;
             bool live = c0 + c < a.width;
             if (a.rband) live = live && !(yf >= a.rband && yf <= a.ny_full - a.rband);
             cx<T> f = mk<T>((T)0, (T)0);
             if (live) { const long fi = (long)yf * a.fpitch + (c0 + c); f = mk<T>(a.FG[fi], a.FH[fi]); }
-            o[(2 * u + side) * NT] = f;
+            o[(KQ * u + q) * NT] = f;
         }
     }
 }

@@ -118,7 +118,7 @@ struct EmuLauncher {
         if (gy == 4 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 8>, 2, lc11>(c, a); }, gz);
         else if (gy == 4 && logMy == 10) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 8>, 2, lc10>(c, a); }, gz);
         else if (gy == 8 && logMy == 11) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 8, 16>, 3, lc11>(c, a); }, gz);
-        else if (gy == 2 && logMy == 12) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 4, 4>, 1, lc11 - 1>(c, a); }, gz);
+        else if (gy == 2 && logMy == 12) run(gx, gy, nt, smem, [&](EmuCtx& c) { col_fband_body<T, Seq<16, 16, 16>, 1, lc11 - 1>(c, a); }, gz);
     }
     template <typename T> void col_fband_pack(int gx, int gy, int logMy, const ColFBandArgs<T>& a, cx<T>* out) {
         constexpr int nt = sizeof(T) == 4 ? 1024 : 512;
@@ -126,7 +126,7 @@ struct EmuLauncher {
         if (gy == 4 && logMy == 11) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 16, 8>, 2, lc11>(c, a, out); });
         else if (gy == 4 && logMy == 10) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 8, 8>, 2, lc10>(c, a, out); });
         else if (gy == 8 && logMy == 11) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 8, 16>, 3, lc11>(c, a, out); });
-        else if (gy == 2 && logMy == 12) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 16, 4, 4>, 1, lc11 - 1>(c, a, out); });
+        else if (gy == 2 && logMy == 12) run(gx, gy, nt, 0, [&](EmuCtx& c) { col_fband_pack_body<T, Seq<16, 16, 16>, 1, lc11 - 1>(c, a, out); });
     }
     template <typename T> void col_deriv(int gx, int gy, int nt, size_t smem, const ColDerivArgs<T>& a, int nz) {
         dispatch_seq(a.logL, [&](auto seq) {

@@ -1,4 +1,4 @@
-// Stand-alone timing probe of the R = 2 single-pass column stage (csrc/fft_fband.hpp, col_fband_body<T, Seq<16,16,4,4>, 1, LC>) at the
+// Stand-alone timing probe of the R = 2 single-pass column stage (csrc/fft_fband.hpp, col_fband_body<T, Seq<16,16,16>, 1, LC>) at the
 // wide band's geometry (8192 rows on the 4096-row grid, 1138 columns): HIP-event time and, with -DSTAMPS, the cycle counter at the
 // phase boundaries of every workgroup's first lane.  Build on the GPU box (tools/r05_fband_probe.sh); not part of the library.
 #include <hip/hip_runtime.h>
@@ -26,7 +26,7 @@ typedef PREC T;
 constexpr int LC = sizeof(T) == 8 ? 1 : 2, NTH = sizeof(T) == 8 ? 512 : 1024;
 __global__ __launch_bounds__(NTH, (sizeof(T) == 8 ? 2 : 4)) void probe_kernel(ColFBandArgs<T> a) {
     GpuCtx c{oa_dyn_smem};
-    col_fband_body<T, Seq<16, 16, 4, 4>, 1, LC>(c, a);
+    col_fband_body<T, Seq<16, 16, 16>, 1, LC>(c, a);
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv) {
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     unsigned long long t0 = ~0ull, tend = 0;
     for (int g = 0; g < ng; ++g) { t0 = std::min(t0, st[(size_t)g * NSTAMP]); tend = std::max(tend, st[(size_t)g * NSTAMP + 7]); }
     printf("stamps (100 MHz ticks): kernel span %llu; mean / max per phase over %d workgroups\n", tend - t0, ng);
-    const char* names[8] = {"", "tables + barrier", "filter reads issued", "tile load + forward (4 stages)", "filters applied, leg buffers written", "inverse round 1 (H, Gx) + stores issued", "Gy to buffer 0", "inverse round 2 (Gy)"};
+    const char* names[8] = {"", "tables + barrier", "filter reads issued", "tile load + forward", "filters applied, leg buffers written", "inverse round 1 (H, Gx) + stores issued", "Gy to buffer 0", "inverse round 2 (Gy)"};
     for (int i = 1; i < 8; ++i) {
         double d = 0, mx = 0; for (int g = 0; g < ng; ++g) { const double v = (double)(st[(size_t)g * NSTAMP + i] - st[(size_t)g * NSTAMP + i - 1]); d += v; mx = std::max(mx, v); }
         printf("  phase %d %-42s mean %7.0f  max %7.0f\n", i, names[i], d / ng, mx);
