@@ -294,8 +294,8 @@ struct HipLauncher {
     // 8192-point rows, <= 512 kept columns (and 4096-point rows, <= 256: 4096^2 maps, float 18.9 us against 23.5 us of the general
     // pass, float64 37.2 against 41.0): the one-cross-wave-exchange kernel (fft_r2c_rs4096.hpp), both precisions.  Measured
     // at 8192^2 (profiles/r03x_r2c_variants.txt): float64 121 us against 131 us of the general pass, float 65 us against 71 us of
-    // the one-wave-per-row kernel.  The prefetch order pays in float (65 vs 68 us) and costs in float64 (126 vs 121 us: 256
-    // registers, spills): default per precision, OA_RS4096_PF=0/1 overrides.  OA_NO_RS4096=1: the older kernels (A/B).
+    // the one-wave-per-row kernel.  The prefetch order pays in float (65 vs 68 us); in float64 only with the taps in two halves (below).
+    // OA_RS4096_PF=0/1 overrides (experiment builds).  OA_NO_RS4096=1: the older kernels (A/B).
     template <typename T>
     bool row_rs4096(const RowArgs<T>& a) {
         static const bool off = exp_env("OA_NO_RS4096") != nullptr;
@@ -304,7 +304,10 @@ struct HipLauncher {
         const bool l13 = sizeof(T) == 8 && a.lr == 3 && a.logL == 13 && a.wcols <= 512 && a.logTw >= 14;      // 16384-point rows, R = 8 (float64)
         const bool l12w = a.lr == 1 && a.logL == 12 && a.wcols <= 1280 && a.logTw >= 13;                       // the wide band, R = 2
         if (rc || !(l12w || (!off && (l12 || l11 || l13)))) return false;
-        const bool nopf = pfenv >= 0 ? pfenv == 0 : (sizeof(T) == 8 && (l12 || l12w));     // (4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
+        // (prefetch order everywhere.  8192-point float64 rows: with all 16 taps requested right after stage 0 it cost registers and time
+        //  in rounds 3-4 (126 vs 121 us); in two halves of 8 it is 110 vs 116 us, the wide-band kernel 120 vs 130 us, +1 % on the job --
+        //  profiles/r05_r2c_prefetch.txt.  4096-point float64 rows: 37.2 us with the prefetch, 39.1 without)
+        const bool nopf = pfenv >= 0 ? pfenv == 0 : false;
         const size_t smem = l13 ? rs_lds_bytes<T, 13>() : (l12w ? rs_lds_bytes<T, 12, 5>() : (l12 ? rs_lds_bytes<T, 12>() : rs_lds_bytes<T, 11>()));
         const int NTr = l13 ? 512 : ((l12 || l12w) ? RS4096_NT : 128);
         void (*kern)(RowArgs<T>) = l12 ? (nopf ? row_r2c_rs4096_kernel<T, false> : row_r2c_rs4096_kernel<T, true>)

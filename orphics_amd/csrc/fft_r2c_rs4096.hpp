@@ -36,7 +36,10 @@ template <int LOGL> constexpr int rs_nt() { return (1 << LOGL) / 16; }
 template <int LOGL> constexpr int rs_ncol() { return LOGL == 13 ? 1 : 2; }          // kept columns per thread
 template <int LOGL> constexpr int rs_twn() { return LOGL == 13 ? 192 : 128; }       // entries reserved for the two-level W_L table
 #ifndef OA_RS4096_PFH
-#define OA_RS4096_PFH 16
+#define OA_RS4096_PFH 8      // (float64, 8192-point rows: 8 taps right after stage 0, 8 behind the first sub-transform stage -- round 5, profiles/r05_r2c_prefetch.txt)
+#endif
+#ifndef OA_RS2048_PFH
+#define OA_RS2048_PFH 16
 #endif
 #ifndef OA_RS8192_PFH
 #define OA_RS8192_PFH 8      // (float64, 16384-point rows: all 16 taps across the first sub-transform stage spill 14 registers)
@@ -131,7 +134,7 @@ OA_HD void row_r2c_rs_body(Ctx& ctx, const RowArgs<T>& a) {
     auto row_of = [](int step) { return R == 4 ? (((step & 1) << 1) | (step >> 1)) : step; };
     // prefetch of the next row in two halves (PFH = taps issued right after stage 0; the rest after the first sub-transform
     // stage, whose butterfly + 15 factors are the register peak): float64 has no room for all 16 taps across that stage
-    constexpr int PFH = sizeof(T) == 8 ? (LOGL == 13 ? OA_RS8192_PFH : OA_RS4096_PFH) : 16;
+    constexpr int PFH = sizeof(T) == 8 ? (LOGL == 13 ? OA_RS8192_PFH : (LOGL == 12 ? OA_RS4096_PFH : OA_RS2048_PFH)) : 16;
     auto next_taps = [&](long grp, int step, int t0, int t1) {
         if (step + 1 < R) taps(grp, row_of(step + 1), t0, t1);
         else if (grp + gstep < ngroups) taps(grp + gstep, 0, t0, t1);
