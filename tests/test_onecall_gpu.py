@@ -547,6 +547,15 @@ def test_rebinding_filters_at_the_same_addresses_repacks_the_divergence_tables()
     e._pipe_owner = None                                     # the host mirror re-binds (same pointers, new contents)
     second = run()
     assert np.abs(second / first - 1).max() > 1e-2          # the new noise level changes the normalisation
+    # ... and what comes out is the second estimator's result: its OWN planes through the same plan (this also covers the packed
+    # (FG, FH) table of the R-split column stage, which both the fused and the separate-histogram runs below would share if stale)
+    acc2 = (torch.zeros(1, dtype=torch.int64, device=e.device), torch.zeros(19, dtype=torch.float64, device=e.device),
+            torch.zeros(19, 19, dtype=torch.float64, device=e.device))
+    q2.bind_bins(ids, 21, g.area / float(N * N) ** 2)
+    q2.tt_moments(m, *acc2)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(second, acc2[1].cpu().numpy(), rtol=1e-12)
+    e._pipe_owner = None
     eb.set_option("div_bin", 0)
     try:
         sep = run()
