@@ -187,7 +187,7 @@ int oa_plan_col_grid(const oa_plan* p);
  * Same arithmetic up to the order of the column butterflies; results agree with the multi-pass path to rounding. */
 int oa_plan_rsplit(const oa_plan* p);
 /* 1 when this plan's one-call moment entries (oa_qe_tt_moments, oa_qe_tt_moments2, oa_mc_run) bin |kappa_hat|^2 and update
- * n, S, C in the tail of the single-pass divergence launch (coarse grids of 1024 / 2048 rows, bins bound) instead of two more
+ * n, S, C in the tail of the single-pass divergence launch (coarse grids of 1024 / 2048 / 4096 rows, bins bound) instead of two more
  * launches over the kappa plane; 0: the separate histogram launches.  Same per-mode arithmetic either way; the order of the
  * float64 sums differs (bandpowers agree to ~1e-15).  When fused, these entries do not write the plan-owned kappa plane
  * (oa_plan_kappa) unless the mean-field stack of oa_mc_run needs it; oa_qe_tt always does.  oa_plan_set_option(p, OA_OPT_DIV_BIN, 0)

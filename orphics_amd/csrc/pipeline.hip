@@ -210,8 +210,10 @@ int oa_plan_div_fused(const oa_plan* p) {
     if (!q->FG || !q->ids || !q->opt_divbin) return 0;
     const int rows = q->my ? q->my : p->ny;            // rows of the grid the divergence runs on
     const bool sp = p->dtype == OA_F32 ? Fft2dPlan<float>::single_pass_div() : Fft2dPlan<double>::single_pass_div();
-    const long tiles = ((q->wk > 0 ? q->wk : p->nx / 2 + 1) + (rows == 4096 ? 1 : 3)) / (rows == 4096 ? 2 : 4);        // (float64: 4-column tiles, 2 on 4096 rows; float: twice that)
-    return (sp && (rows == 1024 || rows == 2048 || rows == 4096) && tiles * MC_BATCH_MAX * q->nids <= (long)(oa_bin_scratch_bytes(q->nids) / 8) * MC_BATCH_MAX) ? 1 : 0;
+    if (!(sp && (rows == 1024 || rows == 2048 || rows == 4096))) return 0;
+    const int logc = div_tile_logc(p, rows);           // columns per 128 KB tile of this grid and precision
+    const long tiles = ((long)(q->wk > 0 ? q->wk : p->nx / 2 + 1) + (1 << logc) - 1) >> logc;
+    return (tiles * MC_BATCH_MAX * q->nids <= (long)(oa_bin_scratch_bytes(q->nids) / 8) * MC_BATCH_MAX) ? 1 : 0;
 }
 
 int oa_plan_set_filters(oa_plan* p, const void* FG, const void* FH, const void* Fnorm, int leg_cols, int kappa_cols,
