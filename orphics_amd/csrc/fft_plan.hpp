@@ -358,10 +358,11 @@ struct Fft2dPlan {
     bool legs_cols_batch(Launcher& q, const cx<T>* src0, long off1, long off2, unsigned long long srcsel, const T* const* ftab, int ngrad, int nh, const T* lxd, const T* lyd, cx<T>* pool, long ostride, int wmax,
                          int rband, long pin, long pout, int selbits = 2) const {
         const long pi = pin > 0 ? pin : kp, po = pout > 0 ? pout : kp;
-        // (2048-row grids -- 8192^2 maps -- run the kernel too, OA_LEGS_SP_2048=1, but no faster than the two passes: 17 planes x
-        //  48 tiles of 128 KB are 3.2 rounds of workgroups, 2697 vs 2755 MV reconstructions/s; 1024-row grids: +7 % in oa_mc_run)
-        static const bool sp2048 = exp_env("OA_LEGS_SP_2048") != nullptr;
-        if (legs_single_pass() && (logNy == 10 || (logNy == 11 && sp2048))) {
+        // (2048-row grids -- 8192^2 maps: float32 is no faster in one pass than in two -- 17 planes x 48 tiles of 128 KB are 3.2 rounds of
+        //  workgroups, 3156 vs 3309 MV reconstructions/s --, float64 is: 1848 vs 1775 (round 5, tools/r05_mv_f64.sh); experiment builds:
+        //  OA_LEGS_SP_2048=1 / 0 forces it on / off.  1024-row grids: +7 % in oa_mc_run)
+        static const int sp2048 = [] { const char* e = exp_env("OA_LEGS_SP_2048"); return e ? atoi(e) : -1; }();
+        if (legs_single_pass() && (logNy == 10 || (logNy == 11 && (sp2048 >= 0 ? sp2048 != 0 : sizeof(T) == 8)))) {
             const int lt = sizeof(T) == 4 ? 14 : 13, lc = lt - logNy, Cs = 1 << lc;
             ColLegsArgs<T> a{};
             a.kX = src0; a.kY = src0; a.FG = nullptr; a.FH = nullptr; a.ftab = ftab; a.lxd = lxd; a.lyd = lyd; a.gx = pool; a.gy = pool; a.h = pool;
