@@ -51,11 +51,7 @@ struct DivBinTail {
         const int nw = blockDim.x >> 6;
         for (int i = threadIdx.x; i < nw * f.nids; i += blockDim.x) rows[i] = 0.0;
     }
-#ifdef OA_DIVBIN_NOIDS      // timing experiment only: no id loads
-    __device__ __forceinline__ int id_at(unsigned yfull, int col) const { return 1 + (int)((yfull + col) & 7u); }
-#else
     __device__ __forceinline__ int id_at(unsigned yfull, int col) const { return f.ids[(long)yfull * f.ipitch + col]; }
-#endif
     // tile-major copy of the ids on the coarse grid ([tile][coarse row][C], DivBinFuse::ids_t): contiguous per tile instead of 16- /
     // 32-byte row segments of the full-pitch plane (7.3 / 15.3 MB fetched for 3.5 MB: profiles/r04_overfetch.txt)
     __device__ __forceinline__ bool packed_ids() const { return f.ids_t != nullptr; }

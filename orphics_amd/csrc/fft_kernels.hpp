@@ -1854,14 +1854,10 @@ OA_HD void col_div_body(Ctx& ctx, const ColDivArgs<T>& a, Tail tail = Tail{}) {
                 pw[u * RL + t] = (T)0;
                 idv[u * RL + t] = -1;
                 if (ok) {
-#ifdef OA_DIV_NOFN           // traffic experiment only (wrong values): no loads of the normalisation plane
-                    cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * (T)(1 + (i & 1));
-#else
                     // (tile-major tables: entry [tile][k][c]; single pass: k is the coarse row)
                     const long ti_ = (((long)tile << logL) + k) * (1 << logC) + c;
                     const T fn = a.Fn_t ? a.Fn_t[ti_] : Fnb[i];
                     cx<T> d = mul_pi(va[u * RL + t] * lx + vb[u * RL + t] * a.lyd[y + up]) * fn;
-#endif
                     if (a.out) {
                         if (a.accumulate) d = d + outb[i];
                         outb[i] = d;
